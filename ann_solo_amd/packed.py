@@ -1,0 +1,113 @@
+"""Packed (SoA) spectra: the device-resident replacement of the per-spectrum
+``MsmsSpectrum`` objects the reference materialises one HDF5 read at a time
+(/root/reference/src/ann_solo/reader.py:218-246, spectral_library.py:449-455).
+
+Layout: ``offsets i32[n+1]``, ``mz f32[]``, ``intensity f32[]``,
+``charge u8[]`` (fragment-charge annotation, 0 = none; what spectrum_match.pyx:74-79
+derives from ``annotation``), ``precursor_mz f64[n]``, ``precursor_charge i32[n]``.
+Peaks of one spectrum are ascending in m/z and already processed
+(``process_spectrum``, spectrum.py:57-119).
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+
+@dataclass
+class PackedSpectra:
+    offsets: torch.Tensor            # int32 [n+1]
+    mz: torch.Tensor                 # float32 [P]
+    intensity: torch.Tensor          # float32 [P]
+    charge: torch.Tensor             # uint8 [P]
+    precursor_mz: torch.Tensor       # float64 [n]
+    precursor_charge: torch.Tensor   # int32 [n]
+    identifiers: Optional[list] = None
+
+    @property
+    def n(self) -> int:
+        return self.offsets.numel() - 1
+
+    def __len__(self):
+        return self.n
+
+    @property
+    def device(self):
+        return self.mz.device
+
+    def to(self, device) -> 'PackedSpectra':
+        return PackedSpectra(*(t.to(device) for t in self._tensors()),
+                             identifiers=self.identifiers)
+
+    def _tensors(self):
+        return (self.offsets, self.mz, self.intensity, self.charge, self.precursor_mz,
+                self.precursor_charge)
+
+    def contiguous(self):
+        return PackedSpectra(*(t.contiguous() for t in self._tensors()),
+                             identifiers=self.identifiers)
+
+    def select(self, rows) -> 'PackedSpectra':
+        """Gather a subset of spectra (rows: 1-D int tensor/array) into a new pack."""
+        rows = torch.as_tensor(rows, dtype=torch.int64, device=self.device)
+        off = self.offsets.to(torch.int64)
+        cnt = off[rows + 1] - off[rows]
+        new_off = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=self.device)
+        new_off[1:] = torch.cumsum(cnt, 0)
+        total = int(new_off[-1])
+        seg = torch.repeat_interleave(torch.arange(rows.numel(), device=self.device), cnt,
+                                      output_size=total)
+        pos = torch.arange(total, device=self.device) - new_off[seg] + off[rows][seg]
+        ids = None
+        if self.identifiers is not None:
+            ids = [self.identifiers[int(r)] for r in rows.cpu()]
+        return PackedSpectra(new_off.to(torch.int32), self.mz[pos], self.intensity[pos],
+                             self.charge[pos], self.precursor_mz[rows],
+                             self.precursor_charge[rows], identifiers=ids)
+
+    def numpy(self):
+        """(offsets, mz, intensity, charge, precursor_mz, precursor_charge) as numpy."""
+        return tuple(t.detach().cpu().numpy() for t in self._tensors())
+
+    @staticmethod
+    def from_numpy(offsets, mz, intensity, charge, precursor_mz, precursor_charge,
+                   device='cpu', identifiers=None) -> 'PackedSpectra':
+        if charge is None:
+            charge = np.zeros(len(mz), np.uint8)
+        return PackedSpectra(
+            torch.as_tensor(np.ascontiguousarray(offsets, np.int32), device=device),
+            torch.as_tensor(np.ascontiguousarray(mz, np.float32), device=device),
+            torch.as_tensor(np.ascontiguousarray(intensity, np.float32), device=device),
+            torch.as_tensor(np.ascontiguousarray(charge, np.uint8), device=device),
+            torch.as_tensor(np.ascontiguousarray(precursor_mz, np.float64), device=device),
+            torch.as_tensor(np.ascontiguousarray(precursor_charge, np.int32), device=device),
+            identifiers=identifiers)
+
+    @staticmethod
+    def from_spectra(spectra, device='cpu') -> 'PackedSpectra':
+        """Pack reference-style spectrum objects (``.mz .intensity .precursor_mz
+        .precursor_charge`` and either ``.charge`` or ``.annotation``)."""
+        offs = [0]
+        mzs, ints, chgs, pmz, pz, ids = [], [], [], [], [], []
+        for s in spectra:
+            mz = np.asarray(s.mz, np.float32)
+            mzs.append(mz)
+            ints.append(np.asarray(s.intensity, np.float32))
+            chg = getattr(s, 'charge', None)
+            if chg is None:
+                ann = getattr(s, 'annotation', None)
+                chg = np.zeros(len(mz), np.uint8)
+                if ann is not None:          # spectrum_match.pyx:74-79
+                    for i, a in enumerate(ann):
+                        if a is not None:
+                            chg[i] = a.charge
+            chgs.append(np.asarray(chg, np.uint8))
+            offs.append(offs[-1] + len(mz))
+            pmz.append(float(s.precursor_mz))
+            pz.append(int(s.precursor_charge))
+            ids.append(getattr(s, 'identifier', None))
+        cat = (lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt))
+        return PackedSpectra.from_numpy(np.asarray(offs), cat(mzs, np.float32),
+                                        cat(ints, np.float32), cat(chgs, np.uint8),
+                                        np.asarray(pmz), np.asarray(pz), device, ids)

@@ -1,0 +1,347 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference); the GPU box and the
+test-suite only read the committed .npz files. Nothing from the reference is
+copied: its Python modules are imported in place behind small stand-in modules
+for absent third-party packages, and its C++ scorer is called through
+oracle/_ref (compiled from the sources where they lie).
+
+  encoder_golden.npz   spectrum_to_vector / get_dim / hash_idx outputs of the
+                       reference's src/ann_solo/spectrum.py (shim import)
+  rescoring_golden.npz SpectrumMatcher::dot outputs of the reference's
+                       src/ann_solo/SpectrumMatch.cpp (oracle/_ref)
+  similarity_kat.npz   the partial/all/no-match spectra and constants held by
+                       src/tests/spectrum_similarity_test.py (data fixture)
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference/src'
+sys.path.insert(0, ROOT)
+
+
+# ----------------------------------------------------------------- stand-ins
+def _murmur3_32(data: bytes, seed: int) -> int:
+    """MurmurHash3_x86_32 (public domain algorithm) = mmh3.hash(..., signed=False)."""
+    c1, c2, M = 0xcc9e2d51, 0x1b873593, 0xffffffff
+    h = seed & M
+    n = len(data) // 4
+    for i in range(n):
+        k = int.from_bytes(data[4 * i:4 * i + 4], 'little')
+        k = (k * c1) & M
+        k = ((k << 15) | (k >> 17)) & M
+        k = (k * c2) & M
+        h ^= k
+        h = ((h << 13) | (h >> 19)) & M
+        h = (h * 5 + 0xe6546b64) & M
+    tail = data[4 * n:]
+    k = 0
+    if len(tail) >= 3:
+        k ^= tail[2] << 16
+    if len(tail) >= 2:
+        k ^= tail[1] << 8
+    if len(tail) >= 1:
+        k ^= tail[0]
+        k = (k * c1) & M
+        k = ((k << 15) | (k >> 17)) & M
+        k = (k * c2) & M
+        h ^= k
+    h ^= len(data)
+    h ^= h >> 16
+    h = (h * 0x85ebca6b) & M
+    h ^= h >> 13
+    h = (h * 0xc2b2ae35) & M
+    h ^= h >> 16
+    return h
+
+
+MURMUR_KATS = [(b'', 0, 0), (b'', 1, 0x514E28B7), (b'', 0xffffffff, 0x81F16F39),
+               (b'\0\0\0\0', 0, 0x2362F9DE), (b'aaaa', 0x9747b28c, 0x5A97808A),
+               (b'Hello, world!', 0x9747b28c, 0x24884CBA),
+               (b'The quick brown fox jumps over the lazy dog', 0x9747b28c, 0x2FA826CD),
+               (b'foo', 0, 0xF6A5C420)]
+
+
+def _install_shims():
+    for data, seed, want in MURMUR_KATS:
+        assert _murmur3_32(data, seed) == want, (data, seed)
+    mmh3 = types.ModuleType('mmh3')
+
+    def _hash(key, seed=0, signed=True):
+        if isinstance(key, str):
+            key = key.encode('utf-8')
+        h = _murmur3_32(key, seed)
+        return h - (1 << 32) if signed and h & 0x80000000 else h
+    mmh3.hash = _hash
+    sys.modules['mmh3'] = mmh3
+
+    numba = types.ModuleType('numba')
+    numba.njit = lambda f=None, **kw: f if f is not None else (lambda g: g)
+    sys.modules['numba'] = numba
+
+    su = types.ModuleType('spectrum_utils')
+    sus = types.ModuleType('spectrum_utils.spectrum')
+
+    class MsmsSpectrum:          # minimal: sorted float32 peaks + precursor
+        def __init__(self, identifier, precursor_mz, precursor_charge, mz, intensity,
+                     annotation=None, retention_time=None, peptide=None, is_decoy=False):
+            mz = np.asarray(mz)
+            order = np.argsort(mz, kind='stable')
+            self.identifier = identifier
+            self.precursor_mz = precursor_mz
+            self.precursor_charge = precursor_charge
+            self._mz = np.asarray(mz, np.float32)[order]
+            self._intensity = np.asarray(intensity, np.float32)[order]
+            self.annotation = None
+            self.peptide = peptide
+            self.is_decoy = is_decoy
+            self.retention_time = retention_time
+
+        @property
+        def mz(self):
+            return self._mz
+
+        @property
+        def intensity(self):
+            return self._intensity
+    sus.MsmsSpectrum = MsmsSpectrum
+    su.spectrum = sus
+    sys.modules['spectrum_utils'] = su
+    sys.modules['spectrum_utils.spectrum'] = sus
+
+    import argparse
+    cap = types.ModuleType('configargparse')
+
+    class ArgParser(argparse.ArgumentParser):
+        def __init__(self, *a, **kw):
+            for k in ('default_config_files', 'args_for_setting_config_path',
+                      'formatter_class'):
+                kw.pop(k, None)
+            super().__init__(*a, **kw)
+    cap.ArgParser = ArgParser
+    cap.ArgumentDefaultsHelpFormatter = argparse.ArgumentDefaultsHelpFormatter
+    cap.ArgumentDefaultsRawHelpFormatter = argparse.ArgumentDefaultsHelpFormatter
+    sys.modules['configargparse'] = cap
+
+    pkg = types.ModuleType('ann_solo')
+    pkg.__path__ = [os.path.join(REF, 'ann_solo')]
+    sys.modules['ann_solo'] = pkg
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_encoder():
+    _install_shims()
+    _load('ann_solo.config', os.path.join(REF, 'ann_solo/config.py'))
+    spectrum = _load('ann_solo.spectrum', os.path.join(REF, 'ann_solo/spectrum.py'))
+    from ann_solo_amd import synthetic
+    lib, aux = synthetic.make_library(96, seed=7, device='cpu')
+    q, _ = synthetic.make_queries(lib, aux, 32, seed=8)
+    offsets, mz, inten = [], [], []
+    for pack in (lib, q):
+        o, m, i, _, _, _ = pack.numpy()
+        for s in range(pack.n):
+            mz.append(m[o[s]:o[s + 1]])
+            inten.append(i[o[s]:o[s + 1]])
+    rng = np.random.default_rng(3)
+    # edge cases: bin-boundary m/z, hash collisions, a 1-peak and an empty spectrum,
+    # values right at min_mz / max_mz, raw (un-normalised) intensities
+    edge = np.array([11.0, 10.96 + 0.04 * 3, 10.96 + 0.04 * 3 + 1e-4, 0.12 + 10.96, 500.0,
+                     500.02, 500.039, 500.04, 1234.5678, 2009.99, 2010.0], np.float32)
+    mz.append(edge)
+    inten.append(rng.random(len(edge)).astype(np.float32) * 100)
+    mz.append(np.array([321.123], np.float32))
+    inten.append(np.array([2.5], np.float32))
+    dense = np.sort(rng.uniform(100, 1900, 300)).astype(np.float32)   # forces collisions
+    mz.append(dense)
+    inten.append(rng.random(300).astype(np.float32))
+    n = len(mz)
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(x) for x in mz])
+    vec = np.zeros((n, 800), np.float32)
+    vec_nonorm = np.zeros((n, 800), np.float32)
+    vec_h64 = np.zeros((n, 64), np.float32)
+    S = sys.modules['spectrum_utils.spectrum'].MsmsSpectrum
+
+    class F64Spectrum:   # m/z as float64 holding float32-rounded values
+        def __init__(self, mz, intensity):
+            self.mz = np.asarray(mz, np.float32).astype(np.float64)
+            self.intensity = np.asarray(intensity, np.float32)
+    for s in range(n):
+        sp = F64Spectrum(mz[s], inten[s])
+        spectrum.spectrum_to_vector(sp, 11, 2010, 0.04, 800, True, vec[s])
+        spectrum.spectrum_to_vector(sp, 11, 2010, 0.04, 800, False, vec_nonorm[s])
+        spectrum.spectrum_to_vector(sp, 11, 2010, 0.05, 64, True, vec_h64[s])
+    bins = np.array([0, 1, 2, 100, 12228, 12345, 49975, -1, -17, 7, 99999, 1234567], np.int64)
+    hashes = np.array([spectrum.hash_idx(int(b), 800) for b in bins], np.int32)
+    hashes64 = np.array([spectrum.hash_idx(int(b), 64) for b in bins], np.int32)
+    dims = np.array([spectrum.get_dim(11, 2010, 0.04), spectrum.get_dim(11, 2010, 0.05),
+                     spectrum.get_dim(50, 1500, 1.0005), spectrum.get_dim(0, 2000, 0.1)],
+                    np.float64)
+    dim_args = np.array([[11, 2010, 0.04], [11, 2010, 0.05], [50, 1500, 1.0005],
+                         [0, 2000, 0.1]], np.float64)
+    # bin index of every peak, straight from the reference expression
+    import math
+    min_bound = spectrum.get_dim(11, 2010, 0.04)[1]
+    allmz = np.concatenate(mz).astype(np.float32)
+    bin_idx = np.array([math.floor((np.float64(m) - min_bound) // 0.04) for m in allmz],
+                       np.int64)
+    np.savez_compressed(
+        os.path.join(HERE, 'encoder_golden.npz'), offsets=off, mz=allmz,
+        intensity=np.concatenate(inten).astype(np.float32), vec=vec, vec_nonorm=vec_nonorm,
+        vec_h64=vec_h64, bins=bins, hashes=hashes, hashes64=hashes64, dims=dims,
+        dim_args=dim_args, bin_idx=bin_idx,
+        murmur_kat_seed=np.array([k[1] for k in MURMUR_KATS], np.uint64),
+        murmur_kat_hash=np.array([k[2] for k in MURMUR_KATS], np.uint64),
+        murmur_kat_key=np.array([k[0].hex() for k in MURMUR_KATS]))
+    print('encoder_golden.npz:', n, 'spectra')
+    return spectrum
+
+
+def gen_similarity_kat(spectrum):
+    """The data the reference's own similarity test holds (spectra + constants)."""
+    sim = _load('ann_solo.spectrum_similarity',
+                os.path.join(REF, 'ann_solo/spectrum_similarity.py'))
+    _orig_init = sim.SpectrumSimilarityCalculator.__init__
+
+    def _init(self, ssm, top=None):      # keep the SSM the fixture was built from
+        self.ssm = ssm
+        _orig_init(self, ssm, top)
+    sim.SpectrumSimilarityCalculator.__init__ = _init
+    t = _load('ref_spectrum_similarity_test', os.path.join(REF, 'tests/spectrum_similarity_test.py'))
+    out = {}
+    for name in ('all_match', 'no_match', 'partial_match'):
+        fx = getattr(t, name)
+        fn = getattr(fx, '__wrapped__', None) or getattr(fx, '_fixture_function', None)
+        if fn is None and hasattr(fx, '_get_wrapped_function'):
+            fn = fx._get_wrapped_function()
+        calc = fn()
+        for side, sp in (('q', calc.ssm.query_spectrum), ('l', calc.ssm.library_spectrum)):
+            out[f'{name}_{side}_mz'] = np.asarray(sp.mz, np.float32)
+            out[f'{name}_{side}_intensity'] = np.asarray(sp.intensity, np.float32)
+            out[f'{name}_{side}_pmz'] = np.float64(sp.precursor_mz)
+            out[f'{name}_{side}_charge'] = np.int32(sp.precursor_charge)
+        out[f'{name}_peak_matches'] = np.asarray(calc.ssm.peak_matches, np.int64).reshape(-1, 2)
+        out[f'{name}_cosine'] = np.float64(calc.cosine())
+    np.savez_compressed(os.path.join(HERE, 'similarity_kat.npz'), **out)
+    print('similarity_kat.npz: cosines',
+          [float(out[f'{n}_cosine']) for n in ('all_match', 'no_match', 'partial_match')])
+
+
+def gen_rescoring():
+    from oracle import oracle_py as O
+    from ann_solo_amd import synthetic
+    assert O.ref_lib() is not None, 'oracle/_ref not built'
+    lib, aux = synthetic.make_library(600, seed=11, device='cpu')
+    q, truth = synthetic.make_queries(lib, aux, 160, seed=12)
+    lo, lmz, lin, lch, lpmz, lpz = [np.array(a) for a in lib.numpy()]
+    qo, qmz, qin, qch, qpmz, qpz = [np.array(a) for a in q.numpy()]
+    rng = np.random.default_rng(5)
+    # hand-made edge cases appended to the library
+    extra_mz, extra_in, extra_ch, extra_pmz, extra_pz = [], [], [], [], []
+
+    def add_lib(mz, inten, chg, pmz, pz):
+        extra_mz.append(np.asarray(mz, np.float32))
+        extra_in.append(np.asarray(inten, np.float32))
+        extra_ch.append(np.asarray(chg, np.uint8))
+        extra_pmz.append(pmz)
+        extra_pz.append(pz)
+    # (a) exact duplicates of library row 0 and 1 (score ties: first must win)
+    for r in (0, 0, 1):
+        s = slice(lo[r], lo[r + 1])
+        add_lib(lmz[s], lin[s], lch[s], lpmz[r], lpz[r])
+    # (b) dense candidate: many peaks inside one fragment window
+    base = np.sort(rng.uniform(200, 1200, 12)).astype(np.float32)
+    dm = np.concatenate([base, base + 0.004, base + 0.009, base - 0.006])
+    dm = np.sort(dm).astype(np.float32)
+    di = rng.random(len(dm)).astype(np.float32)
+    di /= np.linalg.norm(di)
+    add_lib(dm, di, rng.integers(0, 4, len(dm)), 700.25, 3)
+    # (c) charges 1..6 with annotations of every kind
+    for z in (1, 2, 3, 4, 5, 6):
+        r = int(rng.integers(0, 600))
+        s = slice(lo[r], lo[r + 1])
+        add_lib(lmz[s], lin[s], rng.integers(0, z + 1, lo[r + 1] - lo[r]), lpmz[r] - 3.3 / z, z)
+    # (d) a candidate far away in m/z: zero matches
+    add_lib(np.linspace(1800, 2000, 12), np.full(12, 12 ** -0.5), np.zeros(12), 999.0, 2)
+    n0 = len(lo) - 1
+    for i in range(len(extra_mz)):
+        lmz = np.concatenate([lmz, extra_mz[i]])
+        lin = np.concatenate([lin, extra_in[i]])
+        lch = np.concatenate([lch, extra_ch[i]])
+        lo = np.concatenate([lo, [lo[-1] + len(extra_mz[i])]]).astype(np.int32)
+    lpmz = np.concatenate([lpmz, extra_pmz])
+    lpz = np.concatenate([lpz, extra_pz]).astype(np.int32)
+    nlib = len(lo) - 1
+    L = O.Spectra(lo, lmz, lin, lch, lpmz, lpz)
+    # queries: synthetic ones + a query identical to the dense candidate's base peaks
+    dq_i = rng.random(len(base)).astype(np.float32)
+    dq_i /= np.linalg.norm(dq_i)
+    qmz = np.concatenate([qmz, base])
+    qin = np.concatenate([qin, dq_i])
+    qch = np.concatenate([qch, np.zeros(len(base), np.uint8)])
+    qo = np.concatenate([qo, [qo[-1] + len(base)]]).astype(np.int32)
+    qpmz = np.concatenate([qpmz, [700.25 + 40.0 / 3]])
+    qpz = np.concatenate([qpz, [3]]).astype(np.int32)
+    Q = O.Spectra(qo, qmz, qin, qch, qpmz, qpz)
+    nq = Q.n
+    src = np.concatenate([truth['source_row'].numpy(), [n0 + 3]])
+    cases = []
+    cand_all, cand_off = [], [0]
+    for qi in range(nq):
+        if qi % 7 == 0:       # |precursor mass difference| < tol: shifts disabled (cpp:20)
+            Q.precursor_mz[qi] = L.precursor_mz[src[qi]] + 0.001
+        for variant in range(3):
+            allow_shift = variant != 1
+            tol = (0.02, 0.02, 0.05)[variant]
+            ncand = int(rng.integers(1, 40))
+            cand = rng.integers(0, nlib, ncand)
+            cand = np.concatenate([cand, [src[qi]]])
+            if variant == 0 and qi < 3:
+                cand = np.concatenate([cand, [n0, n0 + 1, n0 + 2, 0, 1]])   # duplicates
+            if variant == 2:
+                cand = np.concatenate([cand, np.arange(n0 + 3, nlib)])
+            cand = np.unique(cand).astype(np.int64)
+            b, sc, m = O.ref_best_match(Q, qi, L, cand, tol, allow_shift)
+            cases.append((qi, tol, int(allow_shift), b, sc, len(m)))
+            cand_all.append(cand)
+            cand_off.append(cand_off[-1] + len(cand))
+            cases[-1] = cases[-1] + (m,)
+    pm_off = np.zeros(len(cases) + 1, np.int64)
+    pm_off[1:] = np.cumsum([c[5] for c in cases])
+    np.savez_compressed(
+        os.path.join(HERE, 'rescoring_golden.npz'),
+        lib_offsets=L.offsets, lib_mz=L.mz, lib_intensity=L.intensity, lib_charge=L.charge,
+        lib_pmz=L.precursor_mz, lib_pcharge=L.precursor_charge,
+        q_offsets=Q.offsets, q_mz=Q.mz, q_intensity=Q.intensity, q_pmz=Q.precursor_mz,
+        q_pcharge=Q.precursor_charge,
+        case_query=np.array([c[0] for c in cases], np.int32),
+        case_tol=np.array([c[1] for c in cases], np.float64),
+        case_shift=np.array([c[2] for c in cases], np.int32),
+        case_best=np.array([c[3] for c in cases], np.int32),
+        case_score=np.array([c[4] for c in cases], np.float64),
+        cand_offsets=np.array(cand_off, np.int64), cand_rows=np.concatenate(cand_all),
+        pm_offsets=pm_off,
+        pm_pairs=np.concatenate([c[6].reshape(-1, 2) for c in cases]).astype(np.uint32))
+    print('rescoring_golden.npz:', len(cases), 'cases,', nlib, 'library spectra')
+
+
+if __name__ == '__main__':
+    if not os.path.isdir(REF):
+        sys.exit('needs /root/reference (build container only)')
+    sp = gen_encoder()
+    gen_similarity_kat(sp)
+    gen_rescoring()
