@@ -1,0 +1,181 @@
+"""ctypes loader for libannsolo_mi.so (the C ABI of include/annsolo_mi.h).
+
+The product path has no CPU fallback: if the shared library is missing or no HIP
+device is present, every compute call raises ``AnnSoloMiError``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libannsolo_mi.so')
+_lib = None
+
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u8p = C.POINTER(C.c_uint8)
+c_u32p = C.POINTER(C.c_uint32)
+
+
+class AnnSoloMiError(RuntimeError):
+    pass
+
+
+class AslPeaks(C.Structure):
+    _fields_ = [('n', C.c_int32), ('offsets', C.c_void_p), ('mz', C.c_void_p),
+                ('intensity', C.c_void_p), ('charge', C.c_void_p),
+                ('precursor_mz', C.c_void_p), ('precursor_charge', C.c_void_p)]
+
+
+class AslSearchParams(C.Structure):
+    _fields_ = [('min_bound', C.c_double), ('bin_size', C.c_double),
+                ('hash_seed', C.c_uint32), ('k', C.c_int32), ('nprobe', C.c_int32),
+                ('charge', C.c_int32), ('precursor_tol', C.c_double),
+                ('precursor_mode', C.c_int32), ('fragment_mz_tolerance', C.c_double),
+                ('allow_shift', C.c_int32), ('use_ann', C.c_int32)]
+
+
+class AslIndexInfo(C.Structure):
+    _fields_ = [('d', C.c_int32), ('nlist', C.c_int32), ('kind', C.c_int32),
+                ('pq_m', C.c_int32), ('pq_ksub', C.c_int32), ('pq_dsub', C.c_int32),
+                ('ntotal', C.c_int64), ('nlocal', C.c_int64), ('trained', C.c_int32),
+                ('shard_rank', C.c_int32), ('shard_world', C.c_int32)]
+
+
+EXPORTS = [
+    'asl_last_error', 'asl_version', 'asl_get_num_gpus', 'asl_set_device', 'asl_set_stream',
+    'asl_synchronize', 'asl_get_dim', 'asl_hash_idx', 'asl_encode_batch', 'asl_index_create',
+    'asl_index_free', 'asl_index_train', 'asl_index_add', 'asl_index_search',
+    'asl_index_reset', 'asl_index_ntotal', 'asl_index_is_trained', 'asl_index_save',
+    'asl_index_load', 'asl_index_set_niter', 'asl_index_info', 'asl_index_get_centroids',
+    'asl_index_get_codebooks', 'asl_index_set_trained', 'asl_index_get_lists',
+    'asl_index_shard', 'asl_index_shard_map', 'asl_topk_merge', 'asl_index_coarse',
+    'asl_index_pq_lut', 'asl_rescore_batch', 'asl_library_create', 'asl_library_free',
+    'asl_library_size', 'asl_search_batch', 'asl_window_candidates', 'asl_profile_enable',
+    'asl_profile_reset', 'asl_profile_get', 'asl_profile_scanned_vectors',
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile libannsolo_mi.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, 'csrc')
+    stale = force or not os.path.exists(LIB_PATH)
+    if not stale:
+        t = os.path.getmtime(LIB_PATH)
+        deps = [os.path.join(src, f) for f in os.listdir(src)
+                if f.endswith(('.hip', '.hpp'))]
+        deps.append(os.path.join(_HERE, '..', 'include', 'annsolo_mi.h'))
+        stale = any(os.path.getmtime(p) > t for p in deps)
+    if stale:
+        if not os.path.exists('/opt/rocm/bin/hipcc'):
+            raise AnnSoloMiError('hipcc not found and libannsolo_mi.so is stale/missing')
+        subprocess.check_call(['make', '-C', src, '-j8'])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AnnSoloMiError(
+                f'{LIB_PATH} is missing: build it with __graft_entry__.build() '
+                '(there is no CPU fallback)')
+        L = C.CDLL(LIB_PATH)
+        L.asl_last_error.restype = C.c_char_p
+        L.asl_version.restype = C.c_char_p
+        L.asl_hash_idx.restype = C.c_int32
+        L.asl_hash_idx.argtypes = [C.c_int64, C.c_int32, C.c_uint32]
+        L.asl_get_dim.argtypes = [C.c_double, C.c_double, C.c_double, c_i64p, c_f64p, c_f64p]
+        L.asl_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_double, C.c_double, C.c_int32, C.c_uint32, C.c_int,
+                                       C.c_void_p]
+        L.asl_index_create.restype = C.c_void_p
+        L.asl_index_create.argtypes = [C.c_int32] * 5
+        L.asl_index_free.argtypes = [C.c_void_p]
+        L.asl_index_free.restype = None
+        L.asl_index_train.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64]
+        L.asl_index_add.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.asl_index_search.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_void_p]
+        L.asl_index_reset.argtypes = [C.c_void_p]
+        L.asl_index_ntotal.argtypes = [C.c_void_p]
+        L.asl_index_ntotal.restype = C.c_int64
+        L.asl_index_is_trained.argtypes = [C.c_void_p]
+        L.asl_index_save.argtypes = [C.c_void_p, C.c_char_p]
+        L.asl_index_load.argtypes = [C.c_char_p]
+        L.asl_index_load.restype = C.c_void_p
+        L.asl_index_set_niter.argtypes = [C.c_void_p, C.c_int32]
+        L.asl_index_info.argtypes = [C.c_void_p, C.POINTER(AslIndexInfo)]
+        L.asl_index_get_centroids.argtypes = [C.c_void_p, C.c_void_p]
+        L.asl_index_get_codebooks.argtypes = [C.c_void_p, C.c_void_p]
+        L.asl_index_set_trained.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.asl_index_get_lists.argtypes = [C.c_void_p] * 5
+        L.asl_index_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.asl_index_shard_map.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.asl_topk_merge.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+        L.asl_index_coarse.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p]
+        L.asl_index_pq_lut.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.asl_rescore_batch.argtypes = [C.POINTER(AslPeaks), C.POINTER(AslPeaks), C.c_void_p,
+                                        C.c_void_p, C.c_double, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.asl_library_create.restype = C.c_void_p
+        L.asl_library_create.argtypes = [C.POINTER(AslPeaks), C.c_void_p, C.c_void_p]
+        L.asl_library_free.argtypes = [C.c_void_p]
+        L.asl_library_free.restype = None
+        L.asl_library_size.argtypes = [C.c_void_p]
+        L.asl_library_size.restype = C.c_int64
+        L.asl_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(AslPeaks),
+                                       C.POINTER(AslSearchParams), C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_void_p]
+        L.asl_window_candidates.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                            C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
+        L.asl_set_stream.argtypes = [C.c_void_p]
+        L.asl_profile_get.argtypes = [C.c_char_p, c_f64p, c_i64p]
+        L.asl_profile_scanned_vectors.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = lib().asl_last_error()
+        raise AnnSoloMiError(f'libannsolo_mi error {rc}: {msg.decode() if msg else ""}')
+
+
+def ptr(a):
+    """Raw address of a numpy array or torch tensor (host or device), or None."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        if not a.flags['C_CONTIGUOUS']:
+            raise ValueError('array must be C-contiguous')
+        return a.ctypes.data
+    if hasattr(a, 'data_ptr'):
+        if not a.is_contiguous():
+            raise ValueError('tensor must be contiguous')
+        return a.data_ptr()
+    raise TypeError(type(a))
+
+
+def use_torch_stream():
+    """Issue library work on torch's current HIP stream."""
+    import torch
+    check(lib().asl_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+def peaks_struct(p) -> AslPeaks:
+    """AslPeaks view of a PackedSpectra (torch) or a tuple of numpy arrays."""
+    if hasattr(p, 'offsets') and hasattr(p, 'precursor_charge'):
+        arrs = (p.offsets, p.mz, p.intensity, p.charge, p.precursor_mz, p.precursor_charge)
+        n = p.n
+    else:
+        arrs = p
+        n = len(p[0]) - 1
+    return AslPeaks(n, *[ptr(a) for a in arrs])

@@ -1,0 +1,206 @@
+// common.hip -- error state, stream, pointer classification, stage timers.
+#include "common.hpp"
+
+#include <mutex>
+
+namespace asl {
+
+static thread_local std::string g_err;
+static hipStream_t g_stream = nullptr;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+void clear_error() { g_err.clear(); }
+
+hipStream_t stream() { return g_stream; }
+
+int ensure_device() {
+  static int state = 0;  // 0 unknown, 1 ok, -1 none
+  if (state == 0) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    state = (e == hipSuccess && n > 0) ? 1 : -1;
+    if (state < 0) (void)hipGetLastError();
+  }
+  if (state < 0)
+    return fail(ASL_ERR_NO_DEVICE,
+                "no HIP device available: libannsolo_mi has no CPU fallback");
+  return ASL_OK;
+}
+
+bool is_device_ptr(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // plain host memory is reported as an error
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+int sync_stream() {
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  return ASL_OK;
+}
+
+// ---------------------------------------------------------------- profiling
+struct StageProf {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  double total_ms = 0;
+  int64_t launches = 0;
+};
+static std::map<std::string, StageProf> g_prof;
+static bool g_prof_on = false;
+static int64_t g_scanned = 0;
+static std::vector<std::pair<StageProf *, std::pair<hipEvent_t, hipEvent_t>>> g_open;
+
+ProfScope::ProfScope(const char *stage) {
+  if (!g_prof_on) return;
+  StageProf &sp = g_prof[stage];
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!sp.pool.empty()) {
+    ev = sp.pool.back();
+    sp.pool.pop_back();
+  } else {
+    if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess)
+      return;
+  }
+  (void)hipEventRecord(ev.first, g_stream);
+  slot = (int)g_open.size();
+  g_open.push_back({&sp, ev});
+}
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  auto o = g_open[slot];
+  (void)hipEventRecord(o.second.second, g_stream);
+  o.first->pending.push_back(o.second);
+  o.first->launches++;
+  if (slot == (int)g_open.size() - 1) g_open.pop_back();
+}
+void prof_add_scanned(int64_t v) {
+  if (g_prof_on) g_scanned += v;
+}
+
+static void prof_collect(StageProf &sp) {
+  for (auto &ev : sp.pending) {
+    float ms = 0;
+    if (hipEventSynchronize(ev.second) == hipSuccess &&
+        hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess)
+      sp.total_ms += ms;
+    sp.pool.push_back(ev);
+  }
+  sp.pending.clear();
+}
+
+}  // namespace asl
+
+using namespace asl;
+
+extern "C" {
+
+const char *asl_last_error(void) { return g_err.c_str(); }
+const char *asl_version(void) { return "annsolo_mi 0.1.0 (gfx950)"; }
+
+int asl_get_num_gpus(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int asl_set_device(int device) {
+  ASL_TRY(ensure_device());
+  HIP_TRY(hipSetDevice(device));
+  return ASL_OK;
+}
+
+int asl_set_stream(void *s) {
+  g_stream = (hipStream_t)s;
+  return ASL_OK;
+}
+
+int asl_synchronize(void) {
+  ASL_TRY(ensure_device());
+  return sync_stream();
+}
+
+int asl_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return ASL_OK;
+}
+
+int asl_profile_reset(void) {
+  for (auto &kv : g_prof) {
+    prof_collect(kv.second);
+    kv.second.total_ms = 0;
+    kv.second.launches = 0;
+  }
+  g_scanned = 0;
+  return ASL_OK;
+}
+
+int asl_profile_get(const char *stage, double *total_ms, int64_t *launches) {
+  auto it = g_prof.find(stage ? stage : "");
+  if (it == g_prof.end()) {
+    if (total_ms) *total_ms = 0;
+    if (launches) *launches = 0;
+    return ASL_OK;
+  }
+  prof_collect(it->second);
+  if (total_ms) *total_ms = it->second.total_ms;
+  if (launches) *launches = it->second.launches;
+  return ASL_OK;
+}
+
+int64_t asl_profile_scanned_vectors(void) { return g_scanned; }
+
+}  // extern "C"
+
+namespace asl {
+
+int PeaksStage::init(const asl_peaks_t *p) {
+  if (!p || p->n < 0) return fail(ASL_ERR_INVALID, "peaks: null or negative n");
+  dev = DevPeaks();
+  dev.n = p->n;
+  if (p->n == 0) return ASL_OK;
+  if (!p->offsets || !p->precursor_mz || !p->precursor_charge)
+    return fail(ASL_ERR_INVALID, "peaks: offsets/precursor arrays are required");
+  int32_t last = 0;
+  if (is_device_ptr(p->offsets)) {
+    HIP_TRY(hipMemcpyAsync(&last, p->offsets + p->n, sizeof(int32_t), hipMemcpyDeviceToHost,
+                           stream()));
+    ASL_TRY(sync_stream());
+  } else {
+    last = p->offsets[p->n];
+  }
+  if (last < 0) return fail(ASL_ERR_INVALID, "peaks: negative offsets");
+  dev.n_peaks = last;
+  if (last > 0 && (!p->mz || !p->intensity))
+    return fail(ASL_ERR_INVALID, "peaks: mz/intensity arrays are required");
+  ASL_TRY(offsets.init(p->offsets, (size_t)p->n + 1));
+  ASL_TRY(mz.init(p->mz, (size_t)last));
+  ASL_TRY(intensity.init(p->intensity, (size_t)last));
+  ASL_TRY(charge.init(p->charge, (size_t)last));
+  ASL_TRY(pmz.init(p->precursor_mz, (size_t)p->n));
+  ASL_TRY(pcharge.init(p->precursor_charge, (size_t)p->n));
+  dev.offsets = offsets.d;
+  dev.mz = mz.d;
+  dev.intensity = intensity.d;
+  dev.charge = charge.d;
+  dev.precursor_mz = pmz.d;
+  dev.precursor_charge = pcharge.d;
+  return ASL_OK;
+}
+
+}  // namespace asl

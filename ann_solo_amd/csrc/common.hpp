@@ -1,0 +1,168 @@
+// common.hpp -- shared host-side plumbing of libannsolo_mi.so (errors, stream,
+// host/device staging, HIP-event stage timers). gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/annsolo_mi.h"
+
+namespace asl {
+
+int fail(int code, const char *fmt, ...);
+void clear_error();
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return ::asl::fail(ASL_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                         __FILE__, __LINE__);                                              \
+  } while (0)
+
+#define ASL_TRY(expr)          \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != ASL_OK) return rc_; \
+  } while (0)
+
+#define ASL_CHECK_LAUNCH() HIP_TRY(hipGetLastError())
+
+hipStream_t stream();
+int ensure_device();  // ASL_OK if a HIP device is usable
+bool is_device_ptr(const void *p);
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grow-only device buffer.
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p;
+      cap = o.cap;
+      o.p = nullptr;
+      o.cap = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  int reserve(size_t n) {
+    if (n <= cap) return ASL_OK;
+    release();
+    if (n == 0) return ASL_OK;
+    HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
+    cap = n;
+    return ASL_OK;
+  }
+  int upload(const T *src, size_t n) {  // src host or device
+    ASL_TRY(reserve(n));
+    if (n) HIP_TRY(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyDefault, stream()));
+    return ASL_OK;
+  }
+  int download(T *dst, size_t n) const {
+    if (n) HIP_TRY(hipMemcpyAsync(dst, p, n * sizeof(T), hipMemcpyDefault, stream()));
+    return ASL_OK;
+  }
+};
+
+// Read-only argument that may live on the host: gives a device pointer.
+template <class T>
+struct In {
+  const T *d = nullptr;
+  DevBuf<T> own;
+  int init(const T *src, size_t n) {
+    if (src == nullptr || n == 0) {
+      d = nullptr;
+      return ASL_OK;
+    }
+    if (is_device_ptr(src)) {
+      d = src;
+      return ASL_OK;
+    }
+    ASL_TRY(own.upload(src, n));
+    d = own.p;
+    return ASL_OK;
+  }
+};
+
+// Output argument that may live on the host: kernels write to .d, finish() copies back.
+template <class T>
+struct Out {
+  T *d = nullptr;
+  T *host = nullptr;
+  size_t n = 0;
+  DevBuf<T> own;
+  int init(T *dst, size_t count) {
+    n = count;
+    host = nullptr;
+    if (dst == nullptr || count == 0) {
+      d = nullptr;
+      return ASL_OK;
+    }
+    if (is_device_ptr(dst)) {
+      d = dst;
+      return ASL_OK;
+    }
+    ASL_TRY(own.reserve(count));
+    d = own.p;
+    host = dst;
+    return ASL_OK;
+  }
+  bool to_host() const { return host != nullptr; }
+  int finish() {  // enqueue the copy-back (caller synchronises once at the end)
+    if (host && n) HIP_TRY(hipMemcpyAsync(host, d, n * sizeof(T), hipMemcpyDeviceToHost, stream()));
+    return ASL_OK;
+  }
+};
+
+int sync_stream();
+
+// Stage timers (HIP events on the library's stream).
+struct ProfScope {
+  int slot = -1;
+  explicit ProfScope(const char *stage);
+  ~ProfScope();
+};
+void prof_add_scanned(int64_t vectors);
+
+// Device copy of a packed spectra set (pointers are device pointers).
+struct DevPeaks {
+  int32_t n = 0;
+  int64_t n_peaks = 0;
+  const int32_t *offsets = nullptr;
+  const float *mz = nullptr;
+  const float *intensity = nullptr;
+  const uint8_t *charge = nullptr;  // may be nullptr
+  const double *precursor_mz = nullptr;
+  const int32_t *precursor_charge = nullptr;
+};
+
+struct PeaksStage {  // stages an asl_peaks_t whose arrays may be on the host
+  In<int32_t> offsets, pcharge;
+  In<float> mz, intensity;
+  In<uint8_t> charge;
+  In<double> pmz;
+  DevPeaks dev;
+  int init(const asl_peaks_t *p);
+};
+
+}  // namespace asl

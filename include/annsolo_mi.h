@@ -1,0 +1,213 @@
+/*
+ * annsolo_mi.h -- C ABI of libannsolo_mi.so, the MI355X (gfx950) implementation of
+ * ANN-SoLo's open-modification search hot path.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to
+ * /root/reference). INTEGRATION.md shows the ctypes stubs a maintainer of the
+ * reference would add at those seams.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary.
+ *   - return value: 0 on success, a negative ASL_ERR_* code on failure;
+ *     asl_last_error() returns a thread-local message for the last failure.
+ *   - every array argument may be a HOST pointer or a DEVICE (HIP) pointer; the
+ *     library detects which (hipPointerGetAttributes) and stages host buffers.
+ *     Buffers stay owned by the caller. Handles are owned by the library.
+ *   - all work is issued on the stream set by asl_set_stream() (default: the
+ *     null stream). Calls that return results into host memory synchronise that
+ *     stream before returning; calls whose outputs are device pointers do not.
+ *   - one host thread per handle at a time (the reference calls FAISS from one
+ *     thread and serialises index loads, spectral_library.py:44,483).
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     returns ASL_ERR_NO_DEVICE.
+ */
+#ifndef ANNSOLO_MI_H
+#define ANNSOLO_MI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASL_OK 0
+#define ASL_ERR_INVALID (-1)    /* bad argument */
+#define ASL_ERR_NO_DEVICE (-2)  /* no HIP device / runtime error */
+#define ASL_ERR_STATE (-3)      /* e.g. search on an untrained index */
+#define ASL_ERR_CAPACITY (-4)   /* a compiled-in capacity was exceeded (message says which) */
+#define ASL_ERR_IO (-5)
+#define ASL_ERR_HIP (-6)
+
+#define ASL_INDEX_FLAT 0      /* IndexFlatIP: exact inner product            */
+#define ASL_INDEX_IVFFLAT 1   /* IndexIVFFlat(IndexFlatIP, d, nlist, IP)     */
+#define ASL_INDEX_IVFPQ 2     /* IVF + product quantiser, by-residual IP ADC */
+
+#define ASL_TOL_DA 0
+#define ASL_TOL_PPM 1
+
+const char *asl_last_error(void);
+const char *asl_version(void);
+/* number of usable HIP devices (faiss.get_num_gpus(), spectral_library.py:73) */
+int asl_get_num_gpus(void);
+int asl_set_device(int device);
+/* hipStream_t to issue work on (NULL = default stream). */
+int asl_set_stream(void *hip_stream);
+int asl_synchronize(void);
+
+/* ------------------------------------------------------------------ encoder
+ * Replaces spectrum_to_vector / get_dim / hash_idx, src/ann_solo/spectrum.py:122-214
+ * (callers spectral_library.py:158-161,438-440). Batch form: spectrum i owns
+ * peaks [offsets[i], offsets[i+1]). out is row-major [n, hash_len], fully
+ * overwritten. min_bound is get_dim()'s start_dim (10.96 for 11/2010/0.04). */
+int asl_get_dim(double min_mz, double max_mz, double bin_size, int64_t *n_bins,
+                double *start_dim, double *end_dim);
+int32_t asl_hash_idx(int64_t bin_idx, int32_t hash_len, uint32_t seed);
+int asl_encode_batch(const float *mz, const float *intensity, const int32_t *offsets,
+                     int32_t n, double min_bound, double bin_size, int32_t hash_len,
+                     uint32_t seed, int norm, float *out);
+
+/* ------------------------------------------------------------------ ANN index
+ * Replaces the FAISS objects used at spectral_library.py:73-87,167-181,191,
+ * 443-445,487-497: IndexFlatIP, IndexIVFFlat(quantizer, d, nlist, IP), train, add,
+ * search, nprobe, reset, write_index/read_index. Row ids are implicit 0..ntotal-1
+ * in add order. search(): rows sorted by (score desc, id asc); missing results
+ * are I = -1, D = -FLT_MAX. */
+typedef struct asl_index asl_index_t;
+
+asl_index_t *asl_index_create(int32_t d, int32_t nlist, int32_t kind, int32_t pq_m,
+                              int32_t pq_bits);
+void asl_index_free(asl_index_t *idx);
+int asl_index_train(asl_index_t *idx, int64_t n, const float *x, uint64_t seed);
+int asl_index_add(asl_index_t *idx, int64_t n, const float *x);
+int asl_index_search(asl_index_t *idx, int32_t nq, const float *xq, int32_t k,
+                     int32_t nprobe, float *D, int64_t *I);
+int asl_index_reset(asl_index_t *idx);
+int64_t asl_index_ntotal(const asl_index_t *idx);
+int asl_index_is_trained(const asl_index_t *idx);
+int asl_index_save(const asl_index_t *idx, const char *path);
+asl_index_t *asl_index_load(const char *path);
+/* k-means iterations (FAISS ClusteringParameters.niter, default 25) */
+int asl_index_set_niter(asl_index_t *idx, int32_t niter);
+
+/* Introspection, used by the parity tests and by multi-GPU sharding. Sizes via
+ * asl_index_info; every pointer may be NULL to skip. Lists are stored in list
+ * order: ids/codes/vecs of list l are [list_offsets[l], list_offsets[l+1]). */
+typedef struct {
+  int32_t d, nlist, kind, pq_m, pq_ksub, pq_dsub;
+  int64_t ntotal;      /* vectors added through this handle (global count)      */
+  int64_t nlocal;      /* vectors stored on this shard (== ntotal if unsharded) */
+  int32_t trained, shard_rank, shard_world;
+} asl_index_info_t;
+int asl_index_info(const asl_index_t *idx, asl_index_info_t *info);
+int asl_index_get_centroids(const asl_index_t *idx, float *centroids /* [nlist,d] */);
+int asl_index_get_codebooks(const asl_index_t *idx, float *cb /* [m,ksub,dsub] */);
+/* Install externally trained quantisers (FAISS: quantizer.add(centroids) / pq copy). */
+int asl_index_set_trained(asl_index_t *idx, const float *centroids, const float *codebooks);
+int asl_index_get_lists(const asl_index_t *idx, int32_t *list_offsets /* [nlist+1] */,
+                        int32_t *ids /* [nlocal] */, uint8_t *codes /* [nlocal,m] PQ */,
+                        float *vecs /* [nlocal,d] FLAT */);
+/* Keep only the inverted lists owned by `rank` of `world` (greedy longest-list-first
+ * balancing, identical on every rank). Must be called after add(). search() then
+ * returns this shard's partial top-k; combine with asl_topk_merge. */
+int asl_index_shard(asl_index_t *idx, int32_t rank, int32_t world);
+/* list -> owner rank map of the balancing above, for inspection. */
+int asl_index_shard_map(const asl_index_t *idx, int32_t world, int32_t *owner /* [nlist] */);
+
+/* Merge S partial results [S, nq, k] into [nq, k] under (score desc, id asc). */
+int asl_topk_merge(int32_t S, int32_t nq, int32_t k, const float *Ds, const int64_t *Is,
+                   float *D, int64_t *I);
+
+/* Exposed stages of the IVF search (parity tests; each mirrors one oracle function). */
+int asl_index_coarse(asl_index_t *idx, int32_t nq, const float *xq, int32_t nprobe,
+                     float *coarse_D /* [nq,nprobe] */, int32_t *coarse_I /* [nq,nprobe] */);
+int asl_index_pq_lut(asl_index_t *idx, int32_t nq, const float *xq,
+                     float *lut /* [nq,m,ksub] */);
+
+/* ------------------------------------------------------------------ rescoring
+ * Replaces get_best_match (src/ann_solo/spectrum_match.pyx:28-108) and
+ * SpectrumMatcher::dot (src/ann_solo/SpectrumMatch.cpp:8-133), batched over
+ * queries. Spectra are packed SoA; peaks ascending in m/z; `charge` is the
+ * per-peak fragment-charge annotation (0 = none, pyx:74-79; ignored for queries). */
+typedef struct {
+  int32_t n;
+  const int32_t *offsets;          /* [n+1] */
+  const float *mz;                 /* [offsets[n]] */
+  const float *intensity;          /* [offsets[n]] */
+  const uint8_t *charge;           /* [offsets[n]] or NULL (all 0) */
+  const double *precursor_mz;      /* [n] */
+  const int32_t *precursor_charge; /* [n] */
+} asl_peaks_t;
+
+/* Candidates of query q are library rows cand_rows[cand_offsets[q] .. cand_offsets[q+1]).
+ * Entries < 0 are skipped. Outputs (each may be NULL):
+ *   best_cand[q]  position inside the query's candidate list (first strict maximum
+ *                 wins, SpectrumMatch.cpp:118), -1 if the list has no valid entry
+ *   best_score[q] SpectrumMatcher::dot score (double)
+ *   pm_count[q]   number of matched peak pairs of the winner
+ *   pm_pairs      [nq, pm_stride, 2] (query_peak, candidate_peak) in greedy order */
+int asl_rescore_batch(const asl_peaks_t *queries, const asl_peaks_t *library,
+                      const int64_t *cand_rows, const int32_t *cand_offsets,
+                      double fragment_mz_tolerance, int allow_shift, int32_t *best_cand,
+                      double *best_score, int32_t *pm_count, uint32_t *pm_pairs,
+                      int32_t pm_stride);
+
+/* ------------------------------------------------------------------ hot path
+ * One batch of same-charge queries through
+ *   SpectralLibrary._search_batch / _get_library_candidates
+ *   (src/ann_solo/spectral_library.py:328-455)
+ * entirely on the device: encode -> index.search(k) -> precursor-window
+ * post-filter (:417-429,:441-446) -> best match per query (:356-365).
+ * A library handle keeps the packed peak store resident in HBM. */
+typedef struct asl_library asl_library_t;
+/* lib_pmz_f32: spec_info's float32 precursor m/z column (reader.py:184-191), may be
+ * NULL (then (float)precursor_mz). valid: per-spectrum is_valid flag or NULL. */
+asl_library_t *asl_library_create(const asl_peaks_t *library, const float *lib_pmz_f32,
+                                  const uint8_t *valid);
+void asl_library_free(asl_library_t *lib);
+int64_t asl_library_size(const asl_library_t *lib);
+
+typedef struct {
+  double min_bound, bin_size; /* encoder grid (get_dim) */
+  uint32_t hash_seed;         /* 42 */
+  int32_t k;                  /* config.num_candidates */
+  int32_t nprobe;             /* config.num_probe */
+  int32_t charge;             /* precursor charge of this batch */
+  double precursor_tol;       /* config.precursor_tolerance_mass(_open) */
+  int32_t precursor_mode;     /* ASL_TOL_DA / ASL_TOL_PPM */
+  double fragment_mz_tolerance;
+  int32_t allow_shift;        /* config.allow_peak_shifts */
+  int32_t use_ann;            /* 1: ANN top-k AND window (open+ann); 0: window only (std / bf) */
+} asl_search_params_t;
+
+/* Outputs, each [nq] (NULL to skip): best_row = library row of the best match
+ * (-1: no candidate), best_score, n_cand = candidates that reached rescoring,
+ * pm_count / pm_pairs as in asl_rescore_batch; knn_I [nq,k] = raw ANN ids. */
+int asl_search_batch(asl_library_t *lib, asl_index_t *idx, const asl_peaks_t *queries,
+                     const asl_search_params_t *params, int32_t *best_row,
+                     double *best_score, int32_t *n_cand, int32_t *pm_count,
+                     uint32_t *pm_pairs, int32_t pm_stride, int64_t *knn_I);
+
+/* Precursor-window candidate generation alone (spectral_library.py:417-429):
+ * CSR lists of library rows (ascending) whose precursor passes the window. Two-call
+ * protocol: first with cand_rows == NULL to get cand_offsets[nq+1], then with a
+ * buffer of cand_offsets[nq] entries. */
+int asl_window_candidates(asl_library_t *lib, int32_t nq, const double *query_pmz,
+                          int32_t charge, double tol, int32_t mode, int32_t *cand_offsets,
+                          int64_t *cand_rows);
+
+/* ------------------------------------------------------------------ profiling
+ * HIP-event timing of the individual stages of the last asl_search_batch /
+ * asl_index_search calls on the library's stream. Names: "encode","coarse_gemm",
+ * "coarse_select","scan","filter","rescore","rescore_matches". */
+int asl_profile_enable(int on);
+int asl_profile_reset(void);
+/* Accumulated milliseconds and launch count for a stage since the last reset. */
+int asl_profile_get(const char *stage, double *total_ms, int64_t *launches);
+/* Algorithmic work of the scan kernels since the last reset: sum over queries of
+ * probed-list lengths (vectors scored). */
+int64_t asl_profile_scanned_vectors(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANNSOLO_MI_H */

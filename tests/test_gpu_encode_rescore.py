@@ -1,0 +1,148 @@
+"""GPU parity: HIP encoder and rescoring kernels (through the C ABI) vs the oracle
+and vs the committed golden vectors of the reference."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def data():
+    from ann_solo_amd import synthetic
+    lib, aux = synthetic.make_library(3000, seed=21, device='cpu')
+    q, truth = synthetic.make_queries(lib, aux, 300, seed=22)
+    return lib, q, truth
+
+
+def test_encoder_bit_exact_vs_oracle(O, data):
+    from ann_solo_amd import spectrum
+    lib, q, _ = data
+    for pack in (lib, q):
+        o, mz, inten, *_ = pack.numpy()
+        for bin_size, hl, norm in ((0.04, 800, True), (0.04, 800, False), (0.05, 64, True),
+                                   (1.0005, 400, True)):
+            mb = O.get_dim(11, 2010, bin_size)[1]
+            got = spectrum.spectra_to_vectors(mz, inten, o, 11, 2010, bin_size, hl, norm)
+            want = O.encode_batch(mz, inten, o, mb, bin_size, hl, 42, norm)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_encoder_vs_reference_golden(O, golden):
+    from ann_solo_amd import spectrum
+    g = golden('encoder_golden.npz')
+    got = spectrum.spectra_to_vectors(g['mz'], g['intensity'], g['offsets'], 11, 2010, 0.04, 800,
+                                      False)
+    assert np.array_equal(got, g['vec_nonorm'])          # bit-exact bins and fp32 adds
+    got = spectrum.spectra_to_vectors(g['mz'], g['intensity'], g['offsets'], 11, 2010, 0.04, 800)
+    np.testing.assert_allclose(got, g['vec'], rtol=4e-7, atol=0)   # BLAS-order norm: few ulp
+    got = spectrum.spectra_to_vectors(g['mz'], g['intensity'], g['offsets'], 11, 2010, 0.05, 64)
+    np.testing.assert_allclose(got, g['vec_h64'], rtol=4e-7, atol=0)
+    assert [spectrum.hash_idx(int(b), 800) for b in g['bins']] == g['hashes'].tolist()
+    for args, want in zip(g['dim_args'], g['dims']):
+        assert spectrum.get_dim(*args) == (int(want[0]), want[1], want[2])
+
+
+def test_encoder_device_pointers_and_empty(O, data):
+    import torch
+    from ann_solo_amd import spectrum
+    lib, q, _ = data
+    qd = q.to('cuda')
+    out = torch.empty((q.n, 800), dtype=torch.float32, device='cuda')
+    spectrum.spectra_to_vectors(qd.mz, qd.intensity, qd.offsets, 11, 2010, 0.04, 800, True, out)
+    torch.cuda.synchronize()
+    o, mz, inten, *_ = q.numpy()
+    want = O.encode_batch(mz, inten, o, 10.96, 0.04, 800)
+    assert np.array_equal(out.cpu().numpy(), want)
+    # ragged: empty spectrum in the middle, single spectrum, zero spectra
+    mz2 = np.array([100.0, 200.0, 300.5], np.float32)
+    in2 = np.array([1.0, 2.0, 3.0], np.float32)
+    off2 = np.array([0, 2, 2, 3], np.int32)
+    got = spectrum.spectra_to_vectors(mz2, in2, off2, 11, 2010, 0.04, 800, False)
+    want = O.encode_batch(mz2, in2, off2, 10.96, 0.04, 800, 42, False)
+    assert np.array_equal(got, want) and not got[1].any()
+    assert spectrum.spectra_to_vectors(mz2[:0], in2[:0], np.zeros(1, np.int32), 11, 2010, 0.04,
+                                       800).shape == (0, 800)
+
+
+def _check_rescoring(O, Q, L, cand, off, tol, shift, res):
+    best, score, count, pairs = res
+    for qi in range(Q.n):
+        c = cand[off[qi]:off[qi + 1]]
+        b, s, m = O.best_match(Q, qi, L, c, tol, shift)
+        assert best[qi] == b, (qi, best[qi], b)
+        if b < 0:
+            continue
+        assert score[qi] == s                              # same doubles, same order: exact
+        assert count[qi] == len(m)
+        assert pairs[qi, :len(m)].tolist() == m.tolist()   # same deterministic tie rule
+
+
+def test_rescoring_vs_oracle(O, data):
+    from ann_solo_amd import spectrum_match
+    lib, q, truth = data
+    L, Q = O.Spectra(*lib.numpy()), O.Spectra(*q.numpy())
+    rng = np.random.default_rng(0)
+    cands, off = [], [0]
+    for qi in range(q.n):
+        n = int(rng.integers(0, 60))
+        c = np.unique(np.concatenate([rng.integers(0, lib.n, n),
+                                      [int(truth['source_row'][qi])] if qi % 5 else []]))
+        cands.append(c.astype(np.int64))
+        off.append(off[-1] + len(c))
+    cand = np.concatenate(cands)
+    off = np.array(off, np.int32)
+    for tol, shift in ((0.02, True), (0.02, False), (0.05, True)):
+        res = spectrum_match.rescore_batch(q, lib, cand, off, tol, shift)
+        _check_rescoring(O, Q, L, cand, off, tol, shift, res)
+
+
+def test_rescoring_vs_reference_golden(O, golden):
+    """Every case of tests/golden/rescoring_golden.npz (outputs of the reference's own
+    SpectrumMatch.cpp): best index, score within 1e-12, peak matches as a set."""
+    from ann_solo_amd import spectrum_match
+    from ann_solo_amd.packed import PackedSpectra
+    g = golden('rescoring_golden.npz')
+    lib = PackedSpectra.from_numpy(g['lib_offsets'], g['lib_mz'], g['lib_intensity'],
+                                   g['lib_charge'], g['lib_pmz'], g['lib_pcharge'])
+    n_case = len(g['case_query'])
+    for tol, shift in ((0.02, 1), (0.02, 0), (0.05, 1)):
+        sel = np.nonzero((g['case_tol'] == tol) & (g['case_shift'] == shift))[0]
+        qrows = g['case_query'][sel]
+        qo = g['q_offsets']
+        cnt = (qo[qrows + 1] - qo[qrows])
+        off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+        idx = np.concatenate([np.arange(qo[r], qo[r + 1]) for r in qrows])
+        q = PackedSpectra.from_numpy(off, g['q_mz'][idx], g['q_intensity'][idx], None,
+                                     g['q_pmz'][qrows], g['q_pcharge'][qrows])
+        coff = np.concatenate([[0], np.cumsum(g['cand_offsets'][sel + 1] - g['cand_offsets'][sel])])
+        cand = np.concatenate([g['cand_rows'][g['cand_offsets'][c]:g['cand_offsets'][c + 1]]
+                               for c in sel])
+        best, score, count, pairs = spectrum_match.rescore_batch(q, lib, cand,
+                                                                 coff.astype(np.int32), tol, shift)
+        for i, c in enumerate(sel):
+            assert best[i] == g['case_best'][c]
+            assert abs(score[i] - g['case_score'][c]) <= 1e-12
+            want = g['pm_pairs'][g['pm_offsets'][c]:g['pm_offsets'][c + 1]]
+            assert sorted(map(tuple, pairs[i, :count[i]].tolist())) == sorted(map(tuple, want.tolist()))
+    assert n_case > 0
+
+
+def test_get_best_match_dropin(O, golden):
+    """Reference-style call with spectrum objects, incl. the reference test-suite's
+    partial_match pair (spectrum_similarity_test.py:339-341,443)."""
+    from ann_solo_amd import spectrum_match
+    k = golden('similarity_kat.npz')
+
+    class Spec:
+        def __init__(self, mz, inten, pmz, z):
+            self.mz, self.intensity, self.precursor_mz, self.precursor_charge = mz, inten, pmz, z
+            self.annotation = [None] * len(mz)
+    q = Spec(k['partial_match_q_mz'], k['partial_match_q_intensity'], 453.75, 2)
+    c0 = Spec(k['no_match_l_mz'], k['no_match_l_intensity'], 453.75, 2)
+    c1 = Spec(k['partial_match_l_mz'], k['partial_match_l_intensity'], 453.75, 2)
+    cand, score, pm = spectrum_match.get_best_match(q, [c0, c1], 0.02, True)
+    assert cand is c1
+    assert sorted(pm) == sorted(map(tuple, k['partial_match_peak_matches'].tolist()))
+    assert score == pytest.approx(0.44582117, abs=1e-7)
+    with pytest.raises(ValueError):
+        spectrum_match.get_best_match(q, [], 0.02, True)
