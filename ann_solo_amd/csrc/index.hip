@@ -1,0 +1,841 @@
+// index.hip -- the ANN index object behind the FAISS-shaped C ABI
+// (replaces IndexFlatIP / IndexIVFFlat + train/add/search/write_index/read_index used at
+// /root/reference/src/ann_solo/spectral_library.py:73-87,167-181,191,443-445,487-497;
+// IVF-PQ is the north star's addition). Host orchestration only -- every flop runs
+// in the kernels of gemm.hip / ivf_kernels.hip.
+//
+// Training restates FAISS' Clustering (Lloyd iterations, assignment by the
+// quantiser's metric, mean update, empty-cluster split with eps = 1/1024, at most
+// 256 points per centroid) with a library-local RNG; it is deterministic and
+// bit-identical to oracle/asl_oracle.c:orc_kmeans for the same seed.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "common.hpp"
+#include "ivf_kernels.hpp"
+
+namespace asl {
+
+// ------------------------------------------------------------------ RNG (same as the oracle's)
+static inline uint64_t sm64(uint64_t *s) {
+  uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static void rand_perm(int64_t n, uint64_t seed, std::vector<int64_t> &perm) {
+  uint64_t s = seed;
+  perm.resize((size_t)n);
+  for (int64_t i = 0; i < n; i++) perm[(size_t)i] = i;
+  for (int64_t i = 0; i + 1 < n; i++) {
+    int64_t j = i + (int64_t)(sm64(&s) % (uint64_t)(n - i));
+    std::swap(perm[(size_t)i], perm[(size_t)j]);
+  }
+}
+
+template <class T>
+static int dev_append(DevBuf<T> &buf, size_t old_n, const T *src_dev, size_t n) {
+  if (old_n + n > buf.cap) {
+    DevBuf<T> nb;
+    size_t want = std::max(old_n + n, buf.cap + buf.cap / 2);
+    ASL_TRY(nb.reserve(want));
+    if (old_n)
+      HIP_TRY(hipMemcpyAsync(nb.p, buf.p, old_n * sizeof(T), hipMemcpyDeviceToDevice, stream()));
+    ASL_TRY(sync_stream());
+    buf = std::move(nb);
+  }
+  if (n)
+    HIP_TRY(hipMemcpyAsync(buf.p + old_n, src_dev, n * sizeof(T), hipMemcpyDeviceToDevice, stream()));
+  return ASL_OK;
+}
+
+constexpr size_t SCORE_CHUNK_BYTES = (size_t)1 << 30;
+
+}  // namespace asl
+
+using namespace asl;
+
+struct asl_index {
+  int d = 0, nlist = 0, kind = 0, pq_m = 0, pq_bits = 8, ksub = 0, dsub = 0;
+  int niter = 25;
+  bool trained = false;
+  int64_t ntotal = 0;   // global vectors added
+  int64_t n_store = 0;  // vectors stored here
+  int shard_rank = 0, shard_world = 1;
+  DevBuf<float> centroids, codebooks;
+  // add-order storage
+  DevBuf<float> vecs;        // FLAT, IVFFLAT
+  DevBuf<int32_t> vlist;     // IVF kinds: inverted list of each stored vector
+  DevBuf<int32_t> vids;      // global id of each stored vector (only when sharded)
+  bool has_vids = false;
+  DevBuf<uint8_t> codes_add; // IVFPQ
+  // list-order storage (IVFPQ scan layout)
+  DevBuf<uint8_t> codes;
+  DevBuf<int32_t> ids, list_offsets;
+  std::vector<int32_t> h_list_offsets;
+  bool lists_dirty = true;
+  // scratch
+  DevBuf<float> ws_scores, coarse_D, ws_x;
+  DevBuf<int32_t> coarse_I, ws_assign;
+  DevBuf<uint32_t> bitmap;
+  DevBuf<unsigned long long> ws_count;
+};
+
+namespace asl {
+
+// Assign rows of x (device, [n, ld]) to the centroid with the largest inner product
+// (ties: lowest index) -> assign_dev[n].
+static int assign_ip(asl_index *ix, const float *x, int64_t ld, int64_t n, const float *cent,
+                     int k, int d, int32_t *assign_dev) {
+  if (n <= 0) return ASL_OK;
+  int64_t rows = (int64_t)std::max<size_t>(1, SCORE_CHUNK_BYTES / ((size_t)k * 4));
+  rows = std::min<int64_t>(rows, n);
+  ASL_TRY(ix->ws_scores.reserve((size_t)rows * k));
+  for (int64_t r0 = 0; r0 < n; r0 += rows) {
+    const int m = (int)std::min<int64_t>(rows, n - r0);
+    ASL_TRY(gemm_nt_f32(x + (size_t)r0 * ld, cent, ix->ws_scores.p, m, k, d, (int)ld, d, k));
+    ASL_TRY(row_argmax(ix->ws_scores.p, k, m, k, assign_dev + r0));
+  }
+  return ASL_OK;
+}
+
+// Lloyd k-means on the device; see file header. x: device [n, ld].
+static int kmeans_device(asl_index *ix, const float *x, int64_t n, int64_t ld, int d, int k,
+                         int niter, uint64_t seed, bool l2, int max_ppc, float *cent_dev) {
+  if (n < 1) return fail(ASL_ERR_INVALID, "train: no training vectors");
+  int64_t nt = n;
+  const float *xt = x;
+  int64_t ldt = ld;
+  DevBuf<float> sub;
+  DevBuf<int64_t> rows_dev;
+  std::vector<int64_t> perm;
+  if (max_ppc > 0 && n > (int64_t)k * max_ppc) {
+    nt = (int64_t)k * max_ppc;
+    rand_perm(n, seed, perm);
+    ASL_TRY(rows_dev.upload(perm.data(), (size_t)nt));
+    ASL_TRY(sub.reserve((size_t)nt * d));
+    ASL_TRY(gather_rows_f32(x, ld, rows_dev.p, nt, d, sub.p, d));
+    xt = sub.p;
+    ldt = d;
+  }
+  {  // init: k distinct random training points
+    rand_perm(nt, seed + 1, perm);
+    std::vector<int64_t> pick((size_t)k);
+    for (int c = 0; c < k; c++) pick[(size_t)c] = perm[(size_t)(c % nt)];
+    ASL_TRY(rows_dev.upload(pick.data(), (size_t)k));
+    ASL_TRY(gather_rows_f32(xt, ldt, rows_dev.p, k, d, cent_dev, d));
+  }
+  DevBuf<int32_t> assign, order, offsets;
+  ASL_TRY(assign.reserve((size_t)nt));
+  ASL_TRY(order.reserve((size_t)nt));
+  ASL_TRY(offsets.reserve((size_t)k + 1));
+  std::vector<int32_t> h_assign((size_t)nt), h_order((size_t)nt), h_off((size_t)k + 1);
+  std::vector<float> hassign((size_t)k), h_cent;
+  uint64_t rng = seed + 2;
+  for (int it = 0; it < niter; it++) {
+    if (l2)
+      ASL_TRY(l2_assign(xt, ldt, nt, d, cent_dev, k, assign.p));
+    else
+      ASL_TRY(assign_ip(ix, xt, ldt, nt, cent_dev, k, d, assign.p));
+    ASL_TRY(assign.download(h_assign.data(), (size_t)nt));
+    ASL_TRY(sync_stream());
+    // counting sort by cluster (stable: ascending point order inside a cluster)
+    std::fill(h_off.begin(), h_off.end(), 0);
+    for (int64_t i = 0; i < nt; i++) h_off[(size_t)h_assign[(size_t)i] + 1]++;
+    for (int c = 0; c < k; c++) {
+      hassign[(size_t)c] = (float)h_off[(size_t)c + 1];
+      h_off[(size_t)c + 1] += h_off[(size_t)c];
+    }
+    {
+      std::vector<int32_t> cur(h_off.begin(), h_off.end() - 1);
+      for (int64_t i = 0; i < nt; i++) h_order[(size_t)cur[(size_t)h_assign[(size_t)i]]++] = (int32_t)i;
+    }
+    ASL_TRY(order.upload(h_order.data(), (size_t)nt));
+    ASL_TRY(offsets.upload(h_off.data(), (size_t)k + 1));
+    ASL_TRY(centroid_update(xt, ldt, d, k, order.p, offsets.p, cent_dev));
+    bool any_empty = false;
+    for (int c = 0; c < k; c++) any_empty |= hassign[(size_t)c] == 0.0f;
+    if (any_empty) {  // FAISS split_clusters, on the host (rare)
+      h_cent.resize((size_t)k * d);
+      HIP_TRY(hipMemcpyAsync(h_cent.data(), cent_dev, h_cent.size() * 4, hipMemcpyDeviceToHost, stream()));
+      ASL_TRY(sync_stream());
+      const float eps = 1.0f / 1024.0f;
+      for (int ci = 0; ci < k; ci++) {
+        if (hassign[(size_t)ci] != 0.0f) continue;
+        int cj = 0;
+        for (int guard = 0; guard < 64 * k + 64; guard++, cj = (cj + 1) % k) {
+          float p = (hassign[(size_t)cj] - 1.0f) / (float)(nt - k);
+          float r = (float)(sm64(&rng) >> 40) * (1.0f / 16777216.0f);
+          if (r < p) break;
+        }
+        float *a = h_cent.data() + (size_t)ci * d, *b = h_cent.data() + (size_t)cj * d;
+        memcpy(a, b, sizeof(float) * (size_t)d);
+        for (int j = 0; j < d; j++) {
+          if (j % 2 == 0) {
+            a[j] *= 1 + eps;
+            b[j] *= 1 - eps;
+          } else {
+            a[j] *= 1 - eps;
+            b[j] *= 1 + eps;
+          }
+        }
+        hassign[(size_t)ci] = floorf(hassign[(size_t)cj] / 2);
+        hassign[(size_t)cj] -= hassign[(size_t)ci];
+      }
+      HIP_TRY(hipMemcpyAsync(cent_dev, h_cent.data(), h_cent.size() * 4, hipMemcpyHostToDevice, stream()));
+      ASL_TRY(sync_stream());
+    }
+  }
+  ASL_TRY(sync_stream());
+  return ASL_OK;
+}
+
+static int pq_train_device(asl_index *ix, const float *x, int64_t n, uint64_t seed) {
+  const int d = ix->d, m = ix->pq_m, ksub = ix->ksub, dsub = ix->dsub;
+  int64_t nt = n;
+  const int64_t cap = (int64_t)ksub * 256;
+  DevBuf<float> xt;
+  DevBuf<int64_t> rows_dev;
+  if (nt > cap) {
+    nt = cap;
+    std::vector<int64_t> perm;
+    rand_perm(n, seed, perm);
+    ASL_TRY(rows_dev.upload(perm.data(), (size_t)nt));
+  }
+  ASL_TRY(xt.reserve((size_t)nt * d));
+  ASL_TRY(gather_rows_f32(x, d, nt < n ? rows_dev.p : nullptr, nt, d, xt.p, d));
+  DevBuf<int32_t> assign;
+  ASL_TRY(assign.reserve((size_t)nt));
+  ASL_TRY(assign_ip(ix, xt.p, d, nt, ix->centroids.p, ix->nlist, d, assign.p));
+  ASL_TRY(residual(xt.p, assign.p, ix->centroids.p, nt, d, xt.p));
+  ASL_TRY(ix->codebooks.reserve((size_t)m * ksub * dsub));
+  for (int mi = 0; mi < m; mi++)
+    ASL_TRY(kmeans_device(ix, xt.p + (size_t)mi * dsub, nt, d, dsub, ksub, ix->niter,
+                          seed + 16 + (uint64_t)mi, true, 0,
+                          ix->codebooks.p + (size_t)mi * ksub * dsub));
+  return ASL_OK;
+}
+
+// list-ordered copy of the PQ codes (the scan layout) from the add-order master
+static int build_lists(asl_index *ix) {
+  if (!ix->lists_dirty) return ASL_OK;
+  const int64_t n = ix->n_store;
+  std::vector<int32_t> h_vlist((size_t)n), h_order((size_t)n), h_ids;
+  ix->h_list_offsets.assign((size_t)ix->nlist + 1, 0);
+  if (n) {
+    ASL_TRY(ix->vlist.download(h_vlist.data(), (size_t)n));
+    ASL_TRY(sync_stream());
+  }
+  auto &off = ix->h_list_offsets;
+  for (int64_t i = 0; i < n; i++) off[(size_t)h_vlist[(size_t)i] + 1]++;
+  for (int l = 0; l < ix->nlist; l++) off[(size_t)l + 1] += off[(size_t)l];
+  {
+    std::vector<int32_t> cur(off.begin(), off.end() - 1);
+    for (int64_t i = 0; i < n; i++) h_order[(size_t)cur[(size_t)h_vlist[(size_t)i]]++] = (int32_t)i;
+  }
+  ASL_TRY(ix->list_offsets.upload(off.data(), off.size()));
+  DevBuf<int32_t> order;
+  ASL_TRY(order.upload(h_order.data(), (size_t)n));
+  if (ix->kind == ASL_INDEX_IVFPQ) {
+    ASL_TRY(ix->codes.reserve((size_t)std::max<int64_t>(n, 1) * ix->pq_m));
+    ASL_TRY(gather_rows_u8(ix->codes_add.p, order.p, n, ix->pq_m, ix->codes.p));
+  }
+  if (ix->has_vids) {
+    h_ids.resize((size_t)n);
+    std::vector<int32_t> h_vids((size_t)n);
+    if (n) {
+      ASL_TRY(ix->vids.download(h_vids.data(), (size_t)n));
+      ASL_TRY(sync_stream());
+    }
+    for (int64_t i = 0; i < n; i++) h_ids[(size_t)i] = h_vids[(size_t)h_order[(size_t)i]];
+    ASL_TRY(ix->ids.upload(h_ids.data(), (size_t)n));
+  } else {
+    ASL_TRY(ix->ids.upload(h_order.data(), (size_t)n));
+  }
+  ASL_TRY(sync_stream());
+  ix->lists_dirty = false;
+  return ASL_OK;
+}
+
+// coarse quantiser: top-nprobe centroids by inner product -> ix->coarse_D / coarse_I
+static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe) {
+  const int nlist = ix->nlist, d = ix->d;
+  ASL_TRY(ix->coarse_D.reserve((size_t)nq * nprobe));
+  ASL_TRY(ix->coarse_I.reserve((size_t)nq * nprobe));
+  int rows = (int)std::min<int64_t>(nq, std::max<int64_t>(1, (int64_t)(SCORE_CHUNK_BYTES / ((size_t)nlist * 4))));
+  ASL_TRY(ix->ws_scores.reserve((size_t)rows * nlist));
+  for (int r0 = 0; r0 < nq; r0 += rows) {
+    const int m = std::min(rows, nq - r0);
+    {
+      ProfScope ps("coarse_gemm");
+      ASL_TRY(gemm_nt_f32(xq + (size_t)r0 * d, ix->centroids.p, ix->ws_scores.p, m, nlist, d, d, d, nlist));
+    }
+    {
+      ProfScope ps("coarse_select");
+      ASL_TRY(row_topk(ix->ws_scores.p, nlist, m, nlist, nprobe, nullptr, 0, nullptr, nullptr, 0,
+                       ix->coarse_D.p + (size_t)r0 * nprobe, nullptr,
+                       ix->coarse_I.p + (size_t)r0 * nprobe, nprobe));
+    }
+  }
+  return ASL_OK;
+}
+
+// Search with all-device arguments. Exactly one of I64 / I32 may be non-null (or both).
+int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
+                        int64_t *I64, int32_t *I32) {
+  if (nq <= 0) return ASL_OK;
+  if (!ix->trained) return fail(ASL_ERR_STATE, "search: index is not trained");
+  if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: k=%d outside 1..%d", k, TK_MAX_K);
+  const int d = ix->d;
+  const int64_t n = ix->n_store;
+  if (ix->kind == ASL_INDEX_FLAT || ix->kind == ASL_INDEX_IVFFLAT) {
+    const bool ivf = ix->kind == ASL_INDEX_IVFFLAT;
+    int words = 0;
+    if (ivf) {
+      nprobe = std::max(1, std::min(nprobe, ix->nlist));
+      if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
+      ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+      words = (ix->nlist + 31) / 32;
+      ASL_TRY(ix->bitmap.reserve((size_t)nq * words));
+      ASL_TRY(probe_bitmap(ix->coarse_I.p, nq, nprobe, ix->bitmap.p, words));
+      if (n > 0) {
+        ASL_TRY(ix->ws_count.reserve(1));
+        // algorithmic work: vectors in probed lists (needs list sizes)
+        ASL_TRY(build_lists(ix));
+        ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, ix->ws_count.p));
+        unsigned long long sc = 0;
+        HIP_TRY(hipMemcpyAsync(&sc, ix->ws_count.p, 8, hipMemcpyDeviceToHost, stream()));
+        ASL_TRY(sync_stream());
+        prof_add_scanned((int64_t)sc);
+      }
+    }
+    const int64_t ncol = std::max<int64_t>(n, 1);
+    int rows = (int)std::min<int64_t>(nq, std::max<int64_t>(1, (int64_t)(SCORE_CHUNK_BYTES / ((size_t)ncol * 4))));
+    ASL_TRY(ix->ws_scores.reserve((size_t)rows * ncol));
+    for (int r0 = 0; r0 < nq; r0 += rows) {
+      const int m = std::min(rows, nq - r0);
+      ProfScope ps("scan");
+      if (n > 0)
+        ASL_TRY(gemm_nt_f32(xq + (size_t)r0 * d, ix->vecs.p, ix->ws_scores.p, m, (int)n, d, d, d, (int)n));
+      ASL_TRY(row_topk(ix->ws_scores.p, n, m, (int)n, k, ix->has_vids ? ix->vids.p : nullptr, 0,
+                       ivf ? ix->vlist.p : nullptr, ivf ? ix->bitmap.p + (size_t)r0 * words : nullptr,
+                       words, D ? D + (size_t)r0 * k : nullptr, I64 ? I64 + (size_t)r0 * k : nullptr,
+                       I32 ? I32 + (size_t)r0 * k : nullptr, k));
+    }
+    return ASL_OK;
+  }
+  // IVF-PQ
+  nprobe = std::max(1, std::min(nprobe, ix->nlist));
+  if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
+  ASL_TRY(build_lists(ix));
+  ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+  {
+    ProfScope ps("scan");
+    ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, ix->coarse_D.p,
+                    ix->coarse_I.p, nprobe, ix->list_offsets.p, ix->ids.p, ix->codes.p, k, D,
+                    I64, I32));
+  }
+  {
+    ASL_TRY(ix->ws_count.reserve(1));
+    ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, ix->ws_count.p));
+    unsigned long long sc = 0;
+    HIP_TRY(hipMemcpyAsync(&sc, ix->ws_count.p, 8, hipMemcpyDeviceToHost, stream()));
+    ASL_TRY(sync_stream());
+    prof_add_scanned((int64_t)sc);
+  }
+  return ASL_OK;
+}
+
+int index_dim(const asl_index *ix) { return ix->d; }
+
+}  // namespace asl
+
+extern "C" {
+
+asl_index_t *asl_index_create(int32_t d, int32_t nlist, int32_t kind, int32_t pq_m,
+                              int32_t pq_bits) {
+  clear_error();
+  if (d <= 0 || kind < ASL_INDEX_FLAT || kind > ASL_INDEX_IVFPQ) {
+    fail(ASL_ERR_INVALID, "index_create: bad d/kind");
+    return nullptr;
+  }
+  if (kind != ASL_INDEX_FLAT && nlist <= 0) {
+    fail(ASL_ERR_INVALID, "index_create: nlist must be positive");
+    return nullptr;
+  }
+  if (kind == ASL_INDEX_IVFPQ) {
+    if (pq_bits <= 0) pq_bits = 8;
+    if (pq_bits > 8 || pq_m <= 0 || d % pq_m != 0 ||
+        !(pq_m == 4 || pq_m == 8 || pq_m == 16 || pq_m == 32 || pq_m == 64)) {
+      fail(ASL_ERR_INVALID, "index_create: pq_m must be 4/8/16/32/64 and divide d; pq_bits <= 8");
+      return nullptr;
+    }
+  }
+  if (ensure_device() != ASL_OK) return nullptr;
+  asl_index *ix = new asl_index();
+  ix->d = d;
+  ix->nlist = kind == ASL_INDEX_FLAT ? 0 : nlist;
+  ix->kind = kind;
+  if (kind == ASL_INDEX_IVFPQ) {
+    ix->pq_m = pq_m;
+    ix->pq_bits = pq_bits;
+    ix->ksub = 1 << pq_bits;
+    ix->dsub = d / pq_m;
+  }
+  ix->trained = kind == ASL_INDEX_FLAT;
+  return ix;
+}
+
+void asl_index_free(asl_index_t *ix) { delete ix; }
+
+int asl_index_set_niter(asl_index_t *ix, int32_t niter) {
+  if (!ix || niter < 0) return fail(ASL_ERR_INVALID, "set_niter");
+  ix->niter = niter;
+  return ASL_OK;
+}
+
+int asl_index_train(asl_index_t *ix, int64_t n, const float *x, uint64_t seed) {
+  clear_error();
+  if (!ix) return fail(ASL_ERR_INVALID, "train: null index");
+  ASL_TRY(ensure_device());
+  if (ix->kind == ASL_INDEX_FLAT) return ASL_OK;
+  if (n <= 0 || !x) return fail(ASL_ERR_INVALID, "train: no data");
+  if (n < ix->nlist) return fail(ASL_ERR_INVALID, "train: %lld vectors < nlist %d", (long long)n, ix->nlist);
+  In<float> dx;
+  ASL_TRY(dx.init(x, (size_t)n * ix->d));
+  ASL_TRY(ix->centroids.reserve((size_t)ix->nlist * ix->d));
+  ASL_TRY(kmeans_device(ix, dx.d, n, ix->d, ix->d, ix->nlist, ix->niter, seed, false, 256, ix->centroids.p));
+  if (ix->kind == ASL_INDEX_IVFPQ) {
+    if (n < ix->ksub) return fail(ASL_ERR_INVALID, "train: %lld vectors < 2^pq_bits", (long long)n);
+    ASL_TRY(pq_train_device(ix, dx.d, n, seed + 7));
+  }
+  ASL_TRY(sync_stream());
+  ix->trained = true;
+  return ASL_OK;
+}
+
+int asl_index_set_trained(asl_index_t *ix, const float *centroids, const float *codebooks) {
+  clear_error();
+  if (!ix) return fail(ASL_ERR_INVALID, "set_trained: null index");
+  ASL_TRY(ensure_device());
+  if (ix->kind != ASL_INDEX_FLAT) {
+    if (!centroids) return fail(ASL_ERR_INVALID, "set_trained: centroids required");
+    ASL_TRY(ix->centroids.upload(centroids, (size_t)ix->nlist * ix->d));
+  }
+  if (ix->kind == ASL_INDEX_IVFPQ) {
+    if (!codebooks) return fail(ASL_ERR_INVALID, "set_trained: codebooks required");
+    ASL_TRY(ix->codebooks.upload(codebooks, (size_t)ix->pq_m * ix->ksub * ix->dsub));
+  }
+  ASL_TRY(sync_stream());
+  ix->trained = true;
+  return ASL_OK;
+}
+
+int asl_index_add(asl_index_t *ix, int64_t n, const float *x) {
+  clear_error();
+  if (!ix) return fail(ASL_ERR_INVALID, "add: null index");
+  if (!ix->trained) return fail(ASL_ERR_STATE, "add: index is not trained");
+  if (ix->shard_world > 1) return fail(ASL_ERR_STATE, "add: index is already sharded");
+  if (n <= 0) return ASL_OK;
+  if (!x) return fail(ASL_ERR_INVALID, "add: null data");
+  if (ix->ntotal + n > 0x7fffffffLL) return fail(ASL_ERR_CAPACITY, "add: more than 2^31-1 vectors");
+  ASL_TRY(ensure_device());
+  In<float> dx;
+  ASL_TRY(dx.init(x, (size_t)n * ix->d));
+  if (ix->kind != ASL_INDEX_FLAT) {
+    ASL_TRY(ix->ws_assign.reserve((size_t)n));
+    ASL_TRY(assign_ip(ix, dx.d, ix->d, n, ix->centroids.p, ix->nlist, ix->d, ix->ws_assign.p));
+    ASL_TRY(dev_append(ix->vlist, (size_t)ix->n_store, ix->ws_assign.p, (size_t)n));
+  }
+  if (ix->kind == ASL_INDEX_IVFPQ) {
+    DevBuf<uint8_t> codes;
+    ASL_TRY(codes.reserve((size_t)n * ix->pq_m));
+    ASL_TRY(pq_encode(dx.d, ix->ws_assign.p, ix->centroids.p, ix->codebooks.p, n, ix->d, ix->pq_m,
+                      ix->ksub, ix->dsub, codes.p));
+    ASL_TRY(dev_append(ix->codes_add, (size_t)ix->n_store * ix->pq_m, codes.p, (size_t)n * ix->pq_m));
+    ASL_TRY(sync_stream());
+  } else {
+    ASL_TRY(dev_append(ix->vecs, (size_t)ix->n_store * ix->d, dx.d, (size_t)n * ix->d));
+  }
+  ASL_TRY(sync_stream());
+  ix->n_store += n;
+  ix->ntotal += n;
+  ix->lists_dirty = true;
+  return ASL_OK;
+}
+
+int asl_index_reset(asl_index_t *ix) {
+  if (!ix) return fail(ASL_ERR_INVALID, "reset: null index");
+  ix->vecs.release();
+  ix->vlist.release();
+  ix->vids.release();
+  ix->codes_add.release();
+  ix->codes.release();
+  ix->ids.release();
+  ix->ws_scores.release();
+  ix->ntotal = 0;
+  ix->n_store = 0;
+  ix->has_vids = false;
+  ix->shard_rank = 0;
+  ix->shard_world = 1;
+  ix->lists_dirty = true;
+  return ASL_OK;
+}
+
+int64_t asl_index_ntotal(const asl_index_t *ix) { return ix ? ix->ntotal : 0; }
+int asl_index_is_trained(const asl_index_t *ix) { return ix && ix->trained; }
+
+int asl_index_info(const asl_index_t *ix, asl_index_info_t *info) {
+  if (!ix || !info) return fail(ASL_ERR_INVALID, "info: null");
+  info->d = ix->d;
+  info->nlist = ix->nlist;
+  info->kind = ix->kind;
+  info->pq_m = ix->pq_m;
+  info->pq_ksub = ix->ksub;
+  info->pq_dsub = ix->dsub;
+  info->ntotal = ix->ntotal;
+  info->nlocal = ix->n_store;
+  info->trained = ix->trained;
+  info->shard_rank = ix->shard_rank;
+  info->shard_world = ix->shard_world;
+  return ASL_OK;
+}
+
+int asl_index_get_centroids(const asl_index_t *ix, float *out) {
+  clear_error();
+  if (!ix || !out || ix->kind == ASL_INDEX_FLAT || !ix->trained)
+    return fail(ASL_ERR_STATE, "get_centroids: not available");
+  HIP_TRY(hipMemcpyAsync(out, ix->centroids.p, (size_t)ix->nlist * ix->d * 4, hipMemcpyDefault, stream()));
+  return sync_stream();
+}
+
+int asl_index_get_codebooks(const asl_index_t *ix, float *out) {
+  clear_error();
+  if (!ix || !out || ix->kind != ASL_INDEX_IVFPQ || !ix->trained)
+    return fail(ASL_ERR_STATE, "get_codebooks: not available");
+  HIP_TRY(hipMemcpyAsync(out, ix->codebooks.p, (size_t)ix->pq_m * ix->ksub * ix->dsub * 4, hipMemcpyDefault, stream()));
+  return sync_stream();
+}
+
+int asl_index_get_lists(const asl_index_t *cix, int32_t *list_offsets, int32_t *ids,
+                        uint8_t *codes, float *vecs) {
+  clear_error();
+  asl_index *ix = const_cast<asl_index *>(cix);
+  if (!ix || ix->kind == ASL_INDEX_FLAT) return fail(ASL_ERR_STATE, "get_lists: IVF index required");
+  ASL_TRY(build_lists(ix));
+  const int64_t n = ix->n_store;
+  if (list_offsets)
+    HIP_TRY(hipMemcpyAsync(list_offsets, ix->list_offsets.p, ((size_t)ix->nlist + 1) * 4, hipMemcpyDefault, stream()));
+  if (ids && n) HIP_TRY(hipMemcpyAsync(ids, ix->ids.p, (size_t)n * 4, hipMemcpyDefault, stream()));
+  if (codes && n) {
+    if (ix->kind != ASL_INDEX_IVFPQ) return fail(ASL_ERR_STATE, "get_lists: no PQ codes in this index");
+    HIP_TRY(hipMemcpyAsync(codes, ix->codes.p, (size_t)n * ix->pq_m, hipMemcpyDefault, stream()));
+  }
+  if (vecs && n) {
+    if (ix->kind != ASL_INDEX_IVFFLAT) return fail(ASL_ERR_STATE, "get_lists: no flat vectors in this index");
+    // list order = stable sort of add order by list: reuse ids when unsharded
+    std::vector<int32_t> h_vlist((size_t)n);
+    ASL_TRY(ix->vlist.download(h_vlist.data(), (size_t)n));
+    ASL_TRY(sync_stream());
+    std::vector<int64_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return h_vlist[(size_t)a] < h_vlist[(size_t)b]; });
+    DevBuf<int64_t> od;
+    DevBuf<float> tmp;
+    ASL_TRY(od.upload(order.data(), (size_t)n));
+    ASL_TRY(tmp.reserve((size_t)n * ix->d));
+    ASL_TRY(gather_rows_f32(ix->vecs.p, ix->d, od.p, n, ix->d, tmp.p, ix->d));
+    HIP_TRY(hipMemcpyAsync(vecs, tmp.p, (size_t)n * ix->d * 4, hipMemcpyDefault, stream()));
+    ASL_TRY(sync_stream());
+  }
+  return sync_stream();
+}
+
+static void lpt_owner(const std::vector<int64_t> &sizes, int world, std::vector<int32_t> &owner) {
+  const int nlist = (int)sizes.size();
+  std::vector<int> order((size_t)nlist);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sizes[(size_t)a] > sizes[(size_t)b]; });
+  std::vector<int64_t> load((size_t)world, 0);
+  owner.assign((size_t)nlist, 0);
+  for (int l : order) {
+    int best = 0;
+    for (int r = 1; r < world; r++)
+      if (load[(size_t)r] < load[(size_t)best]) best = r;
+    owner[(size_t)l] = best;
+    load[(size_t)best] += sizes[(size_t)l];
+  }
+}
+
+static int list_sizes(asl_index *ix, std::vector<int32_t> &h_vlist, std::vector<int64_t> &sizes) {
+  const int64_t n = ix->n_store;
+  h_vlist.resize((size_t)n);
+  if (n) {
+    ASL_TRY(ix->vlist.download(h_vlist.data(), (size_t)n));
+    ASL_TRY(sync_stream());
+  }
+  sizes.assign((size_t)ix->nlist, 0);
+  for (int64_t i = 0; i < n; i++) sizes[(size_t)h_vlist[(size_t)i]]++;
+  return ASL_OK;
+}
+
+int asl_index_shard_map(const asl_index_t *cix, int32_t world, int32_t *owner_out) {
+  clear_error();
+  asl_index *ix = const_cast<asl_index *>(cix);
+  if (!ix || ix->kind == ASL_INDEX_FLAT || world <= 0 || !owner_out)
+    return fail(ASL_ERR_INVALID, "shard_map: IVF index and world > 0 required");
+  if (ix->shard_world > 1) return fail(ASL_ERR_STATE, "shard_map: call before sharding");
+  std::vector<int32_t> h_vlist, owner;
+  std::vector<int64_t> sizes;
+  ASL_TRY(list_sizes(ix, h_vlist, sizes));
+  lpt_owner(sizes, world, owner);
+  memcpy(owner_out, owner.data(), owner.size() * 4);
+  return ASL_OK;
+}
+
+int asl_index_shard(asl_index_t *ix, int32_t rank, int32_t world) {
+  clear_error();
+  if (!ix || ix->kind == ASL_INDEX_FLAT) return fail(ASL_ERR_INVALID, "shard: IVF index required");
+  if (world <= 0 || rank < 0 || rank >= world) return fail(ASL_ERR_INVALID, "shard: bad rank/world");
+  if (ix->shard_world > 1) return fail(ASL_ERR_STATE, "shard: already sharded");
+  if (world == 1) return ASL_OK;
+  std::vector<int32_t> h_vlist, owner;
+  std::vector<int64_t> sizes;
+  ASL_TRY(list_sizes(ix, h_vlist, sizes));
+  lpt_owner(sizes, world, owner);
+  const int64_t n = ix->n_store;
+  std::vector<int64_t> keep;
+  std::vector<int32_t> keep32, new_vlist;
+  for (int64_t i = 0; i < n; i++)
+    if (owner[(size_t)h_vlist[(size_t)i]] == rank) {
+      keep.push_back(i);
+      keep32.push_back((int32_t)i);
+      new_vlist.push_back(h_vlist[(size_t)i]);
+    }
+  const int64_t nk = (int64_t)keep.size();
+  if (ix->kind == ASL_INDEX_IVFFLAT) {
+    DevBuf<int64_t> kd;
+    DevBuf<float> nv;
+    ASL_TRY(kd.upload(keep.data(), (size_t)nk));
+    ASL_TRY(nv.reserve((size_t)std::max<int64_t>(nk, 1) * ix->d));
+    ASL_TRY(gather_rows_f32(ix->vecs.p, ix->d, kd.p, nk, ix->d, nv.p, ix->d));
+    ASL_TRY(sync_stream());
+    ix->vecs = std::move(nv);
+  } else {
+    DevBuf<int32_t> kd;
+    DevBuf<uint8_t> nc;
+    ASL_TRY(kd.upload(keep32.data(), (size_t)nk));
+    ASL_TRY(nc.reserve((size_t)std::max<int64_t>(nk, 1) * ix->pq_m));
+    ASL_TRY(gather_rows_u8(ix->codes_add.p, kd.p, nk, ix->pq_m, nc.p));
+    ASL_TRY(sync_stream());
+    ix->codes_add = std::move(nc);
+  }
+  ASL_TRY(ix->vlist.upload(new_vlist.data(), (size_t)nk));
+  ASL_TRY(ix->vids.upload(keep32.data(), (size_t)nk));
+  ASL_TRY(sync_stream());
+  ix->has_vids = true;
+  ix->n_store = nk;
+  ix->shard_rank = rank;
+  ix->shard_world = world;
+  ix->lists_dirty = true;
+  return ASL_OK;
+}
+
+int asl_index_coarse(asl_index_t *ix, int32_t nq, const float *xq, int32_t nprobe,
+                     float *coarse_D, int32_t *coarse_I) {
+  clear_error();
+  if (!ix || ix->kind == ASL_INDEX_FLAT || !ix->trained)
+    return fail(ASL_ERR_STATE, "coarse: trained IVF index required");
+  if (nq <= 0) return ASL_OK;
+  nprobe = std::max(1, std::min(nprobe, ix->nlist));
+  if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "coarse: nprobe=%d > %d", nprobe, TK_MAX_K);
+  In<float> dq;
+  ASL_TRY(dq.init(xq, (size_t)nq * ix->d));
+  ASL_TRY(coarse_search(ix, dq.d, nq, nprobe));
+  if (coarse_D)
+    HIP_TRY(hipMemcpyAsync(coarse_D, ix->coarse_D.p, (size_t)nq * nprobe * 4, hipMemcpyDefault, stream()));
+  if (coarse_I)
+    HIP_TRY(hipMemcpyAsync(coarse_I, ix->coarse_I.p, (size_t)nq * nprobe * 4, hipMemcpyDefault, stream()));
+  return sync_stream();
+}
+
+int asl_index_pq_lut(asl_index_t *ix, int32_t nq, const float *xq, float *lut) {
+  clear_error();
+  if (!ix || ix->kind != ASL_INDEX_IVFPQ || !ix->trained)
+    return fail(ASL_ERR_STATE, "pq_lut: trained IVF-PQ index required");
+  if (nq <= 0) return ASL_OK;
+  In<float> dq;
+  Out<float> dl;
+  ASL_TRY(dq.init(xq, (size_t)nq * ix->d));
+  ASL_TRY(dl.init(lut, (size_t)nq * ix->pq_m * ix->ksub));
+  ASL_TRY(pq_lut(dq.d, nq, ix->d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, dl.d));
+  ASL_TRY(dl.finish());
+  return sync_stream();
+}
+
+int asl_index_search(asl_index_t *ix, int32_t nq, const float *xq, int32_t k, int32_t nprobe,
+                     float *D, int64_t *I) {
+  clear_error();
+  if (!ix) return fail(ASL_ERR_INVALID, "search: null index");
+  if (nq <= 0) return ASL_OK;
+  if (!xq || !I) return fail(ASL_ERR_INVALID, "search: null xq / I");
+  ASL_TRY(ensure_device());
+  In<float> dq;
+  Out<float> dD;
+  Out<int64_t> dI;
+  ASL_TRY(dq.init(xq, (size_t)nq * ix->d));
+  ASL_TRY(dD.init(D, (size_t)nq * k));
+  ASL_TRY(dI.init(I, (size_t)nq * k));
+  ASL_TRY(index_search_device(ix, nq, dq.d, k, nprobe, dD.d, dI.d, nullptr));
+  ASL_TRY(dD.finish());
+  ASL_TRY(dI.finish());
+  if (dD.to_host() || dI.to_host() || dq.own.p) ASL_TRY(sync_stream());
+  return ASL_OK;
+}
+
+int asl_topk_merge(int32_t S, int32_t nq, int32_t k, const float *Ds, const int64_t *Is,
+                   float *D, int64_t *I) {
+  clear_error();
+  if (S <= 0 || nq < 0 || k <= 0 || !Ds || !Is || !D || !I) return fail(ASL_ERR_INVALID, "topk_merge: bad arguments");
+  if (nq == 0) return ASL_OK;
+  ASL_TRY(ensure_device());
+  In<float> dDs;
+  In<int64_t> dIs;
+  Out<float> dD;
+  Out<int64_t> dI;
+  ASL_TRY(dDs.init(Ds, (size_t)S * nq * k));
+  ASL_TRY(dIs.init(Is, (size_t)S * nq * k));
+  ASL_TRY(dD.init(D, (size_t)nq * k));
+  ASL_TRY(dI.init(I, (size_t)nq * k));
+  ASL_TRY(topk_merge(dDs.d, dIs.d, S, nq, k, dD.d, dI.d));
+  ASL_TRY(dD.finish());
+  ASL_TRY(dI.finish());
+  if (dD.to_host() || dI.to_host() || dDs.own.p || dIs.own.p) ASL_TRY(sync_stream());
+  return ASL_OK;
+}
+
+// ---------------------------------------------------------------- persistence
+// '<base>_<hash7>_<charge>.idxann' stays the file name (spectral_library.py:98-108);
+// the payload is this library's own little-endian format, not FAISS'.
+struct IdxHeader {
+  char magic[8];
+  int32_t version, d, nlist, kind, pq_m, pq_bits, niter, trained;
+  int64_t ntotal, n_store;
+  int32_t shard_rank, shard_world, has_vids, pad;
+};
+
+int asl_index_save(const asl_index_t *ix, const char *path) {
+  clear_error();
+  if (!ix || !path) return fail(ASL_ERR_INVALID, "save: null");
+  FILE *f = fopen(path, "wb");
+  if (!f) return fail(ASL_ERR_IO, "save: cannot open %s", path);
+  IdxHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "ASLIDX01", 8);
+  h.version = 1;
+  h.d = ix->d;
+  h.nlist = ix->nlist;
+  h.kind = ix->kind;
+  h.pq_m = ix->pq_m;
+  h.pq_bits = ix->pq_bits;
+  h.niter = ix->niter;
+  h.trained = ix->trained;
+  h.ntotal = ix->ntotal;
+  h.n_store = ix->n_store;
+  h.shard_rank = ix->shard_rank;
+  h.shard_world = ix->shard_world;
+  h.has_vids = ix->has_vids;
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+  auto dump = [&](const void *dev, size_t bytes) {
+    if (!ok || bytes == 0) return;
+    std::vector<char> tmp(bytes);
+    if (hipMemcpy(tmp.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+      ok = false;
+      return;
+    }
+    ok = fwrite(tmp.data(), 1, bytes, f) == bytes;
+  };
+  (void)hipStreamSynchronize(stream());
+  if (ix->trained && ix->kind != ASL_INDEX_FLAT) dump(ix->centroids.p, (size_t)ix->nlist * ix->d * 4);
+  if (ix->trained && ix->kind == ASL_INDEX_IVFPQ) dump(ix->codebooks.p, (size_t)ix->pq_m * ix->ksub * ix->dsub * 4);
+  const size_t n = (size_t)ix->n_store;
+  if (ix->kind != ASL_INDEX_FLAT) dump(ix->vlist.p, n * 4);
+  if (ix->has_vids) dump(ix->vids.p, n * 4);
+  if (ix->kind == ASL_INDEX_IVFPQ)
+    dump(ix->codes_add.p, n * ix->pq_m);
+  else
+    dump(ix->vecs.p, n * ix->d * 4);
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) return fail(ASL_ERR_IO, "save: write to %s failed", path);
+  return ASL_OK;
+}
+
+asl_index_t *asl_index_load(const char *path) {
+  clear_error();
+  if (!path) {
+    fail(ASL_ERR_INVALID, "load: null path");
+    return nullptr;
+  }
+  if (ensure_device() != ASL_OK) return nullptr;
+  FILE *f = fopen(path, "rb");
+  if (!f) {
+    fail(ASL_ERR_IO, "load: cannot open %s", path);
+    return nullptr;
+  }
+  IdxHeader h;
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "ASLIDX01", 8) != 0) {
+    fclose(f);
+    fail(ASL_ERR_IO, "load: %s is not an annsolo_mi index", path);
+    return nullptr;
+  }
+  asl_index *ix = new asl_index();
+  ix->d = h.d;
+  ix->nlist = h.nlist;
+  ix->kind = h.kind;
+  ix->pq_m = h.pq_m;
+  ix->pq_bits = h.pq_bits;
+  ix->niter = h.niter;
+  ix->trained = h.trained;
+  ix->ntotal = h.ntotal;
+  ix->n_store = h.n_store;
+  ix->shard_rank = h.shard_rank;
+  ix->shard_world = h.shard_world;
+  ix->has_vids = h.has_vids;
+  if (ix->kind == ASL_INDEX_IVFPQ) {
+    ix->ksub = 1 << ix->pq_bits;
+    ix->dsub = ix->d / ix->pq_m;
+  }
+  bool ok = true;
+  auto slurp = [&](auto &buf, size_t count) {
+    using T = typename std::remove_reference<decltype(*buf.p)>::type;
+    if (!ok || count == 0) return;
+    std::vector<T> tmp(count);
+    if (fread(tmp.data(), sizeof(T), count, f) != count) {
+      ok = false;
+      return;
+    }
+    if (buf.reserve(count) != ASL_OK ||
+        hipMemcpy(buf.p, tmp.data(), count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+      ok = false;
+  };
+  if (ix->trained && ix->kind != ASL_INDEX_FLAT) slurp(ix->centroids, (size_t)ix->nlist * ix->d);
+  if (ix->trained && ix->kind == ASL_INDEX_IVFPQ) slurp(ix->codebooks, (size_t)ix->pq_m * ix->ksub * ix->dsub);
+  const size_t n = (size_t)ix->n_store;
+  if (ix->kind != ASL_INDEX_FLAT) slurp(ix->vlist, n);
+  if (ix->has_vids) slurp(ix->vids, n);
+  if (ix->kind == ASL_INDEX_IVFPQ)
+    slurp(ix->codes_add, n * ix->pq_m);
+  else
+    slurp(ix->vecs, n * ix->d);
+  fclose(f);
+  if (!ok) {
+    delete ix;
+    fail(ASL_ERR_IO, "load: %s is truncated or unreadable", path);
+    return nullptr;
+  }
+  ix->lists_dirty = true;
+  return ix;
+}
+
+}  // extern "C"

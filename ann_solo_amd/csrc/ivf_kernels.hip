@@ -1,0 +1,541 @@
+// ivf_kernels.hip -- device kernels of the hand-written IVF index (replaces the
+// FAISS IndexFlatIP / IndexIVFFlat calls at
+// /root/reference/src/ann_solo/spectral_library.py:167-181,443-445 and adds the
+// IVF-PQ the north star asks for).
+//
+//   row_topk_kernel   exact top-k of one score row per workgroup (coarse top-nprobe,
+//                     IndexFlatIP, and IVF-Flat through a probed-list bitmap mask)
+//   pq_scan_kernel    per query: per-query ADC look-up table built in LDS, the
+//                     packed PQ codes of the probed lists streamed from HBM
+//                     (32 B/vector, coalesced 16-B loads), fused exact top-k
+//   topk_merge_kernel merge of per-shard / per-chunk partial top-k lists
+//   + small helpers (bitmap, argmax, residual/encode, gathers, L2 assignment)
+#include "common.hpp"
+#include "ivf_kernels.hpp"
+#include "topk.hpp"
+
+namespace asl {
+
+// ------------------------------------------------------------------ row top-k
+// scores: [rows, ld]; hit id of column c is ids ? ids[c] : id_base + c.
+// Mask (IVF-Flat): column c is visible to row r iff bit vlist[c] of bitmap[r] is set.
+__global__ __launch_bounds__(TK_NT) void row_topk_kernel(
+    const float *__restrict__ scores, int64_t ld, int n, int k, int cap,
+    const int32_t *__restrict__ ids, int32_t id_base, const int32_t *__restrict__ vlist,
+    const uint32_t *__restrict__ bitmap, int bitmap_words, float *__restrict__ D,
+    int64_t *__restrict__ I64, int32_t *__restrict__ I32, int64_t out_ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64 *buf = reinterpret_cast<u64 *>(smem);
+  u64 *thr = buf + cap;
+  int *ctl = reinterpret_cast<int *>(thr + 1);
+  const int tid = threadIdx.x;
+  const int r = blockIdx.x;
+  StreamTopK<TK_NT> tk;
+  tk.init(buf, ctl, thr, cap, k, tid);
+  const float *row = scores + (size_t)r * ld;
+  const uint32_t *bm = bitmap ? bitmap + (size_t)r * bitmap_words : nullptr;
+  for (int base = 0; base < n; base += TK_NT) {
+    const int c = base + tid;
+    u64 key = 0ull;
+    if (c < n) {
+      bool vis = true;
+      if (bm) {
+        const int l = vlist[c];
+        vis = (bm[l >> 5] >> (l & 31)) & 1u;
+      }
+      if (vis) key = make_key(row[c], (uint32_t)(ids ? ids[c] : id_base + c));
+    }
+    tk.push(key, tid);
+  }
+  tk.finish(D ? D + (size_t)r * out_ld : nullptr, I64 ? I64 + (size_t)r * out_ld : nullptr,
+            I32 ? I32 + (size_t)r * out_ld : nullptr, tid);
+}
+
+int row_topk(const float *scores, int64_t ld, int rows, int n, int k, const int32_t *ids,
+             int32_t id_base, const int32_t *vlist, const uint32_t *bitmap, int bitmap_words,
+             float *D, int64_t *I64, int32_t *I32, int64_t out_ld) {
+  if (rows <= 0) return ASL_OK;
+  if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "top-k: k=%d outside 1..%d", k, TK_MAX_K);
+  const int cap = topk_cap_for(k);
+  const size_t lds = (size_t)cap * 8 + 16;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void *)row_topk_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(row_topk_kernel, dim3(rows), dim3(TK_NT), lds, stream(), scores, ld, n,
+                     k, cap, ids, id_base, vlist, bitmap, bitmap_words, D, I64, I32, out_ld);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// ------------------------------------------------------------------ merge
+// Ds/Is: [S, nq, k] partial lists -> [nq, k].
+__global__ __launch_bounds__(TK_NT) void topk_merge_kernel(
+    const float *__restrict__ Ds, const int64_t *__restrict__ Is, int S, int nq, int k,
+    int cap, float *__restrict__ D, int64_t *__restrict__ I) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64 *buf = reinterpret_cast<u64 *>(smem);
+  u64 *thr = buf + cap;
+  int *ctl = reinterpret_cast<int *>(thr + 1);
+  const int tid = threadIdx.x, q = blockIdx.x;
+  StreamTopK<TK_NT> tk;
+  tk.init(buf, ctl, thr, cap, k, tid);
+  const int total = S * k;
+  for (int base = 0; base < total; base += TK_NT) {
+    const int t = base + tid;
+    u64 key = 0ull;
+    if (t < total) {
+      const int s = t / k, i = t - s * k;
+      const size_t o = ((size_t)s * nq + q) * k + i;
+      const int64_t id = Is[o];
+      if (id >= 0) key = make_key(Ds[o], (uint32_t)id);
+    }
+    tk.push(key, tid);
+  }
+  tk.finish(D + (size_t)q * k, I + (size_t)q * k, nullptr, tid);
+}
+
+int topk_merge(const float *Ds, const int64_t *Is, int S, int nq, int k, float *D, int64_t *I) {
+  if (nq <= 0) return ASL_OK;
+  if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "merge: k=%d outside 1..%d", k, TK_MAX_K);
+  const int cap = topk_cap_for(k);
+  const size_t lds = (size_t)cap * 8 + 16;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void *)topk_merge_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(TK_NT), lds, stream(), Ds, Is, S, nq, k,
+                     cap, D, I);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// ------------------------------------------------------------------ bitmap of probed lists
+__global__ void probe_bitmap_kernel(const int32_t *__restrict__ coarse_I, int nq, int nprobe,
+                                    uint32_t *__restrict__ bitmap, int words) {
+  const int q = blockIdx.x;
+  for (int p = threadIdx.x; p < nprobe; p += blockDim.x) {
+    const int l = coarse_I[(size_t)q * nprobe + p];
+    if (l >= 0) atomicOr(&bitmap[(size_t)q * words + (l >> 5)], 1u << (l & 31));
+  }
+}
+
+int probe_bitmap(const int32_t *coarse_I, int nq, int nprobe, uint32_t *bitmap, int words) {
+  HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)nq * words * sizeof(uint32_t), stream()));
+  hipLaunchKernelGGL(probe_bitmap_kernel, dim3(nq), dim3(128), 0, stream(), coarse_I, nq,
+                     nprobe, bitmap, words);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// ------------------------------------------------------------------ row arg-max (ties: lowest col)
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float *__restrict__ scores,
+                                                         int64_t ld, int n,
+                                                         int32_t *__restrict__ out) {
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float *row = scores + (size_t)r * ld;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = tid; c < n; c += 256) {
+    const float v = row[c];
+    if (v > bv || (v == bv && c < bi)) {
+      bv = v;
+      bi = c;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) {
+      bv = ov;
+      bi = oi;
+    }
+  }
+  if ((tid & 63) == 0) {
+    s_v[tid >> 6] = bv;
+    s_i[tid >> 6] = bi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) {
+        bv = s_v[w];
+        bi = s_i[w];
+      }
+    out[r] = bi == 0x7fffffff ? 0 : bi;
+  }
+}
+
+int row_argmax(const float *scores, int64_t ld, int rows, int n, int32_t *out) {
+  if (rows <= 0) return ASL_OK;
+  hipLaunchKernelGGL(row_argmax_kernel, dim3(rows), dim3(256), 0, stream(), scores, ld, n, out);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// ------------------------------------------------------------------ gathers
+__global__ void gather_rows_f32_kernel(const float *__restrict__ src, int64_t ld_src,
+                                       const int64_t *__restrict__ rows, int64_t n, int d,
+                                       float *__restrict__ dst, int64_t ld_dst) {
+  const int64_t i = blockIdx.x;
+  const int64_t r = rows ? rows[i] : i;
+  for (int j = threadIdx.x; j < d; j += blockDim.x)
+    dst[i * ld_dst + j] = src[r * ld_src + j];
+}
+int gather_rows_f32(const float *src, int64_t ld_src, const int64_t *rows, int64_t n, int d,
+                    float *dst, int64_t ld_dst) {
+  if (n <= 0) return ASL_OK;
+  hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((unsigned)n), dim3(256), 0, stream(), src,
+                     ld_src, rows, n, d, dst, ld_dst);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+__global__ void gather_rows_u8_kernel(const uint8_t *__restrict__ src,
+                                      const int32_t *__restrict__ rows, int64_t n, int m,
+                                      uint8_t *__restrict__ dst) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * m) return;
+  const int64_t i = t / m;
+  const int j = (int)(t - i * m);
+  dst[t] = src[(int64_t)rows[i] * m + j];
+}
+int gather_rows_u8(const uint8_t *src, const int32_t *rows, int64_t n, int m, uint8_t *dst) {
+  if (n <= 0) return ASL_OK;
+  hipLaunchKernelGGL(gather_rows_u8_kernel, dim3((unsigned)cdiv(n * m, 256)), dim3(256), 0,
+                     stream(), src, rows, n, m, dst);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// ------------------------------------------------------------------ k-means update
+// One workgroup per cluster: members (ascending point order) are summed in fp32 in
+// that order, then divided by the count -- the oracle's loop, bit for bit.
+__global__ __launch_bounds__(256) void centroid_update_kernel(
+    const float *__restrict__ x, int64_t ld, int d, const int32_t *__restrict__ order,
+    const int32_t *__restrict__ offsets, float *__restrict__ centroids) {
+  const int c = blockIdx.x;
+  const int b = offsets[c], e = offsets[c + 1];
+  if (e == b) return;  // empty: left for the host-side split
+  const float cnt = (float)(e - b);
+  for (int j = threadIdx.x; j < d; j += 256) {
+    float s = 0.0f;
+    for (int t = b; t < e; ++t) s += x[(size_t)order[t] * ld + j];
+    centroids[(size_t)c * d + j] = s / cnt;
+  }
+}
+int centroid_update(const float *x, int64_t ld, int d, int k, const int32_t *order,
+                    const int32_t *offsets, float *centroids) {
+  hipLaunchKernelGGL(centroid_update_kernel, dim3(k), dim3(256), 0, stream(), x, ld, d, order,
+                     offsets, centroids);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// ------------------------------------------------------------------ L2 assignment (PQ)
+// x: [n, ld] (sub-vector view, dsub <= 32), cb: [ksub, dsub]. Chain
+// acc = fmaf(x-c, x-c, acc) ascending, arg-min with lowest-index ties.
+__global__ __launch_bounds__(256) void l2_assign_kernel(const float *__restrict__ x,
+                                                        int64_t ld, int64_t n, int dsub,
+                                                        const float *__restrict__ cb, int ksub,
+                                                        int32_t *__restrict__ assign) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_cb = reinterpret_cast<float *>(smem);
+  for (int i = threadIdx.x; i < ksub * dsub; i += 256) s_cb[i] = cb[i];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float bs = INFINITY;
+  int best = 0;
+  if (dsub <= PQ_MAX_DSUB) {
+    float xv[PQ_MAX_DSUB];
+#pragma unroll
+    for (int t = 0; t < PQ_MAX_DSUB; ++t) xv[t] = t < dsub ? x[i * ld + t] : 0.0f;
+    for (int c = 0; c < ksub; ++c) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int t = 0; t < PQ_MAX_DSUB; ++t)
+        if (t < dsub) {
+          const float df = xv[t] - s_cb[c * dsub + t];
+          acc = __builtin_fmaf(df, df, acc);
+        }
+      if (acc < bs) {
+        bs = acc;
+        best = c;
+      }
+    }
+  } else {  // wide sub-vectors: operands re-read through L1 (slow path, same arithmetic)
+    for (int c = 0; c < ksub; ++c) {
+      float acc = 0.0f;
+      for (int t = 0; t < dsub; ++t) {
+        const float df = x[i * ld + t] - s_cb[c * dsub + t];
+        acc = __builtin_fmaf(df, df, acc);
+      }
+      if (acc < bs) {
+        bs = acc;
+        best = c;
+      }
+    }
+  }
+  assign[i] = best;
+}
+int l2_assign(const float *x, int64_t ld, int64_t n, int dsub, const float *cb, int ksub,
+              int32_t *assign) {
+  if (n <= 0) return ASL_OK;
+  hipLaunchKernelGGL(l2_assign_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256),
+                     (size_t)ksub * dsub * 4, stream(), x, ld, n, dsub, cb, ksub, assign);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// residual r = x - centroid[assign] (fp32 subtract), in place or to dst
+__global__ void residual_kernel(const float *__restrict__ x, const int32_t *__restrict__ assign,
+                                const float *__restrict__ centroids, int64_t n, int d,
+                                float *__restrict__ dst) {
+  const int64_t i = blockIdx.x;
+  const float *c = centroids + (size_t)assign[i] * d;
+  for (int j = threadIdx.x; j < d; j += blockDim.x)
+    dst[i * d + j] = x[i * d + j] - c[j];
+}
+int residual(const float *x, const int32_t *assign, const float *centroids, int64_t n, int d,
+             float *dst) {
+  if (n <= 0) return ASL_OK;
+  hipLaunchKernelGGL(residual_kernel, dim3((unsigned)n), dim3(256), 0, stream(), x, assign,
+                     centroids, n, d, dst);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// PQ encode: grid (vector tiles, m). code = argmin_c L2(residual_sub, cb[m][c]).
+__global__ __launch_bounds__(256) void pq_encode_kernel(
+    const float *__restrict__ x, const int32_t *__restrict__ assign,
+    const float *__restrict__ centroids, const float *__restrict__ codebooks, int64_t n, int d,
+    int m, int ksub, int dsub, uint8_t *__restrict__ codes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_cb = reinterpret_cast<float *>(smem);
+  const int mi = blockIdx.y;
+  const float *cb = codebooks + (size_t)mi * ksub * dsub;
+  for (int i = threadIdx.x; i < ksub * dsub; i += 256) s_cb[i] = cb[i];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float *xi = x + (size_t)i * d + (size_t)mi * dsub;
+  const float *ci = centroids + (size_t)assign[i] * d + (size_t)mi * dsub;
+  float bs = INFINITY;
+  int best = 0;
+  if (dsub <= PQ_MAX_DSUB) {
+    float rv[PQ_MAX_DSUB];
+#pragma unroll
+    for (int t = 0; t < PQ_MAX_DSUB; ++t) rv[t] = t < dsub ? xi[t] - ci[t] : 0.0f;
+    for (int c = 0; c < ksub; ++c) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int t = 0; t < PQ_MAX_DSUB; ++t)
+        if (t < dsub) {
+          const float df = rv[t] - s_cb[c * dsub + t];
+          acc = __builtin_fmaf(df, df, acc);
+        }
+      if (acc < bs) {
+        bs = acc;
+        best = c;
+      }
+    }
+  } else {
+    for (int c = 0; c < ksub; ++c) {
+      float acc = 0.0f;
+      for (int t = 0; t < dsub; ++t) {
+        const float df = (xi[t] - ci[t]) - s_cb[c * dsub + t];
+        acc = __builtin_fmaf(df, df, acc);
+      }
+      if (acc < bs) {
+        bs = acc;
+        best = c;
+      }
+    }
+  }
+  codes[(size_t)i * m + mi] = (uint8_t)best;
+}
+int pq_encode(const float *x, const int32_t *assign, const float *centroids,
+              const float *codebooks, int64_t n, int d, int m, int ksub, int dsub,
+              uint8_t *codes) {
+  if (n <= 0) return ASL_OK;
+  hipLaunchKernelGGL(pq_encode_kernel, dim3((unsigned)cdiv(n, 256), m), dim3(256),
+                     (size_t)ksub * dsub * 4, stream(), x, assign, centroids, codebooks, n, d,
+                     m, ksub, dsub, codes);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// ------------------------------------------------------------------ PQ LUT + scan
+// LUT[m][c] = ascending-t fmaf chain of q[m*dsub+t] * cb[m][c][t]; thread c owns code c.
+__device__ __forceinline__ void build_lut_lds(const float *__restrict__ xq_row, int d,
+                                              const float *__restrict__ codebooks, int m,
+                                              int ksub, int dsub, float *s_q, float *s_lut,
+                                              int tid) {
+  for (int i = tid; i < d; i += TK_NT) s_q[i] = xq_row[i];
+  __syncthreads();
+  for (int c = tid; c < ksub; c += TK_NT) {
+    for (int mi = 0; mi < m; ++mi) {
+      const float *cb = codebooks + ((size_t)mi * ksub + c) * dsub;
+      const float *qs = s_q + mi * dsub;
+      float acc = 0.0f;
+      for (int t = 0; t < dsub; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
+      s_lut[mi * ksub + c] = acc;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(TK_NT) void pq_lut_kernel(const float *__restrict__ xq, int d,
+                                                       const float *__restrict__ codebooks,
+                                                       int m, int ksub, int dsub,
+                                                       float *__restrict__ lut_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_lut = reinterpret_cast<float *>(smem);
+  float *s_q = s_lut + m * ksub;
+  const int q = blockIdx.x;
+  build_lut_lds(xq + (size_t)q * d, d, codebooks, m, ksub, dsub, s_q, s_lut, threadIdx.x);
+  for (int i = threadIdx.x; i < m * ksub; i += TK_NT) lut_out[(size_t)q * m * ksub + i] = s_lut[i];
+}
+int pq_lut(const float *xq, int nq, int d, const float *codebooks, int m, int ksub, int dsub,
+           float *lut_out) {
+  if (nq <= 0) return ASL_OK;
+  const size_t lds = ((size_t)m * ksub + d) * 4;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void *)pq_lut_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(pq_lut_kernel, dim3(nq), dim3(TK_NT), lds, stream(), xq, d, codebooks, m,
+                     ksub, dsub, lut_out);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// Canonical ADC sum: p_j = sum_t v[j+16t]; 16->1 tree (8,4,2,1); + coarse.
+template <int M>
+__device__ __forceinline__ float adc_score(const float *__restrict__ s_lut, int ksub,
+                                           const uint32_t *__restrict__ cw, float coarse) {
+  float v[M];
+#pragma unroll
+  for (int w = 0; w < M / 4; ++w) {
+    const uint32_t word = cw[w];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int mi = w * 4 + b;
+      v[mi] = s_lut[mi * ksub + ((word >> (8 * b)) & 0xffu)];
+    }
+  }
+  float p[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j < M) {
+      float a = v[j];
+#pragma unroll
+      for (int t = j + 16; t < M; t += 16) a = a + v[t];
+      p[j] = a;
+    } else {
+      p[j] = 0.0f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = p[j] + p[j + 8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) p[j] = p[j] + p[j + 4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) p[j] = p[j] + p[j + 2];
+  return coarse + (p[0] + p[1]);
+}
+
+// One workgroup per query: LUT in LDS, stream the probed lists, fused top-k.
+template <int M>
+__global__ __launch_bounds__(TK_NT) void pq_scan_kernel(
+    const float *__restrict__ xq, int d, const float *__restrict__ codebooks, int ksub,
+    int dsub, const float *__restrict__ coarse_D, const int32_t *__restrict__ coarse_I,
+    int nprobe, const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ ids,
+    const uint8_t *__restrict__ codes, int k, int cap, float *__restrict__ D,
+    int64_t *__restrict__ I64, int32_t *__restrict__ I32) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64 *buf = reinterpret_cast<u64 *>(smem);
+  u64 *thr = buf + cap;
+  int *ctl = reinterpret_cast<int *>(thr + 1);       // 2 ints
+  float *s_lut = reinterpret_cast<float *>(thr + 2);
+  float *s_q = s_lut + M * ksub;
+  const int tid = threadIdx.x, q = blockIdx.x;
+  build_lut_lds(xq + (size_t)q * d, d, codebooks, M, ksub, dsub, s_q, s_lut, tid);
+  StreamTopK<TK_NT> tk;
+  tk.init(buf, ctl, thr, cap, k, tid);
+  for (int p = 0; p < nprobe; ++p) {
+    const int l = coarse_I[(size_t)q * nprobe + p];
+    if (l < 0) continue;  // uniform
+    const float coarse = coarse_D[(size_t)q * nprobe + p];
+    const int start = list_offsets[l], len = list_offsets[l + 1] - start;
+    for (int base = 0; base < len; base += TK_NT) {
+      const int i = base + tid;
+      u64 key = 0ull;
+      if (i < len) {
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(codes + (size_t)(start + i) * M);
+        key = make_key(adc_score<M>(s_lut, ksub, cw, coarse), (uint32_t)ids[start + i]);
+      }
+      tk.push(key, tid);
+    }
+  }
+  tk.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
+            I32 ? I32 + (size_t)q * k : nullptr, tid);
+}
+
+template <int M>
+static int launch_pq_scan(const float *xq, int nq, int d, const float *codebooks, int ksub,
+                          int dsub, const float *coarse_D, const int32_t *coarse_I, int nprobe,
+                          const int32_t *list_offsets, const int32_t *ids, const uint8_t *codes,
+                          int k, float *D, int64_t *I64, int32_t *I32) {
+  const int cap = topk_cap_for(k);
+  const size_t lds = (size_t)cap * 8 + 16 + ((size_t)M * ksub + d) * 4;
+  if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "pq scan: k=%d / m=%d do not fit LDS", k, M);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void *)pq_scan_kernel<M>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(pq_scan_kernel<M>, dim3(nq), dim3(TK_NT), lds, stream(), xq, d, codebooks,
+                     ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, cap,
+                     D, I64, I32);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+int pq_scan(const float *xq, int nq, int d, const float *codebooks, int m, int ksub, int dsub,
+            const float *coarse_D, const int32_t *coarse_I, int nprobe,
+            const int32_t *list_offsets, const int32_t *ids, const uint8_t *codes, int k,
+            float *D, int64_t *I64, int32_t *I32) {
+  if (nq <= 0) return ASL_OK;
+  if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "pq scan: k=%d outside 1..%d", k, TK_MAX_K);
+  switch (m) {
+    case 4: return launch_pq_scan<4>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32);
+    case 8: return launch_pq_scan<8>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32);
+    case 16: return launch_pq_scan<16>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32);
+    case 32: return launch_pq_scan<32>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32);
+    case 64: return launch_pq_scan<64>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32);
+    default: return fail(ASL_ERR_INVALID, "pq scan: pq_m must be one of 4,8,16,32,64 (got %d)", m);
+  }
+}
+
+// sum over queries of probed list lengths (algorithmic work of a scan launch)
+__global__ void scanned_count_kernel(const int32_t *__restrict__ coarse_I, int64_t n,
+                                     const int32_t *__restrict__ list_offsets,
+                                     unsigned long long *__restrict__ out) {
+  unsigned long long acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = coarse_I[i];
+    if (l >= 0) acc += (unsigned long long)(list_offsets[l + 1] - list_offsets[l]);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+int scanned_count(const int32_t *coarse_I, int64_t n, const int32_t *list_offsets,
+                  unsigned long long *out_dev) {
+  HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(unsigned long long), stream()));
+  hipLaunchKernelGGL(scanned_count_kernel, dim3(256), dim3(256), 0, stream(), coarse_I, n,
+                     list_offsets, out_dev);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+}  // namespace asl

@@ -1,0 +1,41 @@
+// ivf_kernels.hpp -- host-callable wrappers of the IVF device kernels (all pointers
+// are device pointers; everything is enqueued on asl::stream()).
+#pragma once
+#include <cstdint>
+
+namespace asl {
+
+constexpr int TK_NT = 256;        // threads per top-k workgroup
+constexpr int TK_MAX_K = 2048;    // largest k / nprobe the LDS top-k supports
+constexpr int PQ_MAX_DSUB = 32;   // register fast path of the PQ L2 kernels
+
+int gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K, int lda,
+                int ldb, int ldc);
+int row_topk(const float *scores, int64_t ld, int rows, int n, int k, const int32_t *ids,
+             int32_t id_base, const int32_t *vlist, const uint32_t *bitmap, int bitmap_words,
+             float *D, int64_t *I64, int32_t *I32, int64_t out_ld);
+int topk_merge(const float *Ds, const int64_t *Is, int S, int nq, int k, float *D, int64_t *I);
+int probe_bitmap(const int32_t *coarse_I, int nq, int nprobe, uint32_t *bitmap, int words);
+int row_argmax(const float *scores, int64_t ld, int rows, int n, int32_t *out);
+int gather_rows_f32(const float *src, int64_t ld_src, const int64_t *rows, int64_t n, int d,
+                    float *dst, int64_t ld_dst);
+int gather_rows_u8(const uint8_t *src, const int32_t *rows, int64_t n, int m, uint8_t *dst);
+int centroid_update(const float *x, int64_t ld, int d, int k, const int32_t *order,
+                    const int32_t *offsets, float *centroids);
+int l2_assign(const float *x, int64_t ld, int64_t n, int dsub, const float *cb, int ksub,
+              int32_t *assign);
+int residual(const float *x, const int32_t *assign, const float *centroids, int64_t n, int d,
+             float *dst);
+int pq_encode(const float *x, const int32_t *assign, const float *centroids,
+              const float *codebooks, int64_t n, int d, int m, int ksub, int dsub,
+              uint8_t *codes);
+int pq_lut(const float *xq, int nq, int d, const float *codebooks, int m, int ksub, int dsub,
+           float *lut_out);
+int pq_scan(const float *xq, int nq, int d, const float *codebooks, int m, int ksub, int dsub,
+            const float *coarse_D, const int32_t *coarse_I, int nprobe,
+            const int32_t *list_offsets, const int32_t *ids, const uint8_t *codes, int k,
+            float *D, int64_t *I64, int32_t *I32);
+int scanned_count(const int32_t *coarse_I, int64_t n, const int32_t *list_offsets,
+                  unsigned long long *out_dev);
+
+}  // namespace asl

@@ -1,0 +1,328 @@
+// search.hip -- one batch of the open-modification hot path, device resident:
+// SpectralLibrary._search_batch / _get_library_candidates
+// (/root/reference/src/ann_solo/spectral_library.py:328-455).
+//
+//   encode (spectrum.py:166-214)  ->  index.search(k) (:443-444)
+//   -> precursor-window post-filter (:417-429 AND :441-446)  ->  best match (:356-365)
+//
+// The reference builds two dense nq x N boolean masks; here the ANN ids are
+// post-filtered in place ([nq,k] int32, -1 = rejected) and the window-only modes
+// (cascade level 'std', --mode bf) binary-search a precursor-sorted copy of the
+// library, so nothing is O(nq*N).
+#include <algorithm>
+
+#include "common.hpp"
+#include "ivf_kernels.hpp"
+
+namespace asl {
+int encode_device(const float *mz, const float *inten, const int32_t *offsets, int32_t n,
+                  double min_bound, double bin_size, int32_t hash_len, uint32_t seed,
+                  int norm, float *out);
+int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
+                        int64_t *I64, int32_t *I32);
+int index_dim(const asl_index *ix);
+int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
+                   const int32_t *rows32, const int32_t *cand_offsets, int32_t stride,
+                   int64_t total_slots, double tol, int allow_shift, int tie_by_row,
+                   double *pair_score, long long *best_slot, int32_t *best_cand,
+                   int32_t *best_row, double *best_score, int32_t *n_valid,
+                   int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride, int *status);
+int rescore_check_status(const int *status_dev);
+
+// spectral_library.py:421-427 (numexpr evaluates in float64)
+__device__ __forceinline__ bool precursor_ok(double q, float lib, int charge, double tol,
+                                             int mode) {
+  const double l = (double)lib;
+  if (mode == ASL_TOL_DA) return fabs(q - l) * (double)charge <= tol;
+  return fabs(q - l) / l * 1000000.0 <= tol;
+}
+
+__global__ void precursor_filter_kernel(const int32_t *__restrict__ knn, int64_t total, int k,
+                                        const double *__restrict__ q_pmz,
+                                        const float *__restrict__ lib_pmz,
+                                        const uint8_t *__restrict__ valid, int charge,
+                                        double tol, int mode, int32_t *__restrict__ cand) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int32_t row = knn[t];
+  int32_t out = -1;
+  if (row >= 0 && (!valid || valid[row]) &&
+      precursor_ok(q_pmz[t / k], lib_pmz[row], charge, tol, mode))
+    out = row;
+  cand[t] = out;
+}
+
+// Window [lo,hi) of each query inside the precursor-sorted library.
+__global__ void window_range_kernel(const double *__restrict__ q_pmz, int nq,
+                                    const float *__restrict__ sorted_pmz, int n, int charge,
+                                    double tol, int mode, int32_t *__restrict__ lo_out,
+                                    int32_t *__restrict__ cnt_out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const double qm = q_pmz[q];
+  int a = 0, b = n;  // p0 = first element with (double)l >= qm
+  while (a < b) {
+    const int mid = (a + b) >> 1;
+    if ((double)sorted_pmz[mid] < qm) a = mid + 1; else b = mid;
+  }
+  const int p0 = a;
+  a = 0; b = p0;     // left side: first index whose value passes
+  while (a < b) {
+    const int mid = (a + b) >> 1;
+    if (precursor_ok(qm, sorted_pmz[mid], charge, tol, mode)) b = mid; else a = mid + 1;
+  }
+  const int lo = a;
+  a = p0; b = n;     // right side: first index whose value fails
+  while (a < b) {
+    const int mid = (a + b) >> 1;
+    if (precursor_ok(qm, sorted_pmz[mid], charge, tol, mode)) a = mid + 1; else b = mid;
+  }
+  lo_out[q] = lo;
+  cnt_out[q] = a - lo;
+}
+
+__global__ void window_fill_kernel(const int32_t *__restrict__ lo, const int32_t *__restrict__ offsets,
+                                   const int32_t *__restrict__ sorted_row,
+                                   const uint8_t *__restrict__ valid, int32_t *__restrict__ cand) {
+  const int q = blockIdx.x;
+  const int b = offsets[q], n = offsets[q + 1] - b, l = lo[q];
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int32_t row = sorted_row[l + t];
+    cand[b + t] = (!valid || valid[row]) ? row : -1;
+  }
+}
+
+}  // namespace asl
+
+using namespace asl;
+
+struct asl_library {
+  int64_t n = 0;
+  DevBuf<int32_t> offsets, pcharge;
+  DevBuf<float> mz, intensity, pmz32;
+  DevBuf<uint8_t> charge, valid;
+  DevBuf<double> pmz;
+  bool has_valid = false;
+  DevPeaks dev;
+  // precursor-sorted view (window search)
+  DevBuf<float> sorted_pmz;
+  DevBuf<int32_t> sorted_row;
+  // scratch
+  DevBuf<float> qvec;
+  DevBuf<int32_t> knn, cand, lo, cnt, woff;
+  DevBuf<double> pair_score;
+  DevBuf<long long> best_slot;
+  DevBuf<int> status;
+};
+
+extern "C" {
+
+asl_library_t *asl_library_create(const asl_peaks_t *p, const float *lib_pmz_f32,
+                                  const uint8_t *valid) {
+  clear_error();
+  if (!p || p->n < 0) {
+    fail(ASL_ERR_INVALID, "library_create: null peaks");
+    return nullptr;
+  }
+  if (ensure_device() != ASL_OK) return nullptr;
+  PeaksStage st;
+  if (st.init(p) != ASL_OK) return nullptr;
+  asl_library *L = new asl_library();
+  L->n = p->n;
+  const size_t n = (size_t)p->n, np = (size_t)st.dev.n_peaks;
+  bool ok = true;
+  auto up = [&](auto &buf, const auto *src, size_t cnt) {
+    if (ok && cnt && buf.upload(src, cnt) != ASL_OK) ok = false;
+  };
+  up(L->offsets, st.dev.offsets, n + 1);
+  up(L->mz, st.dev.mz, np);
+  up(L->intensity, st.dev.intensity, np);
+  if (st.dev.charge) {
+    up(L->charge, st.dev.charge, np);
+  } else if (np) {
+    ok = ok && L->charge.reserve(np) == ASL_OK &&
+         hipMemsetAsync(L->charge.p, 0, np, stream()) == hipSuccess;
+  }
+  up(L->pmz, st.dev.precursor_mz, n);
+  up(L->pcharge, st.dev.precursor_charge, n);
+  // float32 precursor column + precursor-sorted view (host side: one-time, O(n log n))
+  std::vector<double> h_pmz(n);
+  std::vector<float> h_pmz32(n);
+  if (ok && n) {
+    ok = hipMemcpyAsync(h_pmz.data(), L->pmz.p, n * 8, hipMemcpyDeviceToHost, stream()) == hipSuccess &&
+         sync_stream() == ASL_OK;
+    if (lib_pmz_f32) {
+      ok = ok && hipMemcpy(h_pmz32.data(), lib_pmz_f32, n * 4, hipMemcpyDefault) == hipSuccess;
+    } else {
+      for (size_t i = 0; i < n; i++) h_pmz32[i] = (float)h_pmz[i];
+    }
+  }
+  up(L->pmz32, h_pmz32.data(), n);
+  if (valid) {
+    up(L->valid, valid, n);
+    L->has_valid = true;
+  }
+  if (ok && n) {
+    std::vector<int32_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int32_t a, int32_t b) { return h_pmz32[(size_t)a] < h_pmz32[(size_t)b]; });
+    std::vector<float> sp(n);
+    for (size_t i = 0; i < n; i++) sp[i] = h_pmz32[(size_t)order[i]];
+    up(L->sorted_pmz, sp.data(), n);
+    up(L->sorted_row, order.data(), n);
+  }
+  if (ok) ok = sync_stream() == ASL_OK;
+  if (!ok) {
+    delete L;
+    if (!*asl_last_error()) fail(ASL_ERR_HIP, "library_create: device upload failed");
+    return nullptr;
+  }
+  L->dev.n = (int32_t)p->n;
+  L->dev.n_peaks = (int64_t)np;
+  L->dev.offsets = L->offsets.p;
+  L->dev.mz = L->mz.p;
+  L->dev.intensity = L->intensity.p;
+  L->dev.charge = L->charge.p;
+  L->dev.precursor_mz = L->pmz.p;
+  L->dev.precursor_charge = L->pcharge.p;
+  return L;
+}
+
+void asl_library_free(asl_library_t *L) { delete L; }
+int64_t asl_library_size(const asl_library_t *L) { return L ? L->n : 0; }
+
+// CSR window candidates on the device: fills L->woff ([nq+1]) and L->cand; total -> *total.
+static int window_candidates_device(asl_library *L, int nq, const double *q_pmz_dev, int charge,
+                                    double tol, int mode, int64_t *total) {
+  ASL_TRY(L->lo.reserve((size_t)nq));
+  ASL_TRY(L->cnt.reserve((size_t)nq));
+  ASL_TRY(L->woff.reserve((size_t)nq + 1));
+  hipLaunchKernelGGL(window_range_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, stream(),
+                     q_pmz_dev, nq, L->sorted_pmz.p, (int)L->n, charge, tol, mode, L->lo.p, L->cnt.p);
+  ASL_CHECK_LAUNCH();
+  std::vector<int32_t> h_cnt((size_t)nq), h_off((size_t)nq + 1, 0);
+  ASL_TRY(L->cnt.download(h_cnt.data(), (size_t)nq));
+  ASL_TRY(sync_stream());
+  int64_t acc = 0;
+  for (int q = 0; q < nq; q++) {
+    h_off[(size_t)q] = (int32_t)acc;
+    acc += h_cnt[(size_t)q];
+    if (acc > 0x7fffffffLL)
+      return fail(ASL_ERR_CAPACITY, "window: more than 2^31-1 candidate pairs in one batch; "
+                                    "use a smaller batch_size for brute-force open search");
+  }
+  h_off[(size_t)nq] = (int32_t)acc;
+  *total = acc;
+  ASL_TRY(L->woff.upload(h_off.data(), (size_t)nq + 1));
+  ASL_TRY(L->cand.reserve((size_t)std::max<int64_t>(acc, 1)));
+  hipLaunchKernelGGL(window_fill_kernel, dim3(nq), dim3(256), 0, stream(), L->lo.p, L->woff.p,
+                     L->sorted_row.p, L->has_valid ? L->valid.p : nullptr, L->cand.p);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+int asl_window_candidates(asl_library_t *L, int32_t nq, const double *query_pmz, int32_t charge,
+                          double tol, int32_t mode, int32_t *cand_offsets, int64_t *cand_rows) {
+  clear_error();
+  if (!L || nq < 0 || !cand_offsets) return fail(ASL_ERR_INVALID, "window_candidates: bad arguments");
+  if (nq == 0) {
+    cand_offsets[0] = 0;
+    return ASL_OK;
+  }
+  In<double> dq;
+  ASL_TRY(dq.init(query_pmz, (size_t)nq));
+  int64_t total = 0;
+  ASL_TRY(window_candidates_device(L, nq, dq.d, charge, tol, mode, &total));
+  std::vector<int32_t> h_off((size_t)nq + 1), h_cand((size_t)total);
+  ASL_TRY(L->woff.download(h_off.data(), (size_t)nq + 1));
+  if (total) ASL_TRY(L->cand.download(h_cand.data(), (size_t)total));
+  ASL_TRY(sync_stream());
+  // compact invalid rows, ascending row order inside each list (spectral_library.py:451)
+  std::vector<int32_t> out_off((size_t)nq + 1, 0);
+  std::vector<int64_t> rows;
+  rows.reserve((size_t)total);
+  for (int q = 0; q < nq; q++) {
+    const size_t b = rows.size();
+    for (int32_t t = h_off[(size_t)q]; t < h_off[(size_t)q + 1]; t++)
+      if (h_cand[(size_t)t] >= 0) rows.push_back(h_cand[(size_t)t]);
+    std::sort(rows.begin() + (long)b, rows.end());
+    out_off[(size_t)q + 1] = (int32_t)rows.size();
+  }
+  HIP_TRY(hipMemcpy(cand_offsets, out_off.data(), ((size_t)nq + 1) * 4, hipMemcpyDefault));
+  if (cand_rows && !rows.empty())
+    HIP_TRY(hipMemcpy(cand_rows, rows.data(), rows.size() * 8, hipMemcpyDefault));
+  return ASL_OK;
+}
+
+int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *queries,
+                     const asl_search_params_t *P, int32_t *best_row, double *best_score,
+                     int32_t *n_cand, int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride,
+                     int64_t *knn_I) {
+  clear_error();
+  if (!L || !queries || !P) return fail(ASL_ERR_INVALID, "search_batch: null argument");
+  const int nq = queries->n;
+  if (nq == 0) return ASL_OK;
+  if (pm_pairs && pm_stride <= 0) return fail(ASL_ERR_INVALID, "search_batch: pm_stride");
+  if (P->use_ann && !idx) return fail(ASL_ERR_INVALID, "search_batch: use_ann needs an index");
+  ASL_TRY(ensure_device());
+  PeaksStage Q;
+  ASL_TRY(Q.init(queries));
+  Out<int32_t> o_row, o_ncand, o_cnt;
+  Out<double> o_score;
+  Out<uint32_t> o_pairs;
+  Out<int64_t> o_knn;
+  ASL_TRY(o_row.init(best_row, nq));
+  ASL_TRY(o_score.init(best_score, nq));
+  ASL_TRY(o_ncand.init(n_cand, nq));
+  ASL_TRY(o_cnt.init(pm_count, nq));
+  ASL_TRY(o_pairs.init(pm_pairs, (size_t)nq * (pm_pairs ? pm_stride : 0) * 2));
+  ASL_TRY(L->best_slot.reserve((size_t)nq));
+  ASL_TRY(L->status.reserve(1));
+  if (P->use_ann) {
+    const int d = index_dim(idx), k = P->k;
+    if (k <= 0) return fail(ASL_ERR_INVALID, "search_batch: k must be positive");
+    ASL_TRY(o_knn.init(knn_I, (size_t)nq * k));
+    ASL_TRY(L->qvec.reserve((size_t)nq * d));
+    ASL_TRY(L->knn.reserve((size_t)nq * k));
+    ASL_TRY(L->cand.reserve((size_t)nq * k));
+    ASL_TRY(L->pair_score.reserve((size_t)nq * k));
+    ASL_TRY(encode_device(Q.dev.mz, Q.dev.intensity, Q.dev.offsets, nq, P->min_bound, P->bin_size,
+                          d, P->hash_seed, 1, L->qvec.p));
+    ASL_TRY(index_search_device(idx, nq, L->qvec.p, k, P->nprobe, nullptr, o_knn.d, L->knn.p));
+    {
+      ProfScope ps("filter");
+      const int64_t total = (int64_t)nq * k;
+      hipLaunchKernelGGL(precursor_filter_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
+                         stream(), L->knn.p, total, k, Q.dev.precursor_mz, L->pmz32.p,
+                         L->has_valid ? L->valid.p : nullptr, P->charge, P->precursor_tol,
+                         P->precursor_mode, L->cand.p);
+      ASL_CHECK_LAUNCH();
+    }
+    ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->cand.p, nullptr, k, (int64_t)nq * k,
+                           P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
+                           L->best_slot.p, nullptr, o_row.d, o_score.d, o_ncand.d, o_cnt.d,
+                           o_pairs.d, pm_stride, L->status.p));
+  } else {
+    int64_t total = 0;
+    {
+      ProfScope ps("filter");
+      ASL_TRY(window_candidates_device(L, nq, Q.dev.precursor_mz, P->charge, P->precursor_tol,
+                                       P->precursor_mode, &total));
+    }
+    ASL_TRY(L->pair_score.reserve((size_t)std::max<int64_t>(total, 1)));
+    ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->cand.p, L->woff.p, 0, total,
+                           P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
+                           L->best_slot.p, nullptr, o_row.d, o_score.d, o_ncand.d, o_cnt.d,
+                           o_pairs.d, pm_stride, L->status.p));
+  }
+  ASL_TRY(o_row.finish());
+  ASL_TRY(o_score.finish());
+  ASL_TRY(o_ncand.finish());
+  ASL_TRY(o_cnt.finish());
+  ASL_TRY(o_pairs.finish());
+  ASL_TRY(o_knn.finish());
+  return rescore_check_status(L->status.p);  // synchronises the stream
+}
+
+}  // extern "C"

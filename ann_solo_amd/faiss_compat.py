@@ -1,0 +1,224 @@
+"""FAISS-shaped facade over the hand-written gfx950 IVF index (``asl_index_*``).
+
+Covers exactly the FAISS surface the reference touches
+(/root/reference/src/ann_solo/spectral_library.py:73-87,167-181,191,443-445,487-497):
+``IndexFlatIP``, ``IndexIVFFlat``, ``METRIC_INNER_PRODUCT``, ``train``, ``add``,
+``search``, ``nprobe``, ``reset``, ``write_index``/``read_index``, ``get_num_gpus``,
+``StandardGpuResources``, ``GpuClonerOptions``, ``index_cpu_to_gpu``/``setNumProbes`` --
+plus ``IndexIVFPQ`` (the north star's addition). ``import ann_solo_amd.faiss_compat as
+faiss`` is the whole change at those call sites. Indexes always live on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+METRIC_INNER_PRODUCT = 0
+METRIC_L2 = 1
+_KIND_FLAT, _KIND_IVFFLAT, _KIND_IVFPQ = 0, 1, 2
+DEFAULT_SEED = 1234          # FAISS ClusteringParameters.seed
+
+
+def get_num_gpus() -> int:
+    return _lib.lib().asl_get_num_gpus()
+
+
+class StandardGpuResources:
+    """Placeholder: device memory is managed inside libannsolo_mi."""
+
+
+class GpuClonerOptions:
+    useFloat16 = False
+
+
+def _as_f32(x, d):
+    if isinstance(x, np.ndarray):
+        x = np.ascontiguousarray(x, np.float32)
+    elif x.dtype.is_floating_point and str(x.dtype) != 'torch.float32':
+        x = x.float()
+    if x.ndim != 2 or x.shape[1] != d:
+        raise ValueError(f'expected an [n, {d}] float32 matrix')
+    return x if isinstance(x, np.ndarray) else x.contiguous()
+
+
+class Index:
+    def __init__(self, handle, d):
+        if not handle:
+            _lib.check(-1 if not _lib.lib().asl_last_error() else -3)
+        self._h = C.c_void_p(handle)
+        self.d = d
+        self.nprobe = 1
+        self.seed = DEFAULT_SEED
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                _lib.lib().asl_index_free(h)
+            except Exception:
+                pass
+
+    @property
+    def ntotal(self) -> int:
+        return _lib.lib().asl_index_ntotal(self._h)
+
+    @property
+    def is_trained(self) -> bool:
+        return bool(_lib.lib().asl_index_is_trained(self._h))
+
+    def info(self):
+        i = _lib.AslIndexInfo()
+        _lib.check(_lib.lib().asl_index_info(self._h, C.byref(i)))
+        return i
+
+    def set_niter(self, niter: int):
+        _lib.check(_lib.lib().asl_index_set_niter(self._h, int(niter)))
+
+    def train(self, x):
+        x = _as_f32(x, self.d)
+        _lib.check(_lib.lib().asl_index_train(self._h, x.shape[0], _lib.ptr(x), self.seed))
+
+    def add(self, x):
+        x = _as_f32(x, self.d)
+        _lib.check(_lib.lib().asl_index_add(self._h, x.shape[0], _lib.ptr(x)))
+
+    def search(self, x, k, D=None, I=None):
+        """(D float32[nq,k], I int64[nq,k]); rows by (score desc, id asc), -1 padded.
+        numpy in -> numpy out; pass torch device tensors for ``x``/``D``/``I`` to stay in HBM."""
+        x = _as_f32(x, self.d)
+        nq = x.shape[0]
+        if D is None and I is None:
+            if isinstance(x, np.ndarray):
+                D = np.empty((nq, k), np.float32)
+                I = np.empty((nq, k), np.int64)
+            else:
+                import torch
+                D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+                I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+        _lib.check(_lib.lib().asl_index_search(self._h, nq, _lib.ptr(x), int(k), int(self.nprobe),
+                                               _lib.ptr(D), _lib.ptr(I)))
+        return D, I
+
+    def reset(self):
+        _lib.check(_lib.lib().asl_index_reset(self._h))
+
+    def setNumProbes(self, nprobe: int):      # GpuIndexIVF spelling (spectral_library.py:495)
+        self.nprobe = int(nprobe)
+
+    # ---- introspection / sharding (not part of FAISS) ----
+    def centroids(self):
+        i = self.info()
+        out = np.empty((i.nlist, i.d), np.float32)
+        _lib.check(_lib.lib().asl_index_get_centroids(self._h, _lib.ptr(out)))
+        return out
+
+    def codebooks(self):
+        i = self.info()
+        out = np.empty((i.pq_m, i.pq_ksub, i.pq_dsub), np.float32)
+        _lib.check(_lib.lib().asl_index_get_codebooks(self._h, _lib.ptr(out)))
+        return out
+
+    def set_trained(self, centroids, codebooks=None):
+        c = np.ascontiguousarray(centroids, np.float32)
+        cb = None if codebooks is None else np.ascontiguousarray(codebooks, np.float32)
+        _lib.check(_lib.lib().asl_index_set_trained(self._h, _lib.ptr(c), _lib.ptr(cb)))
+
+    def lists(self):
+        """(list_offsets[nlist+1], ids[nlocal], payload) in inverted-list order."""
+        i = self.info()
+        off = np.empty(i.nlist + 1, np.int32)
+        ids = np.empty(i.nlocal, np.int32)
+        codes = vecs = None
+        if i.kind == _KIND_IVFPQ:
+            codes = np.empty((i.nlocal, i.pq_m), np.uint8)
+        else:
+            vecs = np.empty((i.nlocal, i.d), np.float32)
+        _lib.check(_lib.lib().asl_index_get_lists(self._h, _lib.ptr(off), _lib.ptr(ids),
+                                                  _lib.ptr(codes), _lib.ptr(vecs)))
+        return off, ids, codes if codes is not None else vecs
+
+    def coarse(self, x, nprobe):
+        x = _as_f32(x, self.d)
+        nprobe = min(nprobe, self.info().nlist)
+        D = np.empty((x.shape[0], nprobe), np.float32)
+        I = np.empty((x.shape[0], nprobe), np.int32)
+        _lib.check(_lib.lib().asl_index_coarse(self._h, x.shape[0], _lib.ptr(x), nprobe,
+                                               _lib.ptr(D), _lib.ptr(I)))
+        return D, I
+
+    def pq_lut(self, x):
+        x = _as_f32(x, self.d)
+        i = self.info()
+        lut = np.empty((x.shape[0], i.pq_m, i.pq_ksub), np.float32)
+        _lib.check(_lib.lib().asl_index_pq_lut(self._h, x.shape[0], _lib.ptr(x), _lib.ptr(lut)))
+        return lut
+
+    def shard(self, rank: int, world: int):
+        _lib.check(_lib.lib().asl_index_shard(self._h, int(rank), int(world)))
+
+    def shard_map(self, world: int):
+        owner = np.empty(self.info().nlist, np.int32)
+        _lib.check(_lib.lib().asl_index_shard_map(self._h, int(world), _lib.ptr(owner)))
+        return owner
+
+
+class IndexFlatIP(Index):
+    def __init__(self, d):
+        super().__init__(_lib.lib().asl_index_create(d, 0, _KIND_FLAT, 0, 0), d)
+
+
+class IndexIVFFlat(Index):
+    def __init__(self, quantizer, d, nlist, metric=METRIC_INNER_PRODUCT):
+        if metric != METRIC_INNER_PRODUCT:
+            raise ValueError('only METRIC_INNER_PRODUCT is implemented (the reference uses no other)')
+        self.quantizer = quantizer
+        self.nlist = nlist
+        super().__init__(_lib.lib().asl_index_create(d, nlist, _KIND_IVFFLAT, 0, 0), d)
+
+
+class IndexIVFPQ(Index):
+    def __init__(self, quantizer, d, nlist, m, nbits=8, metric=METRIC_INNER_PRODUCT):
+        if metric != METRIC_INNER_PRODUCT:
+            raise ValueError('only METRIC_INNER_PRODUCT is implemented')
+        self.quantizer = quantizer
+        self.nlist = nlist
+        super().__init__(_lib.lib().asl_index_create(d, nlist, _KIND_IVFPQ, m, nbits), d)
+
+
+def write_index(index: Index, path: str):
+    _lib.check(_lib.lib().asl_index_save(index._h, str(path).encode()))
+
+
+def read_index(path: str) -> Index:
+    h = _lib.lib().asl_index_load(str(path).encode())
+    if not h:
+        _lib.check(-5)
+    idx = Index.__new__(Index)
+    Index.__init__(idx, h, 0)
+    idx.d = idx.info().d
+    return idx
+
+
+def index_cpu_to_gpu(res, device, index, co=None):
+    """Indexes of this library are GPU-resident already; kept for call-site parity
+    (spectral_library.py:494)."""
+    return index
+
+
+def topk_merge(Ds, Is):
+    """Merge per-shard results [S,nq,k] -> [nq,k] (numpy or torch device tensors)."""
+    S, nq, k = Ds.shape
+    if isinstance(Ds, np.ndarray):
+        Ds = np.ascontiguousarray(Ds, np.float32)
+        Is = np.ascontiguousarray(Is, np.int64)
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+    else:
+        import torch
+        Ds, Is = Ds.contiguous(), Is.contiguous()
+        D = torch.empty((nq, k), dtype=torch.float32, device=Ds.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=Ds.device)
+    _lib.check(_lib.lib().asl_topk_merge(S, nq, k, _lib.ptr(Ds), _lib.ptr(Is), _lib.ptr(D),
+                                         _lib.ptr(I)))
+    return D, I

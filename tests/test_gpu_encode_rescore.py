@@ -138,7 +138,7 @@ def test_get_best_match_dropin(O, golden):
             self.mz, self.intensity, self.precursor_mz, self.precursor_charge = mz, inten, pmz, z
             self.annotation = [None] * len(mz)
     q = Spec(k['partial_match_q_mz'], k['partial_match_q_intensity'], 453.75, 2)
-    c0 = Spec(k['no_match_l_mz'], k['no_match_l_intensity'], 453.75, 2)
+    c0 = Spec(k['all_match_l_mz'], k['all_match_l_intensity'], 453.75, 2)
     c1 = Spec(k['partial_match_l_mz'], k['partial_match_l_intensity'], 453.75, 2)
     cand, score, pm = spectrum_match.get_best_match(q, [c0, c1], 0.02, True)
     assert cand is c1
