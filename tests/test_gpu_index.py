@@ -1,0 +1,259 @@
+"""GPU parity of the hand-written IVF index (through the C ABI / faiss_compat) against
+the oracle's restatement of the FAISS definitions. Integer / index work is bit-exact:
+identical probe lists, identical codes, identical id sets, identical fp32 scores."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NITER = 6
+SEED = 1234
+
+
+@pytest.fixture(scope='module')
+def vecs(O):
+    from ann_solo_amd import synthetic
+    lib, aux = synthetic.make_library(4000, seed=31, device='cpu')
+    q, truth = synthetic.make_queries(lib, aux, 256, seed=32)
+    o, mz, inten, *_ = lib.numpy()
+    xb = O.encode_batch(mz, inten, o, 10.96, 0.04, 800)
+    o, mz, inten, *_ = q.numpy()
+    xq = O.encode_batch(mz, inten, o, 10.96, 0.04, 800)
+    return xb, xq
+
+
+@pytest.fixture(scope='module')
+def trained(O, vecs):
+    """Oracle-side quantisers (k-means + PQ) shared by several tests."""
+    xb, _ = vecs
+    cen = O.kmeans(xb, 16, NITER, SEED, 0, 256)
+    cb = O.pq_train(xb, cen, 32, 256, NITER, SEED + 7)
+    return cen, cb
+
+
+def test_flat_search_exact(O, vecs):
+    from ann_solo_amd import faiss_compat as faiss
+    xb, xq = vecs
+    idx = faiss.IndexFlatIP(800)
+    idx.add(xb)
+    assert idx.ntotal == len(xb) and idx.is_trained
+    for k in (1, 10, 1024):
+        D, I = idx.search(xq, k)
+        Do, Io = O.flat_search(xb, xq, k)
+        assert np.array_equal(I, Io)
+        assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))   # fmaf chain == MFMA chain
+
+
+def test_gemm_odd_shapes(O):
+    """K not a multiple of 4/16, M/N not multiples of the 128 tile; k > n padding."""
+    from ann_solo_amd import faiss_compat as faiss
+    rng = np.random.default_rng(0)
+    for n, d, nq in ((300, 50, 7), (129, 37, 130), (5, 3, 1)):
+        xb = rng.standard_normal((n, d)).astype(np.float32)
+        xq = rng.standard_normal((nq, d)).astype(np.float32)
+        idx = faiss.IndexFlatIP(d)
+        idx.add(xb)
+        k = min(n + 3, 40)
+        D, I = idx.search(xq, k)
+        Do, Io = O.flat_search(xb, xq, k)
+        assert np.array_equal(I, Io)
+        assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+        if k > n:
+            assert (I[:, n:] == -1).all()
+
+
+def test_kmeans_bit_exact(O, vecs, trained):
+    from ann_solo_amd import faiss_compat as faiss
+    xb, _ = vecs
+    cen, _ = trained
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16, faiss.METRIC_INNER_PRODUCT)
+    idx.set_niter(NITER)
+    idx.seed = SEED
+    assert not idx.is_trained
+    idx.train(xb)
+    assert idx.is_trained
+    assert np.array_equal(idx.centroids().view(np.uint32), cen.view(np.uint32))
+
+
+def test_kmeans_subsample_and_empty_clusters(O):
+    """n > 256*k triggers the permutation subsample; duplicated points force the
+    empty-cluster split."""
+    from ann_solo_amd import faiss_compat as faiss
+    rng = np.random.default_rng(5)
+    base = rng.random((6, 32)).astype(np.float32)
+    x = np.repeat(base, 400, axis=0)               # 2400 points, 6 distinct
+    x += (rng.random(x.shape) < 0.01).astype(np.float32) * 0.001
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(32), 32, 8)
+    idx.set_niter(4)
+    idx.train(x)
+    cen = O.kmeans(x, 8, 4, SEED, 0, 256)
+    assert np.array_equal(idx.centroids().view(np.uint32), cen.view(np.uint32))
+
+
+def test_pq_train_and_encode_bit_exact(O, vecs, trained):
+    from ann_solo_amd import faiss_compat as faiss
+    xb, _ = vecs
+    cen, cb = trained
+    idx = faiss.IndexIVFPQ(faiss.IndexFlatIP(800), 800, 16, 32, 8)
+    idx.set_niter(NITER)
+    idx.seed = SEED
+    idx.train(xb)
+    assert np.array_equal(idx.centroids().view(np.uint32), cen.view(np.uint32))
+    assert np.array_equal(idx.codebooks().view(np.uint32), cb.view(np.uint32))
+    idx.add(xb[:2500])
+    idx.add(xb[2500:])                              # two add() calls: ids keep add order
+    a = O.assign(xb, cen, 0)
+    codes = O.pq_encode(xb, cen, a, cb)
+    ivf = O.HostIVF(cen, a, codes, cb)
+    off, ids, got_codes = idx.lists()
+    assert np.array_equal(off, ivf.list_offsets)
+    assert np.array_equal(ids, ivf.ids)
+    assert np.array_equal(got_codes, ivf.payload)
+
+
+@pytest.fixture(scope='module')
+def pq_index(O, vecs, trained):
+    from ann_solo_amd import faiss_compat as faiss
+    xb, _ = vecs
+    cen, cb = trained
+    idx = faiss.IndexIVFPQ(faiss.IndexFlatIP(800), 800, 16, 32, 8)
+    idx.set_trained(cen, cb)
+    idx.add(xb)
+    a = O.assign(xb, cen, 0)
+    ivf = O.HostIVF(cen, a, O.pq_encode(xb, cen, a, cb), cb)
+    return idx, ivf
+
+
+def test_coarse_and_lut_bit_exact(O, vecs, pq_index):
+    _, xq = vecs
+    idx, ivf = pq_index
+    for nprobe in (1, 4, 16, 99):
+        D, I = idx.coarse(xq, nprobe)
+        Do, Io = O.coarse(xq, ivf.centroids, min(nprobe, 16))
+        assert np.array_equal(I, Io)
+        assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    lut = idx.pq_lut(xq[:8])
+    for i in range(8):
+        assert np.array_equal(lut[i].view(np.uint32), O.pq_lut(xq[i], ivf.codebooks).view(np.uint32))
+
+
+def test_ivfpq_search_identical_to_oracle(O, vecs, pq_index):
+    _, xq = vecs
+    idx, ivf = pq_index
+    for k, nprobe in ((1024, 8), (100, 4), (1, 1), (1024, 16), (2048, 16)):
+        idx.nprobe = nprobe
+        D, I = idx.search(xq, k)
+        Do, Io = ivf.search(xq, k, nprobe)
+        assert np.array_equal(I, Io), (k, nprobe)
+        assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    # rows are sorted by (score desc, id asc) and padded with -1
+    idx.nprobe = 1
+    D, I = idx.search(xq, 1024)
+    assert (I == -1).any()
+    valid = I >= 0
+    assert all((np.diff(D[r][valid[r]]) <= 0).all() for r in range(len(xq)))
+
+
+def test_ivfpq_recall_against_exact(O, vecs, pq_index):
+    """Behavioural check (the only reference-derived one at the FAISS boundary): the
+    IVF-PQ candidates overlap the exact inner-product neighbours."""
+    xb, xq = vecs
+    idx, _ = pq_index
+    idx.nprobe = 16
+    _, I = idx.search(xq, 100)
+    _, Ie = O.flat_search(xb, xq, 100)
+    recall = np.mean([len(set(I[r]) & set(Ie[r])) / 100 for r in range(len(xq))])
+    assert recall > 0.5, recall
+
+
+def test_ivfflat_search_identical_to_oracle(O, vecs, trained):
+    from ann_solo_amd import faiss_compat as faiss
+    xb, xq = vecs
+    cen, _ = trained
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    idx.set_trained(cen)
+    idx.add(xb)
+    a = O.assign(xb, cen, 0)
+    ivf = O.HostIVF(cen, a, xb)
+    off, ids, v = idx.lists()
+    assert np.array_equal(off, ivf.list_offsets) and np.array_equal(ids, ivf.ids)
+    assert np.array_equal(v, ivf.payload)
+    for k, nprobe in ((1024, 8), (10, 2), (1024, 16)):
+        idx.nprobe = nprobe
+        D, I = idx.search(xq, k)
+        Do, Io = ivf.search(xq, k, nprobe)
+        assert np.array_equal(I, Io)
+        assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    # nprobe == nlist is exact search
+    idx.nprobe = 16
+    _, I = idx.search(xq, 50)
+    assert np.array_equal(I, O.flat_search(xb, xq, 50)[1])
+
+
+def test_sharded_search_merges_to_unsharded(O, vecs, trained):
+    from ann_solo_amd import faiss_compat as faiss
+    xb, xq = vecs
+    cen, cb = trained
+    for kind in ('pq', 'flat'):
+        def make():
+            if kind == 'pq':
+                ix = faiss.IndexIVFPQ(faiss.IndexFlatIP(800), 800, 16, 32, 8)
+                ix.set_trained(cen, cb)
+            else:
+                ix = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+                ix.set_trained(cen)
+            ix.add(xb)
+            ix.nprobe = 8
+            return ix
+        full = make()
+        D, I = full.search(xq, 1024)
+        owner = full.shard_map(3)
+        assert set(owner.tolist()) == {0, 1, 2}
+        parts = []
+        for r in range(3):
+            sh = make()
+            sh.shard(r, 3)
+            assert sh.ntotal == len(xb) and sh.info().nlocal < len(xb)
+            parts.append(sh.search(xq, 1024))
+        Ds = np.stack([p[0] for p in parts])
+        Is = np.stack([p[1] for p in parts])
+        Dm, Im = faiss.topk_merge(Ds, Is)
+        assert np.array_equal(Im, I) and np.array_equal(Dm.view(np.uint32), D.view(np.uint32))
+        Do, Io = O.topk_merge(Ds, Is)
+        assert np.array_equal(Im, Io)
+
+
+def test_save_load_roundtrip(tmp_path, vecs, pq_index):
+    from ann_solo_amd import faiss_compat as faiss
+    _, xq = vecs
+    idx, _ = pq_index
+    idx.nprobe = 8
+    D, I = idx.search(xq, 200)
+    p = os.path.join(tmp_path, 'lib_abc1234_2.idxann')
+    faiss.write_index(idx, p)
+    idx2 = faiss.read_index(p)
+    idx2.nprobe = 8
+    assert idx2.ntotal == idx.ntotal and idx2.d == 800 and idx2.is_trained
+    D2, I2 = idx2.search(xq, 200)
+    assert np.array_equal(I, I2) and np.array_equal(D, D2)
+    idx2.reset()
+    assert idx2.ntotal == 0
+    with pytest.raises(Exception):
+        faiss.read_index(os.path.join(tmp_path, 'missing.idxann'))
+
+
+def test_error_behaviour(vecs):
+    from ann_solo_amd import faiss_compat as faiss
+    from ann_solo_amd._lib import AnnSoloMiError
+    xb, xq = vecs
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    with pytest.raises(AnnSoloMiError):
+        idx.add(xb)                      # not trained
+    with pytest.raises(AnnSoloMiError):
+        idx.search(xq, 10)
+    with pytest.raises(AnnSoloMiError):
+        idx.train(xb[:5])                # fewer points than lists
+    with pytest.raises(ValueError):
+        idx.train(xb[:, :10])
