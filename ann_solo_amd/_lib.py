@@ -57,6 +57,7 @@ EXPORTS = [
     'asl_index_pq_lut', 'asl_rescore_batch', 'asl_library_create', 'asl_library_free',
     'asl_library_size', 'asl_search_batch', 'asl_window_candidates', 'asl_profile_enable',
     'asl_profile_reset', 'asl_profile_get', 'asl_profile_scanned_vectors',
+    'asl_rescore_knn', 'asl_lpt_owner',
 ]
 
 
@@ -134,6 +135,10 @@ def lib():
                                        C.POINTER(AslSearchParams), C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p]
+        L.asl_rescore_knn.argtypes = [C.c_void_p, C.POINTER(AslPeaks),
+                                      C.POINTER(AslSearchParams), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.asl_lpt_owner.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         L.asl_window_candidates.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                             C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
         L.asl_set_stream.argtypes = [C.c_void_p]

@@ -86,6 +86,7 @@ ProfScope::~ProfScope() {
   o.first->launches++;
   if (slot == (int)g_open.size() - 1) g_open.pop_back();
 }
+bool prof_enabled() { return g_prof_on; }
 void prof_add_scanned(int64_t v) {
   if (g_prof_on) g_scanned += v;
 }

@@ -143,6 +143,7 @@ struct ProfScope {
   ~ProfScope();
 };
 void prof_add_scanned(int64_t vectors);
+bool prof_enabled();
 
 // Device copy of a packed spectra set (pointers are device pointers).
 struct DevPeaks {

@@ -299,7 +299,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       words = (ix->nlist + 31) / 32;
       ASL_TRY(ix->bitmap.reserve((size_t)nq * words));
       ASL_TRY(probe_bitmap(ix->coarse_I.p, nq, nprobe, ix->bitmap.p, words));
-      if (n > 0) {
+      if (n > 0 && prof_enabled()) {
         ASL_TRY(ix->ws_count.reserve(1));
         // algorithmic work: vectors in probed lists (needs list sizes)
         ASL_TRY(build_lists(ix));
@@ -336,7 +336,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
                     ix->coarse_I.p, nprobe, ix->list_offsets.p, ix->ids.p, ix->codes.p, k, D,
                     I64, I32));
   }
-  {
+  if (prof_enabled()) {
     ASL_TRY(ix->ws_count.reserve(1));
     ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, ix->ws_count.p));
     unsigned long long sc = 0;
@@ -577,6 +577,17 @@ static int list_sizes(asl_index *ix, std::vector<int32_t> &h_vlist, std::vector<
   }
   sizes.assign((size_t)ix->nlist, 0);
   for (int64_t i = 0; i < n; i++) sizes[(size_t)h_vlist[(size_t)i]]++;
+  return ASL_OK;
+}
+
+int asl_lpt_owner(int32_t nlist, const int64_t *sizes, int32_t world, int32_t *owner_out) {
+  clear_error();
+  if (nlist < 0 || world <= 0 || (nlist && (!sizes || !owner_out)))
+    return fail(ASL_ERR_INVALID, "lpt_owner: bad arguments");
+  std::vector<int64_t> sz(sizes, sizes + nlist);
+  std::vector<int32_t> owner;
+  lpt_owner(sz, world, owner);
+  if (nlist) memcpy(owner_out, owner.data(), owner.size() * 4);
   return ASL_OK;
 }
 

@@ -52,6 +52,22 @@ __global__ void precursor_filter_kernel(const int32_t *__restrict__ knn, int64_t
   cand[t] = out;
 }
 
+__global__ void precursor_filter64_kernel(const int64_t *__restrict__ knn, int64_t total, int k,
+                                          const double *__restrict__ q_pmz,
+                                          const float *__restrict__ lib_pmz,
+                                          const uint8_t *__restrict__ valid, int64_t nlib,
+                                          int charge, double tol, int mode,
+                                          int32_t *__restrict__ cand) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t row = knn[t];
+  int32_t out = -1;
+  if (row >= 0 && row < nlib && (!valid || valid[row]) &&
+      precursor_ok(q_pmz[t / k], lib_pmz[row], charge, tol, mode))
+    out = (int32_t)row;
+  cand[t] = out;
+}
+
 // Window [lo,hi) of each query inside the precursor-sorted library.
 __global__ void window_range_kernel(const double *__restrict__ q_pmz, int nq,
                                     const float *__restrict__ sorted_pmz, int n, int charge,
@@ -253,6 +269,53 @@ int asl_window_candidates(asl_library_t *L, int32_t nq, const double *query_pmz,
   if (cand_rows && !rows.empty())
     HIP_TRY(hipMemcpy(cand_rows, rows.data(), rows.size() * 8, hipMemcpyDefault));
   return ASL_OK;
+}
+
+int asl_rescore_knn(asl_library_t *L, const asl_peaks_t *queries, const asl_search_params_t *P,
+                    const int64_t *knn_I, int32_t *best_row, double *best_score,
+                    int32_t *n_cand, int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride) {
+  clear_error();
+  if (!L || !queries || !P || !knn_I) return fail(ASL_ERR_INVALID, "rescore_knn: null argument");
+  const int nq = queries->n, k = P->k;
+  if (nq == 0) return ASL_OK;
+  if (k <= 0) return fail(ASL_ERR_INVALID, "rescore_knn: k must be positive");
+  if (pm_pairs && pm_stride <= 0) return fail(ASL_ERR_INVALID, "rescore_knn: pm_stride");
+  ASL_TRY(ensure_device());
+  PeaksStage Q;
+  ASL_TRY(Q.init(queries));
+  In<int64_t> knn;
+  ASL_TRY(knn.init(knn_I, (size_t)nq * k));
+  Out<int32_t> o_row, o_ncand, o_cnt;
+  Out<double> o_score;
+  Out<uint32_t> o_pairs;
+  ASL_TRY(o_row.init(best_row, nq));
+  ASL_TRY(o_score.init(best_score, nq));
+  ASL_TRY(o_ncand.init(n_cand, nq));
+  ASL_TRY(o_cnt.init(pm_count, nq));
+  ASL_TRY(o_pairs.init(pm_pairs, (size_t)nq * (pm_pairs ? pm_stride : 0) * 2));
+  ASL_TRY(L->best_slot.reserve((size_t)nq));
+  ASL_TRY(L->status.reserve(1));
+  ASL_TRY(L->cand.reserve((size_t)nq * k));
+  ASL_TRY(L->pair_score.reserve((size_t)nq * k));
+  {
+    ProfScope ps("filter");
+    const int64_t total = (int64_t)nq * k;
+    hipLaunchKernelGGL(precursor_filter64_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
+                       stream(), knn.d, total, k, Q.dev.precursor_mz, L->pmz32.p,
+                       L->has_valid ? L->valid.p : nullptr, L->n, P->charge, P->precursor_tol,
+                       P->precursor_mode, L->cand.p);
+    ASL_CHECK_LAUNCH();
+  }
+  ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->cand.p, nullptr, k, (int64_t)nq * k,
+                         P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
+                         L->best_slot.p, nullptr, o_row.d, o_score.d, o_ncand.d, o_cnt.d,
+                         o_pairs.d, pm_stride, L->status.p));
+  ASL_TRY(o_row.finish());
+  ASL_TRY(o_score.finish());
+  ASL_TRY(o_ncand.finish());
+  ASL_TRY(o_cnt.finish());
+  ASL_TRY(o_pairs.finish());
+  return rescore_check_status(L->status.p);
 }
 
 int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *queries,

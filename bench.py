@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Benchmark of the open-modification search hot path on MI355X.
+
+One "step" = one batch of 16 384 same-charge query spectra through the whole hot
+path, device resident: encode (feature hashing) -> IVF-PQ retrieve (coarse GEMM on
+MFMA, ADC scan, top-1024) -> precursor-window post-filter -> (shifted) dot-product
+best match. Workload = BASELINE.json configs[2]: a MassIVE-KB-scale synthetic
+library (2.1 M processed spectra in one precursor-charge partition), IVF-PQ m=32,
+nlist=4096, nprobe=128, k=1024, open window +-500 Da, fragment tolerance 0.02 Da.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+With N>1 the IVF lists are sharded over the ranks (ann_solo_amd/distributed.py) and
+every rank contributes its own 16 384-query slice per step (weak scaling).
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how roofline.achieved
+(algorithmic bytes of the PQ scan / HIP-event kernel time) and cpu_baseline (the
+oracle on the host cores, bounded sample) are defined.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_SCANNED_VECTOR = 36  # 32-B PQ code + 4-B id
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--library-size', type=int, default=2_100_000)
+    ap.add_argument('--batch', type=int, default=16384)
+    ap.add_argument('--nlist', type=int, default=4096)
+    ap.add_argument('--nprobe', type=int, default=128)
+    ap.add_argument('--k', type=int, default=1024)
+    ap.add_argument('--index', default='ivfpq', choices=['ivfpq', 'ivfflat'])
+    ap.add_argument('--pq-m', type=int, default=32)
+    ap.add_argument('--niter', type=int, default=25)
+    ap.add_argument('--open-da', type=float, default=500.0)
+    ap.add_argument('--recall-queries', type=int, default=256)
+    ap.add_argument('--cpu-seconds', type=float, default=20.0,
+                    help='target core-seconds of the CPU baseline sample (0 = skip)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('--gpus N > 1 must be launched with torch.distributed.run '
+                     '(one process per GPU)')
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from ann_solo_amd import _lib, synthetic
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    from ann_solo_amd import faiss_compat as faiss
+    from ann_solo_amd.distributed import HipShardBackend, sharded_search_batch
+
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X (no CPU fallback exists)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    _lib.check(_lib.lib().asl_set_device(local_rank))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    t_build = time.time()
+    charge = 2
+    lib, aux = synthetic.make_library(args.library_size, seed=20240807, device=dev,
+                                      charges=(charge,), charge_p=(1.0,))
+    cfg = Config(num_list=args.nlist, num_probe=args.nprobe, num_candidates=args.k,
+                 index=args.index, pq_m=args.pq_m, kmeans_niter=args.niter, mode='ann',
+                 precursor_tolerance_mass_open=args.open_da, precursor_tolerance_mode_open='Da',
+                 batch_size=args.batch, seed=1234)
+    sl = SpectralLibrary(lib, config=cfg, device=dev)
+    part = sl.partitions[charge]
+    idx = sl._get_ann_index(charge)
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f'[bench] library {lib.n} spectra, {lib.mz.numel()} peaks; index {args.index} '
+            f'nlist={args.nlist} built in {time.time() - t_build:.1f}s')
+
+    # ---- queries: world * batch, identical on every rank, each rank owns one slice
+    q_all, truth = synthetic.make_queries(lib, aux, world * args.batch, seed=42,
+                                          open_range=args.open_da, charge=charge)
+    sl_rows = torch.arange(rank * args.batch, (rank + 1) * args.batch, device=dev)
+    q = q_all.select(sl_rows).contiguous()
+    src_local = truth['source_row'][sl_rows]
+    mod_local = truth['is_modified'][sl_rows]
+
+    # ---- recall@k vs exact inner product (outside the timed region; unsharded index)
+    recall = None
+    if rank == 0 and args.recall_queries > 0:
+        nr = min(args.recall_queries, q.n)
+        qs = q.select(torch.arange(nr, device=dev))
+        r = sl._search_batch(qs, charge, 'open', want_knn=True, device_out=True)
+        vec = sl._encode(part.spectra)
+        flat = faiss.IndexFlatIP(cfg.hash_len)
+        flat.add(vec)
+        del vec
+        _, Ie = flat.search(sl._encode(qs), args.k)
+        del flat
+        knn = r.knn
+        inter = 0
+        for i in range(nr):     # set intersection per query on the device
+            inter += int(torch.isin(knn[i][knn[i] >= 0], Ie[i]).sum())
+        src = src_local[:nr]
+        hit = (knn == src.unsqueeze(1)).any(1)
+        mod = mod_local[:nr]
+        top1 = (r.best_row.to(torch.int64) == src)
+        recall = {'queries': nr, 'k': args.k,
+                  'recall_at_k_vs_exact_ip': inter / float(nr * args.k),
+                  'hit_at_k_source_spectrum': float(hit.float().mean()),
+                  'hit_at_k_modified_only': float(hit[mod].float().mean()) if mod.any() else None,
+                  'top1_is_source_spectrum': float(top1.float().mean())}
+        torch.cuda.empty_cache()
+
+    # ---- shard for N > 1
+    if world > 1:
+        idx.shard(rank, world)
+        backend = HipShardBackend(sl, charge, 'open')
+
+        def step():
+            return sharded_search_batch(backend, q, device_out=True)
+    else:
+        def step():
+            return sl._search_batch(q, charge, 'open', device_out=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    L = _lib.lib()
+    for _ in range(args.warmup):
+        step()
+    L.asl_profile_enable(1)
+    L.asl_profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.asl_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stages = {}
+    for name in ('encode', 'coarse_gemm', 'coarse_select', 'scan', 'filter', 'rescore',
+                 'rescore_matches'):
+        ms, n = C.c_double(), C.c_int64()
+        L.asl_profile_get(name.encode(), C.byref(ms), C.byref(n))
+        stages[name] = {'ms_total': ms.value, 'launches': n.value}
+    scanned = L.asl_profile_scanned_vectors()
+
+    if rank == 0:
+        total_queries = world * args.batch * args.steps
+        scan = stages['scan']
+        roofline = None
+        if scan['launches'] > 0 and scan['ms_total'] > 0:
+            avg_ms = scan['ms_total'] / scan['launches']
+            bytes_per_launch = scanned / scan['launches'] * BYTES_PER_SCANNED_VECTOR
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roofline = {'bound': 'hbm', 'kernel': 'pq_scan_kernel' if args.index == 'ivfpq'
+                        else 'gemm_nt_f32+row_topk (masked IVF-Flat)',
+                        'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                        'avg_launch_ms': round(avg_ms, 4),
+                        'algorithmic_bytes_per_launch': int(bytes_per_launch),
+                        'vectors_scanned_per_query': round(scanned / scan['launches'] /
+                                                           (world * args.batch), 1)}
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            cpu = cpu_baseline(args, sl, part, idx, q, res, charge, cfg)
+        out = {
+            'metric': 'query spectra/sec + recall@k vs brute-force, open-mod search on MassIVE-KB',
+            'value': round(total_queries / elapsed, 2),
+            'unit': 'query spectra/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'configs[2]: MassIVE-KB-scale synthetic library '
+                                   f'({args.library_size} spectra, one charge-{charge} partition), '
+                                   f'{args.index} m={args.pq_m} nlist={args.nlist} nprobe={args.nprobe} '
+                                   f'k={args.k}, open +-{args.open_da:g} Da, shifted dot, '
+                                   f'fragment tol 0.02 Da',
+                       'library_size': args.library_size, 'batch_per_gpu': args.batch,
+                       'global_batch': world * args.batch, 'index': args.index,
+                       'nlist': args.nlist, 'nprobe': args.nprobe, 'k': args.k,
+                       'parallelism': f'ivf-list-shard x{world}' if world > 1 else 'single'},
+            'recall': recall,
+            'stages_ms_per_step': {k: round(v['ms_total'] / args.steps, 3) for k, v in stages.items()},
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, sl, part, idx, q, res, charge, cfg):
+    """The oracle (plain-C port of the reference path, oracle/) on the host cores of this
+    box, on a bounded sample of the SAME batch against the SAME index; doubles as a
+    full-size parity check of the GPU results."""
+    import numpy as np
+    import torch
+    from oracle import oracle_py as O
+    t0 = time.time()
+    Lh = O.Spectra(*part.spectra.to('cpu').numpy())
+    off, ids, payload = idx.lists()
+    info = idx.info()
+    ivf = O.HostIVF.__new__(O.HostIVF)
+    ivf.centroids, ivf.nlist, ivf.d = idx.centroids(), info.nlist, info.d
+    ivf.list_offsets, ivf.ids, ivf.payload = off, ids, payload
+    ivf.codebooks = idx.codebooks() if info.kind == 2 else None
+    ivf.kind = 1 if info.kind == 2 else 0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, O.max_threads()))
+
+    def run(n, threads):
+        qs = q.select(torch.arange(n, device=q.device)).to('cpu')
+        Q = O.Spectra(*qs.numpy())
+        t = time.perf_counter()
+        r = O.search_batch(Q, Lh, part.precursor_mz, charge, ivf, args.k, args.nprobe,
+                           args.open_da, 'Da', cfg.fragment_mz_tolerance, cfg.allow_peak_shifts,
+                           pm_stride=64, nthreads=threads, want_knn=True)
+        return time.perf_counter() - t, r
+    n1 = min(q.n, 64)
+    t1, r1 = run(n1, 1)                       # single core, also calibrates the sample size
+    per_q = t1 / n1
+    n_all = int(min(q.n, max(cores, args.cpu_seconds / max(per_q, 1e-6))))
+    t_all, r_all = run(n_all, cores)
+    best_row = res.best_row[:n_all].cpu().numpy()
+    best_score = res.best_score[:n_all].cpu().numpy()
+    parity = {'queries': n_all,
+              'best_row_equal': bool(np.array_equal(best_row, r_all['best_row'])),
+              'best_score_max_abs_diff': float(np.abs(best_score - r_all['best_score']).max())}
+    log(f'[bench] cpu baseline: {n_all} queries on {cores} threads in {t_all:.2f}s, '
+        f'single core {per_q * 1e3:.2f} ms/query (setup {time.time() - t0:.1f}s)')
+    return {'value': round(n_all / t_all, 2), 'unit': 'query spectra/s', 'cores': cores,
+            'kind': 'port',
+            'sample': f'{n_all} queries of the same batch, same index, all {cores} host threads '
+                      f'(OpenMP over queries)',
+            'single_core_value': round(1.0 / per_q, 2),
+            'single_core_sample': f'{n1} queries, 1 thread',
+            'parity_vs_gpu': parity}
+
+
+if __name__ == '__main__':
+    main()

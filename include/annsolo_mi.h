@@ -113,6 +113,11 @@ int asl_index_shard(asl_index_t *idx, int32_t rank, int32_t world);
 /* list -> owner rank map of the balancing above, for inspection. */
 int asl_index_shard_map(const asl_index_t *idx, int32_t world, int32_t *owner /* [nlist] */);
 
+/* The list -> rank balancing rule by itself (pure host integer code, no device):
+ * lists sorted by size descending (ties: lower list id first), each given to the
+ * currently least-loaded rank (ties: lower rank). */
+int asl_lpt_owner(int32_t nlist, const int64_t *sizes, int32_t world, int32_t *owner);
+
 /* Merge S partial results [S, nq, k] into [nq, k] under (score desc, id asc). */
 int asl_topk_merge(int32_t S, int32_t nq, int32_t k, const float *Ds, const int64_t *Is,
                    float *D, int64_t *I);
@@ -186,6 +191,14 @@ int asl_search_batch(asl_library_t *lib, asl_index_t *idx, const asl_peaks_t *qu
                      const asl_search_params_t *params, int32_t *best_row,
                      double *best_score, int32_t *n_cand, int32_t *pm_count,
                      uint32_t *pm_pairs, int32_t pm_stride, int64_t *knn_I);
+
+/* Same pipeline from the post-filter on, for candidates retrieved elsewhere (the
+ * multi-GPU path: per-shard top-k lists are exchanged and merged first). knn_I is
+ * [nq, k] int64 library rows, -1 padded, as asl_index_search / asl_topk_merge emit. */
+int asl_rescore_knn(asl_library_t *lib, const asl_peaks_t *queries,
+                    const asl_search_params_t *params, const int64_t *knn_I,
+                    int32_t *best_row, double *best_score, int32_t *n_cand,
+                    int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride);
 
 /* Precursor-window candidate generation alone (spectral_library.py:417-429):
  * CSR lists of library rows (ascending) whose precursor passes the window. Two-call
