@@ -1,0 +1,109 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/annsolo_mi.h
+declares; host-only entry points agree with the oracle / golden vectors; compute entry
+points fail loudly without a GPU (no CPU fallback); host-side containers behave."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'annsolo_mi.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(asl_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_every_declared_symbol_is_exported():
+    from ann_solo_amd import _lib
+    L = _lib.lib()
+    names = _declared()
+    assert len(names) >= 40
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) == set(names)
+    assert b'gfx950' in L.asl_version()
+
+
+def test_host_only_entry_points_match_golden(O, golden):
+    from ann_solo_amd import spectrum
+    g = golden('encoder_golden.npz')
+    assert [spectrum.hash_idx(int(b), 800) for b in g['bins']] == g['hashes'].tolist()
+    assert [spectrum.hash_idx(int(b), 64) for b in g['bins']] == g['hashes64'].tolist()
+    for args, want in zip(g['dim_args'], g['dims']):
+        assert spectrum.get_dim(*args) == (int(want[0]), want[1], want[2])
+    assert spectrum.get_dim(11, 2010, 0.04) == (49976, 10.96, 2010.0)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU behaviour')
+def test_no_cpu_fallback():
+    from ann_solo_amd import _lib, spectrum
+    from ann_solo_amd import faiss_compat as faiss
+    assert faiss.get_num_gpus() == 0
+    with pytest.raises(_lib.AnnSoloMiError, match='no HIP device'):
+        spectrum.spectra_to_vectors(np.array([100.0], np.float32), np.array([1.0], np.float32),
+                                    np.array([0, 1], np.int32), 11, 2010, 0.04, 800)
+    with pytest.raises(_lib.AnnSoloMiError):
+        faiss.IndexFlatIP(800)
+
+
+def test_hyperparameter_hash_formula():
+    """spectral_library.py:118-131: sha1 of the JSON of the five index hyper-parameters."""
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    cfg = Config()
+    want = hashlib.sha1(json.dumps({'min_mz': 11, 'max_mz': 2010, 'bin_size': 0.04,
+                                    'hash_len': 800, 'num_list': 256}).encode('utf-8')).hexdigest()
+    sl = SpectralLibrary.__new__(SpectralLibrary)
+    sl.config = cfg
+    assert sl._get_hyperparameter_hash() == want
+    # reference defaults that reach the hot path (config.py:71-216)
+    assert (cfg.num_candidates, cfg.batch_size, cfg.num_list, cfg.num_probe) == (1024, 16384, 256, 128)
+
+
+def test_packed_spectra_select_and_from_spectra():
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.packed import PackedSpectra
+    lib, aux = synthetic.make_library(200, seed=5, device='cpu')
+    rows = torch.tensor([7, 0, 199, 7])
+    sub = lib.select(rows)
+    o, mz, *_ = lib.numpy()
+    so, smz, *_ = sub.numpy()
+    for j, r in enumerate(rows.tolist()):
+        assert np.array_equal(smz[so[j]:so[j + 1]], mz[o[r]:o[r + 1]])
+    assert sub.precursor_mz.tolist() == lib.precursor_mz[rows].tolist()
+
+    class Ann:
+        def __init__(self, c):
+            self.charge = c
+
+    class Spec:
+        pass
+    s = Spec()
+    s.mz, s.intensity = np.array([100., 200.]), np.array([.6, .8])
+    s.precursor_mz, s.precursor_charge, s.annotation = 500.25, 2, [None, Ann(2)]
+    p = PackedSpectra.from_spectra([s, s])
+    assert p.n == 2 and p.charge.tolist() == [0, 2, 0, 2] and p.offsets.tolist() == [0, 2, 4]
+
+
+def test_synthetic_generator_contract():
+    from ann_solo_amd import synthetic
+    a, _ = synthetic.make_library(300, seed=9, device='cpu')
+    b, aux = synthetic.make_library(300, seed=9, device='cpu')
+    assert torch.equal(a.mz, b.mz) and torch.equal(a.intensity, b.intensity)   # seeded
+    o, mz, inten, chg, pmz, pz = a.numpy()
+    cnt = np.diff(o)
+    assert cnt.min() >= 10 and cnt.max() <= 50 and a.n == 300
+    for i in range(a.n):
+        s = slice(o[i], o[i + 1])
+        assert (np.diff(mz[s]) >= 0).all() and mz[s][-1] - mz[s][0] >= 250
+        assert mz[s].min() >= 11 and mz[s].max() <= 2010
+        assert abs(np.linalg.norm(inten[s]) - 1) < 1e-5
+    q, truth = synthetic.make_queries(b, aux, 64, seed=3)
+    assert q.n == 64 and set(truth) == {'source_row', 'is_modified', 'delta_mass'}
+    assert (q.charge == 0).all()
