@@ -57,7 +57,7 @@ EXPORTS = [
     'asl_index_pq_lut', 'asl_rescore_batch', 'asl_library_create', 'asl_library_free',
     'asl_library_size', 'asl_search_batch', 'asl_window_candidates', 'asl_profile_enable',
     'asl_profile_reset', 'asl_profile_get', 'asl_profile_scanned_vectors',
-    'asl_rescore_knn', 'asl_lpt_owner',
+    'asl_rescore_knn', 'asl_lpt_owner', 'asl_index_set_scan_variant',
 ]
 
 
@@ -110,6 +110,7 @@ def lib():
         L.asl_index_load.argtypes = [C.c_char_p]
         L.asl_index_load.restype = C.c_void_p
         L.asl_index_set_niter.argtypes = [C.c_void_p, C.c_int32]
+        L.asl_index_set_scan_variant.argtypes = [C.c_void_p, C.c_int32]
         L.asl_index_info.argtypes = [C.c_void_p, C.POINTER(AslIndexInfo)]
         L.asl_index_get_centroids.argtypes = [C.c_void_p, C.c_void_p]
         L.asl_index_get_codebooks.argtypes = [C.c_void_p, C.c_void_p]

@@ -74,6 +74,11 @@ struct asl_index {
   DevBuf<uint8_t> codes;
   DevBuf<int32_t> ids, list_offsets;
   std::vector<int32_t> h_list_offsets;
+  // 64-vector tiles for pq_scan_v2 (m = 32)
+  DevBuf<uint8_t> codes_tiled;
+  DevBuf<int32_t> ids_tiled, tile_offsets;
+  bool has_tiles = false;
+  int scan_variant = 0;  // 0 = auto (v2 when supported), 1 = force v1
   bool lists_dirty = true;
   // scratch
   DevBuf<float> ws_scores, coarse_D, ws_x;
@@ -253,6 +258,24 @@ static int build_lists(asl_index *ix) {
   } else {
     ASL_TRY(ix->ids.upload(h_order.data(), (size_t)n));
   }
+  ix->has_tiles = false;
+  if (ix->kind == ASL_INDEX_IVFPQ && ix->pq_m == 32 && ix->ksub == 256) {
+    std::vector<int32_t> tile_off((size_t)ix->nlist + 1, 0), dst_slot((size_t)n);
+    for (int l = 0; l < ix->nlist; l++)
+      tile_off[(size_t)l + 1] = tile_off[(size_t)l] + (off[(size_t)l + 1] - off[(size_t)l] + 63) / 64;
+    for (int l = 0; l < ix->nlist; l++)
+      for (int32_t i = off[(size_t)l]; i < off[(size_t)l + 1]; i++)
+        dst_slot[(size_t)i] = tile_off[(size_t)l] * 64 + (i - off[(size_t)l]);
+    const int64_t ntiles = std::max<int64_t>(tile_off[(size_t)ix->nlist], 1);
+    DevBuf<int32_t> slot_dev;
+    ASL_TRY(slot_dev.upload(dst_slot.data(), (size_t)n));
+    ASL_TRY(ix->tile_offsets.upload(tile_off.data(), tile_off.size()));
+    ASL_TRY(ix->codes_tiled.reserve((size_t)ntiles * 2048));
+    ASL_TRY(ix->ids_tiled.reserve((size_t)ntiles * 64));
+    ASL_TRY(tile_codes(ix->codes.p, ix->ids.p, slot_dev.p, n, ntiles, ix->codes_tiled.p, ix->ids_tiled.p));
+    ASL_TRY(sync_stream());
+    ix->has_tiles = true;
+  }
   ASL_TRY(sync_stream());
   ix->lists_dirty = false;
   return ASL_OK;
@@ -332,9 +355,14 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   ASL_TRY(coarse_search(ix, xq, nq, nprobe));
   {
     ProfScope ps("scan");
-    ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, ix->coarse_D.p,
-                    ix->coarse_I.p, nprobe, ix->list_offsets.p, ix->ids.p, ix->codes.p, k, D,
-                    I64, I32));
+    if (ix->has_tiles && ix->scan_variant != 1 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
+      ASL_TRY(pq_scan_v2(xq, nq, d, ix->codebooks.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
+                         nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
+                         ix->ids_tiled.p, k, D, I64, I32));
+    else
+      ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, ix->coarse_D.p,
+                      ix->coarse_I.p, nprobe, ix->list_offsets.p, ix->ids.p, ix->codes.p, k, D,
+                      I64, I32));
   }
   if (prof_enabled()) {
     ASL_TRY(ix->ws_count.reserve(1));
@@ -388,6 +416,12 @@ asl_index_t *asl_index_create(int32_t d, int32_t nlist, int32_t kind, int32_t pq
 }
 
 void asl_index_free(asl_index_t *ix) { delete ix; }
+
+int asl_index_set_scan_variant(asl_index_t *ix, int32_t variant) {
+  if (!ix || variant < 0 || variant > 1) return fail(ASL_ERR_INVALID, "set_scan_variant");
+  ix->scan_variant = variant;
+  return ASL_OK;
+}
 
 int asl_index_set_niter(asl_index_t *ix, int32_t niter) {
   if (!ix || niter < 0) return fail(ASL_ERR_INVALID, "set_niter");

@@ -410,7 +410,8 @@ int pq_lut(const float *xq, int nq, int d, const float *codebooks, int m, int ks
   return ASL_OK;
 }
 
-// Canonical ADC sum: p_j = sum_t v[j+16t]; 16->1 tree (8,4,2,1); + coarse.
+// Canonical ADC sum: p_j = sum_t v[j+16t]; 16->1 mirror tree
+// (j,15-j)(j,7-j)(j,3-j)(0,1); + coarse.
 template <int M>
 __device__ __forceinline__ float adc_score(const float *__restrict__ s_lut, int ksub,
                                            const uint32_t *__restrict__ cw, float coarse) {
@@ -437,11 +438,11 @@ __device__ __forceinline__ float adc_score(const float *__restrict__ s_lut, int 
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) p[j] = p[j] + p[j + 8];
+  for (int j = 0; j < 8; ++j) p[j] = p[j] + p[15 - j];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) p[j] = p[j] + p[j + 4];
+  for (int j = 0; j < 4; ++j) p[j] = p[j] + p[7 - j];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) p[j] = p[j] + p[j + 2];
+  for (int j = 0; j < 2; ++j) p[j] = p[j] + p[3 - j];
   return coarse + (p[0] + p[1]);
 }
 

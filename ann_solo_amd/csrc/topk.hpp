@@ -84,18 +84,20 @@ struct StreamTopK {
     if (ctl[0] > cap - NT) flush(tid);
   }
 
-  __device__ __forceinline__ void flush(int tid) {
+  // Returns the fill level after the flush (identical in every thread).
+  __device__ __forceinline__ int flush(int tid) {
     const int f = ctl[0];
     __syncthreads();
     for (int i = f + tid; i < cap; i += NT) buf[i] = 0ull;
     __syncthreads();
     bitonic_sort_desc<NT>(buf, cap, tid);
+    const int nf = f < k ? f : k;
     if (tid == 0) {
-      const int nf = f < k ? f : k;
       ctl[0] = nf;
       *thr = (nf == k) ? buf[k - 1] : 0ull;
     }
     __syncthreads();
+    return nf;
   }
 
   // Final sort + write-out: D/I rows of length k (missing: -FLT_MAX / -1).

@@ -75,6 +75,9 @@ class Index:
     def set_niter(self, niter: int):
         _lib.check(_lib.lib().asl_index_set_niter(self._h, int(niter)))
 
+    def set_scan_variant(self, variant: int):
+        _lib.check(_lib.lib().asl_index_set_scan_variant(self._h, int(variant)))
+
     def train(self, x):
         x = _as_f32(x, self.d)
         _lib.check(_lib.lib().asl_index_train(self._h, x.shape[0], _lib.ptr(x), self.seed))

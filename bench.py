@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--pq-m', type=int, default=32)
     ap.add_argument('--niter', type=int, default=25)
     ap.add_argument('--open-da', type=float, default=500.0)
+    ap.add_argument('--scan-variant', type=int, default=0, help='0 auto (tiled v2), 1 generic v1')
     ap.add_argument('--recall-queries', type=int, default=256)
     ap.add_argument('--cpu-seconds', type=float, default=20.0,
                     help='target core-seconds of the CPU baseline sample (0 = skip)')
@@ -92,6 +93,8 @@ def main():
     sl = SpectralLibrary(lib, config=cfg, device=dev)
     part = sl.partitions[charge]
     idx = sl._get_ann_index(charge)
+    if args.index == 'ivfpq':
+        idx.set_scan_variant(args.scan_variant)
     torch.cuda.synchronize()
     if rank == 0:
         log(f'[bench] library {lib.n} spectra, {lib.mz.numel()} peaks; index {args.index} '

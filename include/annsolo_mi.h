@@ -89,6 +89,11 @@ asl_index_t *asl_index_load(const char *path);
 /* k-means iterations (FAISS ClusteringParameters.niter, default 25) */
 int asl_index_set_niter(asl_index_t *idx, int32_t niter);
 
+/* PQ scan kernel selection: 0 = automatic (the tiled sub-quantiser-per-lane kernel when
+ * m = 32, 8 bits, nprobe <= 256), 1 = force the generic lane-per-vector kernel. Both
+ * return identical results; the switch exists for A/B measurements. */
+int asl_index_set_scan_variant(asl_index_t *idx, int32_t variant);
+
 /* Introspection, used by the parity tests and by multi-GPU sharding. Sizes via
  * asl_index_info; every pointer may be NULL to skip. Lists are stored in list
  * order: ids/codes/vecs of list l are [list_offsets[l], list_offsets[l+1]). */

@@ -8,7 +8,7 @@
  *   - inner product  = ascending-k fp32 fmaf chain from +0
  *   - L2 distance    = ascending-k chain acc = fmaf(x-c, x-c, acc)
  *   - ADC sum        = p_j = sum_t LUT[j+16t] (t ascending), then the fixed
- *                      16->1 tree (j,j+8)(j,j+4)(j,j+2)(0,1), then + coarse
+ *                      16->1 mirror tree (j,15-j)(j,7-j)(j,3-j)(0,1), then + coarse
  *   - top-k order    = (score desc, id asc)
  */
 #define _GNU_SOURCE
@@ -660,9 +660,10 @@ float orc_adc(const float *lut, int32_t m, int32_t ksub, const uint8_t *code, fl
     }
     p[j] = a;
   }
-  for (int j = 0; j < 8; j++) p[j] = p[j] + p[j + 8];
-  for (int j = 0; j < 4; j++) p[j] = p[j] + p[j + 4];
-  for (int j = 0; j < 2; j++) p[j] = p[j] + p[j + 2];
+  /* fixed "mirror" tree: (j,15-j) (j,7-j) (j,3-j) (0,1) */
+  for (int j = 0; j < 8; j++) p[j] = p[j] + p[15 - j];
+  for (int j = 0; j < 4; j++) p[j] = p[j] + p[7 - j];
+  for (int j = 0; j < 2; j++) p[j] = p[j] + p[3 - j];
   return coarse + (p[0] + p[1]);
 }
 
