@@ -355,10 +355,10 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   ASL_TRY(coarse_search(ix, xq, nq, nprobe));
   {
     ProfScope ps("scan");
-    if (ix->has_tiles && ix->scan_variant != 1 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
+    if (ix->has_tiles && (ix->scan_variant & 0xff) != 1 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
       ASL_TRY(pq_scan_v2(xq, nq, d, ix->codebooks.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
-                         ix->ids_tiled.p, k, D, I64, I32));
+                         ix->ids_tiled.p, k, D, I64, I32, ix->scan_variant >> 8));
     else
       ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, ix->coarse_D.p,
                       ix->coarse_I.p, nprobe, ix->list_offsets.p, ix->ids.p, ix->codes.p, k, D,
@@ -418,7 +418,7 @@ asl_index_t *asl_index_create(int32_t d, int32_t nlist, int32_t kind, int32_t pq
 void asl_index_free(asl_index_t *ix) { delete ix; }
 
 int asl_index_set_scan_variant(asl_index_t *ix, int32_t variant) {
-  if (!ix || variant < 0 || variant > 1) return fail(ASL_ERR_INVALID, "set_scan_variant");
+  if (!ix || variant < 0) return fail(ASL_ERR_INVALID, "set_scan_variant");
   ix->scan_variant = variant;
   return ASL_OK;
 }

@@ -30,7 +30,7 @@
 namespace asl {
 
 constexpr int V2_NT = 256;
-constexpr int V2_T = 2;                      // tiles per wave per round
+constexpr int V2_T = 4;                      // tiles per wave per round
 constexpr int V2_ROUND_TILES = 4 * V2_T;     // tiles per workgroup round
 constexpr int V2_ROUND_VECS = V2_ROUND_TILES * 64;
 constexpr int V2_CHUNK = 512;                // tile-table entries per chunk
@@ -73,12 +73,14 @@ __device__ __forceinline__ float tile_adc(const char *lut_bytes, const uint4 A, 
   return v[0] + dpp_mov<0xB1>(v[1]);                                      // quad_perm [1,0,3,2]
 }
 
+template <int CAP>
 __global__ __launch_bounds__(V2_NT) void pq_scan_v2_kernel(
     const float *__restrict__ xq, int d, const float *__restrict__ codebooks, int dsub,
     const float *__restrict__ coarse_D, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ tile_offsets,
     const uint8_t *__restrict__ codes_tiled, const int32_t *__restrict__ ids_tiled, int k,
-    int cap, float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32) {
+    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int dbg) {
+  constexpr int cap = CAP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u64 *keys = reinterpret_cast<u64 *>(smem);
   u64 *thr_p = keys + cap;
@@ -90,9 +92,12 @@ __global__ __launch_bounds__(V2_NT) void pq_scan_v2_kernel(
   int *s_scan = reinterpret_cast<int *>(table);   // and the prefix scan scratch
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+  long long t_lut_g = 0;
 
   // ---- per-query LUT, rotated sub-quantiser order (conflict-free LDS stores)
-  {
+  // (dbg bits are measurement knobs: 1 no appends, 2 no LUT build, 4 no ADC, 8 no code loads)
+  if (!(dbg & 2)) {
+    const long long tl0 = clock64();
     const float *xq_row = xq + (size_t)q * d;
     for (int i = tid; i < d; i += V2_NT) s_q[i] = xq_row[i];
     __syncthreads();
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(V2_NT) void pq_scan_v2_kernel(
       s_lut[c * V2_M + m] = acc;
     }
     __syncthreads();
+    t_lut_g = clock64() - tl0;
   }
 
   // ---- my probe (thread p < nprobe), exclusive scan of tile counts
@@ -138,8 +144,10 @@ __global__ __launch_bounds__(V2_NT) void pq_scan_v2_kernel(
   const int my_pre = wave_base + incl - my_nt;
   __syncthreads();
 
-  StreamTopK<V2_NT> tk;
+  StreamTopK<V2_NT, CAP> tk;
   tk.init(keys, ctl, thr_p, cap, k, tid);
+  tk.force_rt = (dbg & 16) != 0;
+  tk.slot_ids = ids_tiled;
 
   const char *lut_bytes = reinterpret_cast<const char *>(s_lut);
   const int rho = lane >> 4, j = lane & 15;
@@ -147,7 +155,10 @@ __global__ __launch_bounds__(V2_NT) void pq_scan_v2_kernel(
   const uint32_t offA = (uint32_t)ma * 4u, offB = (uint32_t)mb * 4u;
   const uint32_t chunkA = (uint32_t)(rho * 512 + ma * 16), chunkB = (uint32_t)(rho * 512 + mb * 16);
 
-  int fill = 0, parity = 0;
+  int fill = 0, parity = 0, n_flush = 0, n_app = 0;
+  long long t_flush = 0;
+  const long long t_start = clock64();
+  float dbg_acc = 0.0f;
   for (int c0 = 0; c0 < total; c0 += V2_CHUNK) {
     // tile table of this chunk: every probe writes the entries of its own tiles
     {
@@ -164,35 +175,48 @@ __global__ __launch_bounds__(V2_NT) void pq_scan_v2_kernel(
     }
     __syncthreads();
     const int nent = min(V2_CHUNK, total - c0);
-    for (int r0 = 0; r0 < nent; r0 += V2_ROUND_TILES, parity ^= 1) {
-      const u64 thr = *thr_p;
-      int appended = 0;
-      const uint32_t thr_hi = (uint32_t)(thr >> 32);
-      uint4 A[V2_T], B[V2_T];
-      TileEnt ent[V2_T];
+    const int nrounds = (nent + V2_ROUND_TILES - 1) / V2_ROUND_TILES;
+    uint4 A[V2_T], B[V2_T], A2[V2_T], B2[V2_T];
+    TileEnt ent[V2_T], ent2[V2_T];
+    auto fetch = [&](int rr, uint4 *a, uint4 *b, TileEnt *e) {
 #pragma unroll
       for (int u = 0; u < V2_T; ++u) {
-        const int i = r0 + wave * V2_T + u;
-        ent[u] = table[i < nent ? i : 0];
-        if (i >= nent) ent[u].nvalid = 0;
-        const uint8_t *base = codes_tiled + (size_t)ent[u].tile * 2048;
-        A[u] = *reinterpret_cast<const uint4 *>(base + chunkA);
-        B[u] = *reinterpret_cast<const uint4 *>(base + chunkB);
+        const int i = rr * V2_ROUND_TILES + wave * V2_T + u;
+        e[u] = table[i < nent ? i : 0];
+        if (i >= nent) e[u].nvalid = 0;
+        const uint8_t *base = codes_tiled + (size_t)e[u].tile * 2048;
+        if (!(dbg & 8)) {
+          a[u] = *reinterpret_cast<const uint4 *>(base + chunkA);
+          b[u] = *reinterpret_cast<const uint4 *>(base + chunkB);
+        } else {
+          a[u] = make_uint4(lane, rr, u, 1);
+          b[u] = make_uint4(rr, lane, 2, u);
+        }
       }
+    };
+    fetch(0, A, B, ent);
+    for (int rr = 0; rr < nrounds; ++rr, parity ^= 1) {
+      if (rr + 1 < nrounds) fetch(rr + 1, A2, B2, ent2);   // prefetch across the barrier
+      const uint32_t thr_hi = (uint32_t)(*thr_p >> 32);
+      int appended = 0;
 #pragma unroll
       for (int u = 0; u < V2_T; ++u) {
         if (ent[u].nvalid > 0) {  // wave-uniform
-          const float score = ent[u].coarse + tile_adc(lut_bytes, A[u], B[u], offA, offB);
+          float score;
+          if (!(dbg & 4))
+            score = ent[u].coarse + tile_adc(lut_bytes, A[u], B[u], offA, offB);
+          else
+            score = __uint_as_float((A[u].x ^ B[u].y ^ A[u].z ^ B[u].w) & 0x3fffffffu);
           const uint32_t ob = f2ord(score);
           bool take = false;
-          if (lane < ent[u].nvalid && ob >= thr_hi) {
-            const int32_t id = ids_tiled[(size_t)ent[u].tile * 64 + lane];
-            const u64 key = ((u64)ob << 32) | (u64)(0xFFFFFFFFu - (uint32_t)id);
-            if (key > thr) {
-              const int s = atomicAdd(&ctl[0], 1);
-              keys[s] = key;
-              take = true;
-            }
+          if (dbg & 1) {
+            dbg_acc += score;
+          } else if (lane < ent[u].nvalid && ob >= thr_hi) {
+            // score >= current k-th best score: keep (score, storage slot); the flush
+            // resolves ids and the exact (score desc, id asc) order
+            const int s = atomicAdd(&ctl[0], 1);
+            keys[s] = ((u64)ob << 32) | (u64)(ent[u].tile * 64u + (uint32_t)lane);
+            take = true;
           }
           appended += __popcll(__ballot(take));
         }
@@ -204,12 +228,39 @@ __global__ __launch_bounds__(V2_NT) void pq_scan_v2_kernel(
       __syncthreads();
       fill += s_wcnt[parity * 4] + s_wcnt[parity * 4 + 1] + s_wcnt[parity * 4 + 2] +
               s_wcnt[parity * 4 + 3];
-      if (fill > cap - V2_ROUND_VECS) fill = tk.flush(tid);
+      if (fill > cap - V2_ROUND_VECS) {
+        const long long t0 = clock64();
+        fill = tk.flush(tid);
+        t_flush += clock64() - t0;
+        ++n_flush;
+      }
+      n_app += appended;
+#pragma unroll
+      for (int u = 0; u < V2_T; ++u) {
+        A[u] = A2[u];
+        B[u] = B2[u];
+        ent[u] = ent2[u];
+      }
     }
     __syncthreads();
   }
+  if ((dbg & 1) && dbg_acc == 12345.678f) keys[0] = 1;  // keeps the scores live
+  const long long t_fin0 = clock64();
   tk.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
             I32 ? I32 + (size_t)q * k : nullptr, tid);
+  const long long t_end = clock64();
+  if ((dbg & 32) && D) {  // measurement knob: report flushes / this wave's appends / tiles
+    __syncthreads();
+    if (tid == 0) {
+      D[(size_t)q * k] = (float)n_flush;
+      D[(size_t)q * k + 1] = (float)n_app;
+      D[(size_t)q * k + 2] = (float)total;
+      D[(size_t)q * k + 3] = (float)(t_end - t_start);
+      D[(size_t)q * k + 4] = (float)t_flush;
+      D[(size_t)q * k + 5] = (float)(t_end - t_fin0);
+      D[(size_t)q * k + 6] = (float)t_lut_g;
+    }
+  }
 }
 
 // list-ordered codes [n,32] -> 64-vector tiles (see file header); dst_slot[i] = tile*64 + v
@@ -243,25 +294,39 @@ bool pq_scan_v2_supported(int m, int ksub, int k, int nprobe) {
   return m == V2_M && ksub == V2_KSUB && nprobe <= V2_NT && k >= 1 && k <= TK_MAX_K;
 }
 
+template <int CAP>
+static int launch_v2(const float *xq, int nq, int d, const float *codebooks, int dsub,
+                     const float *coarse_D, const int32_t *coarse_I, int nprobe,
+                     const int32_t *list_offsets, const int32_t *tile_offsets,
+                     const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
+                     int64_t *I64, int32_t *I32, int dbg) {
+  size_t table_bytes = std::max((size_t)V2_CHUNK * sizeof(TileEnt), (size_t)d * 4);
+  const size_t lds = (size_t)CAP * 8 + 64 + (size_t)V2_KSUB * V2_M * 4 + table_bytes;
+  if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "pq scan: k=%d does not fit LDS", k);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void *)pq_scan_v2_kernel<CAP>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(pq_scan_v2_kernel<CAP>, dim3(nq), dim3(V2_NT), lds, stream(), xq, d,
+                     codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets,
+                     codes_tiled, ids_tiled, k, D, I64, I32, dbg);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
 int pq_scan_v2(const float *xq, int nq, int d, const float *codebooks, int dsub,
                const float *coarse_D, const int32_t *coarse_I, int nprobe,
                const int32_t *list_offsets, const int32_t *tile_offsets,
                const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
-               int64_t *I64, int32_t *I32) {
+               int64_t *I64, int32_t *I32, int dbg) {
   if (nq <= 0) return ASL_OK;
-  int cap = topk_cap_for(k);
-  while (cap - k < 2 * V2_ROUND_VECS) cap <<= 1;
-  size_t table_bytes = std::max((size_t)V2_CHUNK * sizeof(TileEnt), (size_t)d * 4);
-  const size_t lds = (size_t)cap * 8 + 64 + (size_t)V2_KSUB * V2_M * 4 + table_bytes;
-  if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "pq scan: k=%d does not fit LDS", k);
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)pq_scan_v2_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(pq_scan_v2_kernel, dim3(nq), dim3(V2_NT), lds, stream(), xq, d, codebooks,
-                     dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets, codes_tiled,
-                     ids_tiled, k, cap, D, I64, I32);
-  ASL_CHECK_LAUNCH();
-  return ASL_OK;
+#define V2_ARGS xq, nq, d, codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets, \
+                codes_tiled, ids_tiled, k, D, I64, I32, dbg
+  // capacity rule: after a flush k keys stay; leave >= k slots of headroom on top of one
+  // round's worst case so flushes stay logarithmic in the number of scanned vectors
+  if (2 * k + V2_ROUND_VECS <= 2048) return launch_v2<2048>(V2_ARGS);
+  if (2 * k + V2_ROUND_VECS <= 4096) return launch_v2<4096>(V2_ARGS);
+  return launch_v2<8192>(V2_ARGS);
+#undef V2_ARGS
 }
 
 }  // namespace asl
