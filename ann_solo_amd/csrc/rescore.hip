@@ -17,6 +17,8 @@
 // Arithmetic mirrors the reference: window tests in double on float->double
 // promoted m/z (cpp:42,53); product = (float)(mult * (double)q_int * (double)c_int)
 // (cpp:81); score = double sum of those floats in sorted order (cpp:104).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace asl {
@@ -46,6 +48,101 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Sort the wave's match list (product desc, generation order asc) and assign greedily
+// (SpectrumMatch.cpp:92-111). Lists of <= 64 matches are sorted in registers with
+// cross-lane shuffles; longer ones in LDS. Returns the score in every lane.
+template <bool EMIT>
+__device__ double resolve_matches(int lane, WaveLds &W, uint32_t *out_pairs, int out_cap,
+                                  int *out_count, int *status) {
+  int M = W.counter;
+  M = __builtin_amdgcn_readfirstlane(M);
+  if (M > RS_MCAP) {
+    if (lane == 0) atomicOr(status, RS_STATUS_MATCHES);
+    M = RS_MCAP;
+  }
+  if (M == 0) return 0.0;
+  unsigned long long rkey = 0ull;
+  uint32_t rpay = 0;
+  const bool small = M <= 64;
+  if (small) {
+    if (lane < M) {
+      rkey = W.keys[lane];
+      rpay = W.pay[lane];
+    }
+    if (M > 1) {
+#pragma unroll
+      for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const unsigned long long ok = __shfl_xor(rkey, j, 64);
+          const uint32_t op = __shfl_xor(rpay, j, 64);
+          const bool keep_max = (((lane & j) == 0) == ((lane & k) == 0));
+          const bool take = ((ok > rkey) == keep_max) && (ok != rkey);
+          rkey = take ? ok : rkey;
+          rpay = take ? op : rpay;
+        }
+      }
+    }
+  } else {
+    int P = 2;
+    while (P < M) P <<= 1;
+    for (int i = M + lane; i < P; i += 64) W.keys[i] = 0ull;
+    wave_sync();
+    for (int k = 2; k <= P; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = lane; t < (P >> 1); t += 64) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int l = i | j;
+          const unsigned long long a = W.keys[i], b = W.keys[l];
+          const bool desc = (i & k) == 0;
+          if (desc ? (a < b) : (a > b)) {
+            W.keys[i] = b;
+            W.keys[l] = a;
+            const uint32_t pa = W.pay[i];
+            W.pay[i] = W.pay[l];
+            W.pay[l] = pa;
+          }
+        }
+        wave_sync();
+      }
+    }
+  }
+
+  // greedy one-to-one assignment on the scalar unit
+  unsigned long long qu0 = 0, qu1 = 0, qu2 = 0, qu3 = 0, cu0 = 0, cu1 = 0, cu2 = 0, cu3 = 0;
+  double score = 0.0;
+  int nm = 0;
+  for (int t = 0; t < M; ++t) {
+    uint32_t pl, pb;
+    if (small) {
+      pl = __builtin_amdgcn_readlane(rpay, t);
+      pb = __builtin_amdgcn_readlane((uint32_t)(rkey >> 32), t);
+    } else {
+      pl = __builtin_amdgcn_readfirstlane(W.pay[t]);
+      pb = __builtin_amdgcn_readfirstlane((uint32_t)(W.keys[t] >> 32));
+    }
+    const uint32_t qi = pl >> 16, ci = pl & 0xffffu;
+    const unsigned long long qbit = 1ull << (qi & 63), cbit = 1ull << (ci & 63);
+    const uint32_t qw = qi >> 6, cw = ci >> 6;
+    const unsigned long long qword = qw == 0 ? qu0 : qw == 1 ? qu1 : qw == 2 ? qu2 : qu3;
+    const unsigned long long cword = cw == 0 ? cu0 : cw == 1 ? cu1 : cw == 2 ? cu2 : cu3;
+    if (!(qword & qbit) && !(cword & cbit)) {
+      score += (double)__uint_as_float(pb);
+      if (qw == 0) qu0 |= qbit; else if (qw == 1) qu1 |= qbit; else if (qw == 2) qu2 |= qbit; else qu3 |= qbit;
+      if (cw == 0) cu0 |= cbit; else if (cw == 1) cu1 |= cbit; else if (cw == 2) cu2 |= cbit; else cu3 |= cbit;
+      if (EMIT) {
+        if (lane == 0 && nm < out_cap) {
+          out_pairs[2 * nm] = qi;
+          out_pairs[2 * nm + 1] = ci;
+        }
+      }
+      ++nm;
+    }
+  }
+  if (EMIT && out_count && lane == 0) *out_count = nm;
+  return score;
 }
 
 // Wave-cooperative SpectrumMatcher::dot for one pair. All 64 lanes call it with
@@ -117,67 +214,7 @@ __device__ double dot_pair_wave(int lane, const QueryLds &Q, int qn, double q_pm
     }
   }
   wave_sync();
-  int M = W.counter;
-  M = __builtin_amdgcn_readfirstlane(M);
-  if (M > RS_MCAP) {
-    if (lane == 0) atomicOr(status, RS_STATUS_MATCHES);
-    M = RS_MCAP;
-  }
-  if (M == 0) return 0.0;
-
-  // cpp:92-93 sort by product, descending; ties = generation order (stable).
-  if (M > 1) {
-    int P = 2;
-    while (P < M) P <<= 1;
-    for (int i = M + lane; i < P; i += 64) W.keys[i] = 0ull;
-    wave_sync();
-    for (int k = 2; k <= P; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int t = lane; t < (P >> 1); t += 64) {
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const int l = i | j;
-          const unsigned long long a = W.keys[i], b = W.keys[l];
-          const bool desc = (i & k) == 0;
-          if (desc ? (a < b) : (a > b)) {
-            W.keys[i] = b;
-            W.keys[l] = a;
-            const uint32_t pa = W.pay[i];
-            W.pay[i] = W.pay[l];
-            W.pay[l] = pa;
-          }
-        }
-        wave_sync();
-      }
-    }
-  }
-
-  // cpp:94-111 greedy one-to-one assignment on the scalar unit.
-  unsigned long long qu0 = 0, qu1 = 0, qu2 = 0, qu3 = 0, cu0 = 0, cu1 = 0, cu2 = 0, cu3 = 0;
-  double score = 0.0;
-  int nm = 0;
-  for (int t = 0; t < M; ++t) {
-    const uint32_t pl = __builtin_amdgcn_readfirstlane(W.pay[t]);
-    const uint32_t pb = __builtin_amdgcn_readfirstlane((uint32_t)(W.keys[t] >> 32));
-    const uint32_t qi = pl >> 16, ci = pl & 0xffffu;
-    const unsigned long long qbit = 1ull << (qi & 63), cbit = 1ull << (ci & 63);
-    const uint32_t qw = qi >> 6, cw = ci >> 6;
-    const unsigned long long qword = qw == 0 ? qu0 : qw == 1 ? qu1 : qw == 2 ? qu2 : qu3;
-    const unsigned long long cword = cw == 0 ? cu0 : cw == 1 ? cu1 : cw == 2 ? cu2 : cu3;
-    if (!(qword & qbit) && !(cword & cbit)) {
-      score += (double)__uint_as_float(pb);
-      if (qw == 0) qu0 |= qbit; else if (qw == 1) qu1 |= qbit; else if (qw == 2) qu2 |= qbit; else qu3 |= qbit;
-      if (cw == 0) cu0 |= cbit; else if (cw == 1) cu1 |= cbit; else if (cw == 2) cu2 |= cbit; else cu3 |= cbit;
-      if (EMIT) {
-        if (lane == 0 && nm < out_cap) {
-          out_pairs[2 * nm] = qi;
-          out_pairs[2 * nm + 1] = ci;
-        }
-      }
-      ++nm;
-    }
-  }
-  if (EMIT && out_count && lane == 0) *out_count = nm;
-  return score;
+  return resolve_matches<EMIT>(lane, W, out_pairs, out_cap, out_count, status);
 }
 
 __device__ __forceinline__ void load_query(int tid, int nthreads, const DevPeaks &Qs, int q,
@@ -236,6 +273,237 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_kernel(
       s = dot_pair_wave<false>(lane, Q, qn, q_pmz, L, (int)row, tol, allow_shift, W[wave],
                                nullptr, 0, nullptr, status);
     if (lane == 0) pair_score[c] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Pass 1, fast path. The binary-search formulation above spends its time in dependent
+// LDS round trips (6 per shift per query peak). Here the QUERY is hashed once per
+// workgroup instead: every query peak is entered into an LDS hash table under the
+// m/z bins of width 2*tol that its window [mz-tol, mz+tol] touches; a candidate peak at
+// shifted position x can only match peaks filed under floor(x / (2*tol)). Lanes are the
+// candidate's peaks (loaded straight from HBM, coalesced), each does one independent
+// probe per shift, and the reference's exact window/cursor predicate is applied to the
+// few hits:  match(i,j,s)  <=>  |q_i - x_j| <= tol  and  (not(q_i - tol > x_j) or j = n_c-1)
+// and every peak between the cursor and j passes the window test (SpectrumMatch.cpp:39-55).
+// A wave owns a contiguous slice of the candidate list: 64 candidates' metadata are
+// gathered at once, the next candidate's peaks are prefetched while one is scored.
+constexpr int RS_HT = 512;       // hash slots
+constexpr int RS_HQ_MAX = 100;   // query peaks the hash path accepts (<= 3 bins each)
+constexpr int RS_EMPTY = (int)0x80000000;
+
+struct HashLds {
+  int bin[RS_HT];
+  int peak[RS_HT];
+};
+
+__device__ __forceinline__ uint32_t hbin(int b) {
+  return ((uint32_t)b * 2654435761u) >> 23;  // 9 bits
+}
+
+constexpr int RS_PF = 8;  // candidates whose peaks are in flight ahead of the scoring
+
+// One (query, candidate) pair on the hash path; lanes are the candidate's peaks.
+__device__ __forceinline__ double score_candidate(int lane, const QueryLds &Q, const HashLds &H,
+                                                  WaveLds &Wv, const DevPeaks &L, int co, int cn,
+                                                  int c_charge, double c_pmz, double q_pmz,
+                                                  double tol, double inv_w, int allow_shift,
+                                                  float a_mz, float a_int, int a_chg, int *status) {
+  if (lane == 0) Wv.counter = 0;
+  const double pmd = (q_pmz - c_pmz) * (double)(unsigned)c_charge;    // cpp:18
+  const int S = (allow_shift && fabs(pmd) >= tol) ? c_charge + 1 : 1;  // cpp:20
+  for (int jb = 0; jb < cn; jb += 64) {
+    const int j = jb + lane;
+    if (j < cn) Wv.c_mz[j] = jb > 0 ? L.mz[co + j] : a_mz;
+  }
+  wave_sync();
+  for (int jb = 0; jb < cn; jb += 64) {
+    const int j = jb + lane;
+    if (j < cn) {
+      float cm = a_mz, ci = a_int;
+      int cc = a_chg;
+      if (jb > 0) {
+        cm = Wv.c_mz[j];
+        ci = L.intensity[co + j];
+        cc = L.charge ? L.charge[co + j] : 0;
+      }
+      for (int s = 0; s < S; ++s) {
+        double mult = 0.0;
+        if (s == 0 || cc == s)
+          mult = 1.0;
+        else if (cc == 0)
+          mult = 2.0 / 3.0;
+        if (mult == 0.0) continue;  // this peak cannot pair under shift s (cpp:58-75)
+        const double md = s ? pmd / (double)s : 0.0;
+        const double x = (double)cm + md;
+        const int b = (int)floor(x * inv_w);
+        uint32_t h = hbin(b);
+        for (;;) {
+          const int eb = H.bin[h];
+          if (eb == RS_EMPTY) break;
+          if (eb == b) {
+            const int i = H.peak[h];
+            const double qm = (double)Q.mz[i];
+            const double lim = qm - tol;
+            if (fabs(qm - x) <= tol && (!(lim > x) || j == cn - 1)) {
+              // the reference walks from its cursor: every peak between the cursor and j
+              // must pass the window test too (differs only on fp boundaries)
+              bool run = true;
+              for (int jj = j; jj > 0; --jj) {
+                const double xp = (double)Wv.c_mz[jj - 1] + md;
+                if (lim > xp) break;
+                if (!(fabs(qm - xp) <= tol)) {
+                  run = false;
+                  break;
+                }
+              }
+              if (run) {
+                const float prod = (float)(mult * (double)Q.inten[i] * (double)ci);
+                const int slot = atomicAdd(&Wv.counter, 1);
+                if (slot < RS_MCAP) {
+                  const uint32_t gen = (uint32_t)((i * S + s) * cn + j);
+                  Wv.keys[slot] = ((unsigned long long)__float_as_uint(prod) << 32) |
+                                  (unsigned long long)(0xFFFFFFFFu - gen);
+                  Wv.pay[slot] = ((uint32_t)i << 16) | (uint32_t)j;
+                }
+              }
+            }
+          }
+          h = (h + 1) & (RS_HT - 1);
+        }
+      }
+    }
+  }
+  wave_sync();
+  return resolve_matches<false>(lane, Wv, nullptr, 0, nullptr, status);
+}
+
+__global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
+    DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
+    double *__restrict__ pair_score, int *status) {
+  __shared__ QueryLds Q;
+  __shared__ HashLds H;
+  __shared__ WaveLds W[RS_WAVES];
+  const int q = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  long long c0, c1;
+  cv.range(q, c0, c1);
+  if (c0 >= c1) return;
+  int qn;
+  load_query(tid, blockDim.x, Qs, q, Q, qn, status);
+  for (int i = tid; i < RS_HT; i += blockDim.x) H.bin[i] = RS_EMPTY;
+  __syncthreads();
+  if (!(tol > 0.0) || qn > RS_HQ_MAX) {  // workgroup-uniform: binary-search formulation
+    const double q_pmz0 = Qs.precursor_mz[q];
+    const long long step = (long long)RS_WAVES * gridDim.y;
+    for (long long c = c0 + (long long)blockIdx.y * RS_WAVES + wave; c < c1; c += step) {
+      const long long row = cv.row(c);
+      double sc = -1.0;
+      if (row >= 0 && row < L.n)
+        sc = dot_pair_wave<false>(lane, Q, qn, q_pmz0, L, (int)row, tol, allow_shift, W[wave],
+                                  nullptr, 0, nullptr, status);
+      if (lane == 0) pair_score[c] = sc;
+    }
+    return;
+  }
+  const double inv_w = 1.0 / (2.0 * tol);
+  if (tid < qn) {
+    const double qm = (double)Q.mz[tid];
+    const int blo = (int)floor((qm - tol) * inv_w - 1e-3);
+    const int bhi = (int)floor((qm + tol) * inv_w + 1e-3);
+    for (int b = blo; b <= bhi; ++b) {
+      uint32_t h = hbin(b);
+      for (;;) {
+        const int old = atomicCAS(&H.bin[h], RS_EMPTY, b);
+        if (old == RS_EMPTY) {
+          H.peak[h] = tid;
+          break;
+        }
+        h = (h + 1) & (RS_HT - 1);
+      }
+    }
+  }
+  __syncthreads();
+  const double q_pmz = Qs.precursor_mz[q];
+  WaveLds &Wv = W[wave];
+
+  // contiguous slice of the candidate list for this wave
+  const long long n = c1 - c0;
+  const long long parts = (long long)RS_WAVES * gridDim.y;
+  const long long per = (n + parts - 1) / parts;
+  const long long wb = c0 + ((long long)blockIdx.y * RS_WAVES + wave) * per;
+  const long long we = wb + per < c1 ? wb + per : c1;
+
+  for (long long base = wb; base < we; base += 64) {
+    const long long c = base + lane;
+    long long row = -1;
+    if (c < we) row = cv.row(c);
+    const bool okr = row >= 0 && row < L.n;
+    int m_co = 0, m_cn = 0, m_chg = 0;
+    double m_pmz = 0.0;
+    if (okr) {
+      m_co = L.offsets[row];
+      m_cn = L.offsets[row + 1] - m_co;
+      m_chg = L.precursor_charge[row];
+      m_pmz = L.precursor_mz[row];
+    }
+    double my_score = -1.0;
+    const int cnt = (int)((we - base) < 64 ? (we - base) : 64);
+    // peaks are prefetched RS_PF candidates ahead (a dependent HBM gather per candidate):
+    // group g+1's loads are issued before group g is scored
+    float pmz_a[RS_PF], pint_a[RS_PF], pmz_b[RS_PF], pint_b[RS_PF];
+    int pchg_a[RS_PF], pchg_b[RS_PF];
+    auto fetch_group = [&](int g0, float *fm, float *fi, int *fc) {
+#pragma unroll
+      for (int u = 0; u < RS_PF; ++u) {
+        const int l = g0 + u;
+        fm[u] = 0.0f;
+        fi[u] = 0.0f;
+        fc[u] = 0;
+        if (l < cnt) {  // uniform
+          const int co = __shfl(m_co, l), cn = __shfl(m_cn, l);
+          if (lane < cn) {
+            fm[u] = L.mz[co + lane];
+            fi[u] = L.intensity[co + lane];
+            fc[u] = L.charge ? L.charge[co + lane] : 0;
+          }
+        }
+      }
+    };
+    fetch_group(0, pmz_a, pint_a, pchg_a);
+    for (int g0 = 0; g0 < cnt; g0 += RS_PF) {
+      if (g0 + RS_PF < cnt) fetch_group(g0 + RS_PF, pmz_b, pint_b, pchg_b);
+#pragma unroll
+      for (int u = 0; u < RS_PF; ++u) {
+        const int l = g0 + u;
+        if (l >= cnt) break;  // uniform
+        const float a_mz = pmz_a[u], a_int = pint_a[u];
+        const int a_chg = pchg_a[u];
+        const int is_ok = __shfl((int)okr, l);
+        if (!is_ok) continue;  // wave-uniform
+        const int co = __shfl(m_co, l);
+        int cn = __shfl(m_cn, l);
+        const int c_charge = __shfl(m_chg, l);
+        const double c_pmz = __shfl(m_pmz, l);
+        if (cn > RS_MAXP) {
+          if (lane == 0) atomicOr(status, RS_STATUS_PEAKS);
+          cn = RS_MAXP;
+        }
+        double score = 0.0;
+        if (cn > 0 && qn > 0) {
+          score = score_candidate(lane, Q, H, Wv, L, co, cn, c_charge, c_pmz, q_pmz, tol, inv_w,
+                                  allow_shift, a_mz, a_int, a_chg, status);
+        }
+        if (lane == l) my_score = score;
+      }
+#pragma unroll
+      for (int u = 0; u < RS_PF; ++u) {
+        pmz_a[u] = pmz_b[u];
+        pint_a[u] = pint_b[u];
+        pchg_a[u] = pchg_b[u];
+      }
+    }
+    if (c < we) pair_score[c] = my_score;
   }
 }
 
@@ -332,8 +600,15 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
     int64_t avg = total_slots / (nq > 0 ? nq : 1);
     int ysplit = 1;
     if (nq < 2048 && avg > 4096) ysplit = (int)std::min<int64_t>(64, cdiv(avg, 4096));
-    hipLaunchKernelGGL(rescore_score_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
-                       stream(), Q, L, cv, tol, allow_shift, pair_score, status);
+    // the v2 kernel falls back to the binary-search formulation per query when tol <= 0 or
+    // the query has more than RS_HQ_MAX peaks
+    static const bool force_v1 = getenv("ASL_RESCORE_V1") != nullptr;  // A/B knob
+    if (!force_v1)
+      hipLaunchKernelGGL(rescore_score_v2_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
+                         stream(), Q, L, cv, tol, allow_shift, pair_score, status);
+    else
+      hipLaunchKernelGGL(rescore_score_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
+                         stream(), Q, L, cv, tol, allow_shift, pair_score, status);
     ASL_CHECK_LAUNCH();
     hipLaunchKernelGGL(rescore_argmax_kernel, dim3(nq), dim3(64), 0, stream(), cv, nq,
                        pair_score, tie_by_row, best_cand, best_slot, best_score, n_valid);
