@@ -355,7 +355,12 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   ASL_TRY(coarse_search(ix, xq, nq, nprobe));
   {
     ProfScope ps("scan");
-    if (ix->has_tiles && (ix->scan_variant & 0xff) != 1 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
+    const int sv = ix->scan_variant & 0xff;
+    if (ix->has_tiles && sv != 1 && sv != 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
+      ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
+                         nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
+                         ix->ids_tiled.p, k, D, I64, I32, sv, ix->scan_variant >> 8));
+    else if (ix->has_tiles && sv == 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
       ASL_TRY(pq_scan_v2(xq, nq, d, ix->codebooks.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
                          ix->ids_tiled.p, k, D, I64, I32, ix->scan_variant >> 8));

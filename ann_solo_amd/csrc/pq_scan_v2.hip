@@ -25,6 +25,7 @@
 // order so its 64 KiB/query of stores are conflict-free too.
 #include "common.hpp"
 #include "ivf_kernels.hpp"
+#include "pq_tile.hpp"
 #include "topk.hpp"
 
 namespace asl {
@@ -35,43 +36,6 @@ constexpr int V2_ROUND_TILES = 4 * V2_T;     // tiles per workgroup round
 constexpr int V2_ROUND_VECS = V2_ROUND_TILES * 64;
 constexpr int V2_CHUNK = 512;                // tile-table entries per chunk
 constexpr int V2_M = 32, V2_KSUB = 256;
-
-struct TileEnt {
-  uint32_t tile;   // global tile index into codes_tiled / ids_tiled
-  float coarse;    // q . centroid of the tile's list
-  int32_t nvalid;  // vectors in the tile (64 except a list's last tile)
-  int32_t pad;
-};
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
-}
-
-__device__ __forceinline__ float lut_at(const char *lut_bytes, uint32_t word, int byte_idx,
-                                        uint32_t lane_off) {
-  const uint32_t c = (word >> (8 * byte_idx)) & 0xffu;
-  return *reinterpret_cast<const float *>(lut_bytes + ((c << 7) + lane_off));
-}
-
-// 64 ADC sums of one tile: lane l returns the sum of vector l (without the coarse term).
-__device__ __forceinline__ float tile_adc(const char *lut_bytes, const uint4 A, const uint4 B,
-                                          uint32_t offA, uint32_t offB) {
-  float v[16];
-  const uint32_t a[4] = {A.x, A.y, A.z, A.w};
-  const uint32_t b[4] = {B.x, B.y, B.z, B.w};
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-    v[r] = lut_at(lut_bytes, a[r >> 2], r & 3, offA) + lut_at(lut_bytes, b[r >> 2], r & 3, offB);
-#pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] = v[r] + dpp_mov<0x140>(v[r ^ 15]);   // row_mirror
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = v[r] + dpp_mov<0x141>(v[r ^ 7]);    // row_half_mirror
-#pragma unroll
-  for (int r = 0; r < 2; ++r) v[r] = v[r] + dpp_mov<0x1B>(v[r ^ 3]);     // quad_perm [3,2,1,0]
-  return v[0] + dpp_mov<0xB1>(v[1]);                                      // quad_perm [1,0,3,2]
-}
 
 template <int CAP>
 __global__ __launch_bounds__(V2_NT) void pq_scan_v2_kernel(

@@ -89,9 +89,11 @@ asl_index_t *asl_index_load(const char *path);
 /* k-means iterations (FAISS ClusteringParameters.niter, default 25) */
 int asl_index_set_niter(asl_index_t *idx, int32_t niter);
 
-/* PQ scan kernel selection: 0 = automatic (the tiled sub-quantiser-per-lane kernel when
- * m = 32, 8 bits, nprobe <= 256), 1 = force the generic lane-per-vector kernel. Both
- * return identical results; the switch exists for A/B measurements. */
+/* PQ scan kernel selection (all return identical results; the switch exists for A/B
+ * measurements): 0 = automatic (tiled sub-quantiser-per-lane kernel with histogram top-k
+ * when m = 32, 8 bits, nprobe <= 256), 1 = generic lane-per-vector kernel, 2 = tiled kernel
+ * with sort-based top-k, 3 / 4 = tiled + histogram top-k with a 2048- / 4096-key buffer.
+ * Bits 8+ are measurement knobs of the kernels (results invalid when set). */
 int asl_index_set_scan_variant(asl_index_t *idx, int32_t variant);
 
 /* Introspection, used by the parity tests and by multi-GPU sharding. Sizes via
