@@ -301,6 +301,14 @@ __device__ __forceinline__ uint32_t hbin(int b) {
   return ((uint32_t)b * 2654435761u) >> 23;  // 9 bits
 }
 
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double rl_d(double v, int l) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, l);
+  const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 constexpr int RS_PF = 8;  // candidates whose peaks are in flight ahead of the scoring
 
 // One (query, candidate) pair on the hash path; lanes are the candidate's peaks.
@@ -317,32 +325,39 @@ __device__ __forceinline__ double score_candidate(int lane, const QueryLds &Q, c
     if (j < cn) Wv.c_mz[j] = jb > 0 ? L.mz[co + j] : a_mz;
   }
   wave_sync();
+  // mass_diff[s] = pmd / s (cpp:26-31): lane s does the (expensive, exact) fp64 division
+  // once, every lane then reads the quotient it needs with v_readlane
+  const double md_lane = (lane > 0 && lane < S) ? pmd / (double)lane : 0.0;
+  const float inv_w_f = (float)inv_w;
   for (int jb = 0; jb < cn; jb += 64) {
     const int j = jb + lane;
-    if (j < cn) {
-      float cm = a_mz, ci = a_int;
-      int cc = a_chg;
-      if (jb > 0) {
-        cm = Wv.c_mz[j];
-        ci = L.intensity[co + j];
-        cc = L.charge ? L.charge[co + j] : 0;
-      }
-      for (int s = 0; s < S; ++s) {
+    const bool act = j < cn;
+    float cm = a_mz, ci = a_int;
+    int cc = a_chg;
+    if (jb > 0 && act) {
+      cm = Wv.c_mz[j];
+      ci = L.intensity[co + j];
+      cc = L.charge ? L.charge[co + j] : 0;
+    }
+    for (int s = 0; s < S; ++s) {      // wave-uniform trip count
+      const double md = rl_d(md_lane, s);
+      if (act) {
         double mult = 0.0;
         if (s == 0 || cc == s)
           mult = 1.0;
         else if (cc == 0)
           mult = 2.0 / 3.0;
         if (mult == 0.0) continue;  // this peak cannot pair under shift s (cpp:58-75)
-        const double md = s ? pmd / (double)s : 0.0;
-        const double x = (double)cm + md;
-        const int b = (int)floor(x * inv_w);
+        // bin of the shifted peak in fp32 (the query was filed with a margin that covers
+        // the fp32 rounding); the exact fp64 window test runs on the rare hits only
+        const int b = (int)floorf((cm + (float)md) * inv_w_f);
         uint32_t h = hbin(b);
         for (;;) {
           const int eb = H.bin[h];
           if (eb == RS_EMPTY) break;
           if (eb == b) {
             const int i = H.peak[h];
+            const double x = (double)cm + md;
             const double qm = (double)Q.mz[i];
             const double lim = qm - tol;
             if (fabs(qm - x) <= tol && (!(lim > x) || j == cn - 1)) {
@@ -393,7 +408,10 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
   load_query(tid, blockDim.x, Qs, q, Q, qn, status);
   for (int i = tid; i < RS_HT; i += blockDim.x) H.bin[i] = RS_EMPTY;
   __syncthreads();
-  if (!(tol > 0.0) || qn > RS_HQ_MAX) {  // workgroup-uniform: binary-search formulation
+  // fp32 evaluation of a probe bin (m/z <= ~2600): error bound in bin units; the query
+  // peaks are filed with that margin on both sides (still <= 3 bins per peak)
+  const double margin = 1e-3 + (tol > 0.0 ? (0.5 / tol) * (3.75e-4 + 2600.0 * 1.2e-7) : 1.0);
+  if (!(tol > 0.0) || qn > RS_HQ_MAX || margin > 0.45) {  // uniform: binary-search formulation
     const double q_pmz0 = Qs.precursor_mz[q];
     const long long step = (long long)RS_WAVES * gridDim.y;
     for (long long c = c0 + (long long)blockIdx.y * RS_WAVES + wave; c < c1; c += step) {
@@ -409,8 +427,8 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
   const double inv_w = 1.0 / (2.0 * tol);
   if (tid < qn) {
     const double qm = (double)Q.mz[tid];
-    const int blo = (int)floor((qm - tol) * inv_w - 1e-3);
-    const int bhi = (int)floor((qm + tol) * inv_w + 1e-3);
+    const int blo = (int)floor((qm - tol) * inv_w - margin);
+    const int bhi = (int)floor((qm + tol) * inv_w + margin);
     for (int b = blo; b <= bhi; ++b) {
       uint32_t h = hbin(b);
       for (;;) {
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
         fi[u] = 0.0f;
         fc[u] = 0;
         if (l < cnt) {  // uniform
-          const int co = __shfl(m_co, l), cn = __shfl(m_cn, l);
+          const int co = rl_i(m_co, l), cn = rl_i(m_cn, l);
           if (lane < cn) {
             fm[u] = L.mz[co + lane];
             fi[u] = L.intensity[co + lane];
@@ -479,12 +497,12 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
         if (l >= cnt) break;  // uniform
         const float a_mz = pmz_a[u], a_int = pint_a[u];
         const int a_chg = pchg_a[u];
-        const int is_ok = __shfl((int)okr, l);
+        const int is_ok = rl_i((int)okr, l);
         if (!is_ok) continue;  // wave-uniform
-        const int co = __shfl(m_co, l);
-        int cn = __shfl(m_cn, l);
-        const int c_charge = __shfl(m_chg, l);
-        const double c_pmz = __shfl(m_pmz, l);
+        const int co = rl_i(m_co, l);
+        int cn = rl_i(m_cn, l);
+        const int c_charge = rl_i(m_chg, l);
+        const double c_pmz = rl_d(m_pmz, l);
         if (cn > RS_MAXP) {
           if (lane == 0) atomicOr(status, RS_STATUS_PEAKS);
           cn = RS_MAXP;
