@@ -57,7 +57,7 @@ EXPORTS = [
     'asl_index_pq_lut', 'asl_rescore_batch', 'asl_library_create', 'asl_library_free',
     'asl_library_size', 'asl_search_batch', 'asl_window_candidates', 'asl_profile_enable',
     'asl_profile_reset', 'asl_profile_get', 'asl_profile_scanned_vectors',
-    'asl_rescore_knn', 'asl_lpt_owner', 'asl_index_set_scan_variant',
+    'asl_rescore_knn', 'asl_lpt_owner', 'asl_index_set_scan_variant', 'asl_index_search_preassigned',
 ]
 
 
@@ -102,6 +102,9 @@ def lib():
         L.asl_index_add.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.asl_index_search.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p]
+        L.asl_index_search_preassigned.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p]
         L.asl_index_reset.argtypes = [C.c_void_p]
         L.asl_index_ntotal.argtypes = [C.c_void_p]
         L.asl_index_ntotal.restype = C.c_int64

@@ -306,7 +306,8 @@ static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe) {
 
 // Search with all-device arguments. Exactly one of I64 / I32 may be non-null (or both).
 int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
-                        int64_t *I64, int32_t *I32) {
+                        int64_t *I64, int32_t *I32, const float *pre_D = nullptr,
+                        const int32_t *pre_I = nullptr) {
   if (nq <= 0) return ASL_OK;
   if (!ix->trained) return fail(ASL_ERR_STATE, "search: index is not trained");
   if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: k=%d outside 1..%d", k, TK_MAX_K);
@@ -352,7 +353,14 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   nprobe = std::max(1, std::min(nprobe, ix->nlist));
   if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
   ASL_TRY(build_lists(ix));
-  ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+  if (!pre_D) {
+    ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+  } else {  // search_preassigned: adopt the caller's probe lists
+    ASL_TRY(ix->coarse_D.reserve((size_t)nq * nprobe));
+    ASL_TRY(ix->coarse_I.reserve((size_t)nq * nprobe));
+    HIP_TRY(hipMemcpyAsync(ix->coarse_D.p, pre_D, (size_t)nq * nprobe * 4, hipMemcpyDeviceToDevice, stream()));
+    HIP_TRY(hipMemcpyAsync(ix->coarse_I.p, pre_I, (size_t)nq * nprobe * 4, hipMemcpyDeviceToDevice, stream()));
+  }
   {
     ProfScope ps("scan");
     const int sv = ix->scan_variant & 0xff;
@@ -741,6 +749,32 @@ int asl_index_search(asl_index_t *ix, int32_t nq, const float *xq, int32_t k, in
   ASL_TRY(dD.finish());
   ASL_TRY(dI.finish());
   if (dD.to_host() || dI.to_host() || dq.own.p) ASL_TRY(sync_stream());
+  return ASL_OK;
+}
+
+int asl_index_search_preassigned(asl_index_t *ix, int32_t nq, const float *xq, int32_t k,
+                                 int32_t nprobe, const float *coarse_D,
+                                 const int32_t *coarse_I, float *D, int64_t *I) {
+  clear_error();
+  if (!ix || ix->kind != ASL_INDEX_IVFPQ)
+    return fail(ASL_ERR_INVALID, "search_preassigned: IVF-PQ index required");
+  if (nq <= 0) return ASL_OK;
+  if (!xq || !I || !coarse_D || !coarse_I) return fail(ASL_ERR_INVALID, "search_preassigned: null argument");
+  if (nprobe < 1 || nprobe > ix->nlist) return fail(ASL_ERR_INVALID, "search_preassigned: nprobe outside 1..nlist");
+  ASL_TRY(ensure_device());
+  In<float> dq, dcD;
+  In<int32_t> dcI;
+  Out<float> dD;
+  Out<int64_t> dI;
+  ASL_TRY(dq.init(xq, (size_t)nq * ix->d));
+  ASL_TRY(dcD.init(coarse_D, (size_t)nq * nprobe));
+  ASL_TRY(dcI.init(coarse_I, (size_t)nq * nprobe));
+  ASL_TRY(dD.init(D, (size_t)nq * k));
+  ASL_TRY(dI.init(I, (size_t)nq * k));
+  ASL_TRY(index_search_device(ix, nq, dq.d, k, nprobe, dD.d, dI.d, nullptr, dcD.d, dcI.d));
+  ASL_TRY(dD.finish());
+  ASL_TRY(dI.finish());
+  if (dD.to_host() || dI.to_host() || dq.own.p || dcD.own.p || dcI.own.p) ASL_TRY(sync_stream());
   return ASL_OK;
 }
 

@@ -19,7 +19,7 @@ int encode_device(const float *mz, const float *inten, const int32_t *offsets, i
                   double min_bound, double bin_size, int32_t hash_len, uint32_t seed,
                   int norm, float *out);
 int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
-                        int64_t *I64, int32_t *I32);
+                        int64_t *I64, int32_t *I32, const float *pre_D, const int32_t *pre_I);
 int index_dim(const asl_index *ix);
 int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
                    const int32_t *rows32, const int32_t *cand_offsets, int32_t stride,
@@ -352,7 +352,8 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
     ASL_TRY(L->pair_score.reserve((size_t)nq * k));
     ASL_TRY(encode_device(Q.dev.mz, Q.dev.intensity, Q.dev.offsets, nq, P->min_bound, P->bin_size,
                           d, P->hash_seed, 1, L->qvec.p));
-    ASL_TRY(index_search_device(idx, nq, L->qvec.p, k, P->nprobe, nullptr, o_knn.d, L->knn.p));
+    ASL_TRY(index_search_device(idx, nq, L->qvec.p, k, P->nprobe, nullptr, o_knn.d, L->knn.p,
+                                nullptr, nullptr));
     {
       ProfScope ps("filter");
       const int64_t total = (int64_t)nq * k;

@@ -61,6 +61,18 @@ class HipShardBackend:
         self.index.nprobe = self.sl._num_probe
         return self.index.search(vectors, self.k)
 
+    # coarse quantiser on the rank's own slice only (probe lists are identical on every
+    # rank, so they are all-gathered instead of being recomputed world times)
+    supports_preassigned = True
+
+    def coarse(self, vectors: torch.Tensor):
+        if self.index.info().kind != 2:
+            return None
+        return self.index.coarse(vectors, self.sl._num_probe)
+
+    def shard_search_preassigned(self, vectors, coarse_D, coarse_I):
+        return self.index.search_preassigned(vectors, self.k, coarse_D, coarse_I)
+
     def merge(self, Ds: torch.Tensor, Is: torch.Tensor):
         from . import faiss_compat
         return faiss_compat.topk_merge(Ds, Is)
@@ -107,12 +119,26 @@ def exchange_partials(D: torch.Tensor, I: torch.Tensor, world: int, group=None):
         dist.all_to_all_single(Do, D, group=group)
         dist.all_to_all_single(Io, I, group=group)
         return Do.view(world, nq_local, k), Io.view(world, nq_local, k)
-    Dg = [torch.empty_like(D) for _ in range(world)]
-    Ig = [torch.empty_like(I) for _ in range(world)]
-    dist.all_gather(Dg, D, group=group)
-    dist.all_gather(Ig, I, group=group)
+    dev = D.device
+    Dc, Ic = D.cpu(), I.cpu()          # gloo: collectives on host tensors
+    Dg = [torch.empty_like(Dc) for _ in range(world)]
+    Ig = [torch.empty_like(Ic) for _ in range(world)]
+    dist.all_gather(Dg, Dc, group=group)
+    dist.all_gather(Ig, Ic, group=group)
     sl = slice(rank * nq_local, (rank + 1) * nq_local)
-    return torch.stack([d[sl] for d in Dg]), torch.stack([i[sl] for i in Ig])
+    return (torch.stack([d[sl] for d in Dg]).to(dev), torch.stack([i[sl] for i in Ig]).to(dev))
+
+
+def _all_gather_rows(x: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """Concatenate every rank's [n, ...] tensor along dim 0 (rank order)."""
+    if dist.get_backend(group) == 'nccl':
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype,
+                          device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        return out
+    parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(world)]
+    dist.all_gather(parts, x.cpu().contiguous(), group=group)
+    return torch.cat(parts).to(x.device)
 
 
 def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, device_out=False):
@@ -123,9 +149,13 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     if world == 1:
         D, I = backend.shard_search(vec)
         return backend.rescore_knn(queries_local, I, device_out)
-    allvec = torch.empty((world * vec.shape[0], vec.shape[1]), dtype=vec.dtype, device=vec.device)
-    dist.all_gather_into_tensor(allvec, vec.contiguous(), group=group)
-    D, I = backend.shard_search(allvec)
+    allvec = _all_gather_rows(vec, world, group)
+    co = backend.coarse(vec) if getattr(backend, 'supports_preassigned', False) else None
+    if co is not None:
+        cD, cI = _all_gather_rows(co[0], world, group), _all_gather_rows(co[1], world, group)
+        D, I = backend.shard_search_preassigned(allvec, cD, cI)
+    else:
+        D, I = backend.shard_search(allvec)
     Ds, Is = exchange_partials(D, I, world, group)
     _, knn = backend.merge(Ds.contiguous(), Is.contiguous())
     return backend.rescore_knn(queries_local, knn, device_out)

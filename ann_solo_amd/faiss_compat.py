@@ -141,9 +141,33 @@ class Index:
                                                   _lib.ptr(codes), _lib.ptr(vecs)))
         return off, ids, codes if codes is not None else vecs
 
+    def search_preassigned(self, x, k, coarse_D, coarse_I):
+        """IndexIVF.search_preassigned: scan with caller-supplied probe lists
+        (``coarse_D``/``coarse_I`` [nq, nprobe] as ``coarse()`` returns them)."""
+        x = _as_f32(x, self.d)
+        nq, nprobe = coarse_I.shape
+        if isinstance(x, np.ndarray):
+            D = np.empty((nq, k), np.float32)
+            I = np.empty((nq, k), np.int64)
+        else:
+            import torch
+            D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+        _lib.check(_lib.lib().asl_index_search_preassigned(
+            self._h, nq, _lib.ptr(x), int(k), int(nprobe), _lib.ptr(coarse_D),
+            _lib.ptr(coarse_I), _lib.ptr(D), _lib.ptr(I)))
+        return D, I
+
     def coarse(self, x, nprobe):
         x = _as_f32(x, self.d)
         nprobe = min(nprobe, self.info().nlist)
+        if not isinstance(x, np.ndarray):
+            import torch
+            D = torch.empty((x.shape[0], nprobe), dtype=torch.float32, device=x.device)
+            I = torch.empty((x.shape[0], nprobe), dtype=torch.int32, device=x.device)
+            _lib.check(_lib.lib().asl_index_coarse(self._h, x.shape[0], _lib.ptr(x), nprobe,
+                                                   _lib.ptr(D), _lib.ptr(I)))
+            return D, I
         D = np.empty((x.shape[0], nprobe), np.float32)
         I = np.empty((x.shape[0], nprobe), np.int32)
         _lib.check(_lib.lib().asl_index_coarse(self._h, x.shape[0], _lib.ptr(x), nprobe,

@@ -75,12 +75,19 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X (no CPU fallback exists)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    _lib.check(_lib.lib().asl_set_device(local_rank))
+    # ASL_BENCH_BACKEND=gloo runs every rank on GPU 0 with host-side collectives: a
+    # functional check of the sharded path on a 1-GPU box, never a performance number
+    backend = os.environ.get('ASL_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    _lib.check(_lib.lib().asl_set_device(dev_index))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     t_build = time.time()
     charge = 2
@@ -136,12 +143,22 @@ def main():
         torch.cuda.empty_cache()
 
     # ---- shard for N > 1
+    shard_check = None
     if world > 1:
+        ns = min(256, q.n)
+        ref = sl._search_batch(q.select(torch.arange(ns, device=dev)), charge, 'open',
+                               device_out=True)          # unsharded result of my first queries
         idx.shard(rank, world)
-        backend = HipShardBackend(sl, charge, 'open')
+        shard_backend = HipShardBackend(sl, charge, 'open')
 
         def step():
-            return sharded_search_batch(backend, q, device_out=True)
+            return sharded_search_batch(shard_backend, q, device_out=True)
+        got = step()
+        same = bool(torch.equal(got.best_row[:ns], ref.best_row) and
+                    torch.equal(got.best_score[:ns], ref.best_score))
+        flag = torch.tensor([int(same)], device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        shard_check = {'queries_per_rank': ns, 'sharded_equals_unsharded': bool(flag.item())}
     else:
         def step():
             return sl._search_batch(q, charge, 'open', device_out=True)
@@ -165,7 +182,8 @@ def main():
     elapsed = time.perf_counter() - t0
     L.asl_profile_enable(0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -214,6 +232,7 @@ def main():
                        'nlist': args.nlist, 'nprobe': args.nprobe, 'k': args.k,
                        'parallelism': f'ivf-list-shard x{world}' if world > 1 else 'single'},
             'recall': recall,
+            'shard_check': shard_check,
             'stages_ms_per_step': {k: round(v['ms_total'] / args.steps, 3) for k, v in stages.items()},
             'roofline': roofline,
             'cpu_baseline': cpu,

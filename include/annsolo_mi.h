@@ -125,6 +125,15 @@ int asl_index_shard_map(const asl_index_t *idx, int32_t world, int32_t *owner /*
  * currently least-loaded rank (ties: lower rank). */
 int asl_lpt_owner(int32_t nlist, const int64_t *sizes, int32_t world, int32_t *owner);
 
+/* IndexIVF::search_preassigned: like asl_index_search but with the coarse quantiser's
+ * answer supplied by the caller (coarse_D / coarse_I [nq, nprobe], as asl_index_coarse
+ * emits; -1 entries are skipped). Used by the sharded search: every rank quantises only
+ * its own slice of the batch, the probe lists are all-gathered, and each rank scans its
+ * own inverted lists for the whole batch. IVF-PQ only. */
+int asl_index_search_preassigned(asl_index_t *idx, int32_t nq, const float *xq, int32_t k,
+                                 int32_t nprobe, const float *coarse_D,
+                                 const int32_t *coarse_I, float *D, int64_t *I);
+
 /* Merge S partial results [S, nq, k] into [nq, k] under (score desc, id asc). */
 int asl_topk_merge(int32_t S, int32_t nq, int32_t k, const float *Ds, const int64_t *Is,
                    float *D, int64_t *I);
