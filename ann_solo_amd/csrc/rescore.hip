@@ -302,6 +302,11 @@ __device__ __forceinline__ uint32_t hbin(int b) {
 }
 
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ long long rl_ll(long long v, int l) {
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)(unsigned long long)v, l);
+  const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)((unsigned long long)v >> 32), l);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double rl_d(double v, int l) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, l);
@@ -309,36 +314,29 @@ __device__ __forceinline__ double rl_d(double v, int l) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-constexpr int RS_PF = 8;  // candidates whose peaks are in flight ahead of the scoring
+constexpr int RS_PF = 4;   // candidates staged per burst (4 x 64 peaks = WaveLds::c_mz/c_int/c_chg)  // candidates whose peaks are in flight ahead of the scoring
 
 // One (query, candidate) pair on the hash path; lanes are the candidate's peaks.
 __device__ __forceinline__ double score_candidate(int lane, const QueryLds &Q, const HashLds &H,
-                                                  WaveLds &Wv, const DevPeaks &L, int co, int cn,
-                                                  int c_charge, double c_pmz, double q_pmz,
-                                                  double tol, double inv_w, int allow_shift,
-                                                  float a_mz, float a_int, int a_chg, int *status) {
+                                                  WaveLds &Wv, int slot, int cn, int c_charge,
+                                                  double c_pmz, double q_pmz, double tol,
+                                                  double inv_w, int allow_shift, int *status) {
   if (lane == 0) Wv.counter = 0;
   const double pmd = (q_pmz - c_pmz) * (double)(unsigned)c_charge;    // cpp:18
   const int S = (allow_shift && fabs(pmd) >= tol) ? c_charge + 1 : 1;  // cpp:20
-  for (int jb = 0; jb < cn; jb += 64) {
-    const int j = jb + lane;
-    if (j < cn) Wv.c_mz[j] = jb > 0 ? L.mz[co + j] : a_mz;
-  }
-  wave_sync();
+  const float *s_mz = Wv.c_mz + slot * 64;   // this candidate's staged peaks (cn <= 64)
+  const float a_mz = lane < cn ? s_mz[lane] : 0.0f;
+  const float a_int = lane < cn ? Wv.c_int[slot * 64 + lane] : 0.0f;
+  const int a_chg = lane < cn ? Wv.c_chg[slot * 64 + lane] : 0;
   // mass_diff[s] = pmd / s (cpp:26-31): lane s does the (expensive, exact) fp64 division
   // once, every lane then reads the quotient it needs with v_readlane
   const double md_lane = (lane > 0 && lane < S) ? pmd / (double)lane : 0.0;
   const float inv_w_f = (float)inv_w;
-  for (int jb = 0; jb < cn; jb += 64) {
-    const int j = jb + lane;
+  {
+    const int j = lane;
     const bool act = j < cn;
-    float cm = a_mz, ci = a_int;
-    int cc = a_chg;
-    if (jb > 0 && act) {
-      cm = Wv.c_mz[j];
-      ci = L.intensity[co + j];
-      cc = L.charge ? L.charge[co + j] : 0;
-    }
+    const float cm = a_mz, ci = a_int;
+    const int cc = a_chg;
     for (int s = 0; s < S; ++s) {      // wave-uniform trip count
       const double md = rl_d(md_lane, s);
       if (act) {
@@ -365,7 +363,7 @@ __device__ __forceinline__ double score_candidate(int lane, const QueryLds &Q, c
               // must pass the window test too (differs only on fp boundaries)
               bool run = true;
               for (int jj = j; jj > 0; --jj) {
-                const double xp = (double)Wv.c_mz[jj - 1] + md;
+                const double xp = (double)s_mz[jj - 1] + md;
                 if (lim > xp) break;
                 if (!(fabs(qm - xp) <= tol)) {
                   run = false;
@@ -374,12 +372,12 @@ __device__ __forceinline__ double score_candidate(int lane, const QueryLds &Q, c
               }
               if (run) {
                 const float prod = (float)(mult * (double)Q.inten[i] * (double)ci);
-                const int slot = atomicAdd(&Wv.counter, 1);
-                if (slot < RS_MCAP) {
+                const int mslot = atomicAdd(&Wv.counter, 1);
+                if (mslot < RS_MCAP) {
                   const uint32_t gen = (uint32_t)((i * S + s) * cn + j);
-                  Wv.keys[slot] = ((unsigned long long)__float_as_uint(prod) << 32) |
-                                  (unsigned long long)(0xFFFFFFFFu - gen);
-                  Wv.pay[slot] = ((uint32_t)i << 16) | (uint32_t)j;
+                  Wv.keys[mslot] = ((unsigned long long)__float_as_uint(prod) << 32) |
+                                   (unsigned long long)(0xFFFFFFFFu - gen);
+                  Wv.pay[mslot] = ((uint32_t)i << 16) | (uint32_t)j;
                 }
               }
             }
@@ -467,59 +465,55 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
     }
     double my_score = -1.0;
     const int cnt = (int)((we - base) < 64 ? (we - base) : 64);
-    // peaks are prefetched RS_PF candidates ahead (a dependent HBM gather per candidate):
-    // group g+1's loads are issued before group g is scored
-    float pmz_a[RS_PF], pint_a[RS_PF], pmz_b[RS_PF], pint_b[RS_PF];
-    int pchg_a[RS_PF], pchg_b[RS_PF];
-    auto fetch_group = [&](int g0, float *fm, float *fi, int *fc) {
-#pragma unroll
-      for (int u = 0; u < RS_PF; ++u) {
-        const int l = g0 + u;
-        fm[u] = 0.0f;
-        fi[u] = 0.0f;
-        fc[u] = 0;
-        if (l < cnt) {  // uniform
-          const int co = rl_i(m_co, l), cn = rl_i(m_cn, l);
-          if (lane < cn) {
-            fm[u] = L.mz[co + lane];
-            fi[u] = L.intensity[co + lane];
-            fc[u] = L.charge ? L.charge[co + lane] : 0;
-          }
-        }
-      }
-    };
-    fetch_group(0, pmz_a, pint_a, pchg_a);
+    // Bursts of RS_PF candidates: all their peak loads are issued back to back (straight
+    // line, so hipcc keeps them in flight together), parked in this wave's LDS staging
+    // area, and the candidates are then scored from LDS with no global load in the way.
     for (int g0 = 0; g0 < cnt; g0 += RS_PF) {
-      if (g0 + RS_PF < cnt) fetch_group(g0 + RS_PF, pmz_b, pint_b, pchg_b);
+      float fm[RS_PF], fi[RS_PF];
+      int fc[RS_PF];
+#pragma unroll
+      for (int u = 0; u < RS_PF; ++u) {
+        const int l = g0 + u < cnt ? g0 + u : cnt - 1;
+        const int co = rl_i(m_co, l), cn = rl_i(m_cn, l);
+        const bool ld = lane < cn && g0 + u < cnt;
+        fm[u] = ld ? L.mz[co + lane] : 0.0f;
+        fi[u] = ld ? L.intensity[co + lane] : 0.0f;
+        fc[u] = (ld && L.charge) ? L.charge[co + lane] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < RS_PF; ++u) {
+        Wv.c_mz[u * 64 + lane] = fm[u];
+        Wv.c_int[u * 64 + lane] = fi[u];
+        Wv.c_chg[u * 64 + lane] = (uint8_t)fc[u];
+      }
+      wave_sync();
 #pragma unroll
       for (int u = 0; u < RS_PF; ++u) {
         const int l = g0 + u;
-        if (l >= cnt) break;  // uniform
-        const float a_mz = pmz_a[u], a_int = pint_a[u];
-        const int a_chg = pchg_a[u];
-        const int is_ok = rl_i((int)okr, l);
-        if (!is_ok) continue;  // wave-uniform
-        const int co = rl_i(m_co, l);
-        int cn = rl_i(m_cn, l);
-        const int c_charge = rl_i(m_chg, l);
-        const double c_pmz = rl_d(m_pmz, l);
-        if (cn > RS_MAXP) {
-          if (lane == 0) atomicOr(status, RS_STATUS_PEAKS);
-          cn = RS_MAXP;
+        if (l < cnt && rl_i((int)okr, l)) {   // wave-uniform
+          const int cn = rl_i(m_cn, l);
+          const int c_charge = rl_i(m_chg, l);
+          const double c_pmz = rl_d(m_pmz, l);
+          double score = 0.0;
+          if (cn > 64) {   // rare: more peaks than a staging slot holds -> after the bursts
+            score = -2.0;
+          } else if (cn > 0 && qn > 0) {
+            score = score_candidate(lane, Q, H, Wv, u, cn, c_charge, c_pmz, q_pmz, tol, inv_w,
+                                    allow_shift, status);
+          }
+          if (lane == l) my_score = score;
         }
-        double score = 0.0;
-        if (cn > 0 && qn > 0) {
-          score = score_candidate(lane, Q, H, Wv, L, co, cn, c_charge, c_pmz, q_pmz, tol, inv_w,
-                                  allow_shift, a_mz, a_int, a_chg, status);
-        }
-        if (lane == l) my_score = score;
       }
-#pragma unroll
-      for (int u = 0; u < RS_PF; ++u) {
-        pmz_a[u] = pmz_b[u];
-        pint_a[u] = pint_b[u];
-        pchg_a[u] = pchg_b[u];
-      }
+      wave_sync();
+    }
+    // candidates with more than 64 peaks: binary-search formulation (uses the whole staging area)
+    unsigned long long big = __ballot(my_score == -2.0);
+    while (big) {
+      const int l = __builtin_ctzll(big);
+      big &= big - 1;
+      const double sc = dot_pair_wave<false>(lane, Q, qn, q_pmz, L, (int)rl_ll(row, l), tol,
+                                             allow_shift, Wv, nullptr, 0, nullptr, status);
+      if (lane == l) my_score = sc;
     }
     if (c < we) pair_score[c] = my_score;
   }
