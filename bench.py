@@ -203,10 +203,11 @@ def main():
             avg_ms = scan['ms_total'] / scan['launches']
             bytes_per_launch = scanned / scan['launches'] * BYTES_PER_SCANNED_VECTOR
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            roofline = {'bound': 'hbm', 'kernel': 'pq_scan_kernel' if args.index == 'ivfpq'
+            roofline = {'bound': 'hbm', 'kernel': 'pq_scan_v3_kernel' if args.index == 'ivfpq'
                         else 'gemm_nt_f32+row_topk (masked IVF-Flat)',
                         'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                        'frac': round(achieved / HBM_PEAK_GBS, 5),
+                        'traffic': pmc_traffic(args, world),
                         'avg_launch_ms': round(avg_ms, 4),
                         'algorithmic_bytes_per_launch': int(bytes_per_launch),
                         'vectors_scanned_per_query': round(scanned / scan['launches'] /
@@ -241,6 +242,23 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, world):
+    """HBM-side bytes per scan launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in
+    its own run, scripts/pmc.sh; FETCH_SIZE is in KiB and reads 1/2 of a wide coalesced stream
+    on gfx950, MI355X_MICROARCH.md). Only valid for the exact default workload; else null."""
+    default = (world == 1 and args.library_size == 2_100_000 and args.nlist == 4096 and
+               args.nprobe == 128 and args.k == 1024 and args.batch == 16384 and
+               args.index == 'ivfpq' and args.scan_variant == 0)
+    path = os.path.join(ROOT, 'profiles', 'r01_v3_pmc_traffic.json')
+    if not default or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return int(json.load(f)['scan_hbm_bytes_per_launch'])
+    except Exception:
+        return None
 
 
 def cpu_baseline(args, sl, part, idx, q, res, charge, cfg):
