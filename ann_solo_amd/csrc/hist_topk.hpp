@@ -1,0 +1,198 @@
+// hist_topk.hpp -- exact top-k of a long candidate stream for one 256-thread workgroup
+// WITHOUT sorting while streaming (used by pq_scan_v3.hip and flat_scan.hip).
+//
+//   * hist[512]: counts of the appended candidates per score bucket (monotone linear
+//     bucketing of the fp32 score over [-1, 2)),
+//   * bstar: the highest bucket with at least k appended candidates at or above it.
+// A candidate whose bucket is below bstar can never be among the k best (k candidates with
+// strictly larger scores exist): it is not stored; when the key buffer runs full it is
+// compacted by the same test (one prefix scan, no sort). Keys carry a storage SLOT; ids
+// are resolved and the survivors sorted exactly once, in finish(), under
+// (score desc, id asc). If compaction cannot free the buffer (thousands of bit-identical
+// scores) the workgroup switches to StreamTopK's exact sort-and-truncate flushes.
+//
+// Calling discipline (all 256 threads, uniform control flow):
+//   init();  per round: { b = begin_round(); ... offer() per candidate ...; end_round(n_appended_by_my_wave); }
+//   finish(D, I64, I32);
+#pragma once
+#include "topk.hpp"
+
+namespace asl {
+
+constexpr int HT_NT = 256;
+constexpr int HT_NB = 512;
+constexpr float HT_LO = -1.0f, HT_SCALE = HT_NB / 3.0f;
+
+__device__ __forceinline__ int score_bucket(float s) {
+  float t = (s - HT_LO) * HT_SCALE;
+  t = fminf(fmaxf(t, 0.0f), (float)(HT_NB - 1));
+  return (int)t;
+}
+
+// exclusive prefix sum of one int per thread over the workgroup; `part` = 4 LDS ints
+// reserved for this call site. Total in `total`.
+__device__ __forceinline__ int block_excl_scan256(int v, int *part, int tid, int &total) {
+  const int lane = tid & 63, wave = tid >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) part[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int t = part[w];
+    if (w < wave) base += t;
+    total += t;
+  }
+  return base + incl - v;
+}
+
+// LDS footprint: CAP*8 (keys) + 128 (control) + HT_NB*4 (histogram)
+template <int CAP, int ROUND_VECS>
+struct HistTopK {
+  enum { C_FILL = 0, C_BSTAR = 1, C_WCNT = 2 /* 8 */, C_PART_B = 10 /* 4 */, C_PART_C = 14 /* 4 */,
+         C_USER = 18 /* 4 ints for the caller */ };
+  static constexpr int PER = CAP / HT_NT;
+  u64 *keys;
+  u64 *thr_p;
+  int *ctl;
+  int *hist;
+  const int32_t *slot_ids;
+  StreamTopK<HT_NT, CAP> tk;
+  int k, tid, lane, wave;
+  int fill, parity, round_no;
+  bool sort_mode;
+  // per-round snapshot
+  int bstar;
+  uint32_t thr_hi;
+
+  static constexpr size_t lds_bytes() { return (size_t)CAP * 8 + 128 + (size_t)HT_NB * 4; }
+
+  // `base` must be 16-byte aligned; returns the first byte after the structure's LDS
+  __device__ __forceinline__ char *init(char *base, int k_, const int32_t *slot_ids_, int tid_) {
+    keys = reinterpret_cast<u64 *>(base);
+    thr_p = keys + CAP;
+    ctl = reinterpret_cast<int *>(thr_p + 1);
+    hist = reinterpret_cast<int *>(thr_p + 16);
+    slot_ids = slot_ids_;
+    k = k_;
+    tid = tid_;
+    lane = tid & 63;
+    wave = tid >> 6;
+    fill = parity = round_no = 0;
+    sort_mode = false;
+    tk.init(keys, ctl, thr_p, CAP, k, tid);
+    for (int i = tid; i < HT_NB; i += HT_NT) hist[i] = 0;
+    if (tid == 0) ctl[C_BSTAR] = 0;
+    __syncthreads();
+    return reinterpret_cast<char *>(hist + HT_NB);
+  }
+
+  __device__ __forceinline__ void begin_round() {
+    thr_hi = (uint32_t)(*thr_p >> 32);
+    bstar = ctl[C_BSTAR];
+  }
+
+  // one candidate per lane; returns true if it was kept (count kept lanes per wave with
+  // __ballot and pass the sum to end_round)
+  __device__ __forceinline__ bool offer(bool valid, float score, uint32_t slot) {
+    const uint32_t ob = f2ord(score);
+    const int b = score_bucket(score);
+    const bool pass = sort_mode ? (ob >= thr_hi) : (b >= bstar);
+    if (valid && pass) {
+      const int s = atomicAdd(&ctl[C_FILL], 1);
+      keys[s] = ((u64)ob << 32) | (u64)slot;
+      if (!sort_mode) atomicAdd(&hist[b], 1);
+      return true;
+    }
+    return false;
+  }
+
+  __device__ __forceinline__ void update_bstar() {
+    constexpr int BPT = HT_NB / HT_NT;  // buckets per thread, highest buckets in thread 0
+    int h[BPT], s = 0;
+#pragma unroll
+    for (int u = 0; u < BPT; ++u) {
+      h[u] = hist[HT_NB - 1 - (tid * BPT + u)];
+      s += h[u];
+    }
+    int tot;
+    int above = block_excl_scan256(s, ctl + C_PART_B, tid, tot);
+    if (above < k && above + s >= k) {
+      int b = HT_NB - 1 - tid * BPT;
+#pragma unroll
+      for (int u = 0; u < BPT; ++u) {
+        above += h[u];
+        if (above >= k) break;
+        --b;
+      }
+      ctl[C_BSTAR] = b;
+    }
+    __syncthreads();
+  }
+
+  // drop every buffered key whose bucket is below bstar; returns the new fill
+  __device__ __forceinline__ int compact() {
+    update_bstar();
+    const int bs = ctl[C_BSTAR];
+    u64 kk[PER];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid + u * HT_NT;
+      kk[u] = i < fill ? keys[i] : 0ull;
+      if (kk[u] != 0ull && score_bucket(ord2f((uint32_t)(kk[u] >> 32))) < bs) kk[u] = 0ull;
+      cnt += kk[u] != 0ull;
+    }
+    int tot;
+    int pos = block_excl_scan256(cnt, ctl + C_PART_C, tid, tot);  // barrier inside: all loaded
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+      if (kk[u] != 0ull) keys[pos++] = kk[u];
+    if (tid == 0) ctl[C_FILL] = tot;
+    __syncthreads();
+    return tot;
+  }
+
+  // `appended` = candidates kept by THIS wave in the round (wave-uniform). The fill level is
+  // tracked identically in every thread from parity-double-buffered per-wave counts, so the
+  // compaction decision cannot race with a faster wave's next round.
+  __device__ __forceinline__ void end_round(int appended) {
+    if (lane == 0) ctl[C_WCNT + parity * 4 + wave] = appended;
+    __syncthreads();
+    fill += ctl[C_WCNT + parity * 4] + ctl[C_WCNT + parity * 4 + 1] +
+            ctl[C_WCNT + parity * 4 + 2] + ctl[C_WCNT + parity * 4 + 3];
+    if (fill > CAP - ROUND_VECS) {
+      if (!sort_mode) {
+        fill = compact();
+        if (fill > CAP - ROUND_VECS) {   // ties defeat the buckets: exact flushes from now on
+          sort_mode = true;
+          tk.slot_ids = slot_ids;
+          tk.conv_from = 0;
+        }
+      }
+      if (sort_mode && fill > CAP - ROUND_VECS) fill = tk.flush(tid);
+    } else if (!sort_mode && (round_no & 3) == 3) {
+      update_bstar();
+    }
+    parity ^= 1;
+    ++round_no;
+  }
+
+  __device__ __forceinline__ void finish(float *D, int64_t *I64, int32_t *I32) {
+    __syncthreads();
+    if (!sort_mode) {
+      fill = compact();          // typically leaves k .. k + one bucket's population
+      tk.slot_ids = slot_ids;    // every surviving key still carries its storage slot
+      tk.conv_from = 0;
+    }
+    tk.finish(D, I64, I32, tid);
+  }
+};
+
+}  // namespace asl

@@ -16,26 +16,14 @@
 //
 // Smaller LDS footprint (key buffer 2048 or 4096) => up to 3 workgroups per CU.
 #include "common.hpp"
+#include "hist_topk.hpp"
 #include "ivf_kernels.hpp"
 #include "pq_tile.hpp"
-#include "topk.hpp"
 
 namespace asl {
 
 constexpr int V3_NT = 256;
-constexpr int V3_NB = 512;      // score buckets
 constexpr int V3_CHUNK = 128;   // tile-table entries per chunk
-constexpr float V3_LO = -1.0f, V3_SCALE = V3_NB / 3.0f;
-
-__device__ __forceinline__ int score_bucket(float s) {
-  float t = (s - V3_LO) * V3_SCALE;
-  t = fminf(fmaxf(t, 0.0f), (float)(V3_NB - 1));
-  return (int)t;
-}
-
-// control block (ints after the 8-byte threshold word)
-enum { C_FILL = 0, C_BSTAR = 1, C_WCNT = 2 /* 8 */, C_PART_A = 10 /* 4 */, C_PART_B = 14 /* 4 */,
-       C_PART_C = 18 /* 4 */ };
 
 template <int CAP, int T>
 __global__ __launch_bounds__(V3_NT) void pq_scan_v3_kernel(
@@ -44,15 +32,12 @@ __global__ __launch_bounds__(V3_NT) void pq_scan_v3_kernel(
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ tile_offsets,
     const uint8_t *__restrict__ codes_tiled, const int32_t *__restrict__ ids_tiled, int k,
     float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int dbg) {
-  constexpr int ROUND_TILES = 4 * T, ROUND_VECS = ROUND_TILES * 64, PER = CAP / V3_NT;
+  constexpr int ROUND_TILES = 4 * T, ROUND_VECS = ROUND_TILES * 64;
+  using TopK = HistTopK<CAP, ROUND_VECS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  u64 *keys = reinterpret_cast<u64 *>(smem);
-  u64 *thr_p = keys + CAP;
-  int *ctl = reinterpret_cast<int *>(thr_p + 1);
-  float *s_lut = reinterpret_cast<float *>(thr_p + 16);  // 128-B control block
-  int *hist = reinterpret_cast<int *>(s_lut + PQT_KSUB * PQT_M);
-  TileEnt *table = reinterpret_cast<TileEnt *>(hist + V3_NB);
-  float *s_q = reinterpret_cast<float *>(keys);  // aliases the key buffer during the LUT build
+  float *s_lut = reinterpret_cast<float *>(smem + TopK::lds_bytes());
+  TileEnt *table = reinterpret_cast<TileEnt *>(s_lut + PQT_KSUB * PQT_M);
+  float *s_q = reinterpret_cast<float *>(smem);  // aliases the key buffer during the LUT build
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
   build_lut_rotated(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, tid);
@@ -70,69 +55,18 @@ __global__ __launch_bounds__(V3_NT) void pq_scan_v3_kernel(
     }
   }
   int total;
-  const int my_pre = block_excl_scan256(my_nt, ctl + C_PART_A, tid, total);
-
-  StreamTopK<V3_NT, CAP> tk;  // init zeroes the keys (which aliased s_q) and the fill
-  tk.init(keys, ctl, thr_p, CAP, k, tid);
-  for (int i = tid; i < V3_NB; i += V3_NT) hist[i] = 0;
-  if (tid == 0) ctl[C_BSTAR] = 0;
+  int *scan_part = reinterpret_cast<int *>(table);   // table is not live yet
+  const int my_pre = block_excl_scan256(my_nt, scan_part, tid, total);
   __syncthreads();
+
+  TopK top;   // init zeroes the keys (which aliased s_q)
+  top.init(smem, k, ids_tiled, tid);
 
   const char *lut_bytes = reinterpret_cast<const char *>(s_lut);
   const int rho = lane >> 4, j = lane & 15;
   const int ma = (rho & 1) ? j + 16 : j, mb = ma ^ 16;
   const uint32_t offA = (uint32_t)ma * 4u, offB = (uint32_t)mb * 4u;
   const uint32_t chunkA = (uint32_t)(rho * 512 + ma * 16), chunkB = (uint32_t)(rho * 512 + mb * 16);
-
-  int fill = 0, parity = 0, round_no = 0;
-  bool sort_mode = false;   // workgroup-uniform
-
-  // highest bucket b with >= k appended candidates in buckets >= b  (0 if fewer than k)
-  auto update_bstar = [&]() {
-    constexpr int BPT = V3_NB / V3_NT;  // buckets per thread, highest buckets in thread 0
-    int h[BPT], s = 0;
-#pragma unroll
-    for (int u = 0; u < BPT; ++u) {
-      h[u] = hist[V3_NB - 1 - (tid * BPT + u)];
-      s += h[u];
-    }
-    int tot;
-    int above = block_excl_scan256(s, ctl + C_PART_B, tid, tot);
-    if (above < k && above + s >= k) {
-      int b = V3_NB - 1 - tid * BPT;
-#pragma unroll
-      for (int u = 0; u < BPT; ++u) {
-        above += h[u];
-        if (above >= k) break;
-        --b;
-      }
-      ctl[C_BSTAR] = b;
-    }
-    __syncthreads();
-  };
-
-  // drop every buffered key whose bucket is below bstar; returns the new fill
-  auto compact = [&]() -> int {
-    update_bstar();
-    const int bs = ctl[C_BSTAR];
-    u64 kk[PER];
-    int cnt = 0;
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int i = tid + u * V3_NT;
-      kk[u] = i < fill ? keys[i] : 0ull;
-      if (kk[u] != 0ull && score_bucket(ord2f((uint32_t)(kk[u] >> 32))) < bs) kk[u] = 0ull;
-      cnt += kk[u] != 0ull;
-    }
-    int tot;
-    int pos = block_excl_scan256(cnt, ctl + C_PART_C, tid, tot);  // barrier inside: all loaded
-#pragma unroll
-    for (int u = 0; u < PER; ++u)
-      if (kk[u] != 0ull) keys[pos++] = kk[u];
-    if (tid == 0) ctl[C_FILL] = tot;
-    __syncthreads();
-    return tot;
-  };
 
   for (int c0 = 0; c0 < total; c0 += V3_CHUNK) {
     {
@@ -164,45 +98,20 @@ __global__ __launch_bounds__(V3_NT) void pq_scan_v3_kernel(
       }
     };
     fetch(0, A, B, ent);
-    for (int rr = 0; rr < nrounds; ++rr, parity ^= 1, ++round_no) {
+    for (int rr = 0; rr < nrounds; ++rr) {
       if (rr + 1 < nrounds) fetch(rr + 1, A2, B2, ent2);   // prefetch across the barrier
-      const uint32_t thr_hi = (uint32_t)(*thr_p >> 32);
-      const int bstar = ctl[C_BSTAR];
+      top.begin_round();
       int appended = 0;
 #pragma unroll
       for (int u = 0; u < T; ++u) {
         if (ent[u].nvalid > 0) {  // wave-uniform
           const float score = ent[u].coarse + tile_adc(lut_bytes, A[u], B[u], offA, offB);
-          const uint32_t ob = f2ord(score);
-          const int b = score_bucket(score);
-          const bool pass = sort_mode ? (ob >= thr_hi) : (b >= bstar);
-          bool take = false;
-          if (lane < ent[u].nvalid && pass && !(dbg & 1)) {
-            const int s = atomicAdd(&ctl[C_FILL], 1);
-            keys[s] = ((u64)ob << 32) | (u64)(ent[u].tile * 64u + (uint32_t)lane);
-            if (!sort_mode) atomicAdd(&hist[b], 1);
-            take = true;
-          }
+          const bool take = top.offer(lane < ent[u].nvalid && !(dbg & 1), score,
+                                      ent[u].tile * 64u + (uint32_t)lane);
           appended += __popcll(__ballot(take));
         }
       }
-      if (lane == 0) ctl[C_WCNT + parity * 4 + wave] = appended;
-      __syncthreads();
-      fill += ctl[C_WCNT + parity * 4] + ctl[C_WCNT + parity * 4 + 1] +
-              ctl[C_WCNT + parity * 4 + 2] + ctl[C_WCNT + parity * 4 + 3];
-      if (fill > CAP - ROUND_VECS) {
-        if (!sort_mode) {
-          fill = compact();
-          if (fill > CAP - ROUND_VECS) {   // ties defeat the buckets: exact flushes from now on
-            sort_mode = true;
-            tk.slot_ids = ids_tiled;
-            tk.conv_from = 0;
-          }
-        }
-        if (sort_mode && fill > CAP - ROUND_VECS) fill = tk.flush(tid);
-      } else if (!sort_mode && (round_no & 3) == 3) {
-        update_bstar();
-      }
+      top.end_round(appended);
 #pragma unroll
       for (int u = 0; u < T; ++u) {
         A[u] = A2[u];
@@ -212,13 +121,8 @@ __global__ __launch_bounds__(V3_NT) void pq_scan_v3_kernel(
     }
     __syncthreads();
   }
-  if (!sort_mode) {
-    fill = compact();            // typically leaves k .. k + one bucket's population
-    tk.slot_ids = ids_tiled;     // every surviving key still carries its storage slot
-    tk.conv_from = 0;
-  }
-  tk.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
-            I32 ? I32 + (size_t)q * k : nullptr, tid);
+  top.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
+             I32 ? I32 + (size_t)q * k : nullptr);
 }
 
 template <int CAP, int T>
@@ -229,7 +133,7 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                      int64_t *I64, int32_t *I32, int dbg) {
   if ((size_t)d * 4 > (size_t)CAP * 8)
     return fail(ASL_ERR_CAPACITY, "pq scan: d=%d too large for the LDS staging", d);
-  const size_t lds = (size_t)CAP * 8 + 128 + (size_t)PQT_KSUB * PQT_M * 4 + (size_t)V3_NB * 4 +
+  const size_t lds = HistTopK<CAP, 4 * T * 64>::lds_bytes() + (size_t)PQT_KSUB * PQT_M * 4 +
                      (size_t)V3_CHUNK * sizeof(TileEnt);
   if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "pq scan: k=%d does not fit LDS", k);
   if (lds > 64 * 1024)

@@ -66,27 +66,4 @@ __device__ __forceinline__ void build_lut_rotated(const float *__restrict__ xq_r
   __syncthreads();
 }
 
-// exclusive prefix sum of one int per thread over a 256-thread workgroup; `part` = 4 ints of
-// LDS reserved for this call site. Returns the exclusive prefix; total in `total`.
-__device__ __forceinline__ int block_excl_scan256(int v, int *part, int tid, int &total) {
-  const int lane = tid & 63, wave = tid >> 6;
-  int incl = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(incl, off);
-    if (lane >= off) incl += o;
-  }
-  if (lane == 63) part[wave] = incl;
-  __syncthreads();
-  int base = 0;
-  total = 0;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const int t = part[w];
-    if (w < wave) base += t;
-    total += t;
-  }
-  return base + incl - v;
-}
-
 }  // namespace asl
