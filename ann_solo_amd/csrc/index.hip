@@ -78,6 +78,12 @@ struct asl_index {
   DevBuf<uint8_t> codes_tiled;
   DevBuf<int32_t> ids_tiled, tile_offsets;
   bool has_tiles = false;
+  // sparse 64-vector tiles for flat_sparse_scan (IVF-Flat)
+  DevBuf<uint16_t> idx_tiled;
+  DevBuf<float> val_tiled;
+  DevBuf<int32_t> tile_nnz;
+  int nnz_stride = 0;
+  bool has_sparse = false;
   int scan_variant = 0;  // 0 = auto (v2 when supported), 1 = force v1
   bool lists_dirty = true;
   // scratch
@@ -276,6 +282,37 @@ static int build_lists(asl_index *ix) {
     ASL_TRY(sync_stream());
     ix->has_tiles = true;
   }
+  ix->has_sparse = false;
+  if (ix->kind == ASL_INDEX_IVFFLAT && n > 0 && ix->d <= 65535) {
+    DevBuf<int32_t> nnz, nnz_max;
+    ASL_TRY(nnz.reserve((size_t)n));
+    ASL_TRY(nnz_max.reserve(1));
+    ASL_TRY(count_nnz(ix->vecs.p, ix->d, n, nnz.p, nnz_max.p));
+    int32_t h_max = 0;
+    ASL_TRY(nnz_max.download(&h_max, 1));
+    ASL_TRY(sync_stream());
+    if (h_max > 0 && h_max <= 255 && (size_t)h_max * 6 < (size_t)ix->d * 2) {  // sparse enough to pay
+      std::vector<int32_t> tile_off((size_t)ix->nlist + 1, 0), dst_slot((size_t)n);
+      for (int l = 0; l < ix->nlist; l++)
+        tile_off[(size_t)l + 1] = tile_off[(size_t)l] + (off[(size_t)l + 1] - off[(size_t)l] + 63) / 64;
+      for (int l = 0; l < ix->nlist; l++)
+        for (int32_t i = off[(size_t)l]; i < off[(size_t)l + 1]; i++)
+          dst_slot[(size_t)i] = tile_off[(size_t)l] * 64 + (i - off[(size_t)l]);
+      const int64_t ntiles = std::max<int64_t>(tile_off[(size_t)ix->nlist], 1);
+      DevBuf<int32_t> slot_dev;
+      ASL_TRY(slot_dev.upload(dst_slot.data(), (size_t)n));
+      ASL_TRY(ix->tile_offsets.upload(tile_off.data(), tile_off.size()));
+      ix->nnz_stride = h_max;
+      ASL_TRY(ix->idx_tiled.reserve((size_t)ntiles * h_max * 64));
+      ASL_TRY(ix->val_tiled.reserve((size_t)ntiles * h_max * 64));
+      ASL_TRY(ix->tile_nnz.reserve((size_t)ntiles));
+      ASL_TRY(ix->ids_tiled.reserve((size_t)ntiles * 64));
+      ASL_TRY(sparsify_tiles(ix->vecs.p, ix->d, order.p, slot_dev.p, ix->ids.p, n, ntiles, h_max,
+                             ix->idx_tiled.p, ix->val_tiled.p, ix->tile_nnz.p, ix->ids_tiled.p));
+      ASL_TRY(sync_stream());
+      ix->has_sparse = true;
+    }
+  }
   ASL_TRY(sync_stream());
   ix->lists_dirty = false;
   return ASL_OK;
@@ -320,6 +357,25 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       nprobe = std::max(1, std::min(nprobe, ix->nlist));
       if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
       ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+      ASL_TRY(build_lists(ix));
+      if (ix->has_sparse && (ix->scan_variant & 0xff) != 1 &&
+          flat_sparse_supported(d, k, nprobe, ix->nnz_stride)) {
+        {
+          ProfScope ps("scan");
+          ASL_TRY(flat_sparse_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
+                                   ix->tile_offsets.p, ix->idx_tiled.p, ix->val_tiled.p,
+                                   ix->tile_nnz.p, ix->nnz_stride, ix->ids_tiled.p, k, D, I64, I32));
+        }
+        if (prof_enabled()) {
+          ASL_TRY(ix->ws_count.reserve(1));
+          ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, ix->ws_count.p));
+          unsigned long long sc = 0;
+          HIP_TRY(hipMemcpyAsync(&sc, ix->ws_count.p, 8, hipMemcpyDeviceToHost, stream()));
+          ASL_TRY(sync_stream());
+          prof_add_scanned((int64_t)sc);
+        }
+        return ASL_OK;
+      }
       words = (ix->nlist + 31) / 32;
       ASL_TRY(ix->bitmap.reserve((size_t)nq * words));
       ASL_TRY(probe_bitmap(ix->coarse_I.p, nq, nprobe, ix->bitmap.p, words));

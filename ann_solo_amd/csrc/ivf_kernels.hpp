@@ -48,6 +48,16 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                int64_t *I64, int32_t *I32, int variant, int dbg);
 int tile_codes(const uint8_t *codes, const int32_t *ids, const int32_t *dst_slot, int64_t n,
                int64_t ntiles, uint8_t *codes_tiled, int32_t *ids_tiled);
+bool flat_sparse_supported(int d, int k, int nprobe, int nnz_stride);
+int flat_sparse_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
+                     const int32_t *list_offsets, const int32_t *tile_offsets,
+                     const uint16_t *idx_tiled, const float *val_tiled, const int32_t *tile_nnz,
+                     int nnz_stride, const int32_t *ids_tiled, int k, float *D, int64_t *I64,
+                     int32_t *I32);
+int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_max_dev);
+int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t *dst_slot,
+                   const int32_t *ids, int64_t n, int64_t ntiles, int nnz_stride,
+                   uint16_t *idx_tiled, float *val_tiled, int32_t *tile_nnz, int32_t *ids_tiled);
 int scanned_count(const int32_t *coarse_I, int64_t n, const int32_t *list_offsets,
                   unsigned long long *out_dev);
 
