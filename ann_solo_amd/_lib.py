@@ -39,6 +39,13 @@ class AslSearchParams(C.Structure):
                 ('allow_shift', C.c_int32), ('use_ann', C.c_int32)]
 
 
+class AslProcessParams(C.Structure):
+    _fields_ = [('min_mz', C.c_double), ('max_mz', C.c_double), ('remove_precursor', C.c_int32),
+                ('remove_precursor_tolerance', C.c_double), ('min_intensity', C.c_double),
+                ('max_peaks', C.c_int32), ('scaling', C.c_int32), ('min_peaks', C.c_int32),
+                ('min_mz_range', C.c_double)]
+
+
 class AslIndexInfo(C.Structure):
     _fields_ = [('d', C.c_int32), ('nlist', C.c_int32), ('kind', C.c_int32),
                 ('pq_m', C.c_int32), ('pq_ksub', C.c_int32), ('pq_dsub', C.c_int32),
@@ -57,7 +64,7 @@ EXPORTS = [
     'asl_index_pq_lut', 'asl_rescore_batch', 'asl_library_create', 'asl_library_free',
     'asl_library_size', 'asl_search_batch', 'asl_window_candidates', 'asl_profile_enable',
     'asl_profile_reset', 'asl_profile_get', 'asl_profile_scanned_vectors',
-    'asl_rescore_knn', 'asl_lpt_owner', 'asl_index_set_scan_variant', 'asl_index_search_preassigned',
+    'asl_rescore_knn', 'asl_lpt_owner', 'asl_index_set_scan_variant', 'asl_index_search_preassigned', 'asl_process_batch',
 ]
 
 
@@ -105,6 +112,8 @@ def lib():
         L.asl_index_search_preassigned.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p]
+        L.asl_process_batch.argtypes = [C.POINTER(AslPeaks), C.POINTER(AslProcessParams),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.asl_index_reset.argtypes = [C.c_void_p]
         L.asl_index_ntotal.argtypes = [C.c_void_p]
         L.asl_index_ntotal.restype = C.c_int64

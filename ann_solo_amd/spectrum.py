@@ -74,3 +74,46 @@ def _accumulate(vector, spectrum, min_mz, max_mz, bin_size, hash_len, norm):
     if norm:
         acc = acc / np.linalg.norm(acc)
     return acc
+
+
+def process_spectra(raw, is_library: bool, config=None, device='cuda'):
+    """Batched ``process_spectrum`` (reference spectrum.py:57-119) on the device.
+
+    ``raw``: PackedSpectra of raw peaks (ascending m/z); ``config``: an object with the
+    reference's preprocessing flags (``ann_solo_amd.spectral_library.Config`` lacks them, so
+    the reference defaults are used for missing attributes). Returns ``(processed
+    PackedSpectra on ``device``, valid bool tensor)``; invalid spectra come back empty.
+    Peak charge annotations follow their peaks."""
+    import ctypes as C
+    import torch
+    from .packed import PackedSpectra
+    g = lambda k, dflt: getattr(config, k, dflt) if config is not None else dflt
+    scaling = g('scaling', 'rank')
+    scaling = {'rank': 1, 'sqrt': 2, 'root': 2, None: 0}[scaling]
+    max_peaks = g('max_peaks_used_library', 50) if is_library else g('max_peaks_used', 50)
+    if g('resolution', None) is not None:
+        raise NotImplementedError('config.resolution (m/z rounding) is not implemented on the device')
+    P = _lib.AslProcessParams(float(g('min_mz', 11)), float(g('max_mz', 2010)),
+                              int(bool(g('remove_precursor', False))),
+                              float(g('remove_precursor_tolerance', 0.0)),
+                              float(g('min_intensity', 0.01)), int(max_peaks), scaling,
+                              int(g('min_peaks', 10)), float(g('min_mz_range', 250.0)))
+    r = raw.to(device).contiguous()
+    n = r.n
+    dev = r.mz.device
+    o_mz = torch.zeros((n, max_peaks), dtype=torch.float32, device=dev)
+    o_in = torch.zeros((n, max_peaks), dtype=torch.float32, device=dev)
+    o_src = torch.zeros((n, max_peaks), dtype=torch.int32, device=dev)
+    o_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    o_val = torch.zeros(n, dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().asl_process_batch(C.byref(_lib.peaks_struct(r)), C.byref(P),
+                                            _lib.ptr(o_mz), _lib.ptr(o_in), _lib.ptr(o_src),
+                                            _lib.ptr(o_cnt), _lib.ptr(o_val)))
+    slot = torch.arange(max_peaks, device=dev).expand(n, -1) < o_cnt.unsqueeze(1)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = torch.cumsum(o_cnt.to(torch.int64), 0)
+    src_abs = (o_src.to(torch.int64) + r.offsets[:-1].to(torch.int64).unsqueeze(1))[slot]
+    out = PackedSpectra(offsets.to(torch.int32), o_mz[slot], o_in[slot], r.charge[src_abs],
+                        r.precursor_mz.clone(), r.precursor_charge.clone(),
+                        identifiers=raw.identifiers)
+    return out, o_val.bool()

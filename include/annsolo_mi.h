@@ -172,6 +172,27 @@ int asl_rescore_batch(const asl_peaks_t *queries, const asl_peaks_t *library,
                       double *best_score, int32_t *pm_count, uint32_t *pm_pairs,
                       int32_t pm_stride);
 
+/* ------------------------------------------------------------------ peak preprocessing
+ * Replaces process_spectrum (src/ann_solo/spectrum.py:57-119: spectrum_utils set_mz_range,
+ * remove_precursor_peak(tol,'Da',2), filter_intensity, scale_intensity, L2 norm, and the
+ * validity checks of :13-36), batched. Raw peaks ascending in m/z, <= 4096 per spectrum.
+ * Outputs are padded to max_peaks per spectrum: out_mz / out_intensity / out_src
+ * [n, max_peaks] (out_src = index of the kept peak inside its raw spectrum, may be NULL),
+ * out_count[n], out_valid[n] (is_valid). scaling: 0 none, 1 rank, 2 root. */
+typedef struct {
+  double min_mz, max_mz;              /* config.min_mz / max_mz (inclusive) */
+  int32_t remove_precursor;           /* config.remove_precursor */
+  double remove_precursor_tolerance;  /* config.remove_precursor_tolerance (Da) */
+  double min_intensity;               /* config.min_intensity (relative to the base peak) */
+  int32_t max_peaks;                  /* config.max_peaks_used(_library), <= 256 */
+  int32_t scaling;
+  int32_t min_peaks;                  /* config.min_peaks */
+  double min_mz_range;                /* config.min_mz_range */
+} asl_process_params_t;
+int asl_process_batch(const asl_peaks_t *raw, const asl_process_params_t *params,
+                      float *out_mz, float *out_intensity, int32_t *out_src,
+                      int32_t *out_count, uint8_t *out_valid);
+
 /* ------------------------------------------------------------------ hot path
  * One batch of same-charge queries through
  *   SpectralLibrary._search_batch / _get_library_candidates

@@ -155,6 +155,114 @@ void orc_encode_batch(const float *mz, const float *intensity, const int32_t *of
 }
 
 /* ------------------------------------------------------------------------ */
+/* process_spectrum: spectrum.py:57-119 over spectrum_utils 0.3.x             */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  float inten;
+  int32_t idx;
+} orc_pk_t;
+
+/* (intensity desc, index desc): the order a stable ascending argsort read from its tail gives */
+static int pk_cmp(const void *a, const void *b) {
+  const orc_pk_t *x = (const orc_pk_t *)a, *y = (const orc_pk_t *)b;
+  if (x->inten != y->inten) return x->inten > y->inten ? -1 : 1;
+  return x->idx > y->idx ? -1 : (x->idx < y->idx);
+}
+
+static int spectrum_ok(const float *mz, const uint8_t *keep, int32_t n, int min_peaks,
+                       double min_range) { /* spectrum.py:13-36 */
+  int cnt = 0, first = -1, last = -1;
+  for (int32_t i = 0; i < n; i++)
+    if (keep[i]) {
+      if (first < 0) first = i;
+      last = i;
+      cnt++;
+    }
+  return cnt >= min_peaks && cnt > 0 && (double)(mz[last] - mz[first]) >= min_range;
+}
+
+int orc_process_spectrum(const float *mz, const float *intensity, int32_t n, double precursor_mz,
+                         int32_t precursor_charge, const orc_process_params_t *p,
+                         float *out_mz, float *out_int, int32_t *out_src, int32_t *n_out) {
+  *n_out = 0;
+  if (n <= 0) return 0;
+  uint8_t *keep = (uint8_t *)malloc((size_t)n);
+  /* spectrum.py:79 set_mz_range: inclusive on both sides */
+  for (int32_t i = 0; i < n; i++) keep[i] = (double)mz[i] >= p->min_mz && (double)mz[i] <= p->max_mz;
+  if (!spectrum_ok(mz, keep, n, p->min_peaks, p->min_mz_range)) {
+    free(keep);
+    return 0;
+  }
+  /* spectrum.py:90-92 remove_precursor_peak(tol, 'Da', 2) */
+  if (p->remove_precursor) {
+    const double adduct = 1.0072766;
+    double neutral = (precursor_mz - adduct) * (double)precursor_charge;
+    for (int charge = precursor_charge; charge >= 1; charge--)
+      for (int iso = 0; iso <= 2; iso++) {
+        double rm = (neutral + iso) / charge + adduct;
+        for (int32_t i = 0; i < n; i++)
+          if (keep[i] && fabs((double)mz[i] - rm) <= p->remove_precursor_tolerance) keep[i] = 0;
+      }
+    if (!spectrum_ok(mz, keep, n, p->min_peaks, p->min_mz_range)) {
+      free(keep);
+      return 0;
+    }
+  }
+  /* spectrum.py:97-99 filter_intensity: strictly above min_intensity * max, top max_peaks */
+  orc_pk_t *pk = (orc_pk_t *)malloc(sizeof(orc_pk_t) * (size_t)n);
+  int m = 0;
+  for (int32_t i = 0; i < n; i++)
+    if (keep[i]) {
+      pk[m].inten = intensity[i];
+      pk[m].idx = i;
+      m++;
+    }
+  qsort(pk, (size_t)m, sizeof(orc_pk_t), pk_cmp);
+  double thresh = p->min_intensity * (double)pk[0].inten;
+  memset(keep, 0, (size_t)n);
+  int kept = 0;
+  for (int r = 0; r < m && r < p->max_peaks; r++)
+    if ((double)pk[r].inten > thresh) {
+      keep[pk[r].idx] = 1;
+      kept++;
+    }
+  if (!spectrum_ok(mz, keep, n, p->min_peaks, p->min_mz_range)) {
+    free(keep);
+    free(pk);
+    return 0;
+  }
+  /* spectrum.py:104-110 scale_intensity; :112 L2 norm (canonical ascending fmaf chain) */
+  float *val = (float *)calloc((size_t)n, sizeof(float));
+  for (int r = 0; r < kept; r++) {
+    int32_t i = pk[r].idx;
+    if (p->scaling == 1)
+      val[i] = (float)(p->max_peaks - r);
+    else if (p->scaling == 2)
+      val[i] = sqrtf(intensity[i]);
+    else
+      val[i] = intensity[i];
+  }
+  float acc = 0.0f;
+  for (int32_t i = 0; i < n; i++)
+    if (keep[i]) acc = fmaf(val[i], val[i], acc);
+  float nrm = sqrtf(acc);
+  int o = 0;
+  for (int32_t i = 0; i < n; i++)
+    if (keep[i]) {
+      out_mz[o] = mz[i];
+      out_int[o] = val[i] / nrm;
+      out_src[o] = i;
+      o++;
+    }
+  *n_out = o;
+  free(val);
+  free(keep);
+  free(pk);
+  return 1;
+}
+
+/* ------------------------------------------------------------------------ */
 /* Rescoring: SpectrumMatch.cpp:8-133                                        */
 /* ------------------------------------------------------------------------ */
 

@@ -61,6 +61,25 @@ void orc_encode_batch(const float *mz, const float *intensity, const int32_t *of
                       int32_t n, double min_bound, double bin_size, int32_t hash_len,
                       uint32_t seed, int norm, float *out /* [n,hash_len] */);
 
+/* ---- process_spectrum: spectrum.py:57-119 (+ spectrum_utils 0.3.x semantics; PARITY
+ * UNPINNED: spectrum_utils is un-vendored and the reference has no test for it).
+ * Input peaks ascending in m/z. Outputs up to max_peaks kept peaks (ascending m/z) with
+ * their source index; returns 1 if the spectrum is valid, 0 otherwise (outputs then
+ * undefined, *n_out = 0). scaling: 0 none, 1 rank, 2 root (sqrt). */
+typedef struct {
+  double min_mz, max_mz;
+  int32_t remove_precursor;
+  double remove_precursor_tolerance;
+  double min_intensity;
+  int32_t max_peaks;
+  int32_t scaling;
+  int32_t min_peaks;
+  double min_mz_range;
+} orc_process_params_t;
+int orc_process_spectrum(const float *mz, const float *intensity, int32_t n, double precursor_mz,
+                         int32_t precursor_charge, const orc_process_params_t *p,
+                         float *out_mz, float *out_int, int32_t *out_src, int32_t *n_out);
+
 /* ---- rescoring: SpectrumMatch.cpp:8-133 -------------------------------- */
 /* One (query,candidate) pair. matches_out (may be NULL) receives (q_idx,c_idx)
  * pairs in greedy order; returns the score. n_matches_out may be NULL. */

@@ -143,6 +143,31 @@ def encode_batch(mz, intensity, offsets, min_bound, bin_size, hash_len, seed=42,
     return out
 
 
+class OrcProcessParams(C.Structure):
+    _fields_ = [('min_mz', C.c_double), ('max_mz', C.c_double), ('remove_precursor', C.c_int32),
+                ('remove_precursor_tolerance', C.c_double), ('min_intensity', C.c_double),
+                ('max_peaks', C.c_int32), ('scaling', C.c_int32), ('min_peaks', C.c_int32),
+                ('min_mz_range', C.c_double)]
+
+
+def process_spectrum(mz, intensity, precursor_mz, precursor_charge, min_mz=11, max_mz=2010,
+                     remove_precursor=False, remove_precursor_tolerance=0.0, min_intensity=0.01,
+                     max_peaks=50, scaling='rank', min_peaks=10, min_mz_range=250.0):
+    mz, intensity = _c(mz, np.float32), _c(intensity, np.float32)
+    P = OrcProcessParams(min_mz, max_mz, int(remove_precursor), remove_precursor_tolerance,
+                         min_intensity, max_peaks, {'rank': 1, 'root': 2, 'sqrt': 2, None: 0}[scaling],
+                         min_peaks, min_mz_range)
+    om, oi = np.zeros(max_peaks, np.float32), np.zeros(max_peaks, np.float32)
+    src = np.zeros(max_peaks, np.int32)
+    n = C.c_int32()
+    L = lib()
+    L.orc_process_spectrum.restype = C.c_int
+    ok = L.orc_process_spectrum(_p(mz, c_f32p), _p(intensity, c_f32p), C.c_int32(len(mz)),
+                                C.c_double(precursor_mz), C.c_int32(precursor_charge), C.byref(P),
+                                _p(om, c_f32p), _p(oi, c_f32p), _p(src, c_i32p), C.byref(n))
+    return bool(ok), om[:n.value].copy(), oi[:n.value].copy(), src[:n.value].copy()
+
+
 # ---------------------------------------------------------------- rescoring
 def dot_pair(q_mz, q_int, q_pmz, c_mz, c_int, c_chg, c_pmz, c_charge, tol, allow_shift):
     q_mz, q_int = _c(q_mz, np.float32), _c(q_int, np.float32)
