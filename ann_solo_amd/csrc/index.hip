@@ -64,6 +64,8 @@ struct asl_index {
   int64_t n_store = 0;  // vectors stored here
   int shard_rank = 0, shard_world = 1;
   DevBuf<float> centroids, codebooks;
+  DevBuf<float> codebooks_t;  // [m][dsub][ksub] copy for the tiled scan's LUT build
+  bool cbt_ready = false;
   // add-order storage
   DevBuf<float> vecs;        // FLAT, IVFFLAT
   DevBuf<int32_t> vlist;     // IVF kinds: inverted list of each stored vector
@@ -420,11 +422,24 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   {
     ProfScope ps("scan");
     const int sv = ix->scan_variant & 0xff;
-    if (ix->has_tiles && sv != 1 && sv != 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
-      ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
+    if (ix->has_tiles && sv != 1 && sv != 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe)) {
+      if (!ix->cbt_ready) {
+        const size_t ncb = (size_t)ix->pq_m * ix->ksub * ix->dsub;
+        std::vector<float> h((size_t)ncb), ht((size_t)ncb);
+        ASL_TRY(ix->codebooks.download(h.data(), ncb));
+        ASL_TRY(sync_stream());
+        for (int m = 0; m < ix->pq_m; m++)
+          for (int c = 0; c < ix->ksub; c++)
+            for (int t = 0; t < ix->dsub; t++)
+              ht[((size_t)m * ix->dsub + t) * ix->ksub + c] = h[((size_t)m * ix->ksub + c) * ix->dsub + t];
+        ASL_TRY(ix->codebooks_t.upload(ht.data(), ncb));
+        ASL_TRY(sync_stream());
+        ix->cbt_ready = true;
+      }
+      ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks_t.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
                          ix->ids_tiled.p, k, D, I64, I32, sv, ix->scan_variant >> 8));
-    else if (ix->has_tiles && sv == 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
+    } else if (ix->has_tiles && sv == 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
       ASL_TRY(pq_scan_v2(xq, nq, d, ix->codebooks.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
                          ix->ids_tiled.p, k, D, I64, I32, ix->scan_variant >> 8));
@@ -515,6 +530,7 @@ int asl_index_train(asl_index_t *ix, int64_t n, const float *x, uint64_t seed) {
   }
   ASL_TRY(sync_stream());
   ix->trained = true;
+  ix->cbt_ready = false;
   return ASL_OK;
 }
 
@@ -532,6 +548,7 @@ int asl_index_set_trained(asl_index_t *ix, const float *centroids, const float *
   }
   ASL_TRY(sync_stream());
   ix->trained = true;
+  ix->cbt_ready = false;
   return ASL_OK;
 }
 

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(V3_NT) void pq_scan_v3_kernel(
   float *s_q = reinterpret_cast<float *>(smem);  // aliases the key buffer during the LUT build
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
-  build_lut_rotated(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, tid);
+  build_lut_cbt(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, tid);  // codebooks = cbT[m][t][c]
 
   // ---- my probe (thread p < nprobe) and the exclusive scan of tile counts
   int my_len = 0, my_tile0 = 0, my_nt = 0;
@@ -156,6 +156,7 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
   if (nq <= 0) return ASL_OK;
 #define V3_ARGS xq, nq, d, codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets, \
                 codes_tiled, ids_tiled, k, D, I64, I32, dbg
+  if (variant == 5 && k + 256 + 768 <= 2048) return launch_v3<2048, 3>(V3_ARGS);
   if (variant != 4 && k + 256 + 512 <= 2048) return launch_v3<2048, 2>(V3_ARGS);
   if (k + 256 + 1024 <= 4096) return launch_v3<4096, 4>(V3_ARGS);
   return launch_v3<8192, 4>(V3_ARGS);
