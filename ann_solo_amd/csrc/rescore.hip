@@ -35,6 +35,8 @@ struct WaveLds {
   unsigned long long keys[RS_MCAP];
   uint32_t pay[RS_MCAP];
   uint8_t c_chg[RS_MAXP];
+  uint8_t own_q[RS_MAXP];   // resolve fast path: last lane that claimed a query / candidate peak
+  uint8_t own_c[RS_MAXP];
   int counter;
   int pad[3];
 };
@@ -50,30 +52,94 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int CTRL>
+__device__ __forceinline__ uint32_t rs_dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, false);
+}
+
+// max over the wave, in every lane (row butterflies on DPP, rows joined on the scalar unit)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, rs_dpp<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = max(v, rs_dpp<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = max(v, rs_dpp<0x141>(v));   // row_half_mirror
+  v = max(v, rs_dpp<0x140>(v));   // row_mirror
+  const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return max(max(a, b), max(c, d));
+}
+
+template <int CTRL>
+__device__ __forceinline__ double rs_dpp_d(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = rs_dpp<CTRL>((uint32_t)u), hi = rs_dpp<CTRL>((uint32_t)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Sum over the wave in a fixed tree order; callers use it only where the sum is exact.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += rs_dpp_d<0xB1>(v);
+  v += rs_dpp_d<0x4E>(v);
+  v += rs_dpp_d<0x141>(v);
+  v += rs_dpp_d<0x140>(v);
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
+  double r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t l = __builtin_amdgcn_readlane(lo, 16 * i), h = __builtin_amdgcn_readlane(hi, 16 * i);
+    r[i] = __longlong_as_double((long long)(((unsigned long long)h << 32) | l));
+  }
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
 // Sort the wave's match list (product desc, generation order asc) and assign greedily
 // (SpectrumMatch.cpp:92-111). Lists of <= 64 matches are sorted in registers with
 // cross-lane shuffles; longer ones in LDS. Returns the score in every lane.
-template <bool EMIT>
-__device__ double resolve_matches(int lane, WaveLds &W, uint32_t *out_pairs, int out_cap,
-                                  int *out_count, int *status) {
-  int M = W.counter;
+template <bool EMIT, class WL>
+__device__ double resolve_matches(int lane, WL &W, uint32_t *out_pairs, int out_cap,
+                                  int *out_count, int *status, int kbase = 0, int m_in = -1,
+                                  int mcap = RS_MCAP) {
+  int M = m_in >= 0 ? m_in : W.counter;
   M = __builtin_amdgcn_readfirstlane(M);
-  if (M > RS_MCAP) {
+  if (M > mcap) {
     if (lane == 0) atomicOr(status, RS_STATUS_MATCHES);
-    M = RS_MCAP;
+    M = mcap;
   }
   if (M == 0) return 0.0;
+  unsigned long long *wkeys = W.keys + kbase;
+  uint32_t *wpay = W.pay + kbase;
   unsigned long long rkey = 0ull;
   uint32_t rpay = 0;
   const bool small = M <= 64;
   if (small) {
     if (lane < M) {
-      rkey = W.keys[lane];
-      rpay = W.pay[lane];
+      rkey = wkeys[lane];
+      rpay = wpay[lane];
+    }
+    if (!EMIT && M > 1) {
+      // Fast path: if no query peak and no candidate peak occurs twice, the greedy pass
+      // accepts every match and the score is the plain sum of the products. The products
+      // are fp32; when their exponents span <= 23 binades every partial sum of <= 64 of
+      // them is exactly representable in fp64, so the sum does not depend on the order
+      // and equals the reference's sorted accumulation bit for bit.
+      const bool inl = lane < M;
+      const uint32_t qi = (rpay >> 16) & (RS_MAXP - 1), ci = rpay & (RS_MAXP - 1);
+      if (inl) {
+        W.own_q[qi] = (uint8_t)lane;
+        W.own_c[ci] = (uint8_t)lane;
+      }
+      wave_sync();
+      const bool mine = !inl || (W.own_q[qi] == (uint8_t)lane && W.own_c[ci] == (uint8_t)lane);
+      const uint32_t e = inl ? max((uint32_t)(rkey >> 55) & 0xffu, 1u) : 0u;
+      const uint32_t emax = wave_max_u32(e);
+      const bool exact = !inl || e + 23u >= emax;
+      if (!__ballot(!(mine && exact)))
+        return wave_sum_f64(inl ? (double)__uint_as_float((uint32_t)(rkey >> 32)) : 0.0);
     }
     if (M > 1) {
 #pragma unroll
       for (int k = 2; k <= 64; k <<= 1) {
+        if ((k >> 1) >= M) break;   // sorted runs of nextpow2(M) lanes suffice (wave-uniform)
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
           const unsigned long long ok = __shfl_xor(rkey, j, 64);
@@ -88,21 +154,21 @@ __device__ double resolve_matches(int lane, WaveLds &W, uint32_t *out_pairs, int
   } else {
     int P = 2;
     while (P < M) P <<= 1;
-    for (int i = M + lane; i < P; i += 64) W.keys[i] = 0ull;
+    for (int i = M + lane; i < P; i += 64) wkeys[i] = 0ull;
     wave_sync();
     for (int k = 2; k <= P; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
         for (int t = lane; t < (P >> 1); t += 64) {
           const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
           const int l = i | j;
-          const unsigned long long a = W.keys[i], b = W.keys[l];
+          const unsigned long long a = wkeys[i], b = wkeys[l];
           const bool desc = (i & k) == 0;
           if (desc ? (a < b) : (a > b)) {
-            W.keys[i] = b;
-            W.keys[l] = a;
-            const uint32_t pa = W.pay[i];
-            W.pay[i] = W.pay[l];
-            W.pay[l] = pa;
+            wkeys[i] = b;
+            wkeys[l] = a;
+            const uint32_t pa = wpay[i];
+            wpay[i] = wpay[l];
+            wpay[l] = pa;
           }
         }
         wave_sync();
@@ -120,8 +186,8 @@ __device__ double resolve_matches(int lane, WaveLds &W, uint32_t *out_pairs, int
       pl = __builtin_amdgcn_readlane(rpay, t);
       pb = __builtin_amdgcn_readlane((uint32_t)(rkey >> 32), t);
     } else {
-      pl = __builtin_amdgcn_readfirstlane(W.pay[t]);
-      pb = __builtin_amdgcn_readfirstlane((uint32_t)(W.keys[t] >> 32));
+      pl = __builtin_amdgcn_readfirstlane(wpay[t]);
+      pb = __builtin_amdgcn_readfirstlane((uint32_t)(wkeys[t] >> 32));
     }
     const uint32_t qi = pl >> 16, ci = pl & 0xffffu;
     const unsigned long long qbit = 1ull << (qi & 63), cbit = 1ull << (ci & 63);
@@ -253,7 +319,7 @@ struct CandView {
 
 __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
-    double *__restrict__ pair_score, int *status) {
+    double *__restrict__ pair_score, const int *__restrict__ q_defer, int *status) {
   __shared__ QueryLds Q;
   __shared__ WaveLds W[RS_WAVES];
   const int q = blockIdx.x;
@@ -261,12 +327,15 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_kernel(
   long long c0, c1;
   cv.range(q, c0, c1);
   if (c0 >= c1) return;
+  // second-launch mode: only the pairs the fast kernel marked RS_DEFER (-2)
+  if (q_defer && !q_defer[q]) return;
   int qn;
   load_query(threadIdx.x, blockDim.x, Qs, q, Q, qn, status);
   __syncthreads();
   const double q_pmz = Qs.precursor_mz[q];
   const long long step = (long long)RS_WAVES * gridDim.y;
   for (long long c = c0 + (long long)blockIdx.y * RS_WAVES + wave; c < c1; c += step) {
+    if (q_defer && pair_score[c] != -2.0) continue;
     const long long row = cv.row(c);
     double s = -1.0;
     if (row >= 0 && row < L.n)
@@ -282,20 +351,53 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_kernel(
 // workgroup instead: every query peak is entered into an LDS hash table under the
 // m/z bins of width 2*tol that its window [mz-tol, mz+tol] touches; a candidate peak at
 // shifted position x can only match peaks filed under floor(x / (2*tol)). Lanes are the
-// candidate's peaks (loaded straight from HBM, coalesced), each does one independent
-// probe per shift, and the reference's exact window/cursor predicate is applied to the
-// few hits:  match(i,j,s)  <=>  |q_i - x_j| <= tol  and  (not(q_i - tol > x_j) or j = n_c-1)
+// candidate's peaks, each does one independent probe per shift (a one-word Bloom-style
+// bitmap rejects most probes), and the reference's exact window/cursor predicate is
+// applied to the few hits:
+//   match(i,j,s) <=> |q_i - x_j| <= tol and (not(q_i - tol > x_j) or j = n_c-1)
 // and every peak between the cursor and j passes the window test (SpectrumMatch.cpp:39-55).
-// A wave owns a contiguous slice of the candidate list: 64 candidates' metadata are
-// gathered at once, the next candidate's peaks are prefetched while one is scored.
-constexpr int RS_HT = 512;       // hash slots
-constexpr int RS_HQ_MAX = 100;   // query peaks the hash path accepts (<= 3 bins each)
+//
+// Work distribution: the valid slots of the candidate list are compacted in LDS and dealt
+// out evenly to the waves; a wave gathers 64 candidates' metadata at once, stages the
+// peaks of RS_PF candidates per burst in LDS and scores them two at a time (one candidate
+// per half-wave: an average library spectrum has ~27 peaks).
+//
+// The kernel only handles what fits its small LDS budget (4 workgroups per CU):
+// candidates with <= 64 peaks and <= RS_HC generated matches, queries with <= RS_HQ_MAX
+// peaks, tol > 0. Everything else is marked RS_DEFER and scored by the binary-search
+// kernel in a second launch that skips queries with nothing deferred.
+constexpr int RS_HT = 512;            // hash slots
+constexpr int RS_HQ_MAX = 100;        // query peaks the hash path accepts (<= 3 bins each)
 constexpr int RS_EMPTY = (int)0x80000000;
+constexpr int RS_BM_BITS = 1 << 14;   // bin filter: <= 300 bits set of 16 384
+constexpr int RS_SUPER = 2048;        // candidate slots compacted at a time
+constexpr int RS_PF = 4;              // candidates staged per burst
+constexpr int RS_HC = 128;            // matches per candidate resolved in this kernel
+constexpr double RS_DEFER = -2.0;     // pair_score marker: left to the binary-search kernel
 
 struct HashLds {
   int bin[RS_HT];
-  int peak[RS_HT];
+  uint32_t bm[RS_BM_BITS / 32];
+  uint8_t peak[RS_HT];
 };
+
+struct PairLds {   // per wave
+  float c_mz[RS_PF * 64];
+  float c_int[RS_PF * 64];
+  unsigned long long keys[2 * RS_HC];   // half A, half B
+  uint32_t pay[2 * RS_HC];
+  uint8_t c_chg[RS_PF * 64];
+  uint8_t own_q[RS_MAXP];
+  uint8_t own_c[RS_MAXP];
+  int counter;
+  int pad[3];
+};
+
+__device__ __forceinline__ uint32_t hbit(int b) { return ((uint32_t)b * 2654435761u) >> 18; }
+__device__ __forceinline__ bool bm_test(const HashLds &H, int b) {
+  const uint32_t bit = hbit(b);
+  return (H.bm[bit >> 5] >> (bit & 31)) & 1u;
+}
 
 __device__ __forceinline__ uint32_t hbin(int b) {
   return ((uint32_t)b * 2654435761u) >> 23;  // 9 bits
@@ -314,41 +416,54 @@ __device__ __forceinline__ double rl_d(double v, int l) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-constexpr int RS_PF = 4;   // candidates staged per burst (4 x 64 peaks = WaveLds::c_mz/c_int/c_chg)  // candidates whose peaks are in flight ahead of the scoring
-
-// One (query, candidate) pair on the hash path; lanes are the candidate's peaks.
-__device__ __forceinline__ double score_candidate(int lane, const QueryLds &Q, const HashLds &H,
-                                                  WaveLds &Wv, int slot, int cn, int c_charge,
-                                                  double c_pmz, double q_pmz, double tol,
-                                                  double inv_w, int allow_shift, int *status) {
-  if (lane == 0) Wv.counter = 0;
-  const double pmd = (q_pmz - c_pmz) * (double)(unsigned)c_charge;    // cpp:18
-  const int S = (allow_shift && fabs(pmd) >= tol) ? c_charge + 1 : 1;  // cpp:20
-  const float *s_mz = Wv.c_mz + slot * 64;   // this candidate's staged peaks (cn <= 64)
-  const float a_mz = lane < cn ? s_mz[lane] : 0.0f;
-  const float a_int = lane < cn ? Wv.c_int[slot * 64 + lane] : 0.0f;
-  const int a_chg = lane < cn ? Wv.c_chg[slot * 64 + lane] : 0;
-  // mass_diff[s] = pmd / s (cpp:26-31): lane s does the (expensive, exact) fp64 division
-  // once, every lane then reads the quotient it needs with v_readlane
-  const double md_lane = (lane > 0 && lane < S) ? pmd / (double)lane : 0.0;
+// Two candidates per wave: lanes 0-31 score candidate A, lanes 32-63 candidate B (peaks in
+// passes of 32; cn = 0 leaves a half idle). The probing instruction stream -- the bulk of
+// this instruction-bound kernel -- is shared by both. Per-half match lists live in the two
+// halves of the wave's key buffer. A score of RS_DEFER means the half overflowed RS_HC.
+__device__ __forceinline__ void score_two(int lane, const QueryLds &Q, const HashLds &H,
+                                          PairLds &Wv, int slotA, int slotB, int cnA, int cnB,
+                                          int chgA, int chgB, double pmzA, double pmzB,
+                                          double q_pmz, double tol, double inv_w, int allow_shift,
+                                          int *status, double &scoreA, double &scoreB, int dbg) {
+  const int half = lane >> 5, hl = lane & 31;
+  if (lane == 0) {
+    Wv.pad[0] = 0;
+    Wv.pad[1] = 0;
+  }
+  const double pmdA = (q_pmz - pmzA) * (double)(unsigned)chgA;          // cpp:18
+  const double pmdB = (q_pmz - pmzB) * (double)(unsigned)chgB;
+  const int SA = (allow_shift && fabs(pmdA) >= tol) ? chgA + 1 : 1;      // cpp:20
+  const int SB = (allow_shift && fabs(pmdB) >= tol) ? chgB + 1 : 1;
+  const int slot = half ? slotB : slotA, cn = half ? cnB : cnA, S = half ? SB : SA;
+  const double pmd = half ? pmdB : pmdA;
+  const float *s_mz = Wv.c_mz + slot * 64;
+  const float *s_in = Wv.c_int + slot * 64;
+  const uint8_t *s_ch = Wv.c_chg + slot * 64;
+  // mass_diff[s] = pmd / s (cpp:26-31): lane (32*half + s) performs its half's (expensive,
+  // exact) fp64 division once, every lane then reads the quotient it needs with v_readlane
+  const double md_lane = (hl > 0 && hl < S) ? pmd / (double)hl : 0.0;
   const float inv_w_f = (float)inv_w;
-  {
-    const int j = lane;
+  const int Smax = SA > SB ? SA : SB;
+  const int cmax = cnA > cnB ? cnA : cnB;
+  unsigned long long *keys = Wv.keys + half * RS_HC;
+  uint32_t *pay = Wv.pay + half * RS_HC;
+  wave_sync();
+  for (int jb = 0; jb < ((dbg & 32) ? 0 : cmax); jb += 32) {   // wave-uniform
+    const int j = jb + hl;
     const bool act = j < cn;
-    const float cm = a_mz, ci = a_int;
-    const int cc = a_chg;
-    for (int s = 0; s < S; ++s) {      // wave-uniform trip count
-      const double md = rl_d(md_lane, s);
-      if (act) {
-        double mult = 0.0;
-        if (s == 0 || cc == s)
-          mult = 1.0;
-        else if (cc == 0)
-          mult = 2.0 / 3.0;
-        if (mult == 0.0) continue;  // this peak cannot pair under shift s (cpp:58-75)
-        // bin of the shifted peak in fp32 (the query was filed with a margin that covers
-        // the fp32 rounding); the exact fp64 window test runs on the rare hits only
-        const int b = (int)floorf((cm + (float)md) * inv_w_f);
+    const float cm = act ? s_mz[j] : 0.0f, ci = act ? s_in[j] : 0.0f;
+    const int cc = act ? s_ch[j] : 0;
+    for (int s = 0; s < Smax; ++s) {        // wave-uniform
+      const double mdA = rl_d(md_lane, s), mdB = rl_d(md_lane, 32 + s);
+      const double md = half ? mdB : mdA;
+      // bin of the shifted peak in fp32 (the query was filed with a margin that covers the
+      // fp32 rounding); bitmap reject first, the exact fp64 window test on the rare hits
+      const bool can = act && s < S && (s == 0 || cc == s || cc == 0);   // cpp:58-75
+      const int b = (int)floorf((cm + (float)md) * inv_w_f);
+      const bool maybe = can && bm_test(H, b) && !(dbg & 64);
+      if (!__ballot(maybe)) continue;         // wave-uniform
+      if (maybe) {
+        const double mult = (s == 0 || cc == s) ? 1.0 : 2.0 / 3.0;
         uint32_t h = hbin(b);
         for (;;) {
           const int eb = H.bin[h];
@@ -371,13 +486,13 @@ __device__ __forceinline__ double score_candidate(int lane, const QueryLds &Q, c
                 }
               }
               if (run) {
-                const float prod = (float)(mult * (double)Q.inten[i] * (double)ci);
-                const int mslot = atomicAdd(&Wv.counter, 1);
-                if (mslot < RS_MCAP) {
+                const float prod = (float)(mult * (double)Q.inten[i] * (double)ci);   // cpp:81
+                const int mslot = atomicAdd(&Wv.pad[half], 1);
+                if (mslot < RS_HC) {
                   const uint32_t gen = (uint32_t)((i * S + s) * cn + j);
-                  Wv.keys[mslot] = ((unsigned long long)__float_as_uint(prod) << 32) |
-                                   (unsigned long long)(0xFFFFFFFFu - gen);
-                  Wv.pay[mslot] = ((uint32_t)i << 16) | (uint32_t)j;
+                  keys[mslot] = ((unsigned long long)__float_as_uint(prod) << 32) |
+                                (unsigned long long)(0xFFFFFFFFu - gen);
+                  pay[mslot] = ((uint32_t)i << 16) | (uint32_t)j;
                 }
               }
             }
@@ -388,15 +503,24 @@ __device__ __forceinline__ double score_candidate(int lane, const QueryLds &Q, c
     }
   }
   wave_sync();
-  return resolve_matches<false>(lane, Wv, nullptr, 0, nullptr, status);
+  const int MA = (dbg & 16) ? 0 : __builtin_amdgcn_readfirstlane(Wv.pad[0]);
+  const int MB = (dbg & 16) ? 0 : __builtin_amdgcn_readfirstlane(Wv.pad[1]);
+  scoreA = MA > RS_HC ? RS_DEFER
+           : MA     ? resolve_matches<false>(lane, Wv, nullptr, 0, nullptr, status, 0, MA, RS_HC)
+                    : 0.0;
+  scoreB = MB > RS_HC ? RS_DEFER
+           : MB     ? resolve_matches<false>(lane, Wv, nullptr, 0, nullptr, status, RS_HC, MB, RS_HC)
+                    : 0.0;
 }
 
 __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
-    double *__restrict__ pair_score, int *status) {
+    double *__restrict__ pair_score, int *__restrict__ q_defer, int *status, int dbg) {
   __shared__ QueryLds Q;
   __shared__ HashLds H;
-  __shared__ WaveLds W[RS_WAVES];
+  __shared__ PairLds W[RS_WAVES];
+  __shared__ uint16_t s_list[RS_SUPER];
+  __shared__ int s_nv, s_defer;
   const int q = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   long long c0, c1;
@@ -404,35 +528,35 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
   if (c0 >= c1) return;
   int qn;
   load_query(tid, blockDim.x, Qs, q, Q, qn, status);
-  for (int i = tid; i < RS_HT; i += blockDim.x) H.bin[i] = RS_EMPTY;
-  __syncthreads();
   // fp32 evaluation of a probe bin (m/z <= ~2600): error bound in bin units; the query
   // peaks are filed with that margin on both sides (still <= 3 bins per peak)
   const double margin = 1e-3 + (tol > 0.0 ? (0.5 / tol) * (3.75e-4 + 2600.0 * 1.2e-7) : 1.0);
-  if (!(tol > 0.0) || qn > RS_HQ_MAX || margin > 0.45) {  // uniform: binary-search formulation
-    const double q_pmz0 = Qs.precursor_mz[q];
-    const long long step = (long long)RS_WAVES * gridDim.y;
-    for (long long c = c0 + (long long)blockIdx.y * RS_WAVES + wave; c < c1; c += step) {
-      const long long row = cv.row(c);
-      double sc = -1.0;
-      if (row >= 0 && row < L.n)
-        sc = dot_pair_wave<false>(lane, Q, qn, q_pmz0, L, (int)row, tol, allow_shift, W[wave],
-                                  nullptr, 0, nullptr, status);
-      if (lane == 0) pair_score[c] = sc;
+  if (!(tol > 0.0) || qn > RS_HQ_MAX || margin > 0.45) {   // uniform: whole query deferred
+    for (long long c = c0 + (long long)blockIdx.y * blockDim.x + tid; c < c1;
+         c += (long long)blockDim.x * gridDim.y) {
+      const long long r = cv.row(c);
+      pair_score[c] = (r >= 0 && r < L.n) ? RS_DEFER : -1.0;
     }
+    if (tid == 0) q_defer[q] = 1;
     return;
   }
+  for (int i = tid; i < RS_HT; i += blockDim.x) H.bin[i] = RS_EMPTY;
+  for (int i = tid; i < RS_BM_BITS / 32; i += blockDim.x) H.bm[i] = 0u;
+  if (tid == 0) s_defer = 0;
+  __syncthreads();
   const double inv_w = 1.0 / (2.0 * tol);
   if (tid < qn) {
     const double qm = (double)Q.mz[tid];
     const int blo = (int)floor((qm - tol) * inv_w - margin);
     const int bhi = (int)floor((qm + tol) * inv_w + margin);
     for (int b = blo; b <= bhi; ++b) {
+      const uint32_t bit = hbit(b);
+      atomicOr(&H.bm[bit >> 5], 1u << (bit & 31));
       uint32_t h = hbin(b);
       for (;;) {
         const int old = atomicCAS(&H.bin[h], RS_EMPTY, b);
         if (old == RS_EMPTY) {
-          H.peak[h] = tid;
+          H.peak[h] = (uint8_t)tid;
           break;
         }
         h = (h + 1) & (RS_HT - 1);
@@ -441,82 +565,102 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
   }
   __syncthreads();
   const double q_pmz = Qs.precursor_mz[q];
-  WaveLds &Wv = W[wave];
+  PairLds &Wv = W[wave];
+  const int parts = RS_WAVES * gridDim.y, part = blockIdx.y * RS_WAVES + wave;
 
-  // contiguous slice of the candidate list for this wave
-  const long long n = c1 - c0;
-  const long long parts = (long long)RS_WAVES * gridDim.y;
-  const long long per = (n + parts - 1) / parts;
-  const long long wb = c0 + ((long long)blockIdx.y * RS_WAVES + wave) * per;
-  const long long we = wb + per < c1 ? wb + per : c1;
-
-  for (long long base = wb; base < we; base += 64) {
-    const long long c = base + lane;
-    long long row = -1;
-    if (c < we) row = cv.row(c);
-    const bool okr = row >= 0 && row < L.n;
-    int m_co = 0, m_cn = 0, m_chg = 0;
-    double m_pmz = 0.0;
-    if (okr) {
-      m_co = L.offsets[row];
-      m_cn = L.offsets[row + 1] - m_co;
-      m_chg = L.precursor_charge[row];
-      m_pmz = L.precursor_mz[row];
+  for (long long sb = c0; sb < c1; sb += RS_SUPER) {
+    // ---- compact the valid slots of this super-chunk (order is irrelevant: scores are
+    // written back to their slots)
+    const int sn = (int)((c1 - sb) < RS_SUPER ? (c1 - sb) : RS_SUPER);
+    if (tid == 0) s_nv = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < sn; i0 += blockDim.x) {
+      const int i = i0 + tid;
+      bool ok = false;
+      if (i < sn) {
+        const long long r = cv.row(sb + i);
+        ok = r >= 0 && r < L.n;
+        if (!ok && blockIdx.y == 0) pair_score[sb + i] = -1.0;
+      }
+      const unsigned long long bal = __ballot(ok);
+      int wbase = 0;
+      if (lane == 0 && bal) wbase = atomicAdd(&s_nv, __popcll(bal));
+      wbase = rl_i(wbase, 0);
+      if (ok) s_list[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
     }
-    double my_score = -1.0;
-    const int cnt = (int)((we - base) < 64 ? (we - base) : 64);
-    // Bursts of RS_PF candidates: all their peak loads are issued back to back (straight
-    // line, so hipcc keeps them in flight together), parked in this wave's LDS staging
-    // area, and the candidates are then scored from LDS with no global load in the way.
-    for (int g0 = 0; g0 < cnt; g0 += RS_PF) {
-      float fm[RS_PF], fi[RS_PF];
-      int fc[RS_PF];
-#pragma unroll
-      for (int u = 0; u < RS_PF; ++u) {
-        const int l = g0 + u < cnt ? g0 + u : cnt - 1;
-        const int co = rl_i(m_co, l), cn = rl_i(m_cn, l);
-        const bool ld = lane < cn && g0 + u < cnt;
-        fm[u] = ld ? L.mz[co + lane] : 0.0f;
-        fi[u] = ld ? L.intensity[co + lane] : 0.0f;
-        fc[u] = (ld && L.charge) ? L.charge[co + lane] : 0;
+    __syncthreads();
+    const int nv = s_nv;
+    const int per = (nv + parts - 1) / parts;
+    const int wb = part * per;
+    const int we = wb + per < nv ? wb + per : nv;
+
+    for (int base = wb; base < we; base += 64) {
+      const bool okr = base + lane < we;
+      const long long c = okr ? sb + s_list[base + lane] : -1;
+      int m_co = 0, m_cn = 0, m_chg = 0;
+      double m_pmz = 0.0;
+      if (okr) {
+        const long long row = cv.row(c);
+        m_co = L.offsets[row];
+        m_cn = L.offsets[row + 1] - m_co;
+        m_chg = L.precursor_charge[row];
+        m_pmz = L.precursor_mz[row];
       }
+      double my_score = 0.0;
+      const int cnt = we - base < 64 ? we - base : 64;
+      // Bursts of RS_PF candidates: all their peak loads are issued back to back (straight
+      // line, so hipcc keeps them in flight together), parked in this wave's LDS staging
+      // area, and the candidates are then scored from LDS with no global load in the way.
+      for (int g0 = 0; g0 < cnt; g0 += RS_PF) {
+        float fm[RS_PF], fi[RS_PF];
+        int fc[RS_PF];
 #pragma unroll
-      for (int u = 0; u < RS_PF; ++u) {
-        Wv.c_mz[u * 64 + lane] = fm[u];
-        Wv.c_int[u * 64 + lane] = fi[u];
-        Wv.c_chg[u * 64 + lane] = (uint8_t)fc[u];
-      }
-      wave_sync();
-#pragma unroll
-      for (int u = 0; u < RS_PF; ++u) {
-        const int l = g0 + u;
-        if (l < cnt && rl_i((int)okr, l)) {   // wave-uniform
-          const int cn = rl_i(m_cn, l);
-          const int c_charge = rl_i(m_chg, l);
-          const double c_pmz = rl_d(m_pmz, l);
-          double score = 0.0;
-          if (cn > 64) {   // rare: more peaks than a staging slot holds -> after the bursts
-            score = -2.0;
-          } else if (cn > 0 && qn > 0) {
-            score = score_candidate(lane, Q, H, Wv, u, cn, c_charge, c_pmz, q_pmz, tol, inv_w,
-                                    allow_shift, status);
-          }
-          if (lane == l) my_score = score;
+        for (int u = 0; u < RS_PF; ++u) {
+          const int l = g0 + u < cnt ? g0 + u : cnt - 1;
+          const int co = rl_i(m_co, l), cn = rl_i(m_cn, l);
+          const bool ld = lane < cn && g0 + u < cnt;
+          fm[u] = ld ? L.mz[co + lane] : 0.0f;
+          fi[u] = ld ? L.intensity[co + lane] : 0.0f;
+          fc[u] = (ld && L.charge) ? L.charge[co + lane] : 0;
         }
+#pragma unroll
+        for (int u = 0; u < RS_PF; ++u) {
+          Wv.c_mz[u * 64 + lane] = fm[u];
+          Wv.c_int[u * 64 + lane] = fi[u];
+          Wv.c_chg[u * 64 + lane] = (uint8_t)fc[u];
+        }
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < RS_PF; u += 2) {
+          const int lA = g0 + u, lB = g0 + u + 1;
+          const bool vA = lA < cnt, vB = lB < cnt;   // wave-uniform
+          const int cnA = vA ? rl_i(m_cn, lA) : 0, cnB = vB ? rl_i(m_cn, lB) : 0;
+          const int chA = vA ? rl_i(m_chg, lA) : 0, chB = vB ? rl_i(m_chg, lB) : 0;
+          const bool defA = cnA > 64 || chA >= 31, defB = cnB > 64 || chB >= 31;
+          const bool runA = vA && !defA && cnA > 0 && qn > 0;
+          const bool runB = vB && !defB && cnB > 0 && qn > 0;
+          double sA = 0.0, sB = 0.0;
+          if (dbg & 1) {   // measurement knob: no probing / resolving
+            sA = (double)cnA;
+            sB = (double)cnB;
+          } else if (runA || runB) {
+            score_two(lane, Q, H, Wv, u, u + 1, runA ? cnA : 0, runB ? cnB : 0, chA, chB,
+                      rl_d(m_pmz, vA ? lA : 0), rl_d(m_pmz, vB ? lB : 0), q_pmz, tol, inv_w,
+                      allow_shift, status, sA, sB, dbg);
+          }
+          if (defA) sA = RS_DEFER;
+          if (defB) sB = RS_DEFER;
+          if (vA && lane == lA) my_score = sA;
+          if (vB && lane == lB) my_score = sB;
+        }
+        wave_sync();
       }
-      wave_sync();
+      if (okr) pair_score[c] = my_score;
+      if (__ballot(okr && my_score == RS_DEFER) && lane == 0) s_defer = 1;
     }
-    // candidates with more than 64 peaks: binary-search formulation (uses the whole staging area)
-    unsigned long long big = __ballot(my_score == -2.0);
-    while (big) {
-      const int l = __builtin_ctzll(big);
-      big &= big - 1;
-      const double sc = dot_pair_wave<false>(lane, Q, qn, q_pmz, L, (int)rl_ll(row, l), tol,
-                                             allow_shift, Wv, nullptr, 0, nullptr, status);
-      if (lane == l) my_score = sc;
-    }
-    if (c < we) pair_score[c] = my_score;
+    __syncthreads();   // s_list is rebuilt for the next super-chunk
   }
+  if (tid == 0 && s_defer) q_defer[q] = 1;
 }
 
 // tie_by_row = 0: first position wins ties (get_best_match on a caller-ordered list);
@@ -612,15 +756,26 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
     int64_t avg = total_slots / (nq > 0 ? nq : 1);
     int ysplit = 1;
     if (nq < 2048 && avg > 4096) ysplit = (int)std::min<int64_t>(64, cdiv(avg, 4096));
-    // the v2 kernel falls back to the binary-search formulation per query when tol <= 0 or
-    // the query has more than RS_HQ_MAX peaks
     static const bool force_v1 = getenv("ASL_RESCORE_V1") != nullptr;  // A/B knob
-    if (!force_v1)
+    static const int rs_dbg = getenv("ASL_RESCORE_DBG") ? atoi(getenv("ASL_RESCORE_DBG")) : 0;
+    if (!force_v1) {
+      // hash kernel, then the binary-search kernel on whatever it deferred (its blocks
+      // return at once for queries with nothing deferred)
+      static DevBuf<int> &q_defer = *new DevBuf<int>();   // process lifetime (one device per process)
+      ASL_TRY(q_defer.reserve((size_t)nq));
+      HIP_TRY(hipMemsetAsync(q_defer.p, 0, sizeof(int) * (size_t)nq, stream()));
       hipLaunchKernelGGL(rescore_score_v2_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
-                         stream(), Q, L, cv, tol, allow_shift, pair_score, status);
-    else
+                         stream(), Q, L, cv, tol, allow_shift, pair_score, q_defer.p, status,
+                         rs_dbg);
+      ASL_CHECK_LAUNCH();
       hipLaunchKernelGGL(rescore_score_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
-                         stream(), Q, L, cv, tol, allow_shift, pair_score, status);
+                         stream(), Q, L, cv, tol, allow_shift, pair_score,
+                         (const int *)q_defer.p, status);
+    } else {
+      hipLaunchKernelGGL(rescore_score_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
+                         stream(), Q, L, cv, tol, allow_shift, pair_score, (const int *)nullptr,
+                         status);
+    }
     ASL_CHECK_LAUNCH();
     hipLaunchKernelGGL(rescore_argmax_kernel, dim3(nq), dim3(64), 0, stream(), cv, nq,
                        pair_score, tie_by_row, best_cand, best_slot, best_score, n_valid);
