@@ -26,7 +26,7 @@ constexpr int V3_NT = 256;
 constexpr int V3_CHUNK = 128;   // tile-table entries per chunk
 
 template <int CAP, int T>
-__global__ __launch_bounds__(V3_NT) void pq_scan_v3_kernel(
+__global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kernel(
     const float *__restrict__ xq, int d, const float *__restrict__ codebooks, int dsub,
     const float *__restrict__ coarse_D, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ tile_offsets,
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(V3_NT) void pq_scan_v3_kernel(
   top.init(smem, k, ids_tiled, tid);
 
   const char *lut_bytes = reinterpret_cast<const char *>(s_lut);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int rho = lane >> 4, j = lane & 15;
   const int ma = (rho & 1) ? j + 16 : j, mb = ma ^ 16;
   const uint32_t offA = (uint32_t)ma * 4u, offB = (uint32_t)mb * 4u;
@@ -84,39 +85,51 @@ __global__ __launch_bounds__(V3_NT) void pq_scan_v3_kernel(
     __syncthreads();
     const int nent = min(V3_CHUNK, total - c0);
     const int nrounds = (nent + ROUND_TILES - 1) / ROUND_TILES;
-    uint4 A[T], B[T], A2[T], B2[T];
-    TileEnt ent[T], ent2[T];
+    // Register pipeline, two rounds deep: with one query per workgroup and 12 waves per CU
+    // a single round of prefetch keeps too few bytes in flight to cover the HBM latency.
+    uint4 A0[T], B0[T], A1[T], B1[T], A2[T], B2[T];
+    TileEnt e0[T], e1[T], e2[T];
     auto fetch = [&](int rr, uint4 *a, uint4 *b, TileEnt *e) {
 #pragma unroll
       for (int u = 0; u < T; ++u) {
-        const int i = rr * ROUND_TILES + wave * T + u;
-        e[u] = table[i < nent ? i : 0];
-        if (i >= nent) e[u].nvalid = 0;
+        // the entry is the same for the whole wave: keep it in scalar registers
+        const int i = rr * ROUND_TILES + wave_u * T + u;
+        const TileEnt t = table[i < nent ? i : 0];
+        e[u].tile = __builtin_amdgcn_readfirstlane(t.tile);
+        e[u].coarse = __builtin_bit_cast(
+            float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t.coarse)));
+        e[u].nvalid = i < nent ? __builtin_amdgcn_readfirstlane(t.nvalid) : 0;
         const uint8_t *base = codes_tiled + (size_t)e[u].tile * 2048;
         a[u] = *reinterpret_cast<const uint4 *>(base + chunkA);
         b[u] = *reinterpret_cast<const uint4 *>(base + chunkB);
       }
     };
-    fetch(0, A, B, ent);
-    for (int rr = 0; rr < nrounds; ++rr) {
-      if (rr + 1 < nrounds) fetch(rr + 1, A2, B2, ent2);   // prefetch across the barrier
+    auto process = [&](const uint4 *a, const uint4 *b, const TileEnt *e) {
       top.begin_round();
       int appended = 0;
 #pragma unroll
       for (int u = 0; u < T; ++u) {
-        if (ent[u].nvalid > 0) {  // wave-uniform
-          const float score = ent[u].coarse + tile_adc(lut_bytes, A[u], B[u], offA, offB);
-          const bool take = top.offer(lane < ent[u].nvalid && !(dbg & 1), score,
-                                      ent[u].tile * 64u + (uint32_t)lane);
+        if (e[u].nvalid > 0) {  // wave-uniform
+          const float score = e[u].coarse + tile_adc(lut_bytes, a[u], b[u], offA, offB);
+          const bool take = top.offer(lane < e[u].nvalid && !(dbg & 1), score,
+                                      e[u].tile * 64u + (uint32_t)lane);
           appended += __popcll(__ballot(take));
         }
       }
       top.end_round(appended);
-#pragma unroll
-      for (int u = 0; u < T; ++u) {
-        A[u] = A2[u];
-        B[u] = B2[u];
-        ent[u] = ent2[u];
+    };
+    fetch(0, A0, B0, e0);
+    if (nrounds > 1) fetch(1, A1, B1, e1);
+    for (int rr = 0; rr < nrounds; rr += 3) {
+      if (rr + 2 < nrounds) fetch(rr + 2, A2, B2, e2);
+      process(A0, B0, e0);
+      if (rr + 1 < nrounds) {
+        if (rr + 3 < nrounds) fetch(rr + 3, A0, B0, e0);
+        process(A1, B1, e1);
+      }
+      if (rr + 2 < nrounds) {
+        if (rr + 4 < nrounds) fetch(rr + 4, A1, B1, e1);
+        process(A2, B2, e2);
       }
     }
     __syncthreads();
