@@ -12,6 +12,7 @@
 //   + small helpers (bitmap, argmax, residual/encode, gathers, L2 assignment)
 #include "common.hpp"
 #include "ivf_kernels.hpp"
+#include "hist_topk.hpp"
 #include "topk.hpp"
 
 namespace asl {
@@ -94,9 +95,60 @@ __global__ __launch_bounds__(TK_NT) void topk_merge_kernel(
   tk.finish(D + (size_t)q * k, I + (size_t)q * k, nullptr, tid);
 }
 
+// Histogram-threshold variant (hist_topk.hpp): no sort while streaming, the survivors are
+// sorted once. The S lists are visited in interleaved 64-entry chunks, so that (for the
+// usual sorted partial lists) the best entries of every list come first and the
+// threshold bucket rises after the first rounds; reads stay coalesced (256 B per wave).
+template <int CAP, int PT>
+__global__ __launch_bounds__(HT_NT) void topk_merge_hist_kernel(
+    const float *__restrict__ Ds, const int64_t *__restrict__ Is, int S, int nq, int k,
+    float *__restrict__ D, int64_t *__restrict__ I) {
+  using TopK = HistTopK<CAP, HT_NT * PT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, q = blockIdx.x;
+  TopK top;
+  top.init(smem, k, nullptr, tid);
+  const int kc = (k + 63) >> 6;          // 64-entry chunks per list
+  const int total = kc * S * 64;
+  for (int base = 0; base < total; base += HT_NT * PT) {
+    top.begin_round();
+    int appended = 0;
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+      const int v = base + u * HT_NT + tid;
+      const int c = v >> 6, s = c % S, j = (c / S) * 64 + (v & 63);
+      bool valid = v < total && j < k;
+      float score = 0.0f;
+      int64_t id = -1;
+      if (valid) {
+        const size_t o = ((size_t)s * nq + q) * k + j;
+        score = Ds[o];
+        id = Is[o];
+      }
+      valid = valid && id >= 0;
+      const bool take = top.offer(valid, score, 0xFFFFFFFFu - (uint32_t)id);
+      appended += __popcll(__ballot(take));
+    }
+    top.end_round(appended);
+  }
+  top.finish(D + (size_t)q * k, I + (size_t)q * k, nullptr);
+}
+
 int topk_merge(const float *Ds, const int64_t *Is, int S, int nq, int k, float *D, int64_t *I) {
   if (nq <= 0) return ASL_OK;
   if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "merge: k=%d outside 1..%d", k, TK_MAX_K);
+  if ((int64_t)S * k >= 2048 && k + 256 + 1024 <= 4096) {
+    // CAP 2048 keeps the final sort at 8 keys per thread (~100 VGPRs, 4+ workgroups per CU);
+    // CAP 4096 needs 16 (240 VGPRs, one workgroup per CU)
+    if (k + 256 + 512 <= 2048)
+      hipLaunchKernelGGL((topk_merge_hist_kernel<2048, 2>), dim3(nq), dim3(HT_NT),
+                         (HistTopK<2048, HT_NT * 2>::lds_bytes()), stream(), Ds, Is, S, nq, k, D, I);
+    else
+      hipLaunchKernelGGL((topk_merge_hist_kernel<4096, 4>), dim3(nq), dim3(HT_NT),
+                         (HistTopK<4096, HT_NT * 4>::lds_bytes()), stream(), Ds, Is, S, nq, k, D, I);
+    ASL_CHECK_LAUNCH();
+    return ASL_OK;
+  }
   const int cap = topk_cap_for(k);
   const size_t lds = (size_t)cap * 8 + 16;
   if (lds > 64 * 1024)

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
   float *s_q = reinterpret_cast<float *>(smem);  // aliases the key buffer during the LUT build
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+  const long long t_start = (dbg & 32) ? wall_clock64() : 0;
   build_lut_cbt(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, tid);  // codebooks = cbT[m][t][c]
 
   // ---- my probe (thread p < nprobe) and the exclusive scan of tile counts
@@ -59,8 +60,10 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
   const int my_pre = block_excl_scan256(my_nt, scan_part, tid, total);
   __syncthreads();
 
+  const long long t_lut = (dbg & 32) ? wall_clock64() : 0;
   TopK top;   // init zeroes the keys (which aliased s_q)
   top.init(smem, k, ids_tiled, tid);
+  const long long t_init = (dbg & 32) ? wall_clock64() : 0;
 
   const char *lut_bytes = reinterpret_cast<const char *>(s_lut);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -134,8 +137,20 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
     }
     __syncthreads();
   }
+  const long long t_loop = (dbg & 32) ? wall_clock64() : 0;
   top.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
              I32 ? I32 + (size_t)q * k : nullptr);
+  if ((dbg & 32) && D && k >= 8) {   // measurement: phase durations (100 MHz ticks) replace the scores
+    __syncthreads();
+    if (tid == 0) {
+      float *o = D + (size_t)q * k;
+      o[0] = (float)(t_lut - t_start);
+      o[1] = (float)(t_init - t_lut);
+      o[2] = (float)(t_loop - t_init);
+      o[3] = (float)(wall_clock64() - t_loop);
+      o[4] = (float)total;
+    }
+  }
 }
 
 template <int CAP, int T>

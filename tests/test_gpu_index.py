@@ -225,6 +225,31 @@ def test_sharded_search_merges_to_unsharded(O, vecs, trained):
         assert np.array_equal(Im, Io)
 
 
+@pytest.mark.parametrize('S,k,quant', [(8, 1024, 0), (8, 1024, 64), (2, 1000, 8), (5, 700, 0),
+                                       (2, 64, 0), (16, 1024, 2)])
+def test_topk_merge_synthetic_lists(O, S, k, quant):
+    """Merge of S partial lists: unsorted inputs, -1 padding, heavy score ties (quant levels),
+    ids unique across lists -- identical to the oracle under (score desc, id asc)."""
+    from ann_solo_amd import faiss_compat as faiss
+    rng = np.random.default_rng(S * 1000 + k + quant)
+    nq = 37
+    Ds = rng.uniform(-0.2, 1.0, (S, nq, k)).astype(np.float32)
+    if quant:
+        Ds = (np.floor(Ds * quant) / quant).astype(np.float32)
+    Is = np.empty((S, nq, k), np.int64)
+    for q in range(nq):
+        Is[:, q, :] = rng.permutation(4 * S * k)[:S * k].reshape(S, k)
+    pad = rng.random((S, nq, k)) < 0.15
+    pad[:, 0, :] = True                     # a query with no candidates at all
+    pad[1:, 1, :] = True                    # a query served by one list only
+    Is[pad] = -1
+    Ds[pad] = -3.402823466e+38
+    Dm, Im = faiss.topk_merge(Ds, Is)
+    Do, Io = O.topk_merge(Ds, Is)
+    assert np.array_equal(Im, Io)
+    assert np.array_equal(Dm.view(np.uint32), Do.view(np.uint32))
+
+
 def test_save_load_roundtrip(tmp_path, vecs, pq_index):
     from ann_solo_amd import faiss_compat as faiss
     _, xq = vecs
