@@ -9,9 +9,11 @@ addition. Per batch and charge partition:
   2. every rank searches its own inverted lists for ALL queries: coarse quantiser is
      replicated (identical probe lists everywhere, bit-exact fp32 MFMA chain), the
      PQ/flat scan touches only locally owned lists -> per-shard top-k;
-  3. ONE exchange: all-to-all of the per-shard top-k so that rank r receives the
+  3. the exchange: all-to-all of the per-shard top-k so that rank r receives the
      ``world`` partial lists of its own query slice (1/world of an all-gather's
-     inbound bytes; xGMI is point-to-point, so this maps to direct peer copies);
+     inbound bytes; xGMI is point-to-point, so this maps to direct peer copies). The
+     scan runs in a few query chunks and the all-to-all of one chunk is in flight on
+     RCCL's stream while the next chunk is scanned;
   4. k-way merge under (score desc, id asc) -- identical to the unsharded result by
      construction -- then precursor post-filter + shifted-dot rescoring data-parallel
      over the rank's own queries (the packed peak store is replicated: ~1 GB of 288).
@@ -106,27 +108,34 @@ class HipShardBackend:
         return BatchResult(best_row, best_score, n_cand, pm_count, pm_pairs, knn)
 
 
-def exchange_partials(D: torch.Tensor, I: torch.Tensor, world: int, group=None):
-    """[world*nq_local, k] per-shard results for all queries -> [world, nq_local, k]
-    partial lists of THIS rank's query slice. all-to-all on RCCL; on backends without
-    all-to-all (gloo) an all-gather followed by a slice."""
+def exchange_partials(D: torch.Tensor, I: torch.Tensor, world: int, group=None,
+                      async_op: bool = False):
+    """[world*n, k] per-shard results for n queries of every rank (rank-major) ->
+    [world, n, k] partial lists of THIS rank's n queries. all-to-all on RCCL; on backends
+    without all-to-all (gloo) an all-gather followed by a slice.
+
+    With ``async_op`` the RCCL collectives are only enqueued (on RCCL's own stream, after
+    the work already queued on the current stream); call ``wait()`` on the returned handles
+    before the outputs are consumed. The inputs are kept alive by the returned tuple."""
     nq_all, k = D.shape
-    nq_local = nq_all // world
+    n = nq_all // world
     rank = dist.get_rank(group)
     backend = dist.get_backend(group)
     if backend == 'nccl':
         Do, Io = torch.empty_like(D), torch.empty_like(I)
-        dist.all_to_all_single(Do, D, group=group)
-        dist.all_to_all_single(Io, I, group=group)
-        return Do.view(world, nq_local, k), Io.view(world, nq_local, k)
+        w1 = dist.all_to_all_single(Do, D, group=group, async_op=async_op)
+        w2 = dist.all_to_all_single(Io, I, group=group, async_op=async_op)
+        out = (Do.view(world, n, k), Io.view(world, n, k))
+        return out + ([w1, w2], (D, I)) if async_op else out
     dev = D.device
     Dc, Ic = D.cpu(), I.cpu()          # gloo: collectives on host tensors
     Dg = [torch.empty_like(Dc) for _ in range(world)]
     Ig = [torch.empty_like(Ic) for _ in range(world)]
     dist.all_gather(Dg, Dc, group=group)
     dist.all_gather(Ig, Ic, group=group)
-    sl = slice(rank * nq_local, (rank + 1) * nq_local)
-    return (torch.stack([d[sl] for d in Dg]).to(dev), torch.stack([i[sl] for i in Ig]).to(dev))
+    sl = slice(rank * n, (rank + 1) * n)
+    out = (torch.stack([d[sl] for d in Dg]).to(dev), torch.stack([i[sl] for i in Ig]).to(dev))
+    return out + ([], None) if async_op else out
 
 
 def _all_gather_rows(x: torch.Tensor, world: int, group=None) -> torch.Tensor:
@@ -141,21 +150,53 @@ def _all_gather_rows(x: torch.Tensor, world: int, group=None) -> torch.Tensor:
     return torch.cat(parts).to(x.device)
 
 
-def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, device_out=False):
+def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, device_out=False,
+                         chunks: Optional[int] = None):
     """One batch: ``queries_local`` is this rank's equally sized slice of the global
-    batch. Returns the BatchResult of the local slice (library rows are global)."""
+    batch. Returns the BatchResult of the local slice (library rows are global).
+
+    The shard scan runs in ``chunks`` pieces (the same sub-slice of every rank's queries per
+    piece) so that the all-to-all of one piece travels over xGMI while the next piece is
+    being scanned; the merge of piece c is issued after the scan of piece c+1."""
     world = dist.get_world_size(group)
     vec = backend.encode(queries_local)
     if world == 1:
         D, I = backend.shard_search(vec)
         return backend.rescore_knn(queries_local, I, device_out)
+    n_local = vec.shape[0]
     allvec = _all_gather_rows(vec, world, group)
     co = backend.coarse(vec) if getattr(backend, 'supports_preassigned', False) else None
     if co is not None:
         cD, cI = _all_gather_rows(co[0], world, group), _all_gather_rows(co[1], world, group)
-        D, I = backend.shard_search_preassigned(allvec, cD, cI)
-    else:
-        D, I = backend.shard_search(allvec)
-    Ds, Is = exchange_partials(D, I, world, group)
-    _, knn = backend.merge(Ds.contiguous(), Is.contiguous())
+    if chunks is None:
+        chunks = 4 if dist.get_backend(group) == 'nccl' else 2
+    chunks = max(1, min(chunks, n_local))
+    bounds = [(n_local * c) // chunks for c in range(chunks + 1)]
+    rank_base = torch.arange(world, device=allvec.device).unsqueeze(1) * n_local
+    knn_parts, pending = [], None
+
+    def finish(p):
+        Ds, Is, works, _keep = p
+        for w in works:
+            w.wait()
+        knn_parts.append(backend.merge(Ds.contiguous(), Is.contiguous())[1])
+
+    for c in range(chunks):
+        lo, hi = bounds[c], bounds[c + 1]
+        if hi == lo:
+            continue
+        if chunks == 1:
+            xv, pre = allvec, (cD, cI) if co is not None else None
+        else:   # rows [lo, hi) of every rank's slice, rank-major
+            rows = (rank_base + torch.arange(lo, hi, device=allvec.device).unsqueeze(0)).reshape(-1)
+            xv = allvec.index_select(0, rows)
+            pre = (cD.index_select(0, rows), cI.index_select(0, rows)) if co is not None else None
+        D, I = (backend.shard_search_preassigned(xv, *pre) if pre is not None
+                else backend.shard_search(xv))
+        nxt = exchange_partials(D, I, world, group, async_op=True)
+        if pending is not None:
+            finish(pending)
+        pending = nxt
+    finish(pending)
+    knn = knn_parts[0] if len(knn_parts) == 1 else torch.cat(knn_parts)
     return backend.rescore_knn(queries_local, knn, device_out)
