@@ -18,8 +18,9 @@ addition. Per batch and charge partition:
      construction -- then precursor post-filter + shifted-dot rescoring data-parallel
      over the rank's own queries (the packed peak store is replicated: ~1 GB of 288).
 
-List ownership is the greedy longest-list-first balancing of ``asl_lpt_owner``
-(identical on every rank, no communication). The compute backend is injectable so
+List ownership is the greedy heaviest-first balancing of ``asl_lpt_owner`` over the
+expected scan load of each list (size squared: populous lists are also probed more often);
+identical on every rank, no communication. The compute backend is injectable so
 that the host logic (ownership, exchange, merge order) is covered by world_size-2
 ``gloo`` tests on CPU; the product backend is the HIP library and nothing else.
 """

@@ -113,8 +113,9 @@ int asl_index_set_trained(asl_index_t *idx, const float *centroids, const float 
 int asl_index_get_lists(const asl_index_t *idx, int32_t *list_offsets /* [nlist+1] */,
                         int32_t *ids /* [nlocal] */, uint8_t *codes /* [nlocal,m] PQ */,
                         float *vecs /* [nlocal,d] FLAT */);
-/* Keep only the inverted lists owned by `rank` of `world` (greedy longest-list-first
- * balancing, identical on every rank). Must be called after add(). search() then
+/* Keep only the inverted lists owned by `rank` of `world` (greedy heaviest-first balancing
+ * of the expected scan load, weight = list size squared; identical on every rank, see
+ * asl_lpt_owner). Must be called after add(). search() then
  * returns this shard's partial top-k; combine with asl_topk_merge. */
 int asl_index_shard(asl_index_t *idx, int32_t rank, int32_t world);
 /* list -> owner rank map of the balancing above, for inspection. */

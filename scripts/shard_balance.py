@@ -23,19 +23,29 @@ cI = cI.cpu().numpy()
 off = idx.lists()[0].astype(np.int64)
 sizes = off[1:] - off[:-1]
 owner = idx.shard_map(W)
-assert (owner == lpt_owner(sizes, W)).all()
+assert (owner == lpt_owner(sizes * sizes, W)).all()
 tiles = (sizes + 63) // 64
 print('list sizes: min %d mean %.0f max %d; tiles/list mean %.2f (ideal %.2f)' %
       (sizes.min(), sizes.mean(), sizes.max(), tiles.mean(), sizes.mean() / 64))
-vec_load = np.zeros(W)
-tile_load = np.zeros(W)
-own = owner[cI]                       # [nq, nprobe]
-for r in range(W):
-    sel = own == r
-    vec_load[r] = (sizes[cI] * sel).sum() / cI.shape[0]
-    tile_load[r] = (tiles[cI] * sel).sum() / cI.shape[0]
-print('owned vectors per shard:', [int(sizes[owner == r].sum()) for r in range(W)])
-print('scanned vectors/query per shard:', np.round(vec_load).astype(int).tolist(),
-      'max/mean %.3f' % (vec_load.max() / vec_load.mean()))
-print('tiles/query per shard:', np.round(tile_load).astype(int).tolist(),
-      'max/mean %.3f' % (tile_load.max() / tile_load.mean()))
+
+
+def report(tag, owner):
+    vec_load = np.zeros(W)
+    tile_load = np.zeros(W)
+    own = owner[cI]                       # [nq, nprobe]
+    for r in range(W):
+        sel = own == r
+        vec_load[r] = (sizes[cI] * sel).sum() / cI.shape[0]
+        tile_load[r] = (tiles[cI] * sel).sum() / cI.shape[0]
+    print(tag, 'owned vectors per shard:', [int(sizes[owner == r].sum()) for r in range(W)])
+    print(tag, 'scanned vectors/query per shard:', np.round(vec_load).astype(int).tolist(),
+          'max/mean %.3f' % (vec_load.max() / vec_load.mean()))
+    print(tag, 'tiles/query per shard:', np.round(tile_load).astype(int).tolist(),
+          'max/mean %.3f' % (tile_load.max() / tile_load.mean()))
+
+
+report('[lpt len]', lpt_owner(sizes, W))
+report('[lpt len^2 = asl_index_shard]', owner)
+freq = np.bincount(cI.reshape(-1), minlength=len(sizes)).astype(np.int64)
+report('[lpt len*freq (oracle of the batch)]', lpt_owner(sizes * freq, W))
+print('corr(len, probe freq) = %.3f' % np.corrcoef(sizes, freq)[0, 1])
