@@ -8,11 +8,15 @@ derives from ``annotation``), ``precursor_mz f64[n]``, ``precursor_charge i32[n]
 Peaks of one spectrum are ascending in m/z and already processed
 (``process_spectrum``, spectrum.py:57-119).
 """
+import json
+import struct
 from dataclasses import dataclass
 from typing import Optional
 
 import numpy as np
 import torch
+
+STORE_MAGIC = b'ASLPKS01'
 
 
 @dataclass
@@ -83,6 +87,53 @@ class PackedSpectra:
             torch.as_tensor(np.ascontiguousarray(precursor_mz, np.float64), device=device),
             torch.as_tensor(np.ascontiguousarray(precursor_charge, np.int32), device=device),
             identifiers=identifiers)
+
+    # ------------------------------------------------------------------ on-disk store
+    # the processed-peak store that replaces the per-candidate HDF5 reads
+    # of reader.py:218-246,523-556. One little-endian file:
+    #   magic 'ASLPKS01' | u64 n | u64 P | u32 len(meta) | meta (utf-8 JSON: hyper-hash,
+    #   identifiers) | offsets i64[n+1] | mz f32[P] | intensity f32[P] | charge u8[P] |
+    #   precursor_mz f64[n] | precursor_charge u8[n]
+    # keyed by the SHA-1 hyper-parameter hash the reference keeps in its .spcfg file
+    # (reader.py: config hash check) -- a store written under other settings is rejected.
+    def save(self, path: str, hyperparameter_hash: str = '') -> None:
+        o, mz, it, chg, pmz, pz = self.numpy()
+        if pz.size and (pz.min() < 0 or pz.max() > 255):
+            raise ValueError('precursor charge outside 0..255')
+        ids = None if self.identifiers is None else [
+            i if isinstance(i, (str, type(None))) else int(i) for i in self.identifiers]
+        meta = json.dumps({'hash': hyperparameter_hash, 'identifiers': ids}).encode('utf-8')
+        with open(path, 'wb') as f:
+            f.write(STORE_MAGIC)
+            f.write(struct.pack('<QQI', self.n, int(mz.shape[0]), len(meta)))
+            f.write(meta)
+            for a, dt in ((o, '<i8'), (mz, '<f4'), (it, '<f4'), (chg, 'u1'), (pmz, '<f8'),
+                          (pz, 'u1')):
+                f.write(np.ascontiguousarray(a).astype(dt, copy=False).tobytes())
+
+    @staticmethod
+    def load(path: str, hyperparameter_hash: Optional[str] = None,
+             device='cpu') -> 'PackedSpectra':
+        """Read a store; if ``hyperparameter_hash`` is given it must match the one the store
+        was written under (``ValueError`` otherwise, the reference's ``is_recreated`` case)."""
+        with open(path, 'rb') as f:
+            if f.read(8) != STORE_MAGIC:
+                raise ValueError(f'{path}: not a packed spectrum store')
+            n, P, lm = struct.unpack('<QQI', f.read(20))
+            meta = json.loads(f.read(lm).decode('utf-8'))
+            if hyperparameter_hash is not None and meta.get('hash') != hyperparameter_hash:
+                raise ValueError(f'{path}: written under different hyper-parameters')
+
+            def rd(cnt, dt):
+                a = np.frombuffer(f.read(cnt * np.dtype(dt).itemsize), dtype=dt)
+                if a.shape[0] != cnt:
+                    raise ValueError(f'{path}: truncated')
+                return a
+            o, mz, it = rd(n + 1, '<i8'), rd(P, '<f4'), rd(P, '<f4')
+            chg, pmz, pz = rd(P, 'u1'), rd(n, '<f8'), rd(n, 'u1')
+        if n and (o[0] != 0 or o[-1] != P or (np.diff(o) < 0).any()):
+            raise ValueError(f'{path}: corrupt offsets')
+        return PackedSpectra.from_numpy(o, mz, it, chg, pmz, pz, device, meta.get('identifiers'))
 
     @staticmethod
     def from_spectra(spectra, device='cpu') -> 'PackedSpectra':

@@ -91,6 +91,34 @@ def test_packed_spectra_select_and_from_spectra():
     assert p.n == 2 and p.charge.tolist() == [0, 2, 0, 2] and p.offsets.tolist() == [0, 2, 4]
 
 
+def test_packed_store_round_trip(tmp_path):
+    """On-disk processed-peak store: bit-identical round trip, keyed by
+    the hyper-parameter hash, corrupt/truncated files rejected."""
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.packed import PackedSpectra
+    lib, _ = synthetic.make_library(300, seed=6, device='cpu')
+    lib.identifiers = [f'spec_{i}' for i in range(lib.n)]
+    path = os.path.join(tmp_path, 'lib_abc1234.spstore')
+    lib.save(path, 'abc1234')
+    back = PackedSpectra.load(path, 'abc1234')
+    for a, b in zip(lib.numpy(), back.numpy()):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    assert back.identifiers == lib.identifiers
+    assert PackedSpectra.load(path).n == lib.n               # no hash check requested
+    with pytest.raises(ValueError):
+        PackedSpectra.load(path, 'other')                    # the reference's is_recreated case
+    raw = open(path, 'rb').read()
+    open(path, 'wb').write(raw[:-100])
+    with pytest.raises(ValueError):
+        PackedSpectra.load(path)
+    open(path, 'wb').write(b'NOTASTORE' + raw[9:])
+    with pytest.raises(ValueError):
+        PackedSpectra.load(path)
+    empty = PackedSpectra.from_numpy([0], [], [], None, [], [])
+    empty.save(path)
+    assert PackedSpectra.load(path).n == 0
+
+
 def test_synthetic_generator_contract():
     from ann_solo_amd import synthetic
     a, _ = synthetic.make_library(300, seed=9, device='cpu')
