@@ -125,7 +125,7 @@ class PackedSpectra:
                 raise ValueError(f'{path}: written under different hyper-parameters')
 
             def rd(cnt, dt):
-                a = np.frombuffer(f.read(cnt * np.dtype(dt).itemsize), dtype=dt)
+                a = np.frombuffer(bytearray(f.read(cnt * np.dtype(dt).itemsize)), dtype=dt)
                 if a.shape[0] != cnt:
                     raise ValueError(f'{path}: truncated')
                 return a
