@@ -80,6 +80,13 @@ int orc_process_spectrum(const float *mz, const float *intensity, int32_t n, dou
                          int32_t precursor_charge, const orc_process_params_t *p,
                          float *out_mz, float *out_int, int32_t *out_src, int32_t *n_out);
 
+/* ---- SSM similarity features: spectrum_similarity.py:13-730 (asl_oracle_sim.c) ---- */
+#define ORC_SIM_NFEAT 33
+void orc_ssm_features(const float *q_mz, const float *q_int, int32_t nq, const float *l_mz,
+                      const float *l_int, int32_t nl, const uint32_t *pm /* [npm,2] */,
+                      int32_t npm, double min_mz, double max_mz, double bin_size, int32_t top,
+                      double *out /* [ORC_SIM_NFEAT] */);
+
 /* ---- rescoring: SpectrumMatch.cpp:8-133 -------------------------------- */
 /* One (query,candidate) pair. matches_out (may be NULL) receives (q_idx,c_idx)
  * pairs in greedy order; returns the score. n_matches_out may be NULL. */

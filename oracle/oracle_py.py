@@ -168,6 +168,25 @@ def process_spectrum(mz, intensity, precursor_mz, precursor_charge, min_mz=11, m
     return bool(ok), om[:n.value].copy(), oi[:n.value].copy(), src[:n.value].copy()
 
 
+# ---------------------------------------------------------------- similarity features
+SIM_NFEAT = 33
+
+
+def ssm_features(q_mz, q_int, l_mz, l_int, peak_matches, min_mz=11, max_mz=2010, bin_size=0.04,
+                 top=5):
+    q_mz, q_int = _c(q_mz, np.float32), _c(q_int, np.float32)
+    l_mz, l_int = _c(l_mz, np.float32), _c(l_int, np.float32)
+    pm = _c(np.asarray(peak_matches).reshape(-1, 2), np.uint32)
+    out = np.zeros(SIM_NFEAT, np.float64)
+    L = lib()
+    L.orc_ssm_features.restype = None
+    L.orc_ssm_features(_p(q_mz, c_f32p), _p(q_int, c_f32p), C.c_int32(len(q_mz)),
+                       _p(l_mz, c_f32p), _p(l_int, c_f32p), C.c_int32(len(l_mz)),
+                       _p(pm, c_u32p), C.c_int32(len(pm)), C.c_double(min_mz), C.c_double(max_mz),
+                       C.c_double(bin_size), C.c_int32(top), _p(out, c_f64p))
+    return out
+
+
 # ---------------------------------------------------------------- rescoring
 def dot_pair(q_mz, q_int, q_pmz, c_mz, c_int, c_chg, c_pmz, c_charge, tol, allow_shift):
     q_mz, q_int = _c(q_mz, np.float32), _c(q_int, np.float32)

@@ -13,6 +13,11 @@ oracle/_ref (compiled from the sources where they lie).
                        src/ann_solo/SpectrumMatch.cpp (oracle/_ref)
   similarity_kat.npz   the partial/all/no-match spectra and constants held by
                        src/tests/spectrum_similarity_test.py (data fixture)
+  similarity_expected.json  every `== pytest.approx(value)` constant of that test file
+                       (fixture, method, arguments, value) -- data, not code
+  ssm_features_golden.npz   the 33 similarity features of utils._compute_ssm_features
+                       (src/ann_solo/utils.py:276-457) evaluated by the reference's
+                       SpectrumSimilarityCalculator (scipy of this container) on seeded SSMs
 """
 import importlib.util
 import os
@@ -241,6 +246,139 @@ def gen_similarity_kat(spectrum):
           [float(out[f'{n}_cosine']) for n in ('all_match', 'no_match', 'partial_match')])
 
 
+# Feature columns of ssm_features_golden.npz / asl_ssm_features_batch, in the order of the
+# reference's feature dictionary (utils.py:296-343); (method, args, top)
+SIM_FEATURES = [
+    ('cosine', (), None), ('cosine', (), 5), ('n_matched_peaks', (), None),
+    ('frac_n_peaks_query', (), None), ('frac_n_peaks_library', (), None),
+    ('frac_n_peaks_library', (), 5), ('frac_intensity_query', (), None),
+    ('frac_intensity_library', (), None), ('frac_intensity_library', (), 5),
+    ('mean_squared_error', ('mz',), None), ('mean_squared_error', ('mz',), 5),
+    ('mean_squared_error', ('intensity',), None), ('mean_squared_error', ('intensity',), 5),
+    ('spectral_contrast_angle', (), None), ('spectral_contrast_angle', (), 5),
+    ('hypergeometric_score', 'HG', None), ('kendalltau', (), None), ('ms_for_id_v1', (), None),
+    ('ms_for_id_v2', (), None), ('entropy', (False,), None), ('entropy', (True,), None),
+    ('scribe_fragment_acc', (), None), ('scribe_fragment_acc', (), 5), ('manhattan', (), None),
+    ('euclidean', (), None), ('chebyshev', (), None), ('pearsonr', (), None), ('pearsonr', (), 5),
+    ('spearmanr', (), None), ('spearmanr', (), 5), ('braycurtis', (), None),
+    ('canberra', (), None), ('ruzicka', (), None)]
+
+
+def gen_similarity_expected():
+    """Constants of the reference's similarity tests, as data."""
+    import json
+    import re
+    text = open(os.path.join(REF, 'tests/spectrum_similarity_test.py')).read()
+    out = []
+    for m in re.finditer(r'def (test_\w+)\((.*?)\):\n(.*?)(?=\ndef |\Z)', text, re.S):
+        body = ' '.join(m.group(3).split())
+        params = re.search(r'params = dict\((.*?)\)', body)
+        for a in re.finditer(r'assert (\w+)\.(\w+)\((.*?)\) == pytest\.approx\( ?([^()]*?) ?\)',
+                             body):
+            fixture, method, args, val = a.groups()
+            if args.strip() == '**params':
+                args = params.group(1)
+            out.append({'test': m.group(1), 'fixture': fixture, 'method': method,
+                        'args': args.strip(), 'value': float(eval(val, {'np': np}))})
+    with open(os.path.join(HERE, 'similarity_expected.json'), 'w') as f:
+        json.dump(out, f, indent=0)
+    print('similarity_expected.json:', len(out), 'constants')
+
+
+def gen_ssm_features(spectrum):
+    """Reference SpectrumSimilarityCalculator on seeded SSMs (+ the three KAT fixtures)."""
+    import warnings
+    import scipy.stats
+    # scipy >= 1.11 renamed the two warning classes the reference names (stand-ins only)
+    for old in ('PearsonRConstantInputWarning', 'SpearmanRConstantInputWarning'):
+        if not hasattr(scipy.stats, old):
+            setattr(scipy.stats, old, scipy.stats.ConstantInputWarning)
+    sim = sys.modules['ann_solo.spectrum_similarity']
+    sus = sys.modules['spectrum_utils.spectrum']
+    rng = np.random.default_rng(20240911)
+    kat = np.load(os.path.join(HERE, 'similarity_kat.npz'))
+    cases = []
+    for name in ('all_match', 'no_match', 'partial_match'):
+        cases.append((kat[f'{name}_q_mz'], kat[f'{name}_q_intensity'], kat[f'{name}_l_mz'],
+                      kat[f'{name}_l_intensity'], kat[f'{name}_peak_matches']))
+
+    def unit(x):
+        x = x.astype(np.float32)
+        return x / np.linalg.norm(x)
+
+    def spec(n, scaling):
+        mz = np.sort(rng.uniform(100, 1900, n)).astype(np.float32)
+        if scaling == 'rank':
+            inten = unit(rng.permutation(n) + 1.0 + (50 - n))
+        else:
+            inten = unit(np.sqrt(rng.lognormal(0, 1, n)))
+        return mz, inten
+
+    for c in range(240):
+        nq, nl = int(rng.integers(10, 51)), int(rng.integers(10, 51))
+        scaling = 'rank' if c % 3 else 'sqrt'
+        qmz, qi = spec(nq, scaling)
+        lmz, li = spec(nl, scaling)
+        kind = c % 8
+        if kind == 0:       # identical spectra, every peak matched
+            lmz, li, nl = qmz.copy(), qi.copy(), nq
+            pm = np.stack([np.arange(nq), np.arange(nq)], 1)
+        else:
+            nm = {1: 1, 2: 2, 3: 3}.get(kind, int(rng.integers(1, min(nq, nl) + 1)))
+            if kind == 7:
+                nm = min(nq, nl)
+            a = np.sort(rng.choice(nq, nm, replace=False))
+            b = np.sort(rng.choice(nl, nm, replace=False))
+            if c % 5 == 0:
+                b = rng.permutation(b)       # shifted matches need not be monotone
+            lmz[b] = qmz[a] + rng.normal(0, 0.005, nm).astype(np.float32)
+            order = np.argsort(lmz, kind='stable')
+            inv = np.empty(nl, np.int64)
+            inv[order] = np.arange(nl)
+            lmz, li, b = lmz[order], li[order], inv[b]
+            pm = np.stack([a, b], 1)
+        if c % 11 == 0 and len(pm) > 3:      # tied intensities among matched peaks
+            qi = qi.copy()
+            qi[pm[1, 0]] = qi[pm[0, 0]]
+            qi = unit(qi)
+        top6 = np.sort(li)[-6:]
+        if len(np.unique(top6)) < 6:
+            continue                          # argpartition's choice among ties is unspecified
+        cases.append((qmz, qi, lmz, li, pm.astype(np.int64)))
+
+    class S:
+        pass
+    feats = np.full((len(cases), len(SIM_FEATURES)), np.nan)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for ci, (qmz, qi, lmz, li, pm) in enumerate(cases):
+            ssm = S()
+            ssm.query_spectrum = sus.MsmsSpectrum('q', 500.0, 2, qmz, qi)
+            ssm.library_spectrum = sus.MsmsSpectrum('l', 500.0, 2, lmz, li)
+            ssm.peak_matches = pm
+            calc = {None: sim.SpectrumSimilarityCalculator(ssm),
+                    5: sim.SpectrumSimilarityCalculator(ssm, 5)}
+            for fi, (method, args, top) in enumerate(SIM_FEATURES):
+                if args == 'HG':
+                    v = calc[top].hypergeometric_score(min_mz=11, max_mz=2010, fragment_mz_tol=0.04)
+                else:
+                    v = getattr(calc[top], method)(*args)
+                feats[ci, fi] = float(v)
+    off = lambda xs: np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.int64)
+    np.savez_compressed(
+        os.path.join(HERE, 'ssm_features_golden.npz'),
+        q_offsets=off([c[0] for c in cases]), q_mz=np.concatenate([c[0] for c in cases]),
+        q_intensity=np.concatenate([c[1] for c in cases]),
+        l_offsets=off([c[2] for c in cases]), l_mz=np.concatenate([c[2] for c in cases]),
+        l_intensity=np.concatenate([c[3] for c in cases]),
+        pm_offsets=off([c[4] for c in cases]),
+        pm_pairs=np.concatenate([c[4].reshape(-1, 2) for c in cases]).astype(np.uint32),
+        features=feats,
+        feature_names=np.array([m + ('_' + '_'.join(map(str, a)) if a and a != 'HG' else '') +
+                                ('_top5' if t else '') for m, a, t in SIM_FEATURES]))
+    print('ssm_features_golden.npz:', len(cases), 'SSMs x', len(SIM_FEATURES), 'features')
+
+
 def gen_rescoring():
     from oracle import oracle_py as O
     from ann_solo_amd import synthetic
@@ -344,4 +482,6 @@ if __name__ == '__main__':
         sys.exit('needs /root/reference (build container only)')
     sp = gen_encoder()
     gen_similarity_kat(sp)
+    gen_similarity_expected()
+    gen_ssm_features(sp)
     gen_rescoring()
