@@ -273,7 +273,7 @@ def gen_similarity_expected():
     for m in re.finditer(r'def (test_\w+)\((.*?)\):\n(.*?)(?=\ndef |\Z)', text, re.S):
         body = ' '.join(m.group(3).split())
         params = re.search(r'params = dict\((.*?)\)', body)
-        for a in re.finditer(r'assert (\w+)\.(\w+)\((.*?)\) == pytest\.approx\( ?([^()]*?) ?\)',
+        for a in re.finditer(r'assert (\w+)\.(\w+)\(([^()]*)\) == pytest\.approx\( ?([^()]*?) ?\)',
                              body):
             fixture, method, args, val = a.groups()
             if args.strip() == '**params':
