@@ -194,6 +194,31 @@ int asl_process_batch(const asl_peaks_t *raw, const asl_process_params_t *params
                       float *out_mz, float *out_intensity, int32_t *out_src,
                       int32_t *out_count, uint8_t *out_valid);
 
+/* ------------------------------------------------------------------ SSM features
+ * Replaces the per-SSM SpectrumSimilarityCalculator calls of _compute_ssm_features
+ *   /root/reference/src/ann_solo/utils.py:344-456
+ *   /root/reference/src/ann_solo/spectrum_similarity.py:13-730
+ * For every query i: the similarity features of (query i, library row lib_rows[i]) over
+ * the peak matches pm_pairs[i, :pm_count[i]] that asl_search_batch / asl_rescore_* emit.
+ * features[i, ASL_SSM_NFEAT], in the order of the reference's feature dictionary
+ * (utils.py:309-342; `*_top` = restricted to the `top` = 5 most intense library peaks):
+ *   0 cosine, 1 cosine_top, 2 n_matched_peaks, 3 frac_n_peaks_query, 4 frac_n_peaks_lib,
+ *   5 frac_n_peaks_lib_top, 6 frac_int_query, 7 frac_int_lib, 8 frac_int_lib_top,
+ *   9 mse_mz, 10 mse_mz_top, 11 mse_int, 12 mse_int_top, 13 contrast_angle,
+ *   14 contrast_angle_top, 15 hypergeometric_score(min_mz, max_mz, bin_size), 16 kendalltau,
+ *   17 ms_for_id_v1, 18 ms_for_id_v2, 19 entropy_unweighted, 20 entropy_weighted,
+ *   21 scribe_fragment_acc, 22 scribe_fragment_acc_top, 23 manhattan, 24 euclidean,
+ *   25 chebyshev, 26 pearsonr, 27 pearsonr_top, 28 spearmanr, 29 spearmanr_top,
+ *   30 braycurtis, 31 canberra, 32 ruzicka.
+ * Rows with lib_rows[i] < 0 are NaN (the reference skips SSMs without a match). */
+#define ASL_SSM_NFEAT 33
+int asl_ssm_features_batch(const asl_peaks_t *queries, const asl_peaks_t *library,
+                           const int32_t *lib_rows /* [nq] */,
+                           const uint32_t *pm_pairs /* [nq, pm_stride, 2] */,
+                           const int32_t *pm_count /* [nq] */, int32_t pm_stride,
+                           double min_mz, double max_mz, double bin_size, int32_t top,
+                           double *features /* [nq, ASL_SSM_NFEAT] */);
+
 /* ------------------------------------------------------------------ hot path
  * One batch of same-charge queries through
  *   SpectralLibrary._search_batch / _get_library_candidates
