@@ -212,6 +212,16 @@ def main():
                         'algorithmic_bytes_per_launch': int(bytes_per_launch),
                         'vectors_scanned_per_query': round(scanned / scan['launches'] /
                                                            (world * args.batch), 1)}
+        # post-path step of the same batch, outside the timed region: the 33 SSM similarity
+        # features of every best match (utils._compute_ssm_features), one kernel launch
+        from ann_solo_amd.spectrum_similarity import ssm_features
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        feats = ssm_features(q, part.spectra, res.best_row, res.pm_pairs, res.pm_count)
+        torch.cuda.synchronize()
+        feat_ms = (time.perf_counter() - t1) * 1e3
+        n_ssm = int((res.pm_count > 0).sum())
+        del feats
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(args, sl, part, idx, q, res, charge, cfg)
@@ -235,6 +245,7 @@ def main():
             'recall': recall,
             'shard_check': shard_check,
             'stages_ms_per_step': {k: round(v['ms_total'] / args.steps, 3) for k, v in stages.items()},
+            'post_path': {'ssm_features_ms_per_batch': round(feat_ms, 3), 'ssms': n_ssm},
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
