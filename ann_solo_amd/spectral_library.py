@@ -35,8 +35,21 @@ class Config:
     """The reference's flags that reach the hot path, same names and defaults
     (/root/reference/src/ann_solo/config.py:71-216). ``index``/``pq_m``/``pq_bits`` are
     the additive flags of this implementation."""
+    resolution: Optional[int] = None
     min_mz: int = 11
     max_mz: int = 2010
+    remove_precursor: bool = False
+    remove_precursor_tolerance: float = 0
+    min_intensity: float = 0.01
+    min_peaks: int = 10
+    min_mz_range: float = 250
+    max_peaks_used: int = 50
+    max_peaks_used_library: int = 50
+    scaling: Optional[str] = 'rank'
+    fdr: float = 0.01
+    fdr_min_group_size: int = 100
+    spectral_library_filename: str = ''
+    query_filename: str = ''
     bin_size: float = 0.04
     hash_len: int = 800
     num_candidates: int = 1024

@@ -15,6 +15,8 @@ oracle/_ref (compiled from the sources where they lie).
                        src/tests/spectrum_similarity_test.py (data fixture)
   similarity_expected.json  every `== pytest.approx(value)` constant of that test file
                        (fixture, method, arguments, value) -- data, not code
+  mztab_golden.json    write_mztab (src/ann_solo/writer.py) output for a fixed set of SSMs
+                       under two configurations: inputs + the exact file text
   ssm_features_golden.npz   the 33 similarity features of utils._compute_ssm_features
                        (src/ann_solo/utils.py:276-457) evaluated by the reference's
                        SpectrumSimilarityCalculator (scipy of this container) on seeded SSMs
@@ -379,6 +381,88 @@ def gen_ssm_features(spectrum):
     print('ssm_features_golden.npz:', len(cases), 'SSMs x', len(SIM_FEATURES), 'features')
 
 
+def gen_mztab(spectrum):
+    """The reference's write_mztab (src/ann_solo/writer.py) on a fixed set of SSMs -> golden
+    text + the inputs as JSON. reader.SpectralLibraryReader only types an argument there; a
+    stand-in with get_version() replaces the module (its real imports -- h5py, pyteomics,
+    lxml -- are absent)."""
+    import json
+    import tempfile
+    pkg = sys.modules['ann_solo']
+    pkg.__version__ = '0.3.3'            # src/ann_solo/__init__.py:1 (its other imports need faiss)
+    for line in open(os.path.join(REF, 'ann_solo/__init__.py')):
+        if line.startswith('__version__'):
+            assert line.split('=')[1].strip().strip("'") == pkg.__version__
+    rd = types.ModuleType('ann_solo.reader')
+
+    class SpectralLibraryReader:
+        def get_version(self):
+            return 'null'                # reader.py:289-298
+    rd.SpectralLibraryReader = SpectralLibraryReader
+    sys.modules['ann_solo.reader'] = rd
+    writer = _load('ann_solo.writer', os.path.join(REF, 'ann_solo/writer.py'))
+    config = sys.modules['ann_solo.config'].config
+    sus = sys.modules['spectrum_utils.spectrum']
+    rng = np.random.default_rng(77)
+    ssm_rows = []
+    idents = ['scan=10', 'scan=9', 'scan=100', 'a2', 'A10', 'b1', 'index=3', 'index=21', 'q',
+              'spec_007', 'spec_7', 'spec_70']
+    for i, qid in enumerate(idents):
+        ssm_rows.append(dict(
+            sequence=''.join(rng.choice(list('ACDEFGHIKLMNPQRSTVWY'), int(rng.integers(7, 15)))) +
+            ('/2' if i % 3 == 0 else ''),
+            query_identifier=qid, query_index=int(rng.integers(0, 5000)),
+            library_identifier=int(rng.integers(1, 10 ** 6)) if i % 4 else f'lib_{i}',
+            retention_time=None if i % 5 == 0 else float(np.round(rng.uniform(0, 7200), 3)),
+            charge=int(rng.integers(2, 5)), exp_mass_to_charge=float(rng.uniform(300, 1500)),
+            calc_mass_to_charge=float(np.float32(rng.uniform(300, 1500))),
+            is_decoy=bool(i % 4 == 1),
+            search_engine_score=float('nan') if i == 7 else float(rng.uniform(0, 1)),
+            q=float('nan') if i in (7, 8) else float(rng.uniform(0, 0.01))))
+    cases = {
+        'ann_defaults': '/data/lib/massivekb.splib /data/run/queries.mgf out '
+                        '--precursor_tolerance_mass 20 --precursor_tolerance_mode ppm '
+                        '--precursor_tolerance_mass_open 300 --precursor_tolerance_mode_open Da '
+                        '--fragment_mz_tolerance 0.02 --allow_peak_shifts',
+        'bf_custom': '/data/lib/yeast.splib /data/run/q2.mzML /tmp/res.mztab --mode bf '
+                     '--precursor_tolerance_mass 0.5 --precursor_tolerance_mode Da '
+                     '--fragment_mz_tolerance 0.05 --resolution 2 --remove_precursor '
+                     '--remove_precursor_tolerance 1.5 --scaling sqrt --fdr 0.05',
+    }
+    keys = ['resolution', 'min_mz', 'max_mz', 'remove_precursor', 'remove_precursor_tolerance',
+            'min_intensity', 'min_peaks', 'min_mz_range', 'max_peaks_used',
+            'max_peaks_used_library', 'scaling', 'precursor_tolerance_mass',
+            'precursor_tolerance_mode', 'precursor_tolerance_mass_open',
+            'precursor_tolerance_mode_open', 'fragment_mz_tolerance', 'allow_peak_shifts', 'fdr',
+            'fdr_min_group_size', 'mode', 'bin_size', 'hash_len', 'num_candidates', 'num_list',
+            'num_probe', 'spectral_library_filename', 'query_filename', 'out_filename']
+    out = {'ssms': ssm_rows, 'cases': {}}
+    for name, args in cases.items():
+        config.parse(args.split())
+        ssms = []
+        for r in ssm_rows:
+            q = sus.MsmsSpectrum(r['query_identifier'], r['exp_mass_to_charge'], r['charge'],
+                                 [100.0], [1.0], retention_time=r['retention_time'])
+            q.index = r['query_index']
+            lib = sus.MsmsSpectrum(r['library_identifier'], r['calc_mass_to_charge'], r['charge'],
+                                   [100.0], [1.0], peptide=r['sequence'], is_decoy=r['is_decoy'])
+            ssms.append(spectrum.SpectrumSpectrumMatch(q, lib, None, r['search_engine_score'],
+                                                       r['q']))
+        with tempfile.TemporaryDirectory() as td:
+            cwd = os.getcwd()
+            os.chdir(td)
+            try:
+                fn = writer.write_mztab(ssms, config.out_filename, SpectralLibraryReader())
+                text = open(fn).read()
+            finally:
+                os.chdir(cwd)
+        out['cases'][name] = {'args': args, 'filename': fn, 'config': {k: config[k] for k in keys},
+                              'text': text}
+    with open(os.path.join(HERE, 'mztab_golden.json'), 'w') as f:
+        json.dump(out, f, indent=0)
+    print('mztab_golden.json:', len(cases), 'files x', len(ssm_rows), 'SSMs')
+
+
 def gen_rescoring():
     from oracle import oracle_py as O
     from ann_solo_amd import synthetic
@@ -484,4 +568,5 @@ if __name__ == '__main__':
     gen_similarity_kat(sp)
     gen_similarity_expected()
     gen_ssm_features(sp)
+    gen_mztab(sp)
     gen_rescoring()
