@@ -41,7 +41,8 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
   const long long t_start = (dbg & 32) ? wall_clock64() : 0;
-  build_lut_cbt(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, tid);  // codebooks = cbT[m][t][c]
+  build_lut_cbt(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, reinterpret_cast<uint8_t *>(table),
+                tid);  // codebooks = cbT[m][t][c]; the tile table is not live yet
 
   // ---- my probe (thread p < nprobe) and the exclusive scan of tile counts
   int my_len = 0, my_tile0 = 0, my_nt = 0;
@@ -159,7 +160,8 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                      const int32_t *list_offsets, const int32_t *tile_offsets,
                      const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
                      int64_t *I64, int32_t *I32, int dbg) {
-  if ((size_t)d * 4 > (size_t)CAP * 8)
+  if ((size_t)d * 4 > (size_t)CAP * 8 || dsub > 255 ||
+      (size_t)d * 2 + 4 > (size_t)V3_CHUNK * sizeof(TileEnt) || d != PQT_M * dsub)
     return fail(ASL_ERR_CAPACITY, "pq scan: d=%d too large for the LDS staging", d);
   const size_t lds = HistTopK<CAP, 4 * T * 64>::lds_bytes() + (size_t)PQT_KSUB * PQT_M * 4 +
                      (size_t)V3_CHUNK * sizeof(TileEnt);

@@ -50,20 +50,74 @@ __device__ __forceinline__ float tile_adc(const char *lut_bytes, const uint4 A, 
 // from the TRANSPOSED copy cbT[m][t][c] so that a wave's load is one contiguous 256-B
 // line (the [m][c][t] original makes every lane touch its own cache line: measured 4x
 // slower). The 32 stores of a wave all hit bank m (64-way conflict, 64 LDS cycles each) --
-// cheaper than any scheme that scatters the codebook reads. s_q: staging of the query.
+// cheaper than any scheme that scatters the codebook reads.
+//
+// Zero query components are SKIPPED: fmaf(0, cb, acc) == acc bit for bit (finite
+// codebooks), so the chain over the non-zero components in ascending t is the canonical
+// ascending-t chain. A hashed spectrum has <= 50 non-zeros of 800, which cuts the
+// codebook traffic of a table from 819 KB to ~50 KB (the table build was the largest
+// per-query fixed cost of a sharded search). The non-zeros of all sub-vectors are listed
+// once (wave 0) and walked flat, U codebook loads in flight per thread: the build is
+// latency-bound otherwise. s_q: staging of the query; s_nz: 4 + 2*d bytes of scratch.
 __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, int d,
                                               const float *__restrict__ cbT, int dsub,
-                                              float *s_q, float *s_lut, int tid) {
+                                              float *s_q, float *s_lut, uint8_t *s_nz, int tid) {
+  // s_nz: [0..4) K (int), then K sub-quantiser indices at +4 and K offsets t at +4+d
   for (int i = tid; i < d; i += 256) s_q[i] = xq_row[i];
+  for (int i = tid; i < PQT_KSUB * PQT_M; i += 256) s_lut[i] = 0.0f;   // sub-quantisers without non-zeros
   __syncthreads();
-  const int c = tid;
-  for (int m = 0; m < PQT_M; ++m) {
-    const float *cb = cbT + (size_t)m * dsub * PQT_KSUB + c;
-    const float *qs = s_q + m * dsub;
-    float acc = 0.0f;
-    for (int t = 0; t < dsub; ++t) acc = __builtin_fmaf(qs[t], cb[(size_t)t * PQT_KSUB], acc);
-    s_lut[c * PQT_M + m] = acc;
+  uint8_t *nz_m = s_nz + 4, *nz_t = s_nz + 4 + d;
+  if (tid < 64) {   // wave 0: lane m lists the non-zero components of sub-vector m, in order
+    const int m = tid;
+    int cnt = 0;
+    if (m < PQT_M)
+      for (int t = 0; t < dsub; ++t) cnt += s_q[m * dsub + t] != 0.0f;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (tid >= o) incl += v;
+    }
+    int pos = incl - cnt;
+    if (m < PQT_M)
+      for (int t = 0; t < dsub; ++t)
+        if (s_q[m * dsub + t] != 0.0f) {
+          nz_m[pos] = (uint8_t)m;
+          nz_t[pos] = (uint8_t)t;
+          ++pos;
+        }
+    if (tid == 63) *reinterpret_cast<int *>(s_nz) = incl;
   }
+  __syncthreads();
+  const int K = *reinterpret_cast<const int *>(s_nz);   // block-uniform
+  const int c = tid;
+  constexpr int U = 8;   // codebook loads in flight per thread
+  float acc = 0.0f;
+  int cur = -1;
+  for (int k0 = 0; k0 < K; k0 += U) {
+    float cbv[U], qv[U];
+    int mm[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u < K ? k0 + u : K - 1;
+      mm[u] = nz_m[k];
+      const int e = mm[u] * dsub + nz_t[k];
+      qv[u] = s_q[e];
+      cbv[u] = cbT[(size_t)e * PQT_KSUB + c];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k0 + u < K) {               // block-uniform
+        if (mm[u] != cur) {           // block-uniform: a sub-quantiser's run ends
+          if (cur >= 0) s_lut[c * PQT_M + cur] = acc;
+          acc = 0.0f;
+          cur = mm[u];
+        }
+        acc = __builtin_fmaf(qv[u], cbv[u], acc);
+      }
+    }
+  }
+  if (cur >= 0) s_lut[c * PQT_M + cur] = acc;
   __syncthreads();
 }
 
