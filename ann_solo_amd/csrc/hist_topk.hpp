@@ -184,14 +184,16 @@ struct HistTopK {
     ++round_no;
   }
 
-  __device__ __forceinline__ void finish(float *D, int64_t *I64, int32_t *I32) {
+  __device__ __forceinline__ void finish(float *D, int64_t *I64, int32_t *I32,
+                                         long long *ts = nullptr) {
     __syncthreads();
     if (!sort_mode) {
       fill = compact();          // typically leaves k .. k + one bucket's population
       tk.slot_ids = slot_ids;    // every surviving key still carries its storage slot
       tk.conv_from = 0;
     }
-    tk.finish(D, I64, I32, tid);
+    if (ts) ts[0] = wall_clock64();   // measurement: after the compaction
+    tk.finish(D, I64, I32, tid, ts ? ts + 1 : nullptr);
   }
 };
 

@@ -139,8 +139,9 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
     __syncthreads();
   }
   const long long t_loop = (dbg & 32) ? wall_clock64() : 0;
+  long long ts_fin[2] = {0, 0};
   top.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
-             I32 ? I32 + (size_t)q * k : nullptr);
+             I32 ? I32 + (size_t)q * k : nullptr, (dbg & 32) ? ts_fin : nullptr);
   if ((dbg & 32) && D && k >= 8) {   // measurement: phase durations (100 MHz ticks) replace the scores
     __syncthreads();
     if (tid == 0) {
@@ -150,6 +151,8 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
       o[2] = (float)(t_loop - t_init);
       o[3] = (float)(wall_clock64() - t_loop);
       o[4] = (float)total;
+      o[5] = (float)(ts_fin[0] - t_loop);      // compaction
+      o[6] = (float)(ts_fin[1] - ts_fin[0]);   // id resolution + sort
     }
   }
 }

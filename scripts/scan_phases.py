@@ -24,11 +24,11 @@ def phases(tag):
     idx.set_scan_variant(variant | (32 << 8))
     D, _ = idx.search(vec, 1024)
     torch.cuda.synchronize()
-    D = D[:, :5].double().cpu()
+    D = D[:, :7].double().cpu()
     m = D.mean(0)
     us = m[:4] / 100.0
     print(f'{tag}: LUT {us[0]:.1f} us | init {us[1]:.1f} | tile loop {us[2]:.1f} | finish {us[3]:.1f} '
-          f'| tiles/query {m[4]:.0f} | sum {us.sum():.1f} us/workgroup')
+          f'(compaction {m[5] / 100:.1f}, ids+sort {m[6] / 100:.1f}) | tiles/query {m[4]:.0f} | sum {us.sum():.1f} us/workgroup')
     idx.set_scan_variant(variant)
 
 
