@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "rescore.hpp"
 
 namespace asl {
 
@@ -303,6 +304,12 @@ struct CandView {
   const int32_t *rows32;
   const int32_t *offsets;
   int32_t stride;
+  PrecFilter flt;
+  // row of slot c if it is a candidate of the query (in range, passes the filter), else -1
+  __device__ __forceinline__ long long cand(long long c, double q_pmz, int n_lib) const {
+    const long long r = row(c);
+    return (r >= 0 && r < n_lib && filter_pass(flt, q_pmz, r)) ? r : -1;
+  }
   __device__ __forceinline__ void range(int q, long long &c0, long long &c1) const {
     if (offsets) {
       c0 = offsets[q];
@@ -336,9 +343,9 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_kernel(
   const long long step = (long long)RS_WAVES * gridDim.y;
   for (long long c = c0 + (long long)blockIdx.y * RS_WAVES + wave; c < c1; c += step) {
     if (q_defer && pair_score[c] != -2.0) continue;
-    const long long row = cv.row(c);
+    const long long row = cv.cand(c, q_pmz, L.n);
     double s = -1.0;
-    if (row >= 0 && row < L.n)
+    if (row >= 0)
       s = dot_pair_wave<false>(lane, Q, qn, q_pmz, L, (int)row, tol, allow_shift, W[wave],
                                nullptr, 0, nullptr, status);
     if (lane == 0) pair_score[c] = s;
@@ -528,14 +535,14 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
   if (c0 >= c1) return;
   int qn;
   load_query(tid, blockDim.x, Qs, q, Q, qn, status);
+  const double q_pmz = Qs.precursor_mz[q];
   // fp32 evaluation of a probe bin (m/z <= ~2600): error bound in bin units; the query
   // peaks are filed with that margin on both sides (still <= 3 bins per peak)
   const double margin = 1e-3 + (tol > 0.0 ? (0.5 / tol) * (3.75e-4 + 2600.0 * 1.2e-7) : 1.0);
   if (!(tol > 0.0) || qn > RS_HQ_MAX || margin > 0.45) {   // uniform: whole query deferred
     for (long long c = c0 + (long long)blockIdx.y * blockDim.x + tid; c < c1;
          c += (long long)blockDim.x * gridDim.y) {
-      const long long r = cv.row(c);
-      pair_score[c] = (r >= 0 && r < L.n) ? RS_DEFER : -1.0;
+      pair_score[c] = cv.cand(c, q_pmz, L.n) >= 0 ? RS_DEFER : -1.0;
     }
     if (tid == 0) q_defer[q] = 1;
     return;
@@ -564,7 +571,6 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
     }
   }
   __syncthreads();
-  const double q_pmz = Qs.precursor_mz[q];
   PairLds &Wv = W[wave];
   const int parts = RS_WAVES * gridDim.y, part = blockIdx.y * RS_WAVES + wave;
 
@@ -578,8 +584,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
       const int i = i0 + tid;
       bool ok = false;
       if (i < sn) {
-        const long long r = cv.row(sb + i);
-        ok = r >= 0 && r < L.n;
+        ok = cv.cand(sb + i, q_pmz, L.n) >= 0;
         if (!ok && blockIdx.y == 0) pair_score[sb + i] = -1.0;
       }
       const unsigned long long bal = __ballot(ok);
@@ -745,10 +750,11 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
                    int64_t total_slots, double tol, int allow_shift, int tie_by_row,
                    double *pair_score, long long *best_slot, int32_t *best_cand,
                    int32_t *best_row, double *best_score, int32_t *n_valid,
-                   int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride, int *status) {
+                   int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride, int *status,
+                   const PrecFilter &filter) {
   const int nq = Q.n;
   if (nq == 0) return ASL_OK;
-  CandView cv{rows64, rows32, cand_offsets, stride};
+  CandView cv{rows64, rows32, cand_offsets, stride, filter};
   HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), stream()));
   {
     ProfScope ps("rescore");

@@ -1,0 +1,44 @@
+// rescore.hpp -- interface of the rescoring driver (rescore.hip) shared with search.hip.
+#pragma once
+#include "common.hpp"
+
+namespace asl {
+
+// Precursor-window post-filter of the candidate lists, evaluated inside the rescoring
+// kernel's compaction stage (spectral_library.py:417-429 AND :441-446): a candidate row
+// passes if it is valid and within the window of the query's precursor m/z.
+// lib_pmz == nullptr switches the filter off.
+struct PrecFilter {
+  const float *lib_pmz = nullptr;   // spec_info's float32 precursor m/z column
+  const uint8_t *valid = nullptr;   // is_valid flags (nullptr: all valid)
+  double tol = 0.0;
+  int mode = ASL_TOL_DA;
+  int charge = 0;
+};
+
+// spectral_library.py:421-427 (numexpr evaluates in float64)
+__device__ __forceinline__ bool precursor_ok(double q, float lib, int charge, double tol,
+                                             int mode) {
+  const double l = (double)lib;
+  if (mode == ASL_TOL_DA) return fabs(q - l) * (double)charge <= tol;
+  return fabs(q - l) / l * 1000000.0 <= tol;
+}
+
+__device__ __forceinline__ bool filter_pass(const PrecFilter &f, double q_pmz, long long row) {
+  if (!f.lib_pmz) return true;
+  if (f.valid && !f.valid[row]) return false;
+  return precursor_ok(q_pmz, f.lib_pmz[row], f.charge, f.tol, f.mode);
+}
+
+// Host driver shared by asl_rescore_batch, asl_search_batch and asl_rescore_knn. All pointers
+// are device pointers. pair_score scratch must hold one double per candidate slot.
+int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
+                   const int32_t *rows32, const int32_t *cand_offsets, int32_t stride,
+                   int64_t total_slots, double tol, int allow_shift, int tie_by_row,
+                   double *pair_score, long long *best_slot, int32_t *best_cand,
+                   int32_t *best_row, double *best_score, int32_t *n_valid,
+                   int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride, int *status,
+                   const PrecFilter &filter = PrecFilter());
+int rescore_check_status(const int *status_dev);
+
+}  // namespace asl

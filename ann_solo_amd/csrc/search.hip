@@ -6,13 +6,15 @@
 //   -> precursor-window post-filter (:417-429 AND :441-446)  ->  best match (:356-365)
 //
 // The reference builds two dense nq x N boolean masks; here the ANN ids are
-// post-filtered in place ([nq,k] int32, -1 = rejected) and the window-only modes
+// post-filtered inside the rescoring kernel's candidate compaction (rescore.hpp:
+// PrecFilter) and the window-only modes
 // (cascade level 'std', --mode bf) binary-search a precursor-sorted copy of the
 // library, so nothing is O(nq*N).
 #include <algorithm>
 
 #include "common.hpp"
 #include "ivf_kernels.hpp"
+#include "rescore.hpp"
 
 namespace asl {
 int encode_device(const float *mz, const float *inten, const int32_t *offsets, int32_t n,
@@ -21,53 +23,6 @@ int encode_device(const float *mz, const float *inten, const int32_t *offsets, i
 int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
                         int64_t *I64, int32_t *I32, const float *pre_D, const int32_t *pre_I);
 int index_dim(const asl_index *ix);
-int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
-                   const int32_t *rows32, const int32_t *cand_offsets, int32_t stride,
-                   int64_t total_slots, double tol, int allow_shift, int tie_by_row,
-                   double *pair_score, long long *best_slot, int32_t *best_cand,
-                   int32_t *best_row, double *best_score, int32_t *n_valid,
-                   int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride, int *status);
-int rescore_check_status(const int *status_dev);
-
-// spectral_library.py:421-427 (numexpr evaluates in float64)
-__device__ __forceinline__ bool precursor_ok(double q, float lib, int charge, double tol,
-                                             int mode) {
-  const double l = (double)lib;
-  if (mode == ASL_TOL_DA) return fabs(q - l) * (double)charge <= tol;
-  return fabs(q - l) / l * 1000000.0 <= tol;
-}
-
-__global__ void precursor_filter_kernel(const int32_t *__restrict__ knn, int64_t total, int k,
-                                        const double *__restrict__ q_pmz,
-                                        const float *__restrict__ lib_pmz,
-                                        const uint8_t *__restrict__ valid, int charge,
-                                        double tol, int mode, int32_t *__restrict__ cand) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const int32_t row = knn[t];
-  int32_t out = -1;
-  if (row >= 0 && (!valid || valid[row]) &&
-      precursor_ok(q_pmz[t / k], lib_pmz[row], charge, tol, mode))
-    out = row;
-  cand[t] = out;
-}
-
-__global__ void precursor_filter64_kernel(const int64_t *__restrict__ knn, int64_t total, int k,
-                                          const double *__restrict__ q_pmz,
-                                          const float *__restrict__ lib_pmz,
-                                          const uint8_t *__restrict__ valid, int64_t nlib,
-                                          int charge, double tol, int mode,
-                                          int32_t *__restrict__ cand) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const int64_t row = knn[t];
-  int32_t out = -1;
-  if (row >= 0 && row < nlib && (!valid || valid[row]) &&
-      precursor_ok(q_pmz[t / k], lib_pmz[row], charge, tol, mode))
-    out = (int32_t)row;
-  cand[t] = out;
-}
-
 // Window [lo,hi) of each query inside the precursor-sorted library.
 __global__ void window_range_kernel(const double *__restrict__ q_pmz, int nq,
                                     const float *__restrict__ sorted_pmz, int n, int charge,
@@ -295,21 +250,18 @@ int asl_rescore_knn(asl_library_t *L, const asl_peaks_t *queries, const asl_sear
   ASL_TRY(o_pairs.init(pm_pairs, (size_t)nq * (pm_pairs ? pm_stride : 0) * 2));
   ASL_TRY(L->best_slot.reserve((size_t)nq));
   ASL_TRY(L->status.reserve(1));
-  ASL_TRY(L->cand.reserve((size_t)nq * k));
   ASL_TRY(L->pair_score.reserve((size_t)nq * k));
-  {
-    ProfScope ps("filter");
-    const int64_t total = (int64_t)nq * k;
-    hipLaunchKernelGGL(precursor_filter64_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
-                       stream(), knn.d, total, k, Q.dev.precursor_mz, L->pmz32.p,
-                       L->has_valid ? L->valid.p : nullptr, L->n, P->charge, P->precursor_tol,
-                       P->precursor_mode, L->cand.p);
-    ASL_CHECK_LAUNCH();
-  }
-  ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->cand.p, nullptr, k, (int64_t)nq * k,
+  // the precursor filter runs inside the rescoring kernel's compaction stage
+  PrecFilter flt;
+  flt.lib_pmz = L->pmz32.p;
+  flt.valid = L->has_valid ? L->valid.p : nullptr;
+  flt.tol = P->precursor_tol;
+  flt.mode = P->precursor_mode;
+  flt.charge = P->charge;
+  ASL_TRY(rescore_device(Q.dev, L->dev, knn.d, nullptr, nullptr, k, (int64_t)nq * k,
                          P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
                          L->best_slot.p, nullptr, o_row.d, o_score.d, o_ncand.d, o_cnt.d,
-                         o_pairs.d, pm_stride, L->status.p));
+                         o_pairs.d, pm_stride, L->status.p, flt));
   ASL_TRY(o_row.finish());
   ASL_TRY(o_score.finish());
   ASL_TRY(o_ncand.finish());
@@ -348,25 +300,21 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
     ASL_TRY(o_knn.init(knn_I, (size_t)nq * k));
     ASL_TRY(L->qvec.reserve((size_t)nq * d));
     ASL_TRY(L->knn.reserve((size_t)nq * k));
-    ASL_TRY(L->cand.reserve((size_t)nq * k));
     ASL_TRY(L->pair_score.reserve((size_t)nq * k));
     ASL_TRY(encode_device(Q.dev.mz, Q.dev.intensity, Q.dev.offsets, nq, P->min_bound, P->bin_size,
                           d, P->hash_seed, 1, L->qvec.p));
     ASL_TRY(index_search_device(idx, nq, L->qvec.p, k, P->nprobe, nullptr, o_knn.d, L->knn.p,
                                 nullptr, nullptr));
-    {
-      ProfScope ps("filter");
-      const int64_t total = (int64_t)nq * k;
-      hipLaunchKernelGGL(precursor_filter_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
-                         stream(), L->knn.p, total, k, Q.dev.precursor_mz, L->pmz32.p,
-                         L->has_valid ? L->valid.p : nullptr, P->charge, P->precursor_tol,
-                         P->precursor_mode, L->cand.p);
-      ASL_CHECK_LAUNCH();
-    }
-    ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->cand.p, nullptr, k, (int64_t)nq * k,
+    PrecFilter flt;
+    flt.lib_pmz = L->pmz32.p;
+    flt.valid = L->has_valid ? L->valid.p : nullptr;
+    flt.tol = P->precursor_tol;
+    flt.mode = P->precursor_mode;
+    flt.charge = P->charge;
+    ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->knn.p, nullptr, k, (int64_t)nq * k,
                            P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
                            L->best_slot.p, nullptr, o_row.d, o_score.d, o_ncand.d, o_cnt.d,
-                           o_pairs.d, pm_stride, L->status.p));
+                           o_pairs.d, pm_stride, L->status.p, flt));
   } else {
     int64_t total = 0;
     {
