@@ -184,6 +184,80 @@ struct HistTopK {
     ++round_no;
   }
 
+  // Exact top-k as an UNORDERED SET: no sort. After the compaction every key above the
+  // threshold bucket is in (fewer than k of them, by the definition of bstar); the keys of
+  // the threshold bucket are ranked among themselves by pairwise counting (ids resolved
+  // first, so ties break by id exactly as in the sorted order) and the best k - n_above of
+  // them fill the rest of the row. Rows hold min(k, candidates) hits in an unspecified
+  // order, then -FLT_MAX / -1 padding. `scratch`: CAP keys of LDS that are dead by now.
+  __device__ __forceinline__ void finish_set(float *D, int64_t *I64, int32_t *I32, u64 *scratch) {
+    __syncthreads();
+    if (sort_mode) {               // exact flushes were in use: the sorted row is a valid set
+      tk.finish(D, I64, I32, tid);
+      return;
+    }
+    fill = compact();
+    const int bs = ctl[C_BSTAR];
+    u64 kk[PER];
+    int32_t idv[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid + u * HT_NT;
+      kk[u] = i < fill ? keys[i] : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u)   // all gathers of a thread in flight together
+      idv[u] = (kk[u] != 0ull && slot_ids) ? slot_ids[(uint32_t)kk[u]] : 0;
+    int na = 0, nb = 0;
+    bool above[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      if (kk[u] != 0ull) {
+        if (slot_ids)
+          kk[u] = (kk[u] & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - (uint32_t)idv[u]);
+        above[u] = score_bucket(ord2f((uint32_t)(kk[u] >> 32))) > bs;
+        na += above[u];
+        nb += !above[u];
+      } else {
+        above[u] = false;
+      }
+    }
+    int tot;
+    const int pre = block_excl_scan256(na | (nb << 16), ctl + C_PART_C, tid, tot);
+    const int n_above = tot & 0xffff, n_bound = tot >> 16;
+    int pa = pre & 0xffff, pb = pre >> 16;
+    auto emit = [&](int pos, u64 key) {
+      if (D) D[pos] = key_score(key);
+      if (I64) I64[pos] = (int64_t)key_id(key);
+      if (I32) I32[pos] = (int32_t)key_id(key);
+    };
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      if (kk[u] == 0ull) continue;
+      if (above[u])
+        emit(pa++, kk[u]);
+      else
+        scratch[pb++] = kk[u];
+    }
+    __syncthreads();
+    const int r = k - n_above;          // > 0
+    const int take = n_bound < r ? n_bound : r;
+    for (int i = tid; i < n_bound; i += HT_NT) {
+      const u64 key = scratch[i];
+      int rank = i;
+      if (n_bound > r) {                 // block-uniform
+        rank = 0;
+        for (int j = 0; j < n_bound; ++j) rank += scratch[j] > key;
+      }
+      if (rank < take) emit(n_above + rank, key);
+    }
+    for (int i = n_above + take + tid; i < k; i += HT_NT) {
+      if (D) D[i] = -3.402823466e+38f;
+      if (I64) I64[i] = -1;
+      if (I32) I32[i] = -1;
+    }
+  }
+
   __device__ __forceinline__ void finish(float *D, int64_t *I64, int32_t *I32,
                                          long long *ts = nullptr) {
     __syncthreads();

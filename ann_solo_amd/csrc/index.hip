@@ -87,6 +87,7 @@ struct asl_index {
   int nnz_stride = 0;
   bool has_sparse = false;
   int scan_variant = 0;  // 0 = auto (v2 when supported), 1 = force v1
+  bool unordered = false;  // search rows = exact top-k as a set, unspecified order (no final sort)
   bool lists_dirty = true;
   // scratch
   DevBuf<float> ws_scores, coarse_D, ws_x;
@@ -346,7 +347,7 @@ static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe) {
 // Search with all-device arguments. Exactly one of I64 / I32 may be non-null (or both).
 int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
                         int64_t *I64, int32_t *I32, const float *pre_D = nullptr,
-                        const int32_t *pre_I = nullptr) {
+                        const int32_t *pre_I = nullptr, bool set_mode = false) {
   if (nq <= 0) return ASL_OK;
   if (!ix->trained) return fail(ASL_ERR_STATE, "search: index is not trained");
   if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: k=%d outside 1..%d", k, TK_MAX_K);
@@ -438,7 +439,8 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       }
       ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks_t.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
-                         ix->ids_tiled.p, k, D, I64, I32, sv, ix->scan_variant >> 8));
+                         ix->ids_tiled.p, k, D, I64, I32, sv, (set_mode || ix->unordered) ? 1 : 0,
+                         ix->scan_variant >> 8));
     } else if (ix->has_tiles && sv == 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
       ASL_TRY(pq_scan_v2(xq, nq, d, ix->codebooks.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
@@ -500,6 +502,13 @@ asl_index_t *asl_index_create(int32_t d, int32_t nlist, int32_t kind, int32_t pq
 }
 
 void asl_index_free(asl_index_t *ix) { delete ix; }
+
+int asl_index_set_unordered(asl_index_t *ix, int32_t unordered) {
+  clear_error();
+  if (!ix) return fail(ASL_ERR_INVALID, "set_unordered: null index");
+  ix->unordered = unordered != 0;
+  return ASL_OK;
+}
 
 int asl_index_set_scan_variant(asl_index_t *ix, int32_t variant) {
   if (!ix || variant < 0) return fail(ASL_ERR_INVALID, "set_scan_variant");

@@ -45,7 +45,7 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                const float *coarse_D, const int32_t *coarse_I, int nprobe,
                const int32_t *list_offsets, const int32_t *tile_offsets,
                const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
-               int64_t *I64, int32_t *I32, int variant, int dbg);
+               int64_t *I64, int32_t *I32, int variant, int set_mode, int dbg);
 int tile_codes(const uint8_t *codes, const int32_t *ids, const int32_t *dst_slot, int64_t n,
                int64_t ntiles, uint8_t *codes_tiled, int32_t *ids_tiled);
 bool flat_sparse_supported(int d, int k, int nprobe, int nnz_stride);

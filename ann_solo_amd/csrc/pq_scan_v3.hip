@@ -31,7 +31,8 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
     const float *__restrict__ coarse_D, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ tile_offsets,
     const uint8_t *__restrict__ codes_tiled, const int32_t *__restrict__ ids_tiled, int k,
-    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int dbg) {
+    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode,
+    int dbg) {
   constexpr int ROUND_TILES = 4 * T, ROUND_VECS = ROUND_TILES * 64;
   using TopK = HistTopK<CAP, ROUND_VECS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -140,8 +141,12 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
   }
   const long long t_loop = (dbg & 32) ? wall_clock64() : 0;
   long long ts_fin[2] = {0, 0};
-  top.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
-             I32 ? I32 + (size_t)q * k : nullptr, (dbg & 32) ? ts_fin : nullptr);
+  if (set_mode && CAP * 8 <= PQT_KSUB * PQT_M * 4)   // unordered exact top-k; the LUT is dead: scratch
+    top.finish_set(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
+                   I32 ? I32 + (size_t)q * k : nullptr, reinterpret_cast<u64 *>(s_lut));
+  else
+    top.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
+               I32 ? I32 + (size_t)q * k : nullptr, (dbg & 32) ? ts_fin : nullptr);
   if ((dbg & 32) && D && k >= 8) {   // measurement: phase durations (100 MHz ticks) replace the scores
     __syncthreads();
     if (tid == 0) {
@@ -162,7 +167,7 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                      const float *coarse_D, const int32_t *coarse_I, int nprobe,
                      const int32_t *list_offsets, const int32_t *tile_offsets,
                      const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
-                     int64_t *I64, int32_t *I32, int dbg) {
+                     int64_t *I64, int32_t *I32, int set_mode, int dbg) {
   if ((size_t)d * 4 > (size_t)CAP * 8 || dsub > 255 ||
       (size_t)d * 2 + 4 > (size_t)V3_CHUNK * sizeof(TileEnt) || d != PQT_M * dsub)
     return fail(ASL_ERR_CAPACITY, "pq scan: d=%d too large for the LDS staging", d);
@@ -174,7 +179,7 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((pq_scan_v3_kernel<CAP, T>), dim3(nq), dim3(V3_NT), lds, stream(), xq, d,
                      codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets,
-                     codes_tiled, ids_tiled, k, D, I64, I32, dbg);
+                     codes_tiled, ids_tiled, k, D, I64, I32, set_mode, dbg);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -185,10 +190,10 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                const float *coarse_D, const int32_t *coarse_I, int nprobe,
                const int32_t *list_offsets, const int32_t *tile_offsets,
                const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
-               int64_t *I64, int32_t *I32, int variant, int dbg) {
+               int64_t *I64, int32_t *I32, int variant, int set_mode, int dbg) {
   if (nq <= 0) return ASL_OK;
 #define V3_ARGS xq, nq, d, codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets, \
-                codes_tiled, ids_tiled, k, D, I64, I32, dbg
+                codes_tiled, ids_tiled, k, D, I64, I32, set_mode, dbg
   if (variant == 5 && k + 256 + 768 <= 2048) return launch_v3<2048, 3>(V3_ARGS);
   if (variant != 4 && k + 256 + 512 <= 2048) return launch_v3<2048, 2>(V3_ARGS);
   if (k + 256 + 1024 <= 4096) return launch_v3<4096, 4>(V3_ARGS);

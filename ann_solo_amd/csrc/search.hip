@@ -21,7 +21,8 @@ int encode_device(const float *mz, const float *inten, const int32_t *offsets, i
                   double min_bound, double bin_size, int32_t hash_len, uint32_t seed,
                   int norm, float *out);
 int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
-                        int64_t *I64, int32_t *I32, const float *pre_D, const int32_t *pre_I);
+                        int64_t *I64, int32_t *I32, const float *pre_D, const int32_t *pre_I,
+                        bool set_mode);
 int index_dim(const asl_index *ix);
 // Window [lo,hi) of each query inside the precursor-sorted library.
 __global__ void window_range_kernel(const double *__restrict__ q_pmz, int nq,
@@ -303,8 +304,10 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
     ASL_TRY(L->pair_score.reserve((size_t)nq * k));
     ASL_TRY(encode_device(Q.dev.mz, Q.dev.intensity, Q.dev.offsets, nq, P->min_bound, P->bin_size,
                           d, P->hash_seed, 1, L->qvec.p));
+    // the candidates are consumed as a set (filter + best match): no final sort unless the
+    // caller asked for the ordered neighbour list
     ASL_TRY(index_search_device(idx, nq, L->qvec.p, k, P->nprobe, nullptr, o_knn.d, L->knn.p,
-                                nullptr, nullptr));
+                                nullptr, nullptr, knn_I == nullptr));
     PrecFilter flt;
     flt.lib_pmz = L->pmz32.p;
     flt.valid = L->has_valid ? L->valid.p : nullptr;

@@ -74,6 +74,8 @@ class HipShardBackend:
         return self.index.coarse(vectors, self.sl._num_probe)
 
     def shard_search_preassigned(self, vectors, coarse_D, coarse_I):
+        # per-shard rows go straight into the merge, which orders them: skip the shard's sort
+        self.index.set_unordered(True)
         return self.index.search_preassigned(vectors, self.k, coarse_D, coarse_I)
 
     def merge(self, Ds: torch.Tensor, Is: torch.Tensor):

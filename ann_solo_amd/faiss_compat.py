@@ -181,6 +181,10 @@ class Index:
         _lib.check(_lib.lib().asl_index_pq_lut(self._h, x.shape[0], _lib.ptr(x), _lib.ptr(lut)))
         return lut
 
+    def set_unordered(self, flag: bool = True):
+        """Result rows as exact top-k SETS (unspecified order, no final sort)."""
+        _lib.check(_lib.lib().asl_index_set_unordered(self._h, int(bool(flag))))
+
     def shard(self, rank: int, world: int):
         _lib.check(_lib.lib().asl_index_shard(self._h, int(rank), int(world)))
 

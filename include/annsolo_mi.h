@@ -117,6 +117,10 @@ int asl_index_get_lists(const asl_index_t *idx, int32_t *list_offsets /* [nlist+
  * of the expected scan load, weight = list size squared; identical on every rank, see
  * asl_lpt_owner). Must be called after add(). search() then
  * returns this shard's partial top-k; combine with asl_topk_merge. */
+/* Unordered result rows: subsequent IVF-PQ searches return the exact top-k of every query
+ * as a SET -- same ids and scores, unspecified order inside the row, padding last -- and skip
+ * the final sort. For consumers that re-order anyway (asl_topk_merge of shard results). */
+int asl_index_set_unordered(asl_index_t *idx, int32_t unordered);
 int asl_index_shard(asl_index_t *idx, int32_t rank, int32_t world);
 /* list -> owner rank map of the balancing above, for inspection. */
 int asl_index_shard_map(const asl_index_t *idx, int32_t world, int32_t *owner /* [nlist] */);

@@ -126,6 +126,30 @@ def pq_index(O, vecs, trained):
     return idx, ivf
 
 
+@pytest.mark.parametrize('k,nprobe', [(1024, 8), (200, 16), (1000, 2), (64, 1), (1280, 16), (2048, 16)])
+def test_unordered_rows_hold_the_same_top_k(vecs, pq_index, k, nprobe):
+    """asl_index_set_unordered: same ids with the same scores as the sorted search, any order,
+    padding last (k = 2048 exceeds the set-mode buffer and silently stays sorted)."""
+    _, xq = vecs
+    idx, _ = pq_index
+    idx.nprobe = nprobe
+    D, I = idx.search(xq, k)
+    idx.set_unordered(True)
+    try:
+        Du, Iu = idx.search(xq, k)
+    finally:
+        idx.set_unordered(False)
+    assert not np.array_equal(I, Iu) or k == 2048 or (I < 0).all()
+    for r in range(len(xq)):
+        n = int((I[r] >= 0).sum())
+        assert (Iu[r, :n] >= 0).all() and (Iu[r, n:] == -1).all()
+        o, ou = np.argsort(I[r, :n]), np.argsort(Iu[r, :n])
+        assert np.array_equal(I[r, :n][o], Iu[r, :n][ou])
+        assert np.array_equal(D[r, :n][o].view(np.uint32), Du[r, :n][ou].view(np.uint32))
+    D2, I2 = idx.search(xq, k)                      # and the flag is really off again
+    assert np.array_equal(I2, I)
+
+
 def test_coarse_and_lut_bit_exact(O, vecs, pq_index):
     _, xq = vecs
     idx, ivf = pq_index
