@@ -10,6 +10,8 @@
 //                     (32 B/vector, coalesced 16-B loads), fused exact top-k
 //   topk_merge_kernel merge of per-shard / per-chunk partial top-k lists
 //   + small helpers (bitmap, argmax, residual/encode, gathers, L2 assignment)
+#include <algorithm>
+
 #include "common.hpp"
 #include "ivf_kernels.hpp"
 #include "hist_topk.hpp"
@@ -52,12 +54,126 @@ __global__ __launch_bounds__(TK_NT) void row_topk_kernel(
             I32 ? I32 + (size_t)r * out_ld : nullptr, tid);
 }
 
+// Short rows (n <= 4096, k <= 256; the coarse quantiser's top-nprobe of nlist): the whole row
+// sits in registers, one histogram pass over [row min, row max] finds the bucket of the k-th
+// score, the <= RS_SEL keys at or above it are compacted and sorted once. Rows whose
+// threshold bucket is overfull (mass ties: an all-zero query scores every centroid 0)
+// take the streaming path below inside the same launch.
+constexpr int SEL_VPT = 16, SEL_CAP = 512, SEL_NB = 512;
+
+__global__ __launch_bounds__(TK_NT) void row_select_kernel(
+    const float *__restrict__ scores, int64_t ld, int n, int k, int cap, float *__restrict__ D,
+    int64_t *__restrict__ I64, int32_t *__restrict__ I32, int64_t out_ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64 *buf = reinterpret_cast<u64 *>(smem);              // max(SEL_CAP, cap) keys
+  const int nkeys = cap > SEL_CAP ? cap : SEL_CAP;
+  u64 *thr = buf + nkeys;
+  int *ctl = reinterpret_cast<int *>(thr + 1);            // 4 ints (StreamTopK) + 8 for scans
+  int *hist = ctl + 12;                                   // SEL_NB
+  float *red = reinterpret_cast<float *>(hist + SEL_NB);  // 8 floats
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = blockIdx.x;
+  const float *row = scores + (size_t)r * ld;
+  float v[SEL_VPT];
+  float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+#pragma unroll
+  for (int u = 0; u < SEL_VPT; ++u) {
+    const int c = tid + u * TK_NT;
+    v[u] = c < n ? row[c] : 0.0f;
+    if (c < n) {
+      lo = fminf(lo, v[u]);
+      hi = fmaxf(hi, v[u]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+  }
+  if (lane == 0) {
+    red[wave] = lo;
+    red[4 + wave] = hi;
+  }
+  for (int i = tid; i < SEL_NB; i += TK_NT) hist[i] = 0;
+  __syncthreads();
+  lo = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+  hi = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+  const float scale = hi > lo ? (float)(SEL_NB - 1) / (hi - lo) : 0.0f;   // monotone in the score
+  int bk[SEL_VPT];
+#pragma unroll
+  for (int u = 0; u < SEL_VPT; ++u) {
+    const int c = tid + u * TK_NT;
+    float t = (v[u] - lo) * scale;
+    t = fminf(fmaxf(t, 0.0f), (float)(SEL_NB - 1));
+    bk[u] = (int)t;
+    if (c < n) atomicAdd(&hist[bk[u]], 1);
+  }
+  __syncthreads();
+  // bstar = highest bucket with >= k values at or above it (thread t owns the two buckets
+  // SEL_NB-1-2t, SEL_NB-2-2t)
+  {
+    const int h0 = hist[SEL_NB - 1 - 2 * tid], h1 = hist[SEL_NB - 2 - 2 * tid];
+    int tot;
+    const int above = block_excl_scan256(h0 + h1, ctl + 4, tid, tot);
+    if (tid == 0) ctl[3] = 0;                 // fewer than k values in the row: keep everything
+    __syncthreads();
+    if (above < k && above + h0 + h1 >= k) ctl[3] = (above + h0 >= k) ? SEL_NB - 1 - 2 * tid : SEL_NB - 2 - 2 * tid;
+    __syncthreads();
+  }
+  const int bstar = ctl[3];
+  int cnt = 0;
+#pragma unroll
+  for (int u = 0; u < SEL_VPT; ++u) cnt += (tid + u * TK_NT < n) && bk[u] >= bstar;
+  int total;
+  int pos = block_excl_scan256(cnt, ctl + 8, tid, total);
+  if (total <= SEL_CAP) {    // block-uniform
+    for (int i = total + tid; i < SEL_CAP; i += TK_NT) buf[i] = 0ull;
+#pragma unroll
+    for (int u = 0; u < SEL_VPT; ++u) {
+      const int c = tid + u * TK_NT;
+      if (c < n && bk[u] >= bstar) buf[pos++] = make_key(v[u], (uint32_t)c);
+    }
+    __syncthreads();
+    block_sort_desc<TK_NT, SEL_CAP / TK_NT>(buf, tid, SEL_CAP);
+    const int f = total < k ? total : k;
+    for (int i = tid; i < k; i += TK_NT) {
+      const u64 key = buf[i];
+      const bool ok = i < f;
+      if (D) D[(size_t)r * out_ld + i] = ok ? key_score(key) : -3.402823466e+38f;
+      if (I64) I64[(size_t)r * out_ld + i] = ok ? (int64_t)key_id(key) : -1;
+      if (I32) I32[(size_t)r * out_ld + i] = ok ? (int32_t)key_id(key) : -1;
+    }
+    return;
+  }
+  __syncthreads();
+  StreamTopK<TK_NT> tk;      // mass ties at the threshold: exact streaming selection
+  tk.init(buf, ctl, thr, cap, k, tid);
+  for (int base = 0; base < n; base += TK_NT) {   // re-read the row: keeps v[] out of scratch
+    const int c = base + tid;
+    u64 key = 0ull;
+    if (c < n) {
+      const float x = row[c];
+      const float t = fminf(fmaxf((x - lo) * scale, 0.0f), (float)(SEL_NB - 1));
+      if ((int)t >= bstar) key = make_key(x, (uint32_t)c);
+    }
+    tk.push(key, tid);
+  }
+  tk.finish(D ? D + (size_t)r * out_ld : nullptr, I64 ? I64 + (size_t)r * out_ld : nullptr,
+            I32 ? I32 + (size_t)r * out_ld : nullptr, tid);
+}
+
 int row_topk(const float *scores, int64_t ld, int rows, int n, int k, const int32_t *ids,
              int32_t id_base, const int32_t *vlist, const uint32_t *bitmap, int bitmap_words,
              float *D, int64_t *I64, int32_t *I32, int64_t out_ld) {
   if (rows <= 0) return ASL_OK;
   if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "top-k: k=%d outside 1..%d", k, TK_MAX_K);
   const int cap = topk_cap_for(k);
+  if (n <= SEL_VPT * TK_NT && k <= 256 && !ids && id_base == 0 && !bitmap) {
+    const size_t lds_sel = (size_t)std::max(cap, SEL_CAP) * 8 + 8 + 12 * 4 + SEL_NB * 4 + 8 * 4;
+    hipLaunchKernelGGL(row_select_kernel, dim3(rows), dim3(TK_NT), lds_sel, stream(), scores, ld,
+                       n, k, cap, D, I64, I32, out_ld);
+    ASL_CHECK_LAUNCH();
+    return ASL_OK;
+  }
   const size_t lds = (size_t)cap * 8 + 16;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)row_topk_kernel,

@@ -46,6 +46,30 @@ def test_flat_search_exact(O, vecs):
         assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))   # fmaf chain == MFMA chain
 
 
+@pytest.mark.parametrize('n', [4096, 4095, 1000, 257])
+def test_short_row_select_matches_oracle(O, n):
+    """The register-resident top-k of short rows (coarse top-nprobe of nlist): random rows,
+    duplicated vectors (equal scores -> lowest id first), an all-zero query (every score
+    ties: the streaming fallback), heavy quantisation (overfull threshold bucket)."""
+    from ann_solo_amd import faiss_compat as faiss
+    rng = np.random.default_rng(n)
+    d = 64
+    xb = rng.standard_normal((n, d)).astype(np.float32)
+    xb[n // 2:n // 2 + 40] = xb[3]                       # 41 identical vectors
+    xb[-200:] = np.round(xb[-200:])                      # coarse grid: many equal scores
+    xq = rng.standard_normal((24, d)).astype(np.float32)
+    xq[1] = 0.0                                          # all scores +0
+    xq[2] = np.round(xq[2])
+    xq[3, 1:] = 0.0                                      # scores take few distinct values on the grid rows
+    idx = faiss.IndexFlatIP(d)
+    idx.add(xb)
+    for k in (1, 7, 128, 256):
+        D, I = idx.search(xq, k)
+        Do, Io = O.flat_search(xb, xq, k)
+        assert np.array_equal(I, Io), (n, k)
+        assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+
+
 def test_gemm_odd_shapes(O):
     """K not a multiple of 4/16, M/N not multiples of the 128 tile; k > n padding."""
     from ann_solo_amd import faiss_compat as faiss
