@@ -423,6 +423,58 @@ __device__ __forceinline__ double rl_d(double v, int l) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// Conflict-free resolve of BOTH half-wave match lists in one pass (each <= 32 matches):
+// lanes 0-31 hold A's matches, lanes 32-63 B's; same test and same exact-sum argument as the
+// fast path of resolve_matches, evaluated per half (row reductions on DPP, the two rows of a
+// half joined on the scalar unit). ok bit 0 / 1: A / B resolved here (else the caller runs
+// the general path for that half).
+__device__ __forceinline__ int resolve_two_fast(int lane, PairLds &W, int MA, int MB,
+                                                double &sA, double &sB) {
+  const int half = lane >> 5, hl = lane & 31;
+  const int M = half ? MB : MA;
+  const bool inl = hl < M;
+  unsigned long long key = 0ull;
+  uint32_t pay = 0;
+  if (inl) {
+    key = W.keys[half * RS_HC + hl];
+    pay = W.pay[half * RS_HC + hl];
+  }
+  // query peaks < 128 (RS_HQ_MAX) and candidate peaks < 64 on this path: one table per half
+  const uint32_t qi = half * 128 + ((pay >> 16) & 127), ci = half * 128 + (pay & 127);
+  if (inl) {
+    W.own_q[qi] = (uint8_t)lane;
+    W.own_c[ci] = (uint8_t)lane;
+  }
+  wave_sync();
+  const bool mine = !inl || (W.own_q[qi] == (uint8_t)lane && W.own_c[ci] == (uint8_t)lane);
+  uint32_t e = inl ? max((uint32_t)(key >> 55) & 0xffu, 1u) : 0u;
+  uint32_t v = e;
+  v = max(v, rs_dpp<0xB1>(v));
+  v = max(v, rs_dpp<0x4E>(v));
+  v = max(v, rs_dpp<0x141>(v));
+  v = max(v, rs_dpp<0x140>(v));
+  const uint32_t eA = max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16));
+  const uint32_t eB = max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48));
+  const bool exact = !inl || e + 23u >= (half ? eB : eA);
+  const unsigned long long bad = __ballot(!(mine && exact));
+  double x = inl ? (double)__uint_as_float((uint32_t)(key >> 32)) : 0.0;
+  x += rs_dpp_d<0xB1>(x);
+  x += rs_dpp_d<0x4E>(x);
+  x += rs_dpp_d<0x141>(x);
+  x += rs_dpp_d<0x140>(x);
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
+  double r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t l = __builtin_amdgcn_readlane(lo, 16 * i), h = __builtin_amdgcn_readlane(hi, 16 * i);
+    r[i] = __longlong_as_double((long long)(((unsigned long long)h << 32) | l));
+  }
+  sA = r[0] + r[1];
+  sB = r[2] + r[3];
+  return ((bad & 0xffffffffull) ? 0 : 1) | ((bad >> 32) ? 0 : 2);
+}
+
 // Two candidates per wave: lanes 0-31 score candidate A, lanes 32-63 candidate B (peaks in
 // passes of 32; cn = 0 leaves a half idle). The probing instruction stream -- the bulk of
 // this instruction-bound kernel -- is shared by both. Per-half match lists live in the two
@@ -512,12 +564,16 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds &Q, const Has
   wave_sync();
   const int MA = (dbg & 16) ? 0 : __builtin_amdgcn_readfirstlane(Wv.pad[0]);
   const int MB = (dbg & 16) ? 0 : __builtin_amdgcn_readfirstlane(Wv.pad[1]);
-  scoreA = MA > RS_HC ? RS_DEFER
-           : MA     ? resolve_matches<false>(lane, Wv, nullptr, 0, nullptr, status, 0, MA, RS_HC)
-                    : 0.0;
-  scoreB = MB > RS_HC ? RS_DEFER
-           : MB     ? resolve_matches<false>(lane, Wv, nullptr, 0, nullptr, status, RS_HC, MB, RS_HC)
-                    : 0.0;
+  int ok = 0;
+  if (MA <= 32 && MB <= 32 && !(dbg & 128)) ok = resolve_two_fast(lane, Wv, MA, MB, scoreA, scoreB);
+  if (!(ok & 1))
+    scoreA = MA > RS_HC ? RS_DEFER
+             : MA     ? resolve_matches<false>(lane, Wv, nullptr, 0, nullptr, status, 0, MA, RS_HC)
+                      : 0.0;
+  if (!(ok & 2))
+    scoreB = MB > RS_HC ? RS_DEFER
+             : MB     ? resolve_matches<false>(lane, Wv, nullptr, 0, nullptr, status, RS_HC, MB, RS_HC)
+                      : 0.0;
 }
 
 __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
