@@ -396,6 +396,7 @@ struct PairLds {   // per wave
   uint8_t c_chg[RS_PF * 64];
   uint8_t own_q[RS_MAXP];
   uint8_t own_c[RS_MAXP];
+  double mdt[64];   // mass_diff[s] of half A (0..31) and half B (32..63)
   int counter;
   int pad[3];
 };
@@ -499,8 +500,8 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds &Q, const Has
   const float *s_in = Wv.c_int + slot * 64;
   const uint8_t *s_ch = Wv.c_chg + slot * 64;
   // mass_diff[s] = pmd / s (cpp:26-31): lane (32*half + s) performs its half's (expensive,
-  // exact) fp64 division once, every lane then reads the quotient it needs with v_readlane
-  const double md_lane = (hl > 0 && hl < S) ? pmd / (double)hl : 0.0;
+  // exact) fp64 division once and parks the quotient in LDS for the other lanes
+  Wv.mdt[lane] = (hl > 0 && hl < S) ? pmd / (double)hl : 0.0;
   const float inv_w_f = (float)inv_w;
   const int Smax = SA > SB ? SA : SB;
   const int cmax = cnA > cnB ? cnA : cnB;
@@ -512,12 +513,14 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds &Q, const Has
     const bool act = j < cn;
     const float cm = act ? s_mz[j] : 0.0f, ci = act ? s_in[j] : 0.0f;
     const int cc = act ? s_ch[j] : 0;
+    // shifts this peak takes part in (cpp:58-75): every s < S for an unannotated peak, else
+    // s = 0 and s = its fragment charge
+    const uint32_t smask = !act ? 0u : cc == 0 ? (1u << S) - 1u : (1u | (cc < S ? 1u << cc : 0u));
     for (int s = 0; s < Smax; ++s) {        // wave-uniform
-      const double mdA = rl_d(md_lane, s), mdB = rl_d(md_lane, 32 + s);
-      const double md = half ? mdB : mdA;
+      const double md = Wv.mdt[half * 32 + s];
       // bin of the shifted peak in fp32 (the query was filed with a margin that covers the
       // fp32 rounding); bitmap reject first, the exact fp64 window test on the rare hits
-      const bool can = act && s < S && (s == 0 || cc == s || cc == 0);   // cpp:58-75
+      const bool can = (smask >> s) & 1u;
       const int b = (int)floorf((cm + (float)md) * inv_w_f);
       const bool maybe = can && bm_test(H, b) && !(dbg & 64);
       if (!__ballot(maybe)) continue;         // wave-uniform

@@ -33,7 +33,10 @@ def _check(O, q, lib, cand, off, tol, shift):
     L, Q = O.Spectra(*lib.numpy()), O.Spectra(*q.numpy())
     n_match = 0
     for qi in range(q.n):
-        b, s, m = O.best_match(Q, qi, L, cand[off[qi]:off[qi + 1]], tol, shift)
+        c = cand[off[qi]:off[qi + 1]]
+        pos = np.nonzero((c >= 0) & (c < lib.n))[0]       # the oracle takes valid rows only
+        b, s, m = O.best_match(Q, qi, L, c[pos], tol, shift)
+        b = int(pos[b]) if b >= 0 else -1
         assert best[qi] == b, (qi, best[qi], b)
         if b >= 0:
             assert score[qi] == s and count[qi] == len(m)
