@@ -291,3 +291,72 @@ class SpectralLibrary:
                     if res.best_row[i] >= 0:
                         yield (charge, b0 + i, part.ids[res.best_row[i]], res.peak_matches(i),
                                float(res.best_score[i]))
+
+    # ------------------------------------------------------------------ cascade driver
+    def search(self, query_spectra: Dict[int, PackedSpectra], query_meta: Dict[int, list],
+               library_meta: Dict[int, list], score_ssms=None) -> list:
+        """``SpectralLibrary.search`` (spectral_library.py:193-262) over packed, already
+        processed query spectra split by precursor charge (the file parsing and
+        ``process_spectrum`` filtering of :207-228 happen before; queries of unknown charge
+        are entered once per candidate charge with the same identifier).
+
+        ``query_meta[charge][i]`` / ``library_meta[charge][row]``: mappings with the reference's
+        attribute names (see ``writer.ssms_from_batch``). ``score_ssms(ssms, mode)`` stands
+        for ``utils.score_ssms`` (:319-326, mokapot -- out of scope): it assigns
+        ``search_engine_score`` / ``q`` and returns the SSMs to keep; default: cosine as the
+        score, q = 0 (everything accepted). Returns the list of identifications (one per
+        query identifier), ready for ``writer.write_mztab``."""
+        cfg = self.config
+        identifications = {}
+        do_cascade_open = (cfg.precursor_tolerance_mass_open is not None and
+                           cfg.precursor_tolerance_mode_open is not None)
+        remaining = {z: list(range(q.n)) for z, q in query_spectra.items()}
+        # cascade level 1: standard search (:238-245)
+        for ssm in self._search_cascade(query_spectra, query_meta, library_meta, remaining, 'std',
+                                        score_ssms):
+            if not do_cascade_open or ssm.q < cfg.fdr:
+                identifications[ssm.query_identifier] = ssm
+        if do_cascade_open:
+            # cascade level 2: open search on the queries not identified so far (:249-259)
+            remaining = {z: [i for i in rows if query_meta[z][i]['identifier'] not in identifications]
+                         for z, rows in remaining.items()}
+            for ssm in self._search_cascade(query_spectra, query_meta, library_meta, remaining,
+                                            'open', score_ssms):
+                identifications[ssm.query_identifier] = ssm
+        return list(identifications.values())
+
+    def _search_cascade(self, query_spectra, query_meta, library_meta, rows_by_charge, mode,
+                        score_ssms=None) -> list:
+        """One cascade level (:264-326): batches of ``batch_size`` same-charge queries through
+        ``_search_batch``; per query identifier the FIRST match is kept (the reference compares
+        ``search_engine_score`` values that are still NaN at this point, :312-316, so a later
+        duplicate never replaces an earlier one)."""
+        from .spectrum_similarity import ssm_features
+        from .writer import ssms_from_batch
+        ssms = {}
+        bs = self.config.batch_size
+        for charge, rows in rows_by_charge.items():
+            for b0 in range(0, len(rows), bs):
+                sel = rows[b0:b0 + bs]
+                if not sel:
+                    continue
+                q = query_spectra[charge].select(torch.as_tensor(sel, dtype=torch.int64))
+                res = self._search_batch(q, charge, mode)
+                if res is None:
+                    continue
+                part = self.partitions[charge]
+                cos = ssm_features(q.to(self.device), part.spectra, res.best_row, res.pm_pairs,
+                                   res.pm_count, self.config.min_mz, self.config.max_mz,
+                                   self.config.bin_size)[:, 0]
+                cos = cos.detach().cpu().numpy() if hasattr(cos, 'detach') else cos
+                qm = [query_meta[charge][i] for i in sel]
+                for ssm in ssms_from_batch(res, qm, library_meta[charge], scores=cos):
+                    if ssm.query_identifier not in ssms:
+                        ssms[ssm.query_identifier] = ssm
+        out = list(ssms.values())
+        if score_ssms is not None:
+            return list(score_ssms(out, mode))
+        for ssm in out:        # no scorer: cosine (spectrum_similarity.py:81-106), accepted
+            ssm.q = 0.0
+        return out
+

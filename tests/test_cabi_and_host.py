@@ -135,3 +135,62 @@ def test_synthetic_generator_contract():
     q, truth = synthetic.make_queries(b, aux, 64, seed=3)
     assert q.n == 64 and set(truth) == {'source_row', 'is_modified', 'delta_mass'}
     assert (q.charge == 0).all()
+
+
+def test_search_cascade_control_flow(monkeypatch):
+    """SpectralLibrary.search / _search_cascade host logic (spectral_library.py:193-326) with the
+    device calls stubbed: batching, first-match-wins per identifier, level 2 only for queries
+    level 1 left unidentified, the scorer's q-values gate level 1."""
+    from types import SimpleNamespace
+    from ann_solo_amd import spectrum_similarity
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    from ann_solo_amd import synthetic
+    lib, aux = synthetic.make_library(40, seed=9, device='cpu', charges=(2, 3), charge_p=(0.5, 0.5))
+    calls = []
+
+    class Stub(SpectralLibrary):
+        def _search_batch(self, queries, charge, mode, want_knn=False, device_out=False):
+            calls.append((charge, mode, queries.n))
+            n = queries.n
+            # std finds a match for even precursor charges*rows only; open finds one for everybody
+            found = np.array([(mode == 'open') or (int(round(float(p))) % 2 == 0)
+                              for p in queries.precursor_mz])
+            return SimpleNamespace(best_row=np.where(found, 1, -1).astype(np.int32),
+                                   best_score=np.ones(n), n_candidates=np.ones(n, np.int32),
+                                   pm_count=np.ones(n, np.int32), pm_pairs=np.zeros((n, 1, 2), np.uint32),
+                                   peak_matches=lambda i: np.zeros((1, 2), np.int64))
+    sl = Stub.__new__(Stub)
+    sl.config = Config(batch_size=4)
+    sl.device = torch.device('cpu')
+    sl.partitions = {2: SimpleNamespace(spectra=lib), 3: SimpleNamespace(spectra=lib)}
+    monkeypatch.setattr(spectrum_similarity, 'ssm_features',
+                        lambda q, l, rows, pairs, cnt, *a: np.tile(np.linspace(0.5, 0.9, 33), (q.n, 1)))
+    from ann_solo_amd.packed import PackedSpectra
+    mk = lambda pm, z: PackedSpectra.from_numpy(np.arange(len(pm) + 1) * 2, np.tile([100., 200.], len(pm)),
+                                                np.tile([.6, .8], len(pm)), None, pm, np.full(len(pm), z))
+    qs = {2: mk(np.arange(400, 410, dtype=np.float64), 2), 3: mk(np.array([500., 501., 402.]), 3)}
+    meta = {2: [dict(identifier=f'scan={i}', index=i, precursor_charge=2, precursor_mz=400. + i)
+                for i in range(10)],
+            3: [dict(identifier='scan=100', index=100, precursor_charge=3, precursor_mz=500.),
+                dict(identifier='scan=101', index=101, precursor_charge=3, precursor_mz=501.),
+                dict(identifier='scan=2', index=2, precursor_charge=3, precursor_mz=402.)]}   # charge unknown: tried twice
+    lmeta = {z: [dict(identifier=1000 * z + r, peptide=f'PEP{z}{r}K', precursor_mz=300. + r)
+                 for r in range(lib.n)] for z in (2, 3)}
+    ids = sl.search(qs, meta, lmeta)
+    # level 1: batches of 4 over 10 + 3 queries; level 2: only the 5 + 1 odd-m/z queries remain
+    assert [c for c in calls if c[1] == 'std'] == [(2, 'std', 4), (2, 'std', 4), (2, 'std', 2), (3, 'std', 3)]
+    assert [c for c in calls if c[1] == 'open'] == [(2, 'open', 4), (2, 'open', 1), (3, 'open', 1)]
+    by_id = {s.query_identifier: s for s in ids}
+    assert len(ids) == 12 and set(by_id) == {m['identifier'] for z in meta for m in meta[z]}
+    assert by_id['scan=2'].charge == 2                 # first match wins for the duplicated identifier
+    assert all(s.search_engine_score == 0.5 and s.q == 0.0 for s in ids)
+    # a scorer that rejects everything at level 1 sends every query to level 2
+    calls.clear()
+
+    def scorer(ssms, mode):
+        for s in ssms:
+            s.q = 1.0 if mode == 'std' else 0.001
+        return ssms
+    ids = sl.search(qs, meta, lmeta, score_ssms=scorer)
+    assert sum(c[2] for c in calls if c[1] == 'open') == 13      # both charge copies of scan=2 retried
+    assert len(ids) == 12 and all(s.q == 0.001 for s in ids)

@@ -130,3 +130,57 @@ def test_index_cache_files(tmp_path, world):
     r1 = a._search_batch(q, 3, 'open')
     r0 = sl._search_batch(q, 3, 'open')
     assert np.array_equal(r1.best_row, r0.best_row)
+
+
+def test_search_driver_end_to_end_to_mztab(tmp_path, monkeypatch):
+    """SpectralLibrary.search (cascade std -> open) over packed queries, written with the mzTab
+    mirror: unmodified queries are identified by the standard search, modified ones only by the
+    open search; every row of the file matches the device results."""
+    import torch
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    from ann_solo_amd.writer import write_mztab
+    lib, aux = synthetic.make_library(4000, seed=71, device='cpu', charges=(2,), charge_p=(1.0,))
+    q, truth = synthetic.make_queries(lib, aux, 300, seed=72, charge=2, open_range=300.0)
+    cfg = Config(num_list=32, num_probe=32, num_candidates=1024, index='ivfpq', kmeans_niter=5,
+                 batch_size=128, query_filename='/data/q.mgf', spectral_library_filename='/data/l.splib')
+    sl = SpectralLibrary(lib, config=cfg)
+    qmeta = {2: [dict(identifier=f'scan={i}', index=i, retention_time=0.5 * i, precursor_charge=2,
+                      precursor_mz=float(q.precursor_mz[i])) for i in range(q.n)]}
+    lmeta = {2: [dict(identifier=int(r), peptide=f'PEPTIDE{r}K', precursor_mz=float(p), is_decoy=False)
+                 for r, p in enumerate(sl.partitions[2].precursor_mz)]}
+    seen = []
+
+    def scorer(ssms, mode):          # stands for utils.score_ssms: accept confident matches only
+        seen.append((mode, len(ssms)))
+        for s in ssms:
+            s.q = 0.001 if s.search_engine_score > 0.5 else 0.5
+        return ssms
+    ids = sl.search({2: q}, qmeta, lmeta, score_ssms=scorer)
+    by = {s.query_identifier: s for s in ids}
+    src, mod = truth['source_row'].numpy(), truth['is_modified'].numpy()
+    std = sl._search_batch(q, 2, 'std')
+    opn = sl._search_batch(q, 2, 'open')
+    assert seen[0][0] == 'std' and seen[1][0] == 'open' and seen[1][1] < q.n
+    n_std = n_open = 0
+    for i in range(q.n):
+        s = by.get(f'scan={i}')
+        if s is None:
+            assert opn.best_row[i] < 0
+            continue
+        if std.best_row[i] >= 0 and s.library_identifier == std.best_row[i] and not mod[i]:
+            n_std += 1                                           # kept from level 1
+        else:
+            assert s.library_identifier == opn.best_row[i]       # level 2 result
+            n_open += 1
+    assert n_std > 50 and n_open > 50
+    monkeypatch.chdir(tmp_path)
+    fn = write_mztab(ids, 'out', cfg)
+    rows = [l.rstrip('\n').split('\t') for l in open(fn) if l.startswith('PSM')]
+    assert len(rows) == len(ids) and all(len(r) == 22 for r in rows)
+    nums = [int(r[2].split('=')[1]) for r in rows]
+    assert nums == sorted(nums)                                  # natural order of the identifiers
+    for r in rows[:20]:
+        s = by[r[2]]
+        assert r[1] == s.sequence and float(r[8]) == s.search_engine_score and r[20] == str(s.library_identifier)
+    sl.shutdown()
