@@ -153,6 +153,32 @@ def _all_gather_rows(x: torch.Tensor, world: int, group=None) -> torch.Tensor:
     return torch.cat(parts).to(x.device)
 
 
+def _concat_results(parts):
+    """Concatenate per-chunk results (``BatchResult`` of the HIP backend or the dictionaries of
+    a test backend) along the query axis; peak-match tables are padded to the widest chunk."""
+    if len(parts) == 1:
+        return parts[0]
+    cat = lambda xs: torch.cat(xs) if torch.is_tensor(xs[0]) else np.concatenate(xs)
+    first = parts[0]
+    if isinstance(first, dict):
+        return {k: cat([p[k] for p in parts]) for k in first}
+    stride = max(p.pm_pairs.shape[1] for p in parts)
+
+    def pad(pp):
+        if pp.shape[1] == stride:
+            return pp
+        if torch.is_tensor(pp):
+            out = torch.zeros((pp.shape[0], stride, 2), dtype=pp.dtype, device=pp.device)
+        else:
+            out = np.zeros((pp.shape[0], stride, 2), pp.dtype)
+        out[:, :pp.shape[1]] = pp
+        return out
+    return type(first)(cat([p.best_row for p in parts]), cat([p.best_score for p in parts]),
+                       cat([p.n_candidates for p in parts]), cat([p.pm_count for p in parts]),
+                       cat([pad(p.pm_pairs) for p in parts]),
+                       None if first.knn is None else cat([p.knn for p in parts]))
+
+
 def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, device_out=False,
                          chunks: Optional[int] = None):
     """One batch: ``queries_local`` is this rank's equally sized slice of the global
@@ -160,7 +186,8 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
 
     The shard scan runs in ``chunks`` pieces (the same sub-slice of every rank's queries per
     piece) so that the all-to-all of one piece travels over xGMI while the next piece is
-    being scanned; the merge of piece c is issued after the scan of piece c+1."""
+    being scanned; merge and rescoring of piece c are issued after the scan of piece c+1, so
+    the last piece's exchange hides behind the rescoring of the one before."""
     world = dist.get_world_size(group)
     vec = backend.encode(queries_local)
     if world == 1:
@@ -176,13 +203,16 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     chunks = max(1, min(chunks, n_local))
     bounds = [(n_local * c) // chunks for c in range(chunks + 1)]
     rank_base = torch.arange(world, device=allvec.device).unsqueeze(1) * n_local
-    knn_parts, pending = [], None
+    results, pending = [], None
 
     def finish(p):
-        Ds, Is, works, _keep = p
+        (Ds, Is, works, _keep), lo, hi = p
         for w in works:
             w.wait()
-        knn_parts.append(backend.merge(Ds.contiguous(), Is.contiguous())[1])
+        knn = backend.merge(Ds.contiguous(), Is.contiguous())[1]
+        sub = queries_local if (lo, hi) == (0, n_local) else queries_local.select(
+            torch.arange(lo, hi, device=queries_local.device))
+        results.append(backend.rescore_knn(sub, knn, device_out))
 
     for c in range(chunks):
         lo, hi = bounds[c], bounds[c + 1]
@@ -196,10 +226,9 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
             pre = (cD.index_select(0, rows), cI.index_select(0, rows)) if co is not None else None
         D, I = (backend.shard_search_preassigned(xv, *pre) if pre is not None
                 else backend.shard_search(xv))
-        nxt = exchange_partials(D, I, world, group, async_op=True)
+        nxt = (exchange_partials(D, I, world, group, async_op=True), lo, hi)
         if pending is not None:
             finish(pending)
         pending = nxt
     finish(pending)
-    knn = knn_parts[0] if len(knn_parts) == 1 else torch.cat(knn_parts)
-    return backend.rescore_knn(queries_local, knn, device_out)
+    return _concat_results(results)
