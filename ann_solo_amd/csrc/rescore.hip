@@ -377,10 +377,15 @@ constexpr int RS_HT = 512;            // hash slots
 constexpr int RS_HQ_MAX = 100;        // query peaks the hash path accepts (<= 3 bins each)
 constexpr int RS_EMPTY = (int)0x80000000;
 constexpr int RS_BM_BITS = 1 << 14;   // bin filter: <= 300 bits set of 16 384
-constexpr int RS_SUPER = 2048;        // candidate slots compacted at a time
-constexpr int RS_PF = 4;              // candidates staged per burst
-constexpr int RS_HC = 128;            // matches per candidate resolved in this kernel
+constexpr int RS_SUPER = 512;         // candidate slots compacted at a time
+constexpr int RS_PF = 2;              // candidates staged per burst
+constexpr int RS_HC = 64;             // matches per candidate resolved in this kernel
 constexpr double RS_DEFER = -2.0;     // pair_score marker: left to the binary-search kernel
+
+struct QueryLds2 {   // hash path: at most RS_HQ_MAX query peaks
+  float mz[128];
+  float inten[128];
+};
 
 struct HashLds {
   int bin[RS_HT];
@@ -480,7 +485,7 @@ __device__ __forceinline__ int resolve_two_fast(int lane, PairLds &W, int MA, in
 // passes of 32; cn = 0 leaves a half idle). The probing instruction stream -- the bulk of
 // this instruction-bound kernel -- is shared by both. Per-half match lists live in the two
 // halves of the wave's key buffer. A score of RS_DEFER means the half overflowed RS_HC.
-__device__ __forceinline__ void score_two(int lane, const QueryLds &Q, const HashLds &H,
+__device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const HashLds &H,
                                           PairLds &Wv, int slotA, int slotB, int cnA, int cnB,
                                           int chgA, int chgB, double pmzA, double pmzB,
                                           double q_pmz, double tol, double inv_w, int allow_shift,
@@ -579,10 +584,10 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds &Q, const Has
                       : 0.0;
 }
 
-__global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
+__global__ __launch_bounds__(64 * RS_WAVES, 7) void rescore_score_v2_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
     double *__restrict__ pair_score, int *__restrict__ q_defer, int *status, int dbg) {
-  __shared__ QueryLds Q;
+  __shared__ QueryLds2 Q;
   __shared__ HashLds H;
   __shared__ PairLds W[RS_WAVES];
   __shared__ uint16_t s_list[RS_SUPER];
@@ -592,8 +597,8 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
   long long c0, c1;
   cv.range(q, c0, c1);
   if (c0 >= c1) return;
-  int qn;
-  load_query(tid, blockDim.x, Qs, q, Q, qn, status);
+  const int qo = Qs.offsets[q];
+  const int qn = Qs.offsets[q + 1] - qo;
   const double q_pmz = Qs.precursor_mz[q];
   // fp32 evaluation of a probe bin (m/z <= ~2600): error bound in bin units; the query
   // peaks are filed with that margin on both sides (still <= 3 bins per peak)
@@ -605,6 +610,10 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_v2_kernel(
     }
     if (tid == 0) q_defer[q] = 1;
     return;
+  }
+  for (int i = tid; i < qn; i += blockDim.x) {   // qn <= RS_HQ_MAX here
+    Q.mz[i] = Qs.mz[qo + i];
+    Q.inten[i] = Qs.intensity[qo + i];
   }
   for (int i = tid; i < RS_HT; i += blockDim.x) H.bin[i] = RS_EMPTY;
   for (int i = tid; i < RS_BM_BITS / 32; i += blockDim.x) H.bm[i] = 0u;
