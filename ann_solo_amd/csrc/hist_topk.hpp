@@ -1,4 +1,5 @@
-// hist_topk.hpp -- exact top-k of a long candidate stream for one 256-thread workgroup
+// hist_topk.hpp -- exact top-k of a long candidate stream for one workgroup of NT = 256 or
+// 512 threads
 // WITHOUT sorting while streaming (used by pq_scan_v3.hip and flat_scan.hip).
 //
 //   * hist[512]: counts of the appended candidates per score bucket (monotone linear
@@ -29,9 +30,10 @@ __device__ __forceinline__ int score_bucket(float s) {
   return (int)t;
 }
 
-// exclusive prefix sum of one int per thread over the workgroup; `part` = 4 LDS ints
-// reserved for this call site. Total in `total`.
-__device__ __forceinline__ int block_excl_scan256(int v, int *part, int tid, int &total) {
+// exclusive prefix sum of one int per thread over a workgroup of NW waves; `part` = NW LDS
+// ints reserved for this call site. Total in `total`.
+template <int NW>
+__device__ __forceinline__ int block_excl_scan(int v, int *part, int tid, int &total) {
   const int lane = tid & 63, wave = tid >> 6;
   int incl = v;
 #pragma unroll
@@ -44,26 +46,30 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *part, int tid, int
   int base = 0;
   total = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
     const int t = part[w];
     if (w < wave) base += t;
     total += t;
   }
   return base + incl - v;
 }
+__device__ __forceinline__ int block_excl_scan256(int v, int *part, int tid, int &total) {
+  return block_excl_scan<4>(v, part, tid, total);
+}
 
-// LDS footprint: CAP*8 (keys) + 128 (control) + HT_NB*4 (histogram)
-template <int CAP, int ROUND_VECS>
+// LDS footprint: CAP*8 (keys) + 256 (control) + HT_NB*4 (histogram)
+template <int CAP, int ROUND_VECS, int NT = HT_NT>
 struct HistTopK {
-  enum { C_FILL = 0, C_BSTAR = 1, C_WCNT = 2 /* 8 */, C_PART_B = 10 /* 4 */, C_PART_C = 14 /* 4 */,
-         C_USER = 18 /* 4 ints for the caller */ };
-  static constexpr int PER = CAP / HT_NT;
+  static constexpr int NW = NT / 64;
+  enum { C_FILL = 0, C_BSTAR = 1, C_WCNT = 2 /* 2*NW <= 16 */, C_PART_B = 18 /* NW <= 8 */,
+         C_PART_C = 26 /* NW <= 8 */, C_USER = 34 /* 4 ints for the caller */ };
+  static constexpr int PER = CAP / NT;
   u64 *keys;
   u64 *thr_p;
   int *ctl;
   int *hist;
   const int32_t *slot_ids;
-  StreamTopK<HT_NT, CAP> tk;
+  StreamTopK<NT, CAP> tk;
   int k, tid, lane, wave;
   int fill, parity, round_no;
   bool sort_mode;
@@ -71,14 +77,14 @@ struct HistTopK {
   int bstar;
   uint32_t thr_hi;
 
-  static constexpr size_t lds_bytes() { return (size_t)CAP * 8 + 128 + (size_t)HT_NB * 4; }
+  static constexpr size_t lds_bytes() { return (size_t)CAP * 8 + 256 + (size_t)HT_NB * 4; }
 
   // `base` must be 16-byte aligned; returns the first byte after the structure's LDS
   __device__ __forceinline__ char *init(char *base, int k_, const int32_t *slot_ids_, int tid_) {
     keys = reinterpret_cast<u64 *>(base);
     thr_p = keys + CAP;
     ctl = reinterpret_cast<int *>(thr_p + 1);
-    hist = reinterpret_cast<int *>(thr_p + 16);
+    hist = reinterpret_cast<int *>(thr_p + 32);
     slot_ids = slot_ids_;
     k = k_;
     tid = tid_;
@@ -87,7 +93,7 @@ struct HistTopK {
     fill = parity = round_no = 0;
     sort_mode = false;
     tk.init(keys, ctl, thr_p, CAP, k, tid);
-    for (int i = tid; i < HT_NB; i += HT_NT) hist[i] = 0;
+    for (int i = tid; i < HT_NB; i += NT) hist[i] = 0;
     if (tid == 0) ctl[C_BSTAR] = 0;
     __syncthreads();
     return reinterpret_cast<char *>(hist + HT_NB);
@@ -114,7 +120,7 @@ struct HistTopK {
   }
 
   __device__ __forceinline__ void update_bstar() {
-    constexpr int BPT = HT_NB / HT_NT;  // buckets per thread, highest buckets in thread 0
+    constexpr int BPT = HT_NB / NT;  // buckets per thread (2 or 1), highest buckets in thread 0
     int h[BPT], s = 0;
 #pragma unroll
     for (int u = 0; u < BPT; ++u) {
@@ -122,7 +128,7 @@ struct HistTopK {
       s += h[u];
     }
     int tot;
-    int above = block_excl_scan256(s, ctl + C_PART_B, tid, tot);
+    int above = block_excl_scan<NW>(s, ctl + C_PART_B, tid, tot);
     if (above < k && above + s >= k) {
       int b = HT_NB - 1 - tid * BPT;
 #pragma unroll
@@ -144,13 +150,13 @@ struct HistTopK {
     int cnt = 0;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int i = tid + u * HT_NT;
+      const int i = tid + u * NT;
       kk[u] = i < fill ? keys[i] : 0ull;
       if (kk[u] != 0ull && score_bucket(ord2f((uint32_t)(kk[u] >> 32))) < bs) kk[u] = 0ull;
       cnt += kk[u] != 0ull;
     }
     int tot;
-    int pos = block_excl_scan256(cnt, ctl + C_PART_C, tid, tot);  // barrier inside: all loaded
+    int pos = block_excl_scan<NW>(cnt, ctl + C_PART_C, tid, tot);  // barrier inside: all loaded
 #pragma unroll
     for (int u = 0; u < PER; ++u)
       if (kk[u] != 0ull) keys[pos++] = kk[u];
@@ -163,10 +169,10 @@ struct HistTopK {
   // tracked identically in every thread from parity-double-buffered per-wave counts, so the
   // compaction decision cannot race with a faster wave's next round.
   __device__ __forceinline__ void end_round(int appended) {
-    if (lane == 0) ctl[C_WCNT + parity * 4 + wave] = appended;
+    if (lane == 0) ctl[C_WCNT + parity * NW + wave] = appended;
     __syncthreads();
-    fill += ctl[C_WCNT + parity * 4] + ctl[C_WCNT + parity * 4 + 1] +
-            ctl[C_WCNT + parity * 4 + 2] + ctl[C_WCNT + parity * 4 + 3];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) fill += ctl[C_WCNT + parity * NW + w];
     if (fill > CAP - ROUND_VECS) {
       if (!sort_mode) {
         fill = compact();
@@ -202,7 +208,7 @@ struct HistTopK {
     int32_t idv[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int i = tid + u * HT_NT;
+      const int i = tid + u * NT;
       kk[u] = i < fill ? keys[i] : 0ull;
     }
 #pragma unroll
@@ -223,7 +229,7 @@ struct HistTopK {
       }
     }
     int tot;
-    const int pre = block_excl_scan256(na | (nb << 16), ctl + C_PART_C, tid, tot);
+    const int pre = block_excl_scan<NW>(na | (nb << 16), ctl + C_PART_C, tid, tot);
     const int n_above = tot & 0xffff, n_bound = tot >> 16;
     int pa = pre & 0xffff, pb = pre >> 16;
     auto emit = [&](int pos, u64 key) {
@@ -242,7 +248,7 @@ struct HistTopK {
     __syncthreads();
     const int r = k - n_above;          // > 0
     const int take = n_bound < r ? n_bound : r;
-    for (int i = tid; i < n_bound; i += HT_NT) {
+    for (int i = tid; i < n_bound; i += NT) {
       const u64 key = scratch[i];
       int rank = i;
       if (n_bound > r) {                 // block-uniform
@@ -251,7 +257,7 @@ struct HistTopK {
       }
       if (rank < take) emit(n_above + rank, key);
     }
-    for (int i = n_above + take + tid; i < k; i += HT_NT) {
+    for (int i = n_above + take + tid; i < k; i += NT) {
       if (D) D[i] = -3.402823466e+38f;
       if (I64) I64[i] = -1;
       if (I32) I32[i] = -1;

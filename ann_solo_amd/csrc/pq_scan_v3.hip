@@ -25,16 +25,21 @@ namespace asl {
 constexpr int V3_NT = 256;
 constexpr int V3_CHUNK = 128;   // tile-table entries per chunk
 
-template <int CAP, int T>
-__global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kernel(
+// NW = waves per workgroup. LDS (LUT 32 KB + keys 16 KB + ...) allows three workgroups per CU
+// whatever their size, so 8 waves per workgroup (one tile per wave and round) double the
+// waves that share one LUT and one key buffer: 24 waves per CU at 80 VGPRs instead of 12 at
+// 157 -- measured 8.28 -> 7.46 ms at the bench config (with ONE round of prefetch: at this
+// occupancy the second prefetch stage only costs registers).
+template <int CAP, int T, int NW, int DEPTH = 2>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : (CAP <= 2048 ? 3 : 1))) void pq_scan_v3_kernel(
     const float *__restrict__ xq, int d, const float *__restrict__ codebooks, int dsub,
     const float *__restrict__ coarse_D, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ tile_offsets,
     const uint8_t *__restrict__ codes_tiled, const int32_t *__restrict__ ids_tiled, int k,
     float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode,
     int dbg) {
-  constexpr int ROUND_TILES = 4 * T, ROUND_VECS = ROUND_TILES * 64;
-  using TopK = HistTopK<CAP, ROUND_VECS>;
+  constexpr int NT = 64 * NW, ROUND_TILES = NW * T, ROUND_VECS = ROUND_TILES * 64;
+  using TopK = HistTopK<CAP, ROUND_VECS, NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *s_lut = reinterpret_cast<float *>(smem + TopK::lds_bytes());
   TileEnt *table = reinterpret_cast<TileEnt *>(s_lut + PQT_KSUB * PQT_M);
@@ -42,8 +47,8 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
   const long long t_start = (dbg & 32) ? wall_clock64() : 0;
-  build_lut_cbt(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, reinterpret_cast<uint8_t *>(table),
-                tid);  // codebooks = cbT[m][t][c]; the tile table is not live yet
+  build_lut_cbt<NT>(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, reinterpret_cast<uint8_t *>(table),
+                    tid);  // codebooks = cbT[m][t][c]; the tile table is not live yet
 
   // ---- my probe (thread p < nprobe) and the exclusive scan of tile counts
   int my_len = 0, my_tile0 = 0, my_nt = 0;
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
   }
   int total;
   int *scan_part = reinterpret_cast<int *>(table);   // table is not live yet
-  const int my_pre = block_excl_scan256(my_nt, scan_part, tid, total);
+  const int my_pre = block_excl_scan<NW>(my_nt, scan_part, tid, total);
   __syncthreads();
 
   const long long t_lut = (dbg & 32) ? wall_clock64() : 0;
@@ -124,6 +129,16 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
       top.end_round(appended);
     };
     fetch(0, A0, B0, e0);
+    if constexpr (DEPTH == 1) {
+      for (int rr = 0; rr < nrounds; rr += 2) {
+        if (rr + 1 < nrounds) fetch(rr + 1, A1, B1, e1);
+        process(A0, B0, e0);
+        if (rr + 1 < nrounds) {
+          if (rr + 2 < nrounds) fetch(rr + 2, A0, B0, e0);
+          process(A1, B1, e1);
+        }
+      }
+    } else {
     if (nrounds > 1) fetch(1, A1, B1, e1);
     for (int rr = 0; rr < nrounds; rr += 3) {
       if (rr + 2 < nrounds) fetch(rr + 2, A2, B2, e2);
@@ -136,6 +151,7 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
         if (rr + 4 < nrounds) fetch(rr + 4, A1, B1, e1);
         process(A2, B2, e2);
       }
+    }
     }
     __syncthreads();
   }
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(V3_NT, (CAP <= 2048 ? 3 : 1)) void pq_scan_v3_kerne
   }
 }
 
-template <int CAP, int T>
+template <int CAP, int T, int NW = 4, int DEPTH = 2>
 static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                      const float *coarse_D, const int32_t *coarse_I, int nprobe,
                      const int32_t *list_offsets, const int32_t *tile_offsets,
@@ -171,21 +187,21 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
   if ((size_t)d * 4 > (size_t)CAP * 8 || dsub > 255 ||
       (size_t)d * 2 + 4 > (size_t)V3_CHUNK * sizeof(TileEnt) || d != PQT_M * dsub)
     return fail(ASL_ERR_CAPACITY, "pq scan: d=%d too large for the LDS staging", d);
-  const size_t lds = HistTopK<CAP, 4 * T * 64>::lds_bytes() + (size_t)PQT_KSUB * PQT_M * 4 +
+  const size_t lds = HistTopK<CAP, NW * T * 64, 64 * NW>::lds_bytes() + (size_t)PQT_KSUB * PQT_M * 4 +
                      (size_t)V3_CHUNK * sizeof(TileEnt);
   if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "pq scan: k=%d does not fit LDS", k);
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)pq_scan_v3_kernel<CAP, T>,
+    HIP_TRY(hipFuncSetAttribute((const void *)pq_scan_v3_kernel<CAP, T, NW, DEPTH>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((pq_scan_v3_kernel<CAP, T>), dim3(nq), dim3(V3_NT), lds, stream(), xq, d,
+  hipLaunchKernelGGL((pq_scan_v3_kernel<CAP, T, NW, DEPTH>), dim3(nq), dim3(64 * NW), lds, stream(), xq, d,
                      codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets,
                      codes_tiled, ids_tiled, k, D, I64, I32, set_mode, dbg);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
 
-// variant: 0 = choose by k; 3 = CAP 2048 / 2 tiles per wave (3 workgroups per CU);
-// 4 = CAP 4096 / 4 tiles per wave (2 per CU)
+// variant: 0 = choose by k; 3 = 4-wave workgroups, CAP 2048 / 2 tiles per wave;
+// 4 = CAP 4096 / 4 tiles per wave; 8 = 8-wave workgroups with two rounds of prefetch
 int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                const float *coarse_D, const int32_t *coarse_I, int nprobe,
                const int32_t *list_offsets, const int32_t *tile_offsets,
@@ -194,8 +210,14 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
   if (nq <= 0) return ASL_OK;
 #define V3_ARGS xq, nq, d, codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets, \
                 codes_tiled, ids_tiled, k, D, I64, I32, set_mode, dbg
-  if (variant == 5 && k + 256 + 768 <= 2048) return launch_v3<2048, 3>(V3_ARGS);
-  if (variant != 4 && k + 256 + 512 <= 2048) return launch_v3<2048, 2>(V3_ARGS);
+  // default for k <= 1280: 8 waves per workgroup, one tile per wave and round, one round of
+  // prefetch (24 waves per CU); variants 3 / 5 / 8: the 4-wave kernels and the deeper prefetch
+  if (k + 256 + 512 <= 2048) {
+    if (variant == 3) return launch_v3<2048, 2>(V3_ARGS);
+    if (variant == 5 && k + 256 + 768 <= 2048) return launch_v3<2048, 3>(V3_ARGS);
+    if (variant == 8) return launch_v3<2048, 1, 8>(V3_ARGS);
+    if (variant != 4) return launch_v3<2048, 1, 8, 1>(V3_ARGS);
+  }
   if (k + 256 + 1024 <= 4096) return launch_v3<4096, 4>(V3_ARGS);
   return launch_v3<8192, 4>(V3_ARGS);
 #undef V3_ARGS

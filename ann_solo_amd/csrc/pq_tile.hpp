@@ -59,12 +59,13 @@ __device__ __forceinline__ float tile_adc(const char *lut_bytes, const uint4 A, 
 // per-query fixed cost of a sharded search). The non-zeros of all sub-vectors are listed
 // once (wave 0) and walked flat, U codebook loads in flight per thread: the build is
 // latency-bound otherwise. s_q: staging of the query; s_nz: 4 + 2*d bytes of scratch.
+template <int NT = 256>
 __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, int d,
                                               const float *__restrict__ cbT, int dsub,
                                               float *s_q, float *s_lut, uint8_t *s_nz, int tid) {
   // s_nz: [0..4) K (int), then K sub-quantiser indices at +4 and K offsets t at +4+d
-  for (int i = tid; i < d; i += 256) s_q[i] = xq_row[i];
-  for (int i = tid; i < PQT_KSUB * PQT_M; i += 256) s_lut[i] = 0.0f;   // sub-quantisers without non-zeros
+  for (int i = tid; i < d; i += NT) s_q[i] = xq_row[i];
+  for (int i = tid; i < PQT_KSUB * PQT_M; i += NT) s_lut[i] = 0.0f;   // sub-quantisers without non-zeros
   __syncthreads();
   uint8_t *nz_m = s_nz + 4, *nz_t = s_nz + 4 + d;
   if (tid < 64) {   // wave 0: lane m lists the non-zero components of sub-vector m, in order
@@ -94,7 +95,7 @@ __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, 
   constexpr int U = 8;   // codebook loads in flight per thread
   float acc = 0.0f;
   int cur = -1;
-  for (int k0 = 0; k0 < K; k0 += U) {
+  for (int k0 = 0; k0 < (tid < PQT_KSUB ? K : 0); k0 += U) {   // threads beyond the 256 code words idle
     float cbv[U], qv[U];
     int mm[U];
 #pragma unroll
