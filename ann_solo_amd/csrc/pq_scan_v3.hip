@@ -184,8 +184,8 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                      const int32_t *list_offsets, const int32_t *tile_offsets,
                      const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
                      int64_t *I64, int32_t *I32, int set_mode, int dbg) {
-  if ((size_t)d * 4 > (size_t)CAP * 8 || dsub > 255 ||
-      (size_t)d * 2 + 4 > (size_t)V3_CHUNK * sizeof(TileEnt) || d != PQT_M * dsub)
+  if ((size_t)d * 4 > (size_t)CAP * 8 || dsub > 64 ||
+      (size_t)d * 2 + 8 > (size_t)V3_CHUNK * sizeof(TileEnt) || d != PQT_M * dsub)
     return fail(ASL_ERR_CAPACITY, "pq scan: d=%d too large for the LDS staging", d);
   const size_t lds = HistTopK<CAP, NW * T * 64, 64 * NW>::lds_bytes() + (size_t)PQT_KSUB * PQT_M * 4 +
                      (size_t)V3_CHUNK * sizeof(TileEnt);

@@ -58,21 +58,32 @@ __device__ __forceinline__ float tile_adc(const char *lut_bytes, const uint4 A, 
 // codebook traffic of a table from 819 KB to ~50 KB (the table build was the largest
 // per-query fixed cost of a sharded search). The non-zeros of all sub-vectors are listed
 // once (wave 0) and walked flat, U codebook loads in flight per thread: the build is
-// latency-bound otherwise. s_q: staging of the query; s_nz: 4 + 2*d bytes of scratch.
+// latency-bound otherwise. s_q: staging of the query; s_nz: 8 + 2*d bytes of scratch.
 template <int NT = 256>
 __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, int d,
                                               const float *__restrict__ cbT, int dsub,
                                               float *s_q, float *s_lut, uint8_t *s_nz, int tid) {
-  // s_nz: [0..4) K (int), then K sub-quantiser indices at +4 and K offsets t at +4+d
+  // s_nz: [0..4) K (int), [4..8) K16 = entries of the sub-quantisers 0..15, then K
+  // sub-quantiser indices at +8 and K offsets t at +8+d
   for (int i = tid; i < d; i += NT) s_q[i] = xq_row[i];
   for (int i = tid; i < PQT_KSUB * PQT_M; i += NT) s_lut[i] = 0.0f;   // sub-quantisers without non-zeros
   __syncthreads();
-  uint8_t *nz_m = s_nz + 4, *nz_t = s_nz + 4 + d;
+  uint8_t *nz_m = s_nz + 8, *nz_t = s_nz + 8 + d;
   if (tid < 64) {   // wave 0: lane m lists the non-zero components of sub-vector m, in order
     const int m = tid;
-    int cnt = 0;
+    // per lane a bit mask of its non-zero components, read 8 at a time (independent LDS reads
+    // in flight; one read at a time made this serial listing half of the table build)
+    unsigned long long nzmask = 0ull;     // dsub <= 64 (checked by the launcher)
     if (m < PQT_M)
-      for (int t = 0; t < dsub; ++t) cnt += s_q[m * dsub + t] != 0.0f;
+      for (int t0 = 0; t0 < dsub; t0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = t0 + u < dsub ? s_q[m * dsub + t0 + u] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (v[u] != 0.0f) nzmask |= 1ull << (t0 + u);
+      }
+    const int cnt = __popcll(nzmask);
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -80,22 +91,28 @@ __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, 
       if (tid >= o) incl += v;
     }
     int pos = incl - cnt;
-    if (m < PQT_M)
-      for (int t = 0; t < dsub; ++t)
-        if (s_q[m * dsub + t] != 0.0f) {
-          nz_m[pos] = (uint8_t)m;
-          nz_t[pos] = (uint8_t)t;
-          ++pos;
-        }
-    if (tid == 63) *reinterpret_cast<int *>(s_nz) = incl;
+    while (nzmask) {
+      const int t = __builtin_ctzll(nzmask);
+      nzmask &= nzmask - 1ull;
+      nz_m[pos] = (uint8_t)m;
+      nz_t[pos] = (uint8_t)t;
+      ++pos;
+    }
+    if (tid == 63) reinterpret_cast<int *>(s_nz)[0] = incl;
+    if (tid == 16) reinterpret_cast<int *>(s_nz)[1] = incl - cnt;
   }
   __syncthreads();
-  const int K = *reinterpret_cast<const int *>(s_nz);   // block-uniform
-  const int c = tid;
+  // 256 threads: thread c walks all K entries. 512 threads: the two halves of the workgroup
+  // split the sub-quantisers (0..15 | 16..31), each thread still owns one code word.
+  const int Kall = reinterpret_cast<const int *>(s_nz)[0];
+  const int K16 = reinterpret_cast<const int *>(s_nz)[1];
+  const int c = tid & (PQT_KSUB - 1);
+  const int kbeg = (NT > PQT_KSUB && tid >= PQT_KSUB) ? K16 : 0;
+  const int K = (NT > PQT_KSUB && tid < PQT_KSUB) ? K16 : Kall;   // wave-uniform
   constexpr int U = 8;   // codebook loads in flight per thread
   float acc = 0.0f;
   int cur = -1;
-  for (int k0 = 0; k0 < (tid < PQT_KSUB ? K : 0); k0 += U) {   // threads beyond the 256 code words idle
+  for (int k0 = kbeg; k0 < K; k0 += U) {
     float cbv[U], qv[U];
     int mm[U];
 #pragma unroll
