@@ -13,18 +13,21 @@
 
 namespace asl {
 
-constexpr int SIM_MAXP = 256;    // peaks per spectrum
+constexpr int SIM_MAXP = 256;    // peaks per spectrum (largest instantiation)
 constexpr int SIM_WAVES = 2;     // SSMs per workgroup
 constexpr int SIM_KC = 272;      // exact Kendall recurrence: c <= 33*32/4 = 264
 
-struct SimLds {
-  float q_mz[SIM_MAXP], q_int[SIM_MAXP], l_mz[SIM_MAXP], l_int[SIM_MAXP];
-  float mq[SIM_MAXP], ml[SIM_MAXP], mzq[SIM_MAXP], mzl[SIM_MAXP];   // matched, match order
-  float tq[SIM_MAXP], tl[SIM_MAXP], tzq[SIM_MAXP], tzl[SIM_MAXP];   // matched & in top
-  float uq[SIM_MAXP], ul[SIM_MAXP], tul[SIM_MAXP];                  // unmatched lists
-  double x[2 * SIM_MAXP], y[SIM_MAXP], rx[SIM_MAXP], ry[SIM_MAXP];  // x also holds the merged spectrum
+// MAXP = 128 halves the footprint (15 KB per wave: 10 waves per CU instead of 4); spectra are
+// <= 50 peaks with the reference's defaults, the 256-peak instantiation is the fallback.
+template <int MAXP>
+struct SimLdsT {
+  float q_mz[MAXP], q_int[MAXP], l_mz[MAXP], l_int[MAXP];
+  float mq[MAXP], ml[MAXP], mzq[MAXP], mzl[MAXP];   // matched, match order
+  float tq[MAXP], tl[MAXP], tzq[MAXP], tzl[MAXP];   // matched & in top
+  float uq[MAXP], ul[MAXP], tul[MAXP];              // unmatched lists
+  double x[2 * MAXP], y[MAXP], rx[MAXP], ry[MAXP];  // x also holds the merged spectrum
   double kc[2][SIM_KC];
-  uint8_t used_q[SIM_MAXP], used_l[SIM_MAXP], in_top[SIM_MAXP];
+  uint8_t used_q[MAXP], used_l[MAXP], in_top[MAXP];
 };
 
 __device__ __forceinline__ void sim_sync() {
@@ -142,7 +145,8 @@ __device__ double pearson(int lane, const double *x, const double *y, int n) {
 }
 
 // -log(p) of scipy.stats.kendalltau (tau-b, method 'auto', two-sided) of (x, y)[0..n)
-__device__ double kendall_neglogp(int lane, const float *x, const float *y, int n, SimLds &S) {
+__device__ double kendall_neglogp(int lane, const float *x, const float *y, int n, double *kc0,
+                                  double *kc1) {
   if (n < 2) return 0.0;
   long long dis = 0, xtie = 0, ytie = 0, ntie = 0;
   double tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;   // tie-group statistics (asymptotic variance)
@@ -196,7 +200,7 @@ __device__ double kendall_neglogp(int lane, const float *x, const float *y, int 
     else {   // counts of permutations with <= c inversions (Kendall's recurrence), lane 0
       double s = 0.0;
       if (lane == 0) {
-        double *cur = S.kc[0], *nxt = S.kc[1];
+        double *cur = kc0, *nxt = kc1;
         for (int i = 0; i <= (int)c; i++) cur[i] = 0.0;
         cur[0] = cur[1] = 1.0;
         for (int j = 3; j <= n; j++) {
@@ -270,7 +274,11 @@ __device__ double scribe_of(int lane, const SimView &v) {
   return den == 0.0 ? 10.0 : log(1.0 / den);
 }
 
-__device__ double corr_of(int lane, const SimView &v, bool spearman, SimLds &S) {
+struct SimScratch {
+  double *x, *y, *rx, *ry;
+};
+
+__device__ double corr_of(int lane, const SimView &v, bool spearman, const SimScratch &S) {
   if (!v.n) return 0.0;
   const int n = v.n + v.n_ul;
   sim_sync();
@@ -289,15 +297,17 @@ __device__ double corr_of(int lane, const SimView &v, bool spearman, SimLds &S) 
   return pearson(lane, S.rx, S.ry, n);
 }
 
+template <int MAXP>
 __global__ __launch_bounds__(64 * SIM_WAVES) void ssm_features_kernel(
     DevPeaks Qs, DevPeaks L, const int32_t *__restrict__ lib_rows,
     const uint32_t *__restrict__ pm_pairs, const int32_t *__restrict__ pm_count, int pm_stride,
     double n_bins, int top, double *__restrict__ out, int *status) {
-  __shared__ SimLds W[SIM_WAVES];
+  __shared__ SimLdsT<MAXP> W[SIM_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int q = blockIdx.x * SIM_WAVES + wave;
   if (q >= Qs.n) return;
-  SimLds &S = W[wave];
+  SimLdsT<MAXP> &S = W[wave];
+  const SimScratch scr{S.x, S.y, S.rx, S.ry};
   double *o = out + (size_t)q * ASL_SSM_NFEAT;
   const long long row = lib_rows[q];
   if (row < 0 || row >= L.n) {
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(64 * SIM_WAVES) void ssm_features_kernel(
   }
   const int qo = Qs.offsets[q], lo = L.offsets[row];
   int nq = Qs.offsets[q + 1] - qo, nl = L.offsets[row + 1] - lo;
-  if (nq > SIM_MAXP || nl > SIM_MAXP) {
+  if (nq > MAXP || nl > MAXP) {
     if (lane == 0) atomicOr(status, 1);
     for (int f = lane; f < ASL_SSM_NFEAT; f += 64) o[f] = NAN;
     return;
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(64 * SIM_WAVES) void ssm_features_kernel(
   int npm = pm_count[q];
   if (npm > pm_stride) npm = pm_stride;
   const uint32_t *pm = pm_pairs + (size_t)q * pm_stride * 2;
-  for (int i = lane; i < SIM_MAXP; i += 64) {
+  for (int i = lane; i < MAXP; i += 64) {
     S.used_q[i] = 0;
     S.used_l[i] = 0;
     if (i < nq) {
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(64 * SIM_WAVES) void ssm_features_kernel(
     const double v = -log(wsum(prob));
     f[15] = v < 100.0 ? v : 100.0;
   }
-  f[16] = n ? kendall_neglogp(lane, S.mq, S.ml, n, S) : 0.0;
+  f[16] = n ? kendall_neglogp(lane, S.mq, S.ml, n, S.kc[0], S.kc[1]) : 0.0;
   double sad = 0, ssd = 0, maxd = 0, sadmz = 0, ssum = 0, smin = 0, smax = 0, canb = 0;
   for (int i = lane; i < n; i += 64) {
     const double d = fabs((double)(S.mq[i] - S.ml[i]));
@@ -502,10 +512,10 @@ __global__ __launch_bounds__(64 * SIM_WAVES) void ssm_features_kernel(
   f[23] = n ? sad + s_uq + s_ul : INFINITY;
   f[24] = n ? sqrt(ssd + ssuq + ssul) : INFINITY;
   f[25] = n ? fmax(maxd, fmax(muq, mul)) : INFINITY;
-  f[26] = corr_of(lane, full, false, S);
-  f[27] = corr_of(lane, tv, false, S);
-  f[28] = corr_of(lane, full, true, S);
-  f[29] = corr_of(lane, tv, true, S);
+  f[26] = corr_of(lane, full, false, scr);
+  f[27] = corr_of(lane, tv, false, scr);
+  f[28] = corr_of(lane, full, true, scr);
+  f[29] = corr_of(lane, tv, true, scr);
   f[30] = n ? (sad + s_uq + s_ul) / (ssum + s_uq + s_ul) : 1.0;
   f[31] = n ? canb + (double)nzuq + (double)nzul : INFINITY;
   f[32] = n ? smin / (smax + s_uq + s_ul) : 0.0;
@@ -546,16 +556,28 @@ extern "C" int asl_ssm_features_batch(const asl_peaks_t *queries, const asl_peak
   DevBuf<int> status;
   ASL_TRY(status.reserve(1));
   HIP_TRY(hipMemsetAsync(status.p, 0, sizeof(int), stream()));
+  int st = 0;
   {
     ProfScope ps("ssm_features");
-    hipLaunchKernelGGL(ssm_features_kernel, dim3((unsigned)cdiv(nq, SIM_WAVES)),
+    // 128-peak instantiation first (10 waves per CU); a batch with a longer spectrum is
+    // redone with the 256-peak one
+    hipLaunchKernelGGL(ssm_features_kernel<128>, dim3((unsigned)cdiv(nq, SIM_WAVES)),
                        dim3(64 * SIM_WAVES), 0, stream(), Q.dev, L.dev, rows.d, pairs.d, cnt.d,
                        pm_stride, (double)n_bins, top, o.d, status.p);
     ASL_CHECK_LAUNCH();
+    HIP_TRY(hipMemcpyAsync(&st, status.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    ASL_TRY(sync_stream());
+    if (st & 1) {
+      HIP_TRY(hipMemsetAsync(status.p, 0, sizeof(int), stream()));
+      hipLaunchKernelGGL(ssm_features_kernel<SIM_MAXP>, dim3((unsigned)cdiv(nq, SIM_WAVES)),
+                         dim3(64 * SIM_WAVES), 0, stream(), Q.dev, L.dev, rows.d, pairs.d, cnt.d,
+                         pm_stride, (double)n_bins, top, o.d, status.p);
+      ASL_CHECK_LAUNCH();
+      HIP_TRY(hipMemcpyAsync(&st, status.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+      ASL_TRY(sync_stream());
+    }
   }
   ASL_TRY(o.finish());
-  int st = 0;
-  HIP_TRY(hipMemcpyAsync(&st, status.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
   ASL_TRY(sync_stream());
   if (st & 1) return fail(ASL_ERR_CAPACITY, "ssm_features: a spectrum has more than %d peaks", SIM_MAXP);
   if (st & 2) return fail(ASL_ERR_INVALID, "ssm_features: a peak match index is out of range");

@@ -135,3 +135,31 @@ def test_invalid_peak_match_index_is_an_error():
     # no library row -> NaN row, not an error
     F = sim.ssm_features(P, P, np.full(1, -1, np.int32), pairs, np.ones(1, np.int32))
     assert np.isnan(F).all()
+
+
+def test_long_spectra_take_the_256_peak_instantiation(O):
+    """A batch with a spectrum of more than 128 peaks is redone by the wider kernel; more than
+    256 peaks is a capacity error."""
+    from ann_solo_amd import _lib
+    from ann_solo_amd import spectrum_similarity as sim
+    rng = np.random.default_rng(3)
+    sizes = [40, 200, 130, 12]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    mz = np.concatenate([np.sort(rng.uniform(100, 1900, n)) for n in sizes]).astype(np.float32)
+    it = np.concatenate([(lambda v: v / np.linalg.norm(v))(rng.lognormal(0, 1, n)) for n in sizes]).astype(np.float32)
+    P = _pack(offs, mz, it)
+    pairs = np.zeros((4, 12, 2), np.uint32)
+    cnt = np.array([10, 12, 5, 3], np.int32)
+    for i, n in enumerate(sizes):
+        sel = np.sort(rng.choice(n, cnt[i], replace=False))
+        pairs[i, :cnt[i], 0] = sel
+        pairs[i, :cnt[i], 1] = sel
+    F = sim.ssm_features(P, P, np.arange(4, dtype=np.int32), pairs, cnt)
+    for i in range(4):
+        sl = slice(offs[i], offs[i + 1])
+        want = O.ssm_features(mz[sl], it[sl], mz[sl], it[sl], pairs[i, :cnt[i]])
+        check_features(F[i], want, f'ssm {i}', rel=1e-9, abs_=1e-11)
+    big = _pack(np.array([0, 300]), np.sort(rng.uniform(100, 1900, 300)).astype(np.float32),
+                np.full(300, 300 ** -0.5, np.float32))
+    with pytest.raises(_lib.AnnSoloMiError, match='peaks'):
+        sim.ssm_features(big, big, np.zeros(1, np.int32), pairs[:1], cnt[:1])
