@@ -31,7 +31,7 @@ constexpr int V3_CHUNK = 128;   // tile-table entries per chunk
 // 157 -- measured 8.28 -> 7.46 ms at the bench config (with ONE round of prefetch: at this
 // occupancy the second prefetch stage only costs registers).
 template <int CAP, int T, int NW, int DEPTH = 2>
-__global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : (CAP <= 2048 ? 3 : 1))) void pq_scan_v3_kernel(
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <= 2048 ? 3 : 1))) void pq_scan_v3_kernel(
     const float *__restrict__ xq, int d, const float *__restrict__ codebooks, int dsub,
     const float *__restrict__ coarse_D, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ tile_offsets,
@@ -218,6 +218,8 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
     if (variant == 8) return launch_v3<2048, 1, 8>(V3_ARGS);
     if (variant != 4) return launch_v3<2048, 1, 8, 1>(V3_ARGS);
   }
+  // larger k: 4096-key buffer, still 8 waves per workgroup (two workgroups per CU)
+  if (variant != 4 && k + 256 + 512 <= 4096) return launch_v3<4096, 1, 8, 1>(V3_ARGS);
   if (k + 256 + 1024 <= 4096) return launch_v3<4096, 4>(V3_ARGS);
   return launch_v3<8192, 4>(V3_ARGS);
 #undef V3_ARGS
