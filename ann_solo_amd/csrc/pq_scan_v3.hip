@@ -47,10 +47,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
   const long long t_start = (dbg & 32) ? wall_clock64() : 0;
-  build_lut_cbt<NT>(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, reinterpret_cast<uint8_t *>(table),
-                    tid);  // codebooks = cbT[m][t][c]; the tile table is not live yet
-
-  // ---- my probe (thread p < nprobe) and the exclusive scan of tile counts
+  // ---- my probe (thread p < nprobe): its dependent gathers are issued before the table build
+  // and complete under it
   int my_len = 0, my_tile0 = 0, my_nt = 0;
   float my_coarse = 0.0f;
   if (tid < nprobe) {
@@ -62,6 +60,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
       my_coarse = coarse_D[(size_t)q * nprobe + tid];
     }
   }
+  build_lut_cbt<NT>(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, reinterpret_cast<uint8_t *>(table),
+                    tid);  // codebooks = cbT[m][t][c]; the tile table is not live yet
+
+  // ---- exclusive scan of the probes' tile counts
   int total;
   int *scan_part = reinterpret_cast<int *>(table);   // table is not live yet
   const int my_pre = block_excl_scan<NW>(my_nt, scan_part, tid, total);

@@ -66,9 +66,12 @@ __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, 
   // s_nz: [0..4) K (int), [4..8) K16 = entries of the sub-quantisers 0..15, then K
   // sub-quantiser indices at +8 and K offsets t at +8+d
   for (int i = tid; i < d; i += NT) s_q[i] = xq_row[i];
-  for (int i = tid; i < PQT_KSUB * PQT_M; i += NT) s_lut[i] = 0.0f;   // sub-quantisers without non-zeros
   __syncthreads();
   uint8_t *nz_m = s_nz + 8, *nz_t = s_nz + 8 + d;
+  if (tid >= 64) {  // the other waves zero the table meanwhile (sub-quantisers without non-zeros)
+    float4 *z = reinterpret_cast<float4 *>(s_lut);
+    for (int i = tid - 64; i < PQT_KSUB * PQT_M / 4; i += NT - 64) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (tid < 64) {   // wave 0: lane m lists the non-zero components of sub-vector m, in order
     const int m = tid;
     // per lane a bit mask of its non-zero components, read 8 at a time (independent LDS reads
