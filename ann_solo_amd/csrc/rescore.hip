@@ -674,10 +674,18 @@ __global__ __launch_bounds__(64 * RS_WAVES, 7) void rescore_score_v2_kernel(
       double m_pmz = 0.0;
       if (okr) {
         const long long row = cv.row(c);
-        m_co = L.offsets[row];
-        m_cn = L.offsets[row + 1] - m_co;
-        m_chg = L.precursor_charge[row];
-        m_pmz = L.precursor_mz[row];
+        if (cv.flt.meta) {     // one 32-byte sector per candidate
+          const uint4 a = *reinterpret_cast<const uint4 *>(&cv.flt.meta[row]);
+          m_co = (int)a.x;
+          m_cn = (int)a.y;
+          m_chg = (int)a.z;
+          m_pmz = cv.flt.meta[row].pmz64;
+        } else {
+          m_co = L.offsets[row];
+          m_cn = L.offsets[row + 1] - m_co;
+          m_chg = L.precursor_charge[row];
+          m_pmz = L.precursor_mz[row];
+        }
       }
       double my_score = 0.0;
       const int cnt = we - base < 64 ? we - base : 64;

@@ -8,12 +8,25 @@ namespace asl {
 // kernel's compaction stage (spectral_library.py:417-429 AND :441-446): a candidate row
 // passes if it is valid and within the window of the query's precursor m/z.
 // lib_pmz == nullptr switches the filter off.
+// Everything the rescoring kernel needs to know about a library row, in one 32-byte sector:
+// the candidate filter and the per-candidate metadata cost one random gather each instead of
+// one per field (offsets x2, charge, precursor m/z, window column, validity).
+struct __attribute__((aligned(32))) RowMeta {
+  int32_t off;      // first peak of the spectrum
+  int32_t cn;       // number of peaks
+  int32_t charge;   // precursor charge
+  float pmz32;      // spec_info's float32 precursor m/z column; NaN for invalid spectra
+  double pmz64;     // precursor m/z
+  double pad;
+};
+
 struct PrecFilter {
   const float *lib_pmz = nullptr;   // spec_info's float32 precursor m/z column
   const uint8_t *valid = nullptr;   // is_valid flags (nullptr: all valid)
   double tol = 0.0;
   int mode = ASL_TOL_DA;
   int charge = 0;
+  const RowMeta *meta = nullptr;    // packed rows (asl_library): replaces lib_pmz / valid
 };
 
 // spectral_library.py:421-427 (numexpr evaluates in float64)
@@ -25,6 +38,7 @@ __device__ __forceinline__ bool precursor_ok(double q, float lib, int charge, do
 }
 
 __device__ __forceinline__ bool filter_pass(const PrecFilter &f, double q_pmz, long long row) {
+  if (f.meta) return precursor_ok(q_pmz, f.meta[row].pmz32, f.charge, f.tol, f.mode);
   if (!f.lib_pmz) return true;
   if (f.valid && !f.valid[row]) return false;
   return precursor_ok(q_pmz, f.lib_pmz[row], f.charge, f.tol, f.mode);

@@ -74,6 +74,7 @@ struct asl_library {
   DevBuf<float> mz, intensity, pmz32;
   DevBuf<uint8_t> charge, valid;
   DevBuf<double> pmz;
+  DevBuf<RowMeta> meta;   // packed per-row record for the rescoring kernel
   bool has_valid = false;
   DevPeaks dev;
   // precursor-sorted view (window search)
@@ -133,6 +134,24 @@ asl_library_t *asl_library_create(const asl_peaks_t *p, const float *lib_pmz_f32
   if (valid) {
     up(L->valid, valid, n);
     L->has_valid = true;
+  }
+  if (ok && n) {   // packed rows: invalid spectra get a NaN window column (never a candidate)
+    std::vector<int32_t> h_off(n + 1), h_chg(n);
+    std::vector<uint8_t> h_valid(n, 1);
+    ok = hipMemcpyAsync(h_off.data(), L->offsets.p, (n + 1) * 4, hipMemcpyDeviceToHost, stream()) == hipSuccess &&
+         hipMemcpyAsync(h_chg.data(), L->pcharge.p, n * 4, hipMemcpyDeviceToHost, stream()) == hipSuccess &&
+         sync_stream() == ASL_OK;
+    if (ok && valid) ok = hipMemcpy(h_valid.data(), valid, n, hipMemcpyDefault) == hipSuccess;
+    std::vector<RowMeta> hm(n);
+    for (size_t i = 0; ok && i < n; i++) {
+      hm[i].off = h_off[i];
+      hm[i].cn = h_off[i + 1] - h_off[i];
+      hm[i].charge = h_chg[i];
+      hm[i].pmz32 = h_valid[i] ? h_pmz32[i] : __builtin_nanf("");
+      hm[i].pmz64 = h_pmz[i];
+      hm[i].pad = 0.0;
+    }
+    up(L->meta, hm.data(), n);
   }
   if (ok && n) {
     std::vector<int32_t> order(n);
@@ -256,6 +275,7 @@ int asl_rescore_knn(asl_library_t *L, const asl_peaks_t *queries, const asl_sear
   PrecFilter flt;
   flt.lib_pmz = L->pmz32.p;
   flt.valid = L->has_valid ? L->valid.p : nullptr;
+  flt.meta = L->meta.p;
   flt.tol = P->precursor_tol;
   flt.mode = P->precursor_mode;
   flt.charge = P->charge;
@@ -311,6 +331,7 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
     PrecFilter flt;
     flt.lib_pmz = L->pmz32.p;
     flt.valid = L->has_valid ? L->valid.p : nullptr;
+    flt.meta = L->meta.p;
     flt.tol = P->precursor_tol;
     flt.mode = P->precursor_mode;
     flt.charge = P->charge;
