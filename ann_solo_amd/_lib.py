@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libannsolo_mi.so')
+# ASL_LIB_PATH: load another build of the same library (same-box A/B measurements)
+LIB_PATH = os.environ.get('ASL_LIB_PATH') or os.path.join(_HERE, 'libannsolo_mi.so')
 _lib = None
 
 c_f32p = C.POINTER(C.c_float)

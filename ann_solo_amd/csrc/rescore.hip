@@ -572,6 +572,10 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
   wave_sync();
   const int MA = (dbg & 16) ? 0 : __builtin_amdgcn_readfirstlane(Wv.pad[0]);
   const int MB = (dbg & 16) ? 0 : __builtin_amdgcn_readfirstlane(Wv.pad[1]);
+  if (MA == 0 && MB == 0) {   // wave-uniform: nothing matched
+    scoreA = scoreB = 0.0;
+    return;
+  }
   int ok = 0;
   if (MA <= 32 && MB <= 32 && !(dbg & 128)) ok = resolve_two_fast(lane, Wv, MA, MB, scoreA, scoreB);
   if (!(ok & 1))
