@@ -89,7 +89,7 @@ class HipShardBackend:
         tol_val, tol_mode = sl._tolerance(self.mode)
         q = queries.to(self.device).contiguous()
         nq = q.n
-        stride = int((q.offsets[1:] - q.offsets[:-1]).max()) if nq else 1
+        stride = q.max_peaks()
         if device_out:
             mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=self.device)
             best_row, best_score = mk((nq,), torch.int32), mk((nq,), torch.float64)

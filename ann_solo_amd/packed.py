@@ -40,17 +40,36 @@ class PackedSpectra:
     def device(self):
         return self.mz.device
 
+    def max_peaks(self) -> int:
+        """Largest peak count of a spectrum (>= 1); computed once per pack and cached -- it
+        sizes the peak-match tables and would otherwise cost a device round trip per batch."""
+        m = getattr(self, '_max_peaks', None)
+        if m is None:
+            m = int((self.offsets[1:] - self.offsets[:-1]).max()) if self.n else 1
+            self._max_peaks = m = max(m, 1)
+        return m
+
     def to(self, device) -> 'PackedSpectra':
-        return PackedSpectra(*(t.to(device) for t in self._tensors()),
-                             identifiers=self.identifiers)
+        if torch.device(device) == self.mz.device:
+            return self
+        out = PackedSpectra(*(t.to(device) for t in self._tensors()),
+                            identifiers=self.identifiers)
+        if getattr(self, '_max_peaks', None) is not None:
+            out._max_peaks = self._max_peaks
+        return out
 
     def _tensors(self):
         return (self.offsets, self.mz, self.intensity, self.charge, self.precursor_mz,
                 self.precursor_charge)
 
     def contiguous(self):
-        return PackedSpectra(*(t.contiguous() for t in self._tensors()),
-                             identifiers=self.identifiers)
+        if all(t.is_contiguous() for t in self._tensors()):
+            return self
+        out = PackedSpectra(*(t.contiguous() for t in self._tensors()),
+                            identifiers=self.identifiers)
+        if getattr(self, '_max_peaks', None) is not None:
+            out._max_peaks = self._max_peaks
+        return out
 
     def select(self, rows) -> 'PackedSpectra':
         """Gather a subset of spectra (rows: 1-D int tensor/array) into a new pack."""

@@ -225,7 +225,7 @@ class SpectralLibrary:
         q = queries.to(self.device).contiguous()
         nq = q.n
         k = self._num_candidates
-        stride = int((q.offsets[1:] - q.offsets[:-1]).max()) if nq else 1
+        stride = q.max_peaks()
         xp = torch if device_out else np
         kw = dict(device=self.device) if device_out else {}
         mk = (lambda shape, dt: torch.empty(shape, dtype=dt, **kw)) if device_out else \
