@@ -90,6 +90,15 @@ bool prof_enabled() { return g_prof_on; }
 void prof_add_scanned(int64_t v) {
   if (g_prof_on) g_scanned += v;
 }
+// device-side accumulator of scanned vectors: kernels add to it, nothing waits inside a step
+static unsigned long long *g_scanned_dev = nullptr;
+unsigned long long *prof_scanned_dev() {
+  if (!g_scanned_dev) {
+    if (hipMalloc((void **)&g_scanned_dev, sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(g_scanned_dev, 0, sizeof(unsigned long long), g_stream);
+  }
+  return g_scanned_dev;
+}
 
 static void prof_collect(StageProf &sp) {
   for (auto &ev : sp.pending) {
@@ -148,6 +157,7 @@ int asl_profile_reset(void) {
     kv.second.launches = 0;
   }
   g_scanned = 0;
+  if (g_scanned_dev) (void)hipMemsetAsync(g_scanned_dev, 0, sizeof(unsigned long long), g_stream);
   return ASL_OK;
 }
 
@@ -164,7 +174,12 @@ int asl_profile_get(const char *stage, double *total_ms, int64_t *launches) {
   return ASL_OK;
 }
 
-int64_t asl_profile_scanned_vectors(void) { return g_scanned; }
+int64_t asl_profile_scanned_vectors(void) {
+  unsigned long long dev = 0;
+  if (g_scanned_dev && hipMemcpyAsync(&dev, g_scanned_dev, sizeof(dev), hipMemcpyDeviceToHost, g_stream) == hipSuccess)
+    (void)hipStreamSynchronize(g_stream);
+  return g_scanned + (int64_t)dev;
+}
 
 }  // extern "C"
 

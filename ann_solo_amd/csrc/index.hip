@@ -93,7 +93,6 @@ struct asl_index {
   DevBuf<float> ws_scores, coarse_D, ws_x;
   DevBuf<int32_t> coarse_I, ws_assign;
   DevBuf<uint32_t> bitmap;
-  DevBuf<unsigned long long> ws_count;
 };
 
 namespace asl {
@@ -370,12 +369,9 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
                                    ix->tile_nnz.p, ix->nnz_stride, ix->ids_tiled.p, k, D, I64, I32));
         }
         if (prof_enabled()) {
-          ASL_TRY(ix->ws_count.reserve(1));
-          ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, ix->ws_count.p));
-          unsigned long long sc = 0;
-          HIP_TRY(hipMemcpyAsync(&sc, ix->ws_count.p, 8, hipMemcpyDeviceToHost, stream()));
-          ASL_TRY(sync_stream());
-          prof_add_scanned((int64_t)sc);
+          // vectors scored by this launch, summed on the device (nothing waits inside a step)
+    if (unsigned long long *acc = prof_scanned_dev())
+      ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
         }
         return ASL_OK;
       }
@@ -383,14 +379,11 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       ASL_TRY(ix->bitmap.reserve((size_t)nq * words));
       ASL_TRY(probe_bitmap(ix->coarse_I.p, nq, nprobe, ix->bitmap.p, words));
       if (n > 0 && prof_enabled()) {
-        ASL_TRY(ix->ws_count.reserve(1));
-        // algorithmic work: vectors in probed lists (needs list sizes)
+                // algorithmic work: vectors in probed lists (needs list sizes)
         ASL_TRY(build_lists(ix));
-        ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, ix->ws_count.p));
-        unsigned long long sc = 0;
-        HIP_TRY(hipMemcpyAsync(&sc, ix->ws_count.p, 8, hipMemcpyDeviceToHost, stream()));
-        ASL_TRY(sync_stream());
-        prof_add_scanned((int64_t)sc);
+// vectors scored by this launch, summed on the device (nothing waits inside a step)
+    if (unsigned long long *acc = prof_scanned_dev())
+      ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
       }
     }
     const int64_t ncol = std::max<int64_t>(n, 1);
@@ -451,12 +444,9 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
                       I64, I32));
   }
   if (prof_enabled()) {
-    ASL_TRY(ix->ws_count.reserve(1));
-    ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, ix->ws_count.p));
-    unsigned long long sc = 0;
-    HIP_TRY(hipMemcpyAsync(&sc, ix->ws_count.p, 8, hipMemcpyDeviceToHost, stream()));
-    ASL_TRY(sync_stream());
-    prof_add_scanned((int64_t)sc);
+    // vectors scored by this launch, summed on the device (nothing waits inside a step)
+    if (unsigned long long *acc = prof_scanned_dev())
+      ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
   }
   return ASL_OK;
 }

@@ -700,7 +700,7 @@ __global__ void scanned_count_kernel(const int32_t *__restrict__ coarse_I, int64
 }
 int scanned_count(const int32_t *coarse_I, int64_t n, const int32_t *list_offsets,
                   unsigned long long *out_dev) {
-  HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(unsigned long long), stream()));
+  // accumulates into out_dev (the caller owns its zeroing)
   hipLaunchKernelGGL(scanned_count_kernel, dim3(256), dim3(256), 0, stream(), coarse_I, n,
                      list_offsets, out_dev);
   ASL_CHECK_LAUNCH();
