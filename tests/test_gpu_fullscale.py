@@ -1,0 +1,118 @@
+"""BASELINE-scale (configs[2]: 2.1 M spectra, IVF-PQ m = 32, nlist 4096, nprobe 128, k 1024)
+checks through size-independent properties -- the oracle cannot enumerate this size in test
+time, so only a sample of queries is compared with it:
+  order / uniqueness / padding of the result rows, determinism, unordered rows == sorted rows
+  as sets, search_preassigned == search, three-way sharding + merge == unsharded, the fused
+  path's winners == the oracle's best match over the returned neighbours (sampled)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_LIB = int(os.environ.get('ASL_FULLSCALE_N', 2_100_000))
+
+
+@pytest.fixture(scope='module')
+def world():
+    import torch
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    dev = torch.device('cuda', 0)
+    lib, aux = synthetic.make_library(N_LIB, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
+    cfg = Config(num_list=4096, num_probe=128, num_candidates=1024, index='ivfpq', pq_m=32,
+                 kmeans_niter=2, precursor_tolerance_mass_open=500.0,
+                 precursor_tolerance_mode_open='Da', batch_size=16384, seed=1234)
+    sl = SpectralLibrary(lib, config=cfg, device=dev)
+    q, truth = synthetic.make_queries(lib, aux, 2048, seed=42, open_range=500.0, charge=2)
+    yield sl, q, truth
+    sl.shutdown()
+
+
+def test_result_rows_are_ordered_unique_and_deterministic(world):
+    import torch
+    sl, q, _ = world
+    idx = sl._get_ann_index(2)
+    vec = sl._encode(q)
+    D, I = idx.search(vec, 1024)
+    assert (I >= 0).all() and int(I.max()) < N_LIB                    # 128 lists always hold >= k vectors here
+    assert (D[:, 1:] <= D[:, :-1]).all()                              # descending scores
+    tie = D[:, 1:] == D[:, :-1]
+    assert (I[:, 1:][tie] > I[:, :-1][tie]).all()                     # ties: ascending id
+    assert (I.sort(1)[0][:, 1:] != I.sort(1)[0][:, :-1]).all()        # unique ids per row
+    D2, I2 = idx.search(vec, 1024)
+    assert torch.equal(I, I2) and torch.equal(D, D2)                  # same bits on a second call
+    idx.set_unordered(True)
+    try:
+        Du, Iu = idx.search(vec, 1024)
+    finally:
+        idx.set_unordered(False)
+    o, ou = I.sort(1), Iu.sort(1)
+    assert torch.equal(o[0], ou[0])
+    assert torch.equal(D.gather(1, o[1]), Du.gather(1, ou[1]))
+    cD, cI = idx.coarse(vec, 128)
+    assert (cD[:, 1:] <= cD[:, :-1]).all()
+    Dp, Ip = idx.search_preassigned(vec, 1024, cD, cI)
+    assert torch.equal(Ip, I) and torch.equal(Dp, D)
+    # fewer probes can only remove candidates: the nprobe-32 list is a subset of what the
+    # 32 best lists hold, and its scores are the same numbers
+    idx.nprobe = 32
+    D32, I32 = idx.search(vec[:256], 1024)
+    idx.nprobe = 128
+    hit = (I32.unsqueeze(2) == I[:256].unsqueeze(1)).any(2)
+    assert (hit | (D32 <= D[:256, -1:])).all()                        # (equal scores may tie out)
+
+
+def test_three_shards_merge_to_the_unsharded_result(world, tmp_path):
+    import torch
+    from ann_solo_amd import faiss_compat as faiss
+    sl, q, _ = world
+    idx = sl._get_ann_index(2)
+    vec = sl._encode(q)[:1024].contiguous()
+    D, I = idx.search(vec, 1024)
+    path = os.path.join(tmp_path, 'full_abc1234_2.idxann')
+    faiss.write_index(idx, path)
+    owner = idx.shard_map(3)
+    assert set(owner.tolist()) == {0, 1, 2}
+    parts = []
+    for r in range(3):
+        sh = faiss.read_index(path)
+        sh.nprobe = 128
+        sh.shard(r, 3)
+        sh.set_unordered(True)
+        assert 0 < sh.info().nlocal < N_LIB
+        parts.append(sh.search(vec, 1024))
+        del sh
+    Dm, Im = faiss.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(Im, I) and torch.equal(Dm, D)
+
+
+def test_fused_search_winners_equal_the_oracle_on_a_sample(world, O):
+    sl, q, truth = world
+    res = sl._search_batch(q, 2, 'open', want_knn=True)
+    res2 = sl._search_batch(q, 2, 'open')                             # production call (set mode)
+    assert np.array_equal(res.best_row, res2.best_row) and np.array_equal(res.best_score, res2.best_score)
+    part = sl.partitions[2]
+    rows = np.arange(0, q.n, 32)                                      # 64 sampled queries
+    Q = O.Spectra(*q.numpy())
+    # the library pack is too large to hand to the oracle whole: gather the candidates' spectra
+    o, mz, it, chg, pmz, pz = part.spectra.to('cpu').numpy()
+    pmz32 = part.precursor_mz
+    for i in rows:
+        knn = res.knn[i]
+        cand = np.sort(np.array([r for r in knn if r >= 0 and O.precursor_ok(
+            float(q.precursor_mz[i]), pmz32[r], 2, 500.0, 'Da')], np.int64))
+        assert res.n_candidates[i] == len(cand)
+        if len(cand) == 0:
+            assert res.best_row[i] == -1
+            continue
+        off = np.concatenate([[0], np.cumsum(o[cand + 1] - o[cand])])
+        sel = np.concatenate([np.arange(o[r], o[r + 1]) for r in cand])
+        sub = O.Spectra(off, mz[sel], it[sel], chg[sel], pmz[cand], pz[cand])
+        b, s, m = O.best_match(Q, int(i), sub, np.arange(len(cand), dtype=np.int64), 0.02, True)
+        assert res.best_row[i] == cand[b] and res.best_score[i] == s
+        assert res.peak_matches(int(i)).tolist() == m.tolist()
+    src = truth['source_row'].cpu().numpy()
+    unmod = ~truth['is_modified'].cpu().numpy()
+    assert (res.best_row[unmod] == src[unmod]).mean() > 0.75          # kmeans_niter = 2: coarse but sane
