@@ -673,11 +673,11 @@ __global__ __launch_bounds__(64 * RS_WAVES, 7) void rescore_score_v2_kernel(
 
     for (int base = wb; base < we; base += 64) {
       const bool okr = base + lane < we;
-      const long long c = okr ? sb + s_list[base + lane] : -1;
+      const int slot = okr ? (int)s_list[base + lane] : 0;   // candidate slot = sb + slot
       int m_co = 0, m_cn = 0, m_chg = 0;
       double m_pmz = 0.0;
       if (okr) {
-        const long long row = cv.row(c);
+        const long long row = cv.row(sb + slot);
         if (cv.flt.meta) {     // one 32-byte sector per candidate
           const uint4 a = *reinterpret_cast<const uint4 *>(&cv.flt.meta[row]);
           m_co = (int)a.x;
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 7) void rescore_score_v2_kernel(
         }
         wave_sync();
       }
-      if (okr) pair_score[c] = my_score;
+      if (okr) pair_score[sb + slot] = my_score;
       if (__ballot(okr && my_score == RS_DEFER) && lane == 0) s_defer = 1;
     }
     __syncthreads();   // s_list is rebuilt for the next super-chunk
