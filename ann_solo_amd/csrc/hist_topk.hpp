@@ -73,6 +73,7 @@ struct HistTopK {
   int k, tid, lane, wave;
   int fill, parity, round_no;
   bool sort_mode;
+  bool out_keys = false;   // rows of packed (score, ~id) keys in I64 instead of (D, ids)
   // per-round snapshot
   int bstar;
   uint32_t thr_hi;
@@ -199,7 +200,8 @@ struct HistTopK {
   __device__ __forceinline__ void finish_set(float *D, int64_t *I64, int32_t *I32, u64 *scratch) {
     __syncthreads();
     if (sort_mode) {               // exact flushes were in use: the sorted row is a valid set
-      tk.finish(D, I64, I32, tid);
+      tk.emit_keys = out_keys;
+      tk.finish(out_keys ? nullptr : D, I64, out_keys ? nullptr : I32, tid);
       return;
     }
     fill = compact();
@@ -233,6 +235,10 @@ struct HistTopK {
     const int n_above = tot & 0xffff, n_bound = tot >> 16;
     int pa = pre & 0xffff, pb = pre >> 16;
     auto emit = [&](int pos, u64 key) {
+      if (out_keys) {
+        I64[pos] = (int64_t)key;
+        return;
+      }
       if (D) D[pos] = key_score(key);
       if (I64) I64[pos] = (int64_t)key_id(key);
       if (I32) I32[pos] = (int32_t)key_id(key);
@@ -258,6 +264,10 @@ struct HistTopK {
       if (rank < take) emit(n_above + rank, key);
     }
     for (int i = n_above + take + tid; i < k; i += NT) {
+      if (out_keys) {
+        I64[i] = 0;
+        continue;
+      }
       if (D) D[i] = -3.402823466e+38f;
       if (I64) I64[i] = -1;
       if (I32) I32[i] = -1;
@@ -273,7 +283,8 @@ struct HistTopK {
       tk.conv_from = 0;
     }
     if (ts) ts[0] = wall_clock64();   // measurement: after the compaction
-    tk.finish(D, I64, I32, tid, ts ? ts + 1 : nullptr);
+    tk.emit_keys = out_keys;
+    tk.finish(out_keys ? nullptr : D, I64, out_keys ? nullptr : I32, tid, ts ? ts + 1 : nullptr);
   }
 };
 

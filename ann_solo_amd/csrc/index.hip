@@ -87,7 +87,7 @@ struct asl_index {
   int nnz_stride = 0;
   bool has_sparse = false;
   int scan_variant = 0;  // 0 = auto (v2 when supported), 1 = force v1
-  bool unordered = false;  // search rows = exact top-k as a set, unspecified order (no final sort)
+  int unordered = 0;  // 1: search rows = exact top-k as a set, unspecified order (no final sort); 2: rows of packed keys
   bool lists_dirty = true;
   // scratch
   DevBuf<float> ws_scores, coarse_D, ws_x;
@@ -353,6 +353,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   const int d = ix->d;
   const int64_t n = ix->n_store;
   if (ix->kind == ASL_INDEX_FLAT || ix->kind == ASL_INDEX_IVFFLAT) {
+    if (ix->unordered == 2) return fail(ASL_ERR_STATE, "packed-key rows need an IVF-PQ index");
     const bool ivf = ix->kind == ASL_INDEX_IVFFLAT;
     int words = 0;
     if (ivf) {
@@ -416,6 +417,9 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   {
     ProfScope ps("scan");
     const int sv = ix->scan_variant & 0xff;
+    if (ix->unordered == 2 &&
+        !(ix->has_tiles && sv != 1 && sv != 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe) && I64))
+      return fail(ASL_ERR_STATE, "packed-key rows need the tiled IVF-PQ scan (m = 32, 8 bits) and an int64 output");
     if (ix->has_tiles && sv != 1 && sv != 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe)) {
       if (!ix->cbt_ready) {
         const size_t ncb = (size_t)ix->pq_m * ix->ksub * ix->dsub;
@@ -432,7 +436,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       }
       ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks_t.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
-                         ix->ids_tiled.p, k, D, I64, I32, sv, (set_mode || ix->unordered) ? 1 : 0,
+                         ix->ids_tiled.p, k, D, I64, I32, sv, ix->unordered ? ix->unordered : (set_mode ? 1 : 0),
                          ix->scan_variant >> 8));
     } else if (ix->has_tiles && sv == 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
       ASL_TRY(pq_scan_v2(xq, nq, d, ix->codebooks.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
@@ -496,7 +500,8 @@ void asl_index_free(asl_index_t *ix) { delete ix; }
 int asl_index_set_unordered(asl_index_t *ix, int32_t unordered) {
   clear_error();
   if (!ix) return fail(ASL_ERR_INVALID, "set_unordered: null index");
-  ix->unordered = unordered != 0;
+  if (unordered < 0 || unordered > 2) return fail(ASL_ERR_INVALID, "set_unordered: mode must be 0, 1 or 2");
+  ix->unordered = unordered;
   return ASL_OK;
 }
 
@@ -879,6 +884,24 @@ int asl_topk_merge(int32_t S, int32_t nq, int32_t k, const float *Ds, const int6
   ASL_TRY(dD.finish());
   ASL_TRY(dI.finish());
   if (dD.to_host() || dI.to_host() || dDs.own.p || dIs.own.p) ASL_TRY(sync_stream());
+  return ASL_OK;
+}
+
+int asl_topk_merge_keys(int32_t S, int32_t nq, int32_t k, const int64_t *Ks, float *D, int64_t *I) {
+  clear_error();
+  if (S <= 0 || nq < 0 || k <= 0 || !Ks || !D || !I) return fail(ASL_ERR_INVALID, "topk_merge_keys: bad arguments");
+  if (nq == 0) return ASL_OK;
+  ASL_TRY(ensure_device());
+  In<int64_t> dKs;
+  Out<float> dD;
+  Out<int64_t> dI;
+  ASL_TRY(dKs.init(Ks, (size_t)S * nq * k));
+  ASL_TRY(dD.init(D, (size_t)nq * k));
+  ASL_TRY(dI.init(I, (size_t)nq * k));
+  ASL_TRY(topk_merge_keys(dKs.d, S, nq, k, dD.d, dI.d));
+  ASL_TRY(dD.finish());
+  ASL_TRY(dI.finish());
+  if (dD.to_host() || dI.to_host() || dKs.own.p) ASL_TRY(sync_stream());
   return ASL_OK;
 }
 

@@ -215,7 +215,8 @@ __global__ __launch_bounds__(TK_NT) void topk_merge_kernel(
 // sorted once. The S lists are visited in interleaved 64-entry chunks, so that (for the
 // usual sorted partial lists) the best entries of every list come first and the
 // threshold bucket rises after the first rounds; reads stay coalesced (256 B per wave).
-template <int CAP, int PT>
+// KEYS: Is holds packed (ord(score) << 32 | ~id) keys (0 = empty), Ds is unused.
+template <int CAP, int PT, bool KEYS = false>
 __global__ __launch_bounds__(HT_NT) void topk_merge_hist_kernel(
     const float *__restrict__ Ds, const int64_t *__restrict__ Is, int S, int nq, int k,
     float *__restrict__ D, int64_t *__restrict__ I) {
@@ -236,18 +237,39 @@ __global__ __launch_bounds__(HT_NT) void topk_merge_hist_kernel(
       bool valid = v < total && j < k;
       float score = 0.0f;
       int64_t id = -1;
+      uint32_t slot = 0;
       if (valid) {
         const size_t o = ((size_t)s * nq + q) * k + j;
-        score = Ds[o];
-        id = Is[o];
+        if (KEYS) {
+          const u64 key = (u64)Is[o];
+          valid = key != 0ull;
+          score = key_score(key);
+          slot = (uint32_t)key;
+        } else {
+          score = Ds[o];
+          id = Is[o];
+          valid = id >= 0;
+          slot = 0xFFFFFFFFu - (uint32_t)id;
+        }
       }
-      valid = valid && id >= 0;
-      const bool take = top.offer(valid, score, 0xFFFFFFFFu - (uint32_t)id);
+      const bool take = top.offer(valid, score, slot);
       appended += __popcll(__ballot(take));
     }
     top.end_round(appended);
   }
   top.finish(D + (size_t)q * k, I + (size_t)q * k, nullptr);
+}
+
+// merge of packed-key lists [S, nq, k] (asl_index_set_unordered mode 2)
+int topk_merge_keys(const int64_t *Ks, int S, int nq, int k, float *D, int64_t *I) {
+  if (nq <= 0) return ASL_OK;
+  if (k <= 0 || k + 256 + 512 > 2048)
+    return fail(ASL_ERR_CAPACITY, "merge_keys: k=%d outside 1..1280", k);
+  hipLaunchKernelGGL((topk_merge_hist_kernel<2048, 2, true>), dim3(nq), dim3(HT_NT),
+                     (HistTopK<2048, HT_NT * 2>::lds_bytes()), stream(), (const float *)nullptr, Ks, S,
+                     nq, k, D, I);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
 }
 
 int topk_merge(const float *Ds, const int64_t *Is, int S, int nq, int k, float *D, int64_t *I) {

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
   const long long t_lut = (dbg & 32) ? wall_clock64() : 0;
   TopK top;   // init zeroes the keys (which aliased s_q)
   top.init(smem, k, ids_tiled, tid);
+  top.out_keys = set_mode == 2 && I64 != nullptr;
   const long long t_init = (dbg & 32) ? wall_clock64() : 0;
 
   const char *lut_bytes = reinterpret_cast<const char *>(s_lut);

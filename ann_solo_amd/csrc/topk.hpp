@@ -197,6 +197,7 @@ struct StreamTopK {
   // gathering slot_ids[slot], so the hot loop never waits on an id load.
   const int32_t *slot_ids = nullptr;
   int conv_from = 0;
+  bool emit_keys = false;   // finish(): I receives the packed keys (0 = empty) instead of ids
 
   __device__ __forceinline__ void init(u64 *b, int *c, u64 *t, int cap_, int k_, int tid) {
     buf = b;
@@ -286,7 +287,7 @@ struct StreamTopK {
       const u64 key = buf[i];
       const bool ok = i < f;
       if (D) D[i] = ok ? key_score(key) : -3.402823466e+38f;
-      if (I) I[i] = ok ? (int64_t)key_id(key) : -1;
+      if (I) I[i] = emit_keys ? (ok ? (int64_t)key : 0) : (ok ? (int64_t)key_id(key) : -1);
       if (I32) I32[i] = ok ? (int32_t)key_id(key) : -1;
     }
   }

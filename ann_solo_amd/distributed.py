@@ -9,7 +9,8 @@ addition. Per batch and charge partition:
   2. every rank searches its own inverted lists for ALL queries: coarse quantiser is
      replicated (identical probe lists everywhere, bit-exact fp32 MFMA chain), the
      PQ/flat scan touches only locally owned lists -> per-shard top-k;
-  3. the exchange: all-to-all of the per-shard top-k so that rank r receives the
+  3. the exchange: all-to-all of the per-shard top-k (IVF-PQ: one packed 8-byte key per hit
+     = order-preserving score bits << 32 | ~id) so that rank r receives the
      ``world`` partial lists of its own query slice (1/world of an all-gather's
      inbound bytes; xGMI is point-to-point, so this maps to direct peer copies). The
      scan runs in a few query chunks and the all-to-all of one chunk is in flight on
@@ -76,7 +77,22 @@ class HipShardBackend:
     def shard_search_preassigned(self, vectors, coarse_D, coarse_I):
         # per-shard rows go straight into the merge, which orders them: skip the shard's sort
         self.index.set_unordered(True)
-        return self.index.search_preassigned(vectors, self.k, coarse_D, coarse_I)
+        try:
+            return self.index.search_preassigned(vectors, self.k, coarse_D, coarse_I)
+        finally:
+            self.index.set_unordered(False)
+
+    # packed 8-byte hits for the exchange (instead of 4-byte score + 8-byte id)
+    @property
+    def supports_keys(self):
+        return self.index.info().kind == 2 and self.k + 256 + 512 <= 2048
+
+    def shard_search_keys(self, vectors, coarse_D, coarse_I):
+        return self.index.search_preassigned_keys(vectors, self.k, coarse_D, coarse_I)
+
+    def merge_keys(self, Ks: torch.Tensor):
+        from . import faiss_compat
+        return faiss_compat.topk_merge_keys(Ks)
 
     def merge(self, Ds: torch.Tensor, Is: torch.Tensor):
         from . import faiss_compat
@@ -139,6 +155,24 @@ def exchange_partials(D: torch.Tensor, I: torch.Tensor, world: int, group=None,
     sl = slice(rank * n, (rank + 1) * n)
     out = (torch.stack([d[sl] for d in Dg]).to(dev), torch.stack([i[sl] for i in Ig]).to(dev))
     return out + ([], None) if async_op else out
+
+
+def exchange_keys(K: torch.Tensor, world: int, group=None):
+    """Packed-key variant of ``exchange_partials``: ONE all-to-all of 8 bytes per hit.
+    Returns ([world, n, k] keys of this rank's n queries, work handles, keep-alive)."""
+    nq_all, k = K.shape
+    n = nq_all // world
+    rank = dist.get_rank(group)
+    if dist.get_backend(group) == 'nccl':
+        Ko = torch.empty_like(K)
+        w = dist.all_to_all_single(Ko, K, group=group, async_op=True)
+        return Ko.view(world, n, k), [w], K
+    dev = K.device
+    Kc = K.cpu()
+    Kg = [torch.empty_like(Kc) for _ in range(world)]
+    dist.all_gather(Kg, Kc, group=group)
+    sl = slice(rank * n, (rank + 1) * n)
+    return torch.stack([g[sl] for g in Kg]).to(dev), [], None
 
 
 def _all_gather_rows(x: torch.Tensor, world: int, group=None) -> torch.Tensor:
@@ -205,11 +239,16 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     rank_base = torch.arange(world, device=allvec.device).unsqueeze(1) * n_local
     results, pending = [], None
 
+    use_keys = co is not None and getattr(backend, 'supports_keys', False)
+
     def finish(p):
-        (Ds, Is, works, _keep), lo, hi = p
-        for w in works:
+        payload, lo, hi = p
+        for w in payload[-2]:
             w.wait()
-        knn = backend.merge(Ds.contiguous(), Is.contiguous())[1]
+        if use_keys:
+            knn = backend.merge_keys(payload[0].contiguous())[1]
+        else:
+            knn = backend.merge(payload[0].contiguous(), payload[1].contiguous())[1]
         sub = queries_local if (lo, hi) == (0, n_local) else queries_local.select(
             torch.arange(lo, hi, device=queries_local.device))
         results.append(backend.rescore_knn(sub, knn, device_out))
@@ -224,9 +263,12 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
             rows = (rank_base + torch.arange(lo, hi, device=allvec.device).unsqueeze(0)).reshape(-1)
             xv = allvec.index_select(0, rows)
             pre = (cD.index_select(0, rows), cI.index_select(0, rows)) if co is not None else None
-        D, I = (backend.shard_search_preassigned(xv, *pre) if pre is not None
-                else backend.shard_search(xv))
-        nxt = (exchange_partials(D, I, world, group, async_op=True), lo, hi)
+        if use_keys:
+            nxt = (exchange_keys(backend.shard_search_keys(xv, *pre), world, group), lo, hi)
+        else:
+            D, I = (backend.shard_search_preassigned(xv, *pre) if pre is not None
+                    else backend.shard_search(xv))
+            nxt = (exchange_partials(D, I, world, group, async_op=True), lo, hi)
         if pending is not None:
             finish(pending)
         pending = nxt

@@ -181,9 +181,30 @@ class Index:
         _lib.check(_lib.lib().asl_index_pq_lut(self._h, x.shape[0], _lib.ptr(x), _lib.ptr(lut)))
         return lut
 
-    def set_unordered(self, flag: bool = True):
-        """Result rows as exact top-k SETS (unspecified order, no final sort)."""
-        _lib.check(_lib.lib().asl_index_set_unordered(self._h, int(bool(flag))))
+    def set_unordered(self, mode=True):
+        """Result rows as exact top-k SETS (unspecified order, no final sort). ``mode`` 2 packs
+        every hit into one 64-bit key in the id output (see ``search_preassigned_keys``)."""
+        _lib.check(_lib.lib().asl_index_set_unordered(self._h, int(mode)))
+
+    def search_preassigned_keys(self, x, k, coarse_D, coarse_I):
+        """Like ``search_preassigned`` but returns ONE int64 array [nq, k] of packed hits
+        (order-preserving score bits << 32 | ~id, 0 = empty, unspecified order): 8 bytes per
+        hit for the exchange of a sharded search; merge with ``topk_merge_keys``."""
+        x = _as_f32(x, self.d)
+        nq, nprobe = coarse_I.shape
+        if isinstance(x, np.ndarray):
+            K = np.empty((nq, k), np.int64)
+        else:
+            import torch
+            K = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+        self.set_unordered(2)
+        try:
+            _lib.check(_lib.lib().asl_index_search_preassigned(
+                self._h, nq, _lib.ptr(x), int(k), int(nprobe), _lib.ptr(coarse_D),
+                _lib.ptr(coarse_I), None, _lib.ptr(K)))
+        finally:
+            self.set_unordered(0)
+        return K
 
     def shard(self, rank: int, world: int):
         _lib.check(_lib.lib().asl_index_shard(self._h, int(rank), int(world)))
@@ -235,6 +256,23 @@ def index_cpu_to_gpu(res, device, index, co=None):
     """Indexes of this library are GPU-resident already; kept for call-site parity
     (spectral_library.py:494)."""
     return index
+
+
+def topk_merge_keys(Ks):
+    """Merge per-shard packed-key rows [S,nq,k] (``search_preassigned_keys``) -> sorted
+    (D [nq,k], I [nq,k])."""
+    S, nq, k = Ks.shape
+    if isinstance(Ks, np.ndarray):
+        Ks = np.ascontiguousarray(Ks, np.int64)
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+    else:
+        import torch
+        Ks = Ks.contiguous()
+        D = torch.empty((nq, k), dtype=torch.float32, device=Ks.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=Ks.device)
+    _lib.check(_lib.lib().asl_topk_merge_keys(S, nq, k, _lib.ptr(Ks), _lib.ptr(D), _lib.ptr(I)))
+    return D, I
 
 
 def topk_merge(Ds, Is):

@@ -117,10 +117,15 @@ int asl_index_get_lists(const asl_index_t *idx, int32_t *list_offsets /* [nlist+
  * of the expected scan load, weight = list size squared; identical on every rank, see
  * asl_lpt_owner). Must be called after add(). search() then
  * returns this shard's partial top-k; combine with asl_topk_merge. */
-/* Unordered result rows: subsequent IVF-PQ searches return the exact top-k of every query
- * as a SET -- same ids and scores, unspecified order inside the row, padding last -- and skip
- * the final sort. For consumers that re-order anyway (asl_topk_merge of shard results). */
-int asl_index_set_unordered(asl_index_t *idx, int32_t unordered);
+/* Unordered result rows: with mode 1 subsequent IVF-PQ searches return the exact top-k of
+ * every query as a SET -- same ids and scores, unspecified order inside the row, padding last
+ * -- and skip the final sort. For consumers that re-order anyway (asl_topk_merge of shard
+ * results). Mode 2 additionally packs every hit into one 64-bit key in the int64 output
+ * (order-preserving score bits << 32 | ~id, 0 = empty; D is not written): 8 instead of 12
+ * bytes per hit on the wire of a sharded search; merge with asl_topk_merge_keys. 0 = sorted. */
+int asl_index_set_unordered(asl_index_t *idx, int32_t mode);
+/* Merge of S packed-key lists Ks[S, nq, k] (mode 2 above) -> sorted D[nq,k], I[nq,k]; k <= 1280. */
+int asl_topk_merge_keys(int32_t S, int32_t nq, int32_t k, const int64_t *Ks, float *D, int64_t *I);
 int asl_index_shard(asl_index_t *idx, int32_t rank, int32_t world);
 /* list -> owner rank map of the balancing above, for inspection. */
 int asl_index_shard_map(const asl_index_t *idx, int32_t world, int32_t *owner /* [nlist] */);

@@ -174,6 +174,54 @@ def test_unordered_rows_hold_the_same_top_k(vecs, pq_index, k, nprobe):
     assert np.array_equal(I2, I)
 
 
+def test_packed_key_rows_and_their_merge(vecs, trained):
+    """Mode 2 of asl_index_set_unordered: one 64-bit key per hit carries exactly the (score, id)
+    of the ordinary search; asl_topk_merge_keys over three shards reproduces the unsharded rows;
+    indexes without the tiled PQ scan refuse the mode."""
+    from ann_solo_amd import _lib
+    from ann_solo_amd import faiss_compat as faiss
+    xb, xq = vecs
+    cen, cb = trained
+
+    def make():
+        ix = faiss.IndexIVFPQ(faiss.IndexFlatIP(800), 800, 16, 32, 8)
+        ix.set_trained(cen, cb)
+        ix.add(xb)
+        ix.nprobe = 8
+        return ix
+    full = make()
+    for k in (1024, 100, 7):
+        D, I = full.search(xq, k)
+        cD, cI = full.coarse(xq, 8)
+        K = full.search_preassigned_keys(xq, k, cD, cI).view(np.uint64)
+        ids = np.where(K != 0, 0xFFFFFFFF - (K & np.uint64(0xFFFFFFFF)).astype(np.int64), -1)
+        ordb = (K >> np.uint64(32)).astype(np.uint32)
+        bits = np.where(ordb & 0x80000000, ordb & 0x7fffffff, ~ordb).astype(np.uint32)   # ord2f
+        for r in range(len(xq)):
+            n = int((I[r] >= 0).sum())
+            assert (ids[r] >= 0).sum() == n
+            o, ok = np.argsort(I[r, :n]), np.argsort(np.where(ids[r] >= 0, ids[r], 1 << 40))[:n]
+            assert np.array_equal(I[r, :n][o], ids[r][ok])
+            assert np.array_equal(D[r, :n][o].view(np.uint32), bits[r][ok])
+        D2, I2 = full.search(xq, k)
+        assert np.array_equal(I2, I)                       # the mode does not stick
+    D, I = full.search(xq, 1024)
+    cD, cI = full.coarse(xq, 8)
+    parts = []
+    for r in range(3):
+        sh = make()
+        sh.shard(r, 3)
+        parts.append(sh.search_preassigned_keys(xq, 1024, cD, cI))
+    Dm, Im = faiss.topk_merge_keys(np.stack(parts))
+    assert np.array_equal(Im, I) and np.array_equal(Dm.view(np.uint32), D.view(np.uint32))
+    flat = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    flat.set_trained(cen)
+    flat.add(xb)
+    flat.set_unordered(2)
+    with pytest.raises(_lib.AnnSoloMiError):
+        flat.search(xq, 10)
+
+
 def test_coarse_and_lut_bit_exact(O, vecs, pq_index):
     _, xq = vecs
     idx, ivf = pq_index
