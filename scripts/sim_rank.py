@@ -44,9 +44,9 @@ def timed(fn, reps=3):
 
 t_enc, vec = timed(lambda: be.encode(q))
 t_coarse, _ = timed(lambda: be.coarse(vec))
-t_scan, (D, I) = timed(lambda: be.shard_search_preassigned(allvec, cD, cI))
-Ds, Is = D.view(W, batch, -1).contiguous(), I.view(W, batch, -1).contiguous()
-t_merge, (_, knn) = timed(lambda: be.merge(Ds, Is))
+t_scan, K = timed(lambda: be.shard_search_keys(allvec, cD, cI))
+Ks = K.view(W, batch, -1).contiguous()
+t_merge, (_, knn) = timed(lambda: be.merge_keys(Ks))
 t_resc, _ = timed(lambda: be.rescore_knn(q, knn, True))
 tot = t_enc + t_coarse + t_scan + t_merge + t_resc
 print(f'W={W} batch/rank={batch} variant={variant}: encode {t_enc:.2f} coarse {t_coarse:.2f} '
