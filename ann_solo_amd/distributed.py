@@ -175,16 +175,19 @@ def exchange_keys(K: torch.Tensor, world: int, group=None):
     return torch.stack([g[sl] for g in Kg]).to(dev), [], None
 
 
-def _all_gather_rows(x: torch.Tensor, world: int, group=None) -> torch.Tensor:
-    """Concatenate every rank's [n, ...] tensor along dim 0 (rank order)."""
+def _all_gather_rows(x: torch.Tensor, world: int, group=None, async_op: bool = False):
+    """Concatenate every rank's [n, ...] tensor along dim 0 (rank order). With ``async_op``
+    returns (tensor, work-or-None); ``work.wait()`` before the tensor is read."""
     if dist.get_backend(group) == 'nccl':
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype,
                           device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
-        return out
+        x = x.contiguous()
+        w = dist.all_gather_into_tensor(out, x, group=group, async_op=async_op)
+        return (out, w) if async_op else out
     parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(world)]
     dist.all_gather(parts, x.cpu().contiguous(), group=group)
-    return torch.cat(parts).to(x.device)
+    out = torch.cat(parts).to(x.device)
+    return (out, None) if async_op else out
 
 
 def _concat_results(parts):
@@ -228,10 +231,13 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
         D, I = backend.shard_search(vec)
         return backend.rescore_knn(queries_local, I, device_out)
     n_local = vec.shape[0]
-    allvec = _all_gather_rows(vec, world, group)
+    # the gather of the hashed vectors travels while the coarse quantiser runs on the own slice
+    allvec, w_vec = _all_gather_rows(vec, world, group, async_op=True)
     co = backend.coarse(vec) if getattr(backend, 'supports_preassigned', False) else None
     if co is not None:
         cD, cI = _all_gather_rows(co[0], world, group), _all_gather_rows(co[1], world, group)
+    if w_vec is not None:
+        w_vec.wait()
     if chunks is None:
         chunks = 4 if dist.get_backend(group) == 'nccl' else 2
     chunks = max(1, min(chunks, n_local))
