@@ -31,6 +31,33 @@ def test_every_declared_symbol_is_exported():
     assert b'gfx950' in L.asl_version()
 
 
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/annsolo_mi.h compiles as strict C99 and a C program
+    links against libannsolo_mi.so without any C++ or HIP header."""
+    import shutil
+    import subprocess
+    if not shutil.which('gcc'):
+        pytest.skip('gcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from ann_solo_amd import _lib
+    src = os.path.join(tmp_path, 't.c')
+    with open(src, 'w') as f:
+        f.write('#include <stdio.h>\n#include "annsolo_mi.h"\n'
+                'int main(void) { int64_t n; double a, b;\n'
+                '  if (asl_get_dim(11, 2010, 0.04, &n, &a, &b)) return 2;\n'
+                '  printf("%lld %d %s\\n", (long long)n, asl_hash_idx(12345, 800, 42), asl_version());\n'
+                '  return 0; }\n')
+    exe = os.path.join(tmp_path, 't')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror',
+                           '-I', os.path.join(root, 'include'), src, _lib.LIB_PATH,
+                           '-Wl,-rpath,' + os.path.dirname(_lib.LIB_PATH), '-o', exe])
+    env = dict(os.environ, LD_LIBRARY_PATH='/opt/rocm/lib:' + os.environ.get('LD_LIBRARY_PATH', ''))
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=60)
+    assert out.returncode == 0, out.stderr
+    n, h, ver = out.stdout.split()[:3]
+    assert (int(n), int(h)) == (49976, 584)          # SURVEY.md 8c: get_dim / hash_idx known answers
+
+
 def test_host_only_entry_points_match_golden(O, golden):
     from ann_solo_amd import spectrum
     g = golden('encoder_golden.npz')
