@@ -2,14 +2,17 @@
 // Replaces get_best_match (/root/reference/src/ann_solo/spectrum_match.pyx:28-108)
 // and SpectrumMatcher::dot (/root/reference/src/ann_solo/SpectrumMatch.cpp:8-133).
 //
-// Pass 1 (rescore_score_kernel): one workgroup per query, one 64-lane wavefront
-// per (query, candidate) pair. Query peaks sit in LDS for the whole workgroup;
-// each wave stages its candidate's peaks in LDS, lanes = query peaks run the
-// window search for every shift (binary search instead of the reference's
-// running cursor -- same cursor value because both peak lists ascend), matches
-// go to an LDS list keyed (product desc, generation order asc), a wave-level
-// bitonic sort orders them and a scalar-unit greedy loop assigns them one to one.
-// Only the double score leaves the kernel.
+// Pass 1 (rescore_score_v2_kernel): one workgroup per query. The query's peaks are hashed
+// once into LDS (m/z bins of width 2*tol + a bitmap of occupied bins); the candidate list is
+// filtered (precursor window, rescore.hpp) and compacted in LDS; every wave scores two
+// candidates at a time, one per half-wave, lanes = candidate peaks probing the hash for every
+// shift; matches go to per-half LDS lists keyed (product desc, generation order asc) and are
+// resolved by a conflict-free fast path (exact fp64 tree sum) or a bitonic sort + scalar
+// greedy loop. Built for 7 waves per SIMD. Cases outside its LDS budget are marked and
+// scored by the binary-search formulation:
+// Pass 1b (rescore_score_kernel): one wave per (query, candidate) pair, lanes = query
+// peaks, cursor by binary search (same cursor value as the reference's running cursor
+// because both peak lists ascend). Also the whole pass 1 under ASL_RESCORE_V1.
 // Pass 2 (rescore_argmax_kernel): per query first-strict-maximum (cpp:118-129).
 // Pass 3 (rescore_matches_kernel): the winning pair is re-run once per query to
 // emit its peak_matches in greedy order.
