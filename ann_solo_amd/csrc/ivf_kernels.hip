@@ -3,12 +3,15 @@
 // /root/reference/src/ann_solo/spectral_library.py:167-181,443-445 and adds the
 // IVF-PQ the north star asks for).
 //
-//   row_topk_kernel   exact top-k of one score row per workgroup (coarse top-nprobe,
-//                     IndexFlatIP, and IVF-Flat through a probed-list bitmap mask)
+//   row_select_kernel exact top-k of a SHORT score row held in registers (the coarse
+//                     top-nprobe of nlist): one histogram pass, one small sort
+//   row_topk_kernel   exact streaming top-k of one score row per workgroup (IndexFlatIP,
+//                     long rows, and IVF-Flat through a probed-list bitmap mask)
 //   pq_scan_kernel    per query: per-query ADC look-up table built in LDS, the
 //                     packed PQ codes of the probed lists streamed from HBM
 //                     (32 B/vector, coalesced 16-B loads), fused exact top-k
-//   topk_merge_kernel merge of per-shard / per-chunk partial top-k lists
+//   topk_merge_hist_kernel / topk_merge_kernel  merge of per-shard partial top-k lists
+//                     ((score, id) pairs or packed 64-bit keys), histogram-threshold selection
 //   + small helpers (bitmap, argmax, residual/encode, gathers, L2 assignment)
 #include <algorithm>
 
