@@ -130,7 +130,7 @@ def lib():
         L.asl_index_set_scan_variant.argtypes = [C.c_void_p, C.c_int32]
         L.asl_index_set_unordered.argtypes = [C.c_void_p, C.c_int32]
         L.asl_topk_merge_keys.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                          C.c_void_p]
+                                          C.c_void_p, C.c_int32]
         L.asl_index_info.argtypes = [C.c_void_p, C.POINTER(AslIndexInfo)]
         L.asl_index_get_centroids.argtypes = [C.c_void_p, C.c_void_p]
         L.asl_index_get_codebooks.argtypes = [C.c_void_p, C.c_void_p]

@@ -887,9 +887,10 @@ int asl_topk_merge(int32_t S, int32_t nq, int32_t k, const float *Ds, const int6
   return ASL_OK;
 }
 
-int asl_topk_merge_keys(int32_t S, int32_t nq, int32_t k, const int64_t *Ks, float *D, int64_t *I) {
+int asl_topk_merge_keys(int32_t S, int32_t nq, int32_t k, const int64_t *Ks, float *D, int64_t *I,
+                        int32_t unordered) {
   clear_error();
-  if (S <= 0 || nq < 0 || k <= 0 || !Ks || !D || !I) return fail(ASL_ERR_INVALID, "topk_merge_keys: bad arguments");
+  if (S <= 0 || nq < 0 || k <= 0 || !Ks || !I) return fail(ASL_ERR_INVALID, "topk_merge_keys: bad arguments");
   if (nq == 0) return ASL_OK;
   ASL_TRY(ensure_device());
   In<int64_t> dKs;
@@ -898,7 +899,7 @@ int asl_topk_merge_keys(int32_t S, int32_t nq, int32_t k, const int64_t *Ks, flo
   ASL_TRY(dKs.init(Ks, (size_t)S * nq * k));
   ASL_TRY(dD.init(D, (size_t)nq * k));
   ASL_TRY(dI.init(I, (size_t)nq * k));
-  ASL_TRY(topk_merge_keys(dKs.d, S, nq, k, dD.d, dI.d));
+  ASL_TRY(topk_merge_keys(dKs.d, S, nq, k, dD.d, dI.d, unordered ? 1 : 0));
   ASL_TRY(dD.finish());
   ASL_TRY(dI.finish());
   if (dD.to_host() || dI.to_host() || dKs.own.p) ASL_TRY(sync_stream());

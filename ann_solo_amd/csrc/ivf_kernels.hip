@@ -222,7 +222,7 @@ __global__ __launch_bounds__(TK_NT) void topk_merge_kernel(
 template <int CAP, int PT, bool KEYS = false>
 __global__ __launch_bounds__(HT_NT) void topk_merge_hist_kernel(
     const float *__restrict__ Ds, const int64_t *__restrict__ Is, int S, int nq, int k,
-    float *__restrict__ D, int64_t *__restrict__ I) {
+    float *__restrict__ D, int64_t *__restrict__ I, int unordered) {
   using TopK = HistTopK<CAP, HT_NT * PT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, q = blockIdx.x;
@@ -260,17 +260,21 @@ __global__ __launch_bounds__(HT_NT) void topk_merge_hist_kernel(
     }
     top.end_round(appended);
   }
-  top.finish(D + (size_t)q * k, I + (size_t)q * k, nullptr);
+  if (unordered)   // exact top-k as a set: no sort (scratch = CAP keys behind the structure's LDS)
+    top.finish_set(D ? D + (size_t)q * k : nullptr, I + (size_t)q * k, nullptr,
+                   reinterpret_cast<u64 *>(smem + TopK::lds_bytes()));
+  else
+    top.finish(D ? D + (size_t)q * k : nullptr, I + (size_t)q * k, nullptr);
 }
 
 // merge of packed-key lists [S, nq, k] (asl_index_set_unordered mode 2)
-int topk_merge_keys(const int64_t *Ks, int S, int nq, int k, float *D, int64_t *I) {
+int topk_merge_keys(const int64_t *Ks, int S, int nq, int k, float *D, int64_t *I, int unordered) {
   if (nq <= 0) return ASL_OK;
   if (k <= 0 || k + 256 + 512 > 2048)
     return fail(ASL_ERR_CAPACITY, "merge_keys: k=%d outside 1..1280", k);
-  hipLaunchKernelGGL((topk_merge_hist_kernel<2048, 2, true>), dim3(nq), dim3(HT_NT),
-                     (HistTopK<2048, HT_NT * 2>::lds_bytes()), stream(), (const float *)nullptr, Ks, S,
-                     nq, k, D, I);
+  const size_t lds = HistTopK<2048, HT_NT * 2>::lds_bytes() + (unordered ? (size_t)2048 * 8 : 0);
+  hipLaunchKernelGGL((topk_merge_hist_kernel<2048, 2, true>), dim3(nq), dim3(HT_NT), lds, stream(),
+                     (const float *)nullptr, Ks, S, nq, k, D, I, unordered);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -283,10 +287,10 @@ int topk_merge(const float *Ds, const int64_t *Is, int S, int nq, int k, float *
     // CAP 4096 needs 16 (240 VGPRs, one workgroup per CU)
     if (k + 256 + 512 <= 2048)
       hipLaunchKernelGGL((topk_merge_hist_kernel<2048, 2>), dim3(nq), dim3(HT_NT),
-                         (HistTopK<2048, HT_NT * 2>::lds_bytes()), stream(), Ds, Is, S, nq, k, D, I);
+                         (HistTopK<2048, HT_NT * 2>::lds_bytes()), stream(), Ds, Is, S, nq, k, D, I, 0);
     else
       hipLaunchKernelGGL((topk_merge_hist_kernel<4096, 4>), dim3(nq), dim3(HT_NT),
-                         (HistTopK<4096, HT_NT * 4>::lds_bytes()), stream(), Ds, Is, S, nq, k, D, I);
+                         (HistTopK<4096, HT_NT * 4>::lds_bytes()), stream(), Ds, Is, S, nq, k, D, I, 0);
     ASL_CHECK_LAUNCH();
     return ASL_OK;
   }

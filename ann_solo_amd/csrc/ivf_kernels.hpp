@@ -15,7 +15,7 @@ int row_topk(const float *scores, int64_t ld, int rows, int n, int k, const int3
              int32_t id_base, const int32_t *vlist, const uint32_t *bitmap, int bitmap_words,
              float *D, int64_t *I64, int32_t *I32, int64_t out_ld);
 int topk_merge(const float *Ds, const int64_t *Is, int S, int nq, int k, float *D, int64_t *I);
-int topk_merge_keys(const int64_t *Ks, int S, int nq, int k, float *D, int64_t *I);
+int topk_merge_keys(const int64_t *Ks, int S, int nq, int k, float *D, int64_t *I, int unordered);
 int probe_bitmap(const int32_t *coarse_I, int nq, int nprobe, uint32_t *bitmap, int words);
 int row_argmax(const float *scores, int64_t ld, int rows, int n, int32_t *out);
 int gather_rows_f32(const float *src, int64_t ld_src, const int64_t *rows, int64_t n, int d,

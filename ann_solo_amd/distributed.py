@@ -92,7 +92,7 @@ class HipShardBackend:
 
     def merge_keys(self, Ks: torch.Tensor):
         from . import faiss_compat
-        return faiss_compat.topk_merge_keys(Ks)
+        return faiss_compat.topk_merge_keys(Ks, unordered=True)   # rescoring consumes a set
 
     def merge(self, Ds: torch.Tensor, Is: torch.Tensor):
         from . import faiss_compat

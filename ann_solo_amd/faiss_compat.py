@@ -258,9 +258,9 @@ def index_cpu_to_gpu(res, device, index, co=None):
     return index
 
 
-def topk_merge_keys(Ks):
-    """Merge per-shard packed-key rows [S,nq,k] (``search_preassigned_keys``) -> sorted
-    (D [nq,k], I [nq,k])."""
+def topk_merge_keys(Ks, unordered: bool = False):
+    """Merge per-shard packed-key rows [S,nq,k] (``search_preassigned_keys``) -> (D [nq,k],
+    I [nq,k]), sorted unless ``unordered`` (exact top-k sets, no final sort)."""
     S, nq, k = Ks.shape
     if isinstance(Ks, np.ndarray):
         Ks = np.ascontiguousarray(Ks, np.int64)
@@ -271,7 +271,8 @@ def topk_merge_keys(Ks):
         Ks = Ks.contiguous()
         D = torch.empty((nq, k), dtype=torch.float32, device=Ks.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=Ks.device)
-    _lib.check(_lib.lib().asl_topk_merge_keys(S, nq, k, _lib.ptr(Ks), _lib.ptr(D), _lib.ptr(I)))
+    _lib.check(_lib.lib().asl_topk_merge_keys(S, nq, k, _lib.ptr(Ks), _lib.ptr(D), _lib.ptr(I),
+                                              int(bool(unordered))))
     return D, I
 
 

@@ -124,8 +124,11 @@ int asl_index_get_lists(const asl_index_t *idx, int32_t *list_offsets /* [nlist+
  * (order-preserving score bits << 32 | ~id, 0 = empty; D is not written): 8 instead of 12
  * bytes per hit on the wire of a sharded search; merge with asl_topk_merge_keys. 0 = sorted. */
 int asl_index_set_unordered(asl_index_t *idx, int32_t mode);
-/* Merge of S packed-key lists Ks[S, nq, k] (mode 2 above) -> sorted D[nq,k], I[nq,k]; k <= 1280. */
-int asl_topk_merge_keys(int32_t S, int32_t nq, int32_t k, const int64_t *Ks, float *D, int64_t *I);
+/* Merge of S packed-key lists Ks[S, nq, k] (mode 2 above) -> D[nq,k] (may be NULL), I[nq,k];
+ * k <= 1280. unordered != 0: the rows hold the exact top-k as a set (no final sort), for
+ * consumers such as asl_rescore_knn that do not depend on the order. */
+int asl_topk_merge_keys(int32_t S, int32_t nq, int32_t k, const int64_t *Ks, float *D, int64_t *I,
+                        int32_t unordered);
 int asl_index_shard(asl_index_t *idx, int32_t rank, int32_t world);
 /* list -> owner rank map of the balancing above, for inspection. */
 int asl_index_shard_map(const asl_index_t *idx, int32_t world, int32_t *owner /* [nlist] */);

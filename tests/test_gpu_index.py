@@ -214,6 +214,10 @@ def test_packed_key_rows_and_their_merge(vecs, trained):
         parts.append(sh.search_preassigned_keys(xq, 1024, cD, cI))
     Dm, Im = faiss.topk_merge_keys(np.stack(parts))
     assert np.array_equal(Im, I) and np.array_equal(Dm.view(np.uint32), D.view(np.uint32))
+    Du, Iu = faiss.topk_merge_keys(np.stack(parts), unordered=True)      # same rows as sets
+    o, ou = np.argsort(I, 1), np.argsort(Iu, 1)
+    assert np.array_equal(np.take_along_axis(I, o, 1), np.take_along_axis(Iu, ou, 1))
+    assert np.array_equal(np.take_along_axis(D, o, 1).view(np.uint32), np.take_along_axis(Du, ou, 1).view(np.uint32))
     flat = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
     flat.set_trained(cen)
     flat.add(xb)
