@@ -380,7 +380,7 @@ constexpr int RS_HT = 512;            // hash slots
 constexpr int RS_HQ_MAX = 100;        // query peaks the hash path accepts (<= 3 bins each)
 constexpr int RS_EMPTY = (int)0x80000000;
 constexpr int RS_BM_BITS = 1 << 14;   // bin filter: <= 300 bits set of 16 384
-constexpr int RS_SUPER = 512;         // candidate slots compacted at a time
+constexpr int RS_SUPER = 1024;        // candidate slots compacted at a time
 constexpr int RS_PF = 2;              // candidates staged per burst
 constexpr int RS_HC = 64;             // matches per candidate resolved in this kernel
 constexpr double RS_DEFER = -2.0;     // pair_score marker: left to the binary-search kernel
