@@ -184,7 +184,7 @@ struct HistTopK {
         }
       }
       if (sort_mode && fill > CAP - ROUND_VECS) fill = tk.flush(tid);
-    } else if (!sort_mode && (round_no & 3) == 3) {
+    } else if (!sort_mode && (round_no & 63) == 63) {   // rarely: compactions raise the threshold anyway (every 4th round cost 3 % of the scan)
       update_bstar();
     }
     parity ^= 1;
