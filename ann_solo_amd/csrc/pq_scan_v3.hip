@@ -23,7 +23,15 @@
 namespace asl {
 
 constexpr int V3_NT = 256;
-constexpr int V3_CHUNK = 128;   // tile-table entries per chunk
+constexpr int V3_CHUNK = 256;   // tile-table entries per chunk
+
+// LDS tile-table entry, 8 bytes: tile index (26 bits: ids are int32, so an index holds fewer
+// than 2^25 + nlist tiles) | nvalid - 1 (6 bits), coarse term. Half the size of TileEnt: 256
+// entries per chunk in the same 2 KB, i.e. half as many pipeline restarts (7.05 -> 6.84 ms).
+struct TileEnt8 {
+  uint32_t tile_nv;
+  float coarse;
+};
 
 // NW = waves per workgroup. LDS (LUT 32 KB + keys 16 KB + ...) allows three workgroups per CU
 // whatever their size, so 8 waves per workgroup (one tile per wave and round) double the
@@ -42,7 +50,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
   using TopK = HistTopK<CAP, ROUND_VECS, NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *s_lut = reinterpret_cast<float *>(smem + TopK::lds_bytes());
-  TileEnt *table = reinterpret_cast<TileEnt *>(s_lut + PQT_KSUB * PQT_M);
+  TileEnt8 *table = reinterpret_cast<TileEnt8 *>(s_lut + PQT_KSUB * PQT_M);
   float *s_q = reinterpret_cast<float *>(smem);  // aliases the key buffer during the LUT build
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
@@ -87,11 +95,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
       const int lo = max(my_pre, c0), hi = min(my_pre + my_nt, c0 + V3_CHUNK);
       for (int t = lo; t < hi; ++t) {
         const int local = t - my_pre;
-        TileEnt e;
-        e.tile = (uint32_t)(my_tile0 + local);
+        TileEnt8 e;
+        e.tile_nv = (uint32_t)(my_tile0 + local) | ((uint32_t)(min(64, my_len - local * 64) - 1) << 26);
         e.coarse = my_coarse;
-        e.nvalid = min(64, my_len - local * 64);
-        e.pad = 0;
         table[t - c0] = e;
       }
     }
@@ -107,11 +113,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
       for (int u = 0; u < T; ++u) {
         // the entry is the same for the whole wave: keep it in scalar registers
         const int i = rr * ROUND_TILES + wave_u * T + u;
-        const TileEnt t = table[i < nent ? i : 0];
-        e[u].tile = __builtin_amdgcn_readfirstlane(t.tile);
+        const TileEnt8 t = table[i < nent ? i : 0];
+        const uint32_t tn = __builtin_amdgcn_readfirstlane(t.tile_nv);
+        e[u].tile = tn & 0x3ffffffu;
         e[u].coarse = __builtin_bit_cast(
             float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t.coarse)));
-        e[u].nvalid = i < nent ? __builtin_amdgcn_readfirstlane(t.nvalid) : 0;
+        e[u].nvalid = i < nent ? (int)(tn >> 26) + 1 : 0;
         const uint8_t *base = codes_tiled + (size_t)e[u].tile * 2048;
         a[u] = *reinterpret_cast<const uint4 *>(base + chunkA);
         b[u] = *reinterpret_cast<const uint4 *>(base + chunkB);
@@ -188,10 +195,10 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                      const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
                      int64_t *I64, int32_t *I32, int set_mode, int dbg) {
   if ((size_t)d * 4 > (size_t)CAP * 8 || dsub > 64 ||
-      (size_t)d * 2 + 8 > (size_t)V3_CHUNK * sizeof(TileEnt) || d != PQT_M * dsub)
+      (size_t)d * 2 + 8 > (size_t)V3_CHUNK * sizeof(TileEnt8) || d != PQT_M * dsub)
     return fail(ASL_ERR_CAPACITY, "pq scan: d=%d too large for the LDS staging", d);
   const size_t lds = HistTopK<CAP, NW * T * 64, 64 * NW>::lds_bytes() + (size_t)PQT_KSUB * PQT_M * 4 +
-                     (size_t)V3_CHUNK * sizeof(TileEnt);
+                     (size_t)V3_CHUNK * sizeof(TileEnt8);
   if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "pq scan: k=%d does not fit LDS", k);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)pq_scan_v3_kernel<CAP, T, NW, DEPTH>,
