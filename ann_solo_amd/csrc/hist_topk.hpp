@@ -3,7 +3,7 @@
 // WITHOUT sorting while streaming (used by pq_scan_v3.hip and flat_scan.hip).
 //
 //   * hist[512]: counts of the appended candidates per score bucket (monotone linear
-//     bucketing of the fp32 score over [-1, 2)),
+//     bucketing of the fp32 score over [-0.25, 1)),
 //   * bstar: the highest bucket with at least k appended candidates at or above it.
 // A candidate whose bucket is below bstar can never be among the k best (k candidates with
 // strictly larger scores exist): it is not stored; when the key buffer runs full it is
@@ -22,7 +22,10 @@ namespace asl {
 
 constexpr int HT_NT = 256;
 constexpr int HT_NB = 512;
-constexpr float HT_LO = -1.0f, HT_SCALE = HT_NB / 3.0f;
+// bucket range [-0.25, 1): hashed spectra are non-negative unit vectors, so inner products (and
+// their PQ approximations, up to the quantisation error) live in [0, 1]; scores outside clamp to
+// the end buckets, which only costs resolution there, never exactness
+constexpr float HT_LO = -0.25f, HT_SCALE = HT_NB / 1.25f;
 
 __device__ __forceinline__ int score_bucket(float s) {
   float t = (s - HT_LO) * HT_SCALE;

@@ -4,7 +4,7 @@
 // v2 spent ~40 % of its cycles sorting its 4096-key LDS buffer two or three times per
 // query. Only the k-th best SCORE is needed while scanning, so v3 keeps
 //   * hist[512]: counts of the appended candidates per score bucket (monotone linear
-//     bucketing of the fp32 score over [-1, 2), i.e. 0.006 per bucket),
+//     bucketing of the fp32 score over [-0.25, 1), i.e. 0.0024 per bucket),
 //   * bstar: the highest bucket with at least k appended candidates at or above it.
 // A candidate whose bucket is below bstar can never be among the k best (k candidates
 // with strictly larger scores exist), so it is dropped without being stored; when the key
