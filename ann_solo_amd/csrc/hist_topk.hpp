@@ -100,10 +100,15 @@ struct HistTopK {
     for (int i = tid; i < HT_NB; i += NT) hist[i] = 0;
     if (tid == 0) ctl[C_BSTAR] = 0;
     __syncthreads();
+    bstar = 0;
+    thr_hi = 0;
     return reinterpret_cast<char *>(hist + HT_NB);
   }
 
-  __device__ __forceinline__ void begin_round() {
+  // The threshold snapshot only changes inside end_round (compaction / update / flush), where
+  // every thread refreshes it after the closing barrier: nothing to read per round.
+  __device__ __forceinline__ void begin_round() {}
+  __device__ __forceinline__ void refresh_threshold() {
     thr_hi = (uint32_t)(*thr_p >> 32);
     bstar = ctl[C_BSTAR];
   }
@@ -187,8 +192,10 @@ struct HistTopK {
         }
       }
       if (sort_mode && fill > CAP - ROUND_VECS) fill = tk.flush(tid);
+      refresh_threshold();
     } else if (!sort_mode && (round_no & 63) == 63) {   // rarely: compactions raise the threshold anyway (every 4th round cost 3 % of the scan)
       update_bstar();
+      refresh_threshold();
     }
     parity ^= 1;
     ++round_no;
