@@ -24,6 +24,15 @@ expected scan load of each list (size squared: populous lists are also probed mo
 identical on every rank, no communication. The compute backend is injectable so
 that the host logic (ownership, exchange, merge order) is covered by world_size-2
 ``gloo`` tests on CPU; the product backend is the HIP library and nothing else.
+
+Shard degree. ``world = degree x replicas``: the lists are sharded over the ``degree``
+consecutive ranks of a *shard group* (``make_shard_groups``) and every group holds a full
+copy of the library and serves its own queries -- no traffic between groups. ``degree =
+world`` is the fully list-sharded layout above; ``degree = 1`` is the replicas-only
+fallback of SURVEY.md 8(e) for libraries that fit one GPU (no collective on the data path
+at all). ``pick_shard_degree`` returns the smallest power-of-two degree whose per-GPU share
+of the index fits a memory budget: per-(query, shard) costs (LUT build, top-k finish) are
+paid ``degree`` times, so the smallest degree that fits is the fastest one.
 """
 import ctypes as C
 from typing import Optional
@@ -43,6 +52,40 @@ def lpt_owner(list_sizes, world: int) -> np.ndarray:
     _lib.check(_lib.lib().asl_lpt_owner(len(sizes), _lib.ptr(sizes), int(world),
                                         _lib.ptr(owner)))
     return owner
+
+
+def pick_shard_degree(index_bytes: int, replicated_bytes: int, world: int,
+                      budget_bytes: int = 240 << 30) -> int:
+    """Smallest power-of-two shard degree (dividing ``world``) such that index_bytes/degree +
+    replicated_bytes (peak store, centroids, codebooks, work buffers) fits ``budget_bytes``
+    of one GPU's 288 GB. Returns ``world`` if nothing smaller fits."""
+    d = 1
+    while d < world:
+        if world % d == 0 and index_bytes / d + replicated_bytes <= budget_bytes:
+            return d
+        d *= 2
+    return world
+
+
+def make_shard_groups(degree: int):
+    """Split the default process group into ``world // degree`` shard groups of ``degree``
+    consecutive ranks (consecutive = same xGMI neighbourhood, and the same node first when
+    a job spans nodes). Collective over ALL ranks (every rank creates every group, as
+    ``dist.new_group`` requires). Returns (group of this rank or None when degree == 1 /
+    degree == world, rank inside the group, index of the group)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if degree < 1 or world % degree:
+        raise ValueError(f'shard degree {degree} does not divide the world size {world}')
+    if degree == world:
+        return None, rank, 0
+    mine = None
+    for g in range(world // degree):
+        ranks = list(range(g * degree, (g + 1) * degree))
+        grp = dist.new_group(ranks)
+        if rank in ranks:
+            mine = grp
+    return mine, rank % degree, rank // degree
 
 
 class HipShardBackend:

@@ -52,6 +52,10 @@ def main():
     ap.add_argument('--open-da', type=float, default=500.0)
     ap.add_argument('--scan-variant', type=int, default=0, help='0 auto (tiled v2), 1 generic v1')
     ap.add_argument('--recall-queries', type=int, default=256)
+    ap.add_argument('--shard-degree', type=int, default=0,
+                    help='N > 1: ranks per shard group (lists sharded inside a group, groups are '
+                         'replicas); 0 = N, the fully list-sharded layout of the north star; '
+                         '1 = replicas only')
     ap.add_argument('--cpu-seconds', type=float, default=20.0,
                     help='target core-seconds of the CPU baseline sample (0 = skip)')
     args = ap.parse_args()
@@ -71,7 +75,8 @@ def main():
     from ann_solo_amd import _lib, synthetic
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     from ann_solo_amd import faiss_compat as faiss
-    from ann_solo_amd.distributed import HipShardBackend, sharded_search_batch
+    from ann_solo_amd.distributed import (HipShardBackend, make_shard_groups,
+                                          sharded_search_batch)
 
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X (no CPU fallback exists)')
@@ -142,17 +147,57 @@ def main():
                   'top1_is_source_spectrum': float(top1.float().mean())}
         torch.cuda.empty_cache()
 
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps):
+        """barrier, `steps` calls, barrier; MAX over ranks of the elapsed seconds"""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64,
+                             device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    def unsharded_step():
+        return sl._search_batch(q, charge, 'open', device_out=True)
+
     # ---- shard for N > 1
-    shard_check = None
+    shard_check, alt = None, None
+    degree = 1
     if world > 1:
+        degree = args.shard_degree or world
         ns = min(256, q.n)
         ref = sl._search_batch(q.select(torch.arange(ns, device=dev)), charge, 'open',
                                device_out=True)          # unsharded result of my first queries
-        idx.shard(rank, world)
-        shard_backend = HipShardBackend(sl, charge, 'open')
+        if degree > 1:
+            # the other layout the library supports, for the record (not `value`): every
+            # rank a full replica serving its own slice, no collective on the data path
+            for _ in range(2):
+                unsharded_step()
+            el, _ = timed(unsharded_step, max(3, min(args.steps, 10)))
+            n_alt = max(3, min(args.steps, 10))
+            alt = {'replicas_only': {'value': round(world * args.batch * n_alt / el, 2),
+                                     'ms_per_step': round(el / n_alt * 1e3, 3),
+                                     'steps': n_alt}}
+        group, shard_rank, _ = make_shard_groups(degree)
+        if degree > 1:
+            idx.shard(shard_rank, degree)
+            shard_backend = HipShardBackend(sl, charge, 'open')
 
-        def step():
-            return sharded_search_batch(shard_backend, q, device_out=True)
+            def step():
+                return sharded_search_batch(shard_backend, q, group=group, device_out=True)
+        else:
+            step = unsharded_step
         got = step()
         same = bool(torch.equal(got.best_row[:ns], ref.best_row) and
                     torch.equal(got.best_score[:ns], ref.best_score))
@@ -160,32 +205,15 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         shard_check = {'queries_per_rank': ns, 'sharded_equals_unsharded': bool(flag.item())}
     else:
-        def step():
-            return sl._search_batch(q, charge, 'open', device_out=True)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        step = unsharded_step
 
     L = _lib.lib()
     for _ in range(args.warmup):
         step()
     L.asl_profile_enable(1)
     L.asl_profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, res = timed(step, args.steps)
     L.asl_profile_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     stages = {}
     for name in ('encode', 'coarse_gemm', 'coarse_select', 'scan', 'filter', 'rescore',
@@ -210,8 +238,8 @@ def main():
                         'traffic': pmc_traffic(args, world),
                         'avg_launch_ms': round(avg_ms, 4),
                         'algorithmic_bytes_per_launch': int(bytes_per_launch),
-                        'vectors_scanned_per_query': round(scanned / scan['launches'] /
-                                                           (world * args.batch), 1)}
+                        'vectors_scanned_per_query': round(scanned / args.steps /
+                                                           (degree * args.batch), 1)}
         # post-path step of the same batch, outside the timed region: the 33 SSM similarity
         # features of every best match (utils._compute_ssm_features), one kernel launch
         from ann_solo_amd.spectrum_similarity import ssm_features
@@ -241,9 +269,13 @@ def main():
                        'library_size': args.library_size, 'batch_per_gpu': args.batch,
                        'global_batch': world * args.batch, 'index': args.index,
                        'nlist': args.nlist, 'nprobe': args.nprobe, 'k': args.k,
-                       'parallelism': f'ivf-list-shard x{world}' if world > 1 else 'single'},
+                       'parallelism': 'single' if world == 1 else
+                       (f'ivf-list-shard x{degree}' if degree == world else
+                        f'replicas x{world}' if degree == 1 else
+                        f'ivf-list-shard x{degree} in {world // degree} replica groups')},
             'recall': recall,
             'shard_check': shard_check,
+            'alt_layouts': alt,
             'stages_ms_per_step': {k: round(v['ms_total'] / args.steps, 3) for k, v in stages.items()},
             'post_path': {'ssm_features_ms_per_batch': round(feat_ms, 3), 'ssms': n_ssm},
             'roofline': roofline,

@@ -71,6 +71,64 @@ def test_two_rank_sharded_search_equals_unsharded(tmp_path, kind):
         assert ok == '1' and owner_ok == '1' and int(n) > 0
 
 
+def _replica_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import oracle_py as O
+    from oracle_backend import OracleShardBackend
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.distributed import lpt_owner, make_shard_groups, sharded_search_batch
+    # degree == world: the default group, shard rank == rank
+    g_full, r_full, gi_full = make_shard_groups(world)
+    # degree 1: every rank its own group of one, a full replica serving its own queries
+    group, srank, gidx = make_shard_groups(1)
+    lib, aux = synthetic.make_library(800, seed=93, device='cpu', charges=(2,), charge_p=(1.0,))
+    q_all, _ = synthetic.make_queries(lib, aux, 2 * 12, seed=94, charge=2)
+    lib_np = lib.numpy()
+    xb = O.encode_batch(lib_np[1], lib_np[2], lib_np[0], 10.96, 0.04, 800)
+    cen = O.kmeans(xb, 8, 4, 1234, 0, 256)
+    a = O.assign(xb, cen, 0)
+    pmz32 = lib_np[4].astype(np.float32)
+    be = OracleShardBackend(lib_np, pmz32, cen, a, xb, None, srank, 1, 2, 64, 4, 300, 'Da',
+                            0.02, True, lpt_owner)
+    nloc = q_all.n // world
+    q = q_all.select(torch.arange(rank * nloc, (rank + 1) * nloc))
+    res = sharded_search_batch(be, q, group=group)
+    D, I = be.full.search(be.encode(q).numpy(), 64, 4)
+    ref = be.rescore_knn(q, torch.from_numpy(I))
+    ok = (np.array_equal(res['best_row'], ref['best_row'])
+          and np.array_equal(res['best_score'], ref['best_score']))
+    shape_ok = (g_full is None and r_full == rank and gi_full == 0 and srank == 0
+                and gidx == rank and dist.get_world_size(group) == 1)
+    with open(os.path.join(out_dir, f'rank{rank}.txt'), 'w') as f:
+        f.write(f'{int(ok)} {int(shape_ok)}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_groups_need_no_exchange(tmp_path):
+    """shard degree 1 in a world of 2: two replica groups of one rank each"""
+    world = 2
+    mp.spawn(_replica_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(tmp_path, f'rank{r}.txt')).read().split() == ['1', '1']
+
+
+def test_pick_shard_degree():
+    from ann_solo_amd.distributed import pick_shard_degree
+    gb = 1 << 30
+    assert pick_shard_degree(1 * gb, 2 * gb, 8) == 1            # bench library: replicas only
+    assert pick_shard_degree(400 * gb, 10 * gb, 8) == 2
+    assert pick_shard_degree(1500 * gb, 10 * gb, 8) == 8
+    assert pick_shard_degree(5000 * gb, 10 * gb, 8) == 8         # nothing fits: shard fully
+    assert pick_shard_degree(100 * gb, 0, 1) == 1
+
+
 def test_lpt_owner_rule():
     from ann_solo_amd.distributed import lpt_owner
     sizes = np.array([5, 9, 1, 7, 7, 3])

@@ -14,12 +14,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_sharded_bench_path():
+@pytest.mark.parametrize('degree', [0, 1])
+def test_two_rank_sharded_bench_path(degree):
+    """degree 0 = lists sharded over both ranks; degree 1 = two replicas (no exchange)"""
     env = dict(os.environ, ASL_BENCH_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29517', os.path.join(ROOT, 'bench.py'),
+           '--master-addr', '127.0.0.1', '--master-port', str(29517 + degree),
+           os.path.join(ROOT, 'bench.py'),
            '--gpus', '2', '--steps', '1', '--warmup', '1', '--library-size', '60000', '--nlist',
-           '256', '--niter', '4', '--batch', '1024', '--recall-queries', '64']
+           '256', '--niter', '4', '--batch', '1024', '--recall-queries', '64',
+           '--shard-degree', str(degree)]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     line = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert line, out.stderr[-2000:]
@@ -27,6 +31,11 @@ def test_two_rank_sharded_bench_path():
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2048
     assert d['shard_check']['sharded_equals_unsharded'] is True
     assert d['value'] > 0 and d['roofline']['achieved'] > 0
+    if degree == 0:
+        assert d['config']['parallelism'] == 'ivf-list-shard x2'
+        assert d['alt_layouts']['replicas_only']['value'] > 0
+    else:
+        assert d['config']['parallelism'] == 'replicas x2' and d['alt_layouts'] is None
 
 
 def test_search_preassigned_equals_search():
