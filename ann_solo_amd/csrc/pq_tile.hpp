@@ -112,7 +112,10 @@ __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, 
   const int c = tid & (PQT_KSUB - 1);
   const int kbeg = (NT > PQT_KSUB && tid >= PQT_KSUB) ? K16 : 0;
   const int K = (NT > PQT_KSUB && tid < PQT_KSUB) ? K16 : Kall;   // wave-uniform
-  constexpr int U = 8;   // codebook loads in flight per thread
+#ifndef PQT_LUT_U
+#define PQT_LUT_U 8
+#endif
+  constexpr int U = PQT_LUT_U;   // codebook loads in flight per thread
   float acc = 0.0f;
   int cur = -1;
   for (int k0 = kbeg; k0 < K; k0 += U) {

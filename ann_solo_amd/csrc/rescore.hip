@@ -484,6 +484,14 @@ __device__ __forceinline__ int resolve_two_fast(int lane, PairLds &W, int MA, in
   return ((bad & 0xffffffffull) ? 0 : 1) | ((bad >> 32) ? 0 : 2);
 }
 
+// General resolve of one half's match list, out of line: it is the rare path, and inlined its
+// loop-invariant lane predicates (bitonic directions) get hoisted into scalar registers that
+// the hot loops of the kernel then spill around.
+__device__ __attribute__((noinline)) double resolve_half_slow(int lane, PairLds &W, int *status,
+                                                              int kbase, int M) {
+  return resolve_matches<false>(lane, W, nullptr, 0, nullptr, status, kbase, M, RS_HC);
+}
+
 // Two candidates per wave: lanes 0-31 score candidate A, lanes 32-63 candidate B (peaks in
 // passes of 32; cn = 0 leaves a half idle). The probing instruction stream -- the bulk of
 // this instruction-bound kernel -- is shared by both. Per-half match lists live in the two
@@ -583,17 +591,22 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
   if (MA <= 32 && MB <= 32 && !(dbg & 128)) ok = resolve_two_fast(lane, Wv, MA, MB, scoreA, scoreB);
   if (!(ok & 1))
     scoreA = MA > RS_HC ? RS_DEFER
-             : MA     ? resolve_matches<false>(lane, Wv, nullptr, 0, nullptr, status, 0, MA, RS_HC)
+             : MA     ? resolve_half_slow(lane, Wv, status, 0, MA)
                       : 0.0;
   if (!(ok & 2))
     scoreB = MB > RS_HC ? RS_DEFER
-             : MB     ? resolve_matches<false>(lane, Wv, nullptr, 0, nullptr, status, RS_HC, MB, RS_HC)
+             : MB     ? resolve_half_slow(lane, Wv, status, RS_HC, MB)
                       : 0.0;
 }
 
+// KNOBS: the ablation switches of scripts/pmc_rescore.sh (ASL_RESCORE_DBG) exist only in the
+// instrumented instantiation; the product kernel is compiled with dbg == 0 folded away (the
+// switches cost scalar registers in a kernel that already spills them).
+template <bool KNOBS>
 __global__ __launch_bounds__(64 * RS_WAVES, 7) void rescore_score_v2_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
-    double *__restrict__ pair_score, int *__restrict__ q_defer, int *status, int dbg) {
+    double *__restrict__ pair_score, int *__restrict__ q_defer, int *status, int dbg_arg) {
+  const int dbg = KNOBS ? dbg_arg : 0;
   __shared__ QueryLds2 Q;
   __shared__ HashLds H;
   __shared__ PairLds W[RS_WAVES];
@@ -853,9 +866,14 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
       static DevBuf<int> &q_defer = *new DevBuf<int>();   // process lifetime (one device per process)
       ASL_TRY(q_defer.reserve((size_t)nq));
       HIP_TRY(hipMemsetAsync(q_defer.p, 0, sizeof(int) * (size_t)nq, stream()));
-      hipLaunchKernelGGL(rescore_score_v2_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
-                         stream(), Q, L, cv, tol, allow_shift, pair_score, q_defer.p, status,
-                         rs_dbg);
+      if (rs_dbg)
+        hipLaunchKernelGGL(rescore_score_v2_kernel<true>, dim3(nq, ysplit), dim3(64 * RS_WAVES),
+                           0, stream(), Q, L, cv, tol, allow_shift, pair_score, q_defer.p,
+                           status, rs_dbg);
+      else
+        hipLaunchKernelGGL(rescore_score_v2_kernel<false>, dim3(nq, ysplit), dim3(64 * RS_WAVES),
+                           0, stream(), Q, L, cv, tol, allow_shift, pair_score, q_defer.p,
+                           status, 0);
       ASL_CHECK_LAUNCH();
       hipLaunchKernelGGL(rescore_score_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
                          stream(), Q, L, cv, tol, allow_shift, pair_score,
