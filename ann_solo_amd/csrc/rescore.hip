@@ -602,11 +602,27 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
 // KNOBS: the ablation switches of scripts/pmc_rescore.sh (ASL_RESCORE_DBG) exist only in the
 // instrumented instantiation; the product kernel is compiled with dbg == 0 folded away (the
 // switches cost scalar registers in a kernel that already spills them).
-template <bool KNOBS>
+// FORM: the two shapes the search path calls with -- fixed-stride neighbour lists (1: int32
+// rows, 2: int64 rows), packed row records for the precursor filter, annotated library peaks --
+// are compiled with those facts folded in (each open "is this pointer null" question is a
+// wave-uniform predicate held in scalar registers across the hot loops); 0 = any shape.
+template <bool KNOBS, int FORM>
 __global__ __launch_bounds__(64 * RS_WAVES, 7) void rescore_score_v2_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
     double *__restrict__ pair_score, int *__restrict__ q_defer, int *status, int dbg_arg) {
   const int dbg = KNOBS ? dbg_arg : 0;
+  if (FORM != 0) {
+    cv.offsets = nullptr;
+    cv.flt.lib_pmz = nullptr;
+    cv.flt.valid = nullptr;
+    __builtin_assume(cv.flt.meta != nullptr);
+    __builtin_assume(L.charge != nullptr);
+    if (FORM == 1) {
+      cv.rows64 = nullptr;
+    } else {
+      __builtin_assume(cv.rows64 != nullptr);
+    }
+  }
   __shared__ QueryLds2 Q;
   __shared__ HashLds H;
   __shared__ PairLds W[RS_WAVES];
@@ -866,14 +882,13 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
       static DevBuf<int> &q_defer = *new DevBuf<int>();   // process lifetime (one device per process)
       ASL_TRY(q_defer.reserve((size_t)nq));
       HIP_TRY(hipMemsetAsync(q_defer.p, 0, sizeof(int) * (size_t)nq, stream()));
-      if (rs_dbg)
-        hipLaunchKernelGGL(rescore_score_v2_kernel<true>, dim3(nq, ysplit), dim3(64 * RS_WAVES),
-                           0, stream(), Q, L, cv, tol, allow_shift, pair_score, q_defer.p,
-                           status, rs_dbg);
-      else
-        hipLaunchKernelGGL(rescore_score_v2_kernel<false>, dim3(nq, ysplit), dim3(64 * RS_WAVES),
-                           0, stream(), Q, L, cv, tol, allow_shift, pair_score, q_defer.p,
-                           status, 0);
+      const bool shaped = !cand_offsets && filter.meta && L.charge && (rows64 || rows32);
+      auto kern = rs_dbg ? rescore_score_v2_kernel<true, 0>
+                  : !shaped ? rescore_score_v2_kernel<false, 0>
+                  : rows64  ? rescore_score_v2_kernel<false, 2>
+                            : rescore_score_v2_kernel<false, 1>;
+      hipLaunchKernelGGL(kern, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, tol,
+                         allow_shift, pair_score, q_defer.p, status, rs_dbg);
       ASL_CHECK_LAUNCH();
       hipLaunchKernelGGL(rescore_score_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
                          stream(), Q, L, cv, tol, allow_shift, pair_score,
