@@ -294,7 +294,7 @@ def pmc_traffic(args, world):
     default = (world == 1 and args.library_size == 2_100_000 and args.nlist == 4096 and
                args.nprobe == 128 and args.k == 1024 and args.batch == 16384 and
                args.index == 'ivfpq' and args.scan_variant == 0)
-    path = os.path.join(ROOT, 'profiles', 'r01_v9_pmc_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_v10_pmc_traffic.json')
     if not default or not os.path.exists(path):
         return None
     try:
