@@ -196,4 +196,252 @@ int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t
   return ASL_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Dimension-major ("postings") IVF-Flat. The tiles above stream EVERY stored non-zero of the
+// probed lists (~27 per vector) although a query has <= ~50 non-zero components of 800: only
+// stored entries in those dimensions can contribute. So every inverted list is cut into blocks
+// of FI_BLK vectors and each block keeps, per dimension, the postings (local vector index
+// u16, value f32) of the vectors that are non-zero there -- an inverted file inside the
+// inverted file. A wave takes one (query, block): it zeroes the block's accumulators in LDS
+// and walks the query's non-zero dimensions in ASCENDING order, acc[loc] = fmaf(q_d, val,
+// acc[loc]) over that dimension's postings (a vector occurs at most once per dimension, so
+// the lanes of one step never collide, and steps of one wave reach LDS in program order).
+// Per vector this is the ascending-dimension fp32 chain restricted to the dimensions where
+// both factors are non-zero -- bit-identical to the dense chain, the MFMA GEMM and the oracle
+// (a zero factor leaves the accumulator unchanged) -- at 1/16 of the tile kernel's traffic
+// (50 of 800 dimensions) and 1/4 of its lane-steps. Then all waves offer their accumulators
+// to the workgroup's histogram top-k, vectors with score 0 included (they are candidates of
+// the dense scan too).
+constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CAP = 2048, FI_CHUNK = 128, FI_U = 4;
+
+struct FiUnit {
+  uint32_t blk;   // block index into the per-dimension table
+  int32_t pos0;   // list-order position of the block's first vector
+  int32_t nb;     // vectors in the block
+  int32_t pad;
+};
+
+__global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
+    const float *__restrict__ xq, int d, const int32_t *__restrict__ coarse_I, int nprobe,
+    const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ blk_offsets,
+    const uint2 *__restrict__ ent, const uint16_t *__restrict__ p_loc,
+    const float *__restrict__ p_val, const int32_t *__restrict__ ids, int k,
+    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode) {
+  using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_acc = reinterpret_cast<float *>(smem + TopK::lds_bytes());      // [FI_NW][FI_BLK]
+  float *s_nzv = s_acc + FI_NW * FI_BLK;                                   // [d]
+  FiUnit *table = reinterpret_cast<FiUnit *>(s_nzv + ((d + 3) & ~3));      // [FI_CHUNK]
+  int *s_misc = reinterpret_cast<int *>(table + FI_CHUNK);                 // [16]
+  uint16_t *s_nzd = reinterpret_cast<uint16_t *>(s_misc + 16);             // [d]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+
+  // the query's non-zero components, ascending (staged through the accumulator area)
+  float *s_q = s_acc;
+  for (int i = tid; i < d; i += FI_NT) s_q[i] = xq[(size_t)q * d + i];
+  int my_len = 0, my_pos = 0, my_b0 = 0, my_nb = 0;
+  if (tid < nprobe) {
+    const int l = coarse_I[(size_t)q * nprobe + tid];
+    if (l >= 0) {
+      my_pos = list_offsets[l];
+      my_len = list_offsets[l + 1] - my_pos;
+      my_b0 = blk_offsets[l];
+      my_nb = blk_offsets[l + 1] - my_b0;
+    }
+  }
+  int total;
+  const int my_pre = block_excl_scan<FI_NW>(my_nb, s_misc, tid, total);   // barrier inside: s_q complete
+  if (wave == 0) {
+    int base = 0;
+    for (int j0 = 0; j0 < d; j0 += 64) {
+      const int j = j0 + lane;
+      const float x = j < d ? s_q[j] : 0.0f;
+      const unsigned long long m = __ballot(x != 0.0f);
+      if (x != 0.0f) {
+        const int t = base + __popcll(m & ((1ull << lane) - 1ull));
+        s_nzd[t] = (uint16_t)j;
+        s_nzv[t] = x;
+      }
+      base += __popcll(m);
+    }
+    if (lane == 0) s_misc[8] = base;
+  }
+  __syncthreads();
+  const int K = s_misc[8];
+  TopK top;
+  top.init(smem, k, ids, tid);
+  float *acc = s_acc + wave * FI_BLK;
+
+  for (int c0 = 0; c0 < total; c0 += FI_CHUNK) {
+    {
+      const int lo = max(my_pre, c0), hi = min(my_pre + my_nb, c0 + FI_CHUNK);
+      for (int t = lo; t < hi; ++t) {
+        const int j = t - my_pre;
+        FiUnit u;
+        u.blk = (uint32_t)(my_b0 + j);
+        u.pos0 = my_pos + j * FI_BLK;
+        u.nb = min(FI_BLK, my_len - j * FI_BLK);
+        u.pad = 0;
+        table[t - c0] = u;
+      }
+    }
+    __syncthreads();
+    const int nent = min(FI_CHUNK, total - c0);
+    for (int r0 = 0; r0 < nent; r0 += FI_NW) {
+      const int i = r0 + wave;
+      int nb = 0, pos0 = 0;
+      if (i < nent) {          // wave-uniform
+        const FiUnit u = table[i];
+        nb = __builtin_amdgcn_readfirstlane(u.nb);
+        pos0 = __builtin_amdgcn_readfirstlane(u.pos0);
+        const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.blk);
+        for (int o = lane; o < nb; o += 64) acc[o] = 0.0f;
+        const uint2 *erow = ent + (size_t)blk * d;
+        for (int kk0 = 0; kk0 < K; kk0 += 64) {
+          const int kk = kk0 + lane;
+          uint2 e = make_uint2(0u, 0u);
+          float qv = 0.0f;
+          if (kk < K) {
+            e = erow[s_nzd[kk]];
+            qv = s_nzv[kk];
+          }
+          const int n = min(64, K - kk0);
+          for (int j0 = 0; j0 < n; j0 += FI_U) {
+            uint32_t st[FI_U], cn[FI_U];
+            float qj[FI_U];
+            uint32_t cmax = 0;
+#pragma unroll
+            for (int u = 0; u < FI_U; ++u) {
+              const int j = j0 + u < n ? j0 + u : n - 1;
+              st[u] = (uint32_t)__builtin_amdgcn_readlane((int)e.x, j);
+              cn[u] = j0 + u < n ? (uint32_t)__builtin_amdgcn_readlane((int)e.y, j) : 0u;
+              qj[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), j));
+              cmax = cn[u] > cmax ? cn[u] : cmax;
+            }
+            if (cmax == 0) continue;
+            if (cmax <= 64) {     // the usual case: one step per dimension, FI_U loads in flight
+              uint32_t loc[FI_U];
+              float val[FI_U];
+#pragma unroll
+              for (int u = 0; u < FI_U; ++u) {
+                const bool on = (uint32_t)lane < cn[u];
+                loc[u] = on ? (uint32_t)p_loc[st[u] + lane] : 0u;
+                val[u] = on ? p_val[st[u] + lane] : 0.0f;
+              }
+#pragma unroll
+              for (int u = 0; u < FI_U; ++u)
+                if ((uint32_t)lane < cn[u]) acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);
+            } else {              // a dimension with more postings than lanes: strictly in order
+#pragma unroll
+              for (int u = 0; u < FI_U; ++u)
+                for (uint32_t o = lane; o < cn[u]; o += 64) {
+                  const uint32_t l = p_loc[st[u] + o];
+                  acc[l] = __builtin_fmaf(qj[u], p_val[st[u] + o], acc[l]);
+                }
+            }
+          }
+        }
+      }
+      // every wave offers its block, one row of 64 per round
+      int nbmax = 0;
+#pragma unroll
+      for (int w = 0; w < FI_NW; ++w) nbmax = max(nbmax, r0 + w < nent ? table[r0 + w].nb : 0);
+      for (int r = 0; r * 64 < nbmax; ++r) {
+        top.begin_round();
+        const int v = r * 64 + lane;
+        const bool valid = v < nb;
+        const float score = valid ? acc[v] : 0.0f;
+        const bool take = top.offer(valid, score, (uint32_t)(pos0 + v));
+        top.end_round(__popcll(__ballot(take)));
+      }
+    }
+    __syncthreads();
+  }
+  if (set_mode)   // unordered exact top-k; the accumulators are dead: scratch
+    top.finish_set(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
+                   I32 ? I32 + (size_t)q * k : nullptr, reinterpret_cast<u64 *>(s_acc));
+  else
+    top.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
+               I32 ? I32 + (size_t)q * k : nullptr);
+}
+
+bool flat_inv_supported(int d, int k, int nprobe) {
+  return d <= 4096 && nprobe <= FI_NT && k >= 1 && k + FI_NT + 256 <= FI_CAP;
+}
+
+int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
+                  const int32_t *list_offsets, const int32_t *blk_offsets, const uint2 *ent,
+                  const uint16_t *p_loc, const float *p_val, const int32_t *ids, int k, float *D,
+                  int64_t *I64, int32_t *I32, int set_mode) {
+  if (nq <= 0) return ASL_OK;
+  using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
+  const size_t lds = TopK::lds_bytes() + (size_t)FI_NW * FI_BLK * 4 + (size_t)((d + 3) & ~3) * 4 +
+                     (size_t)FI_CHUNK * sizeof(FiUnit) + 64 + (size_t)((d + 7) & ~7) * 2;
+  if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "flat scan: d=%d does not fit LDS", d);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void *)flat_inv_scan_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(flat_inv_scan_kernel, dim3(nq), dim3(FI_NT), lds, stream(), xq, d, coarse_I,
+                     nprobe, list_offsets, blk_offsets, ent, p_loc, p_val, ids, k, D, I64, I32,
+                     set_mode);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// ---- building the postings from dense rows. pos_blk / pos_loc: block and local index of
+// the list-ordered position i (add-order row order[i]).
+__global__ void inv_count_kernel(const float *__restrict__ vecs, int d,
+                                 const int32_t *__restrict__ order,
+                                 const int32_t *__restrict__ pos_blk, int64_t n,
+                                 uint32_t *__restrict__ cnt) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const float *row = vecs + (size_t)order[i] * d;
+  uint32_t *c = cnt + (size_t)pos_blk[i] * d;
+  for (int j = lane; j < d; j += 64)
+    if (row[j] != 0.0f) atomicAdd(&c[j], 1u);
+}
+
+__global__ void inv_fill_kernel(const float *__restrict__ vecs, int d,
+                                const int32_t *__restrict__ order,
+                                const int32_t *__restrict__ pos_blk,
+                                const uint16_t *__restrict__ pos_loc, int64_t n,
+                                const uint2 *__restrict__ ent, uint32_t *__restrict__ cursor,
+                                uint16_t *__restrict__ p_loc, float *__restrict__ p_val) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const float *row = vecs + (size_t)order[i] * d;
+  const size_t b = (size_t)pos_blk[i] * d;
+  const uint16_t loc = pos_loc[i];
+  for (int j = lane; j < d; j += 64) {
+    const float x = row[j];
+    if (x != 0.0f) {
+      const uint32_t p = ent[b + j].x + atomicAdd(&cursor[b + j], 1u);
+      p_loc[p] = loc;
+      p_val[p] = x;
+    }
+  }
+}
+
+int inv_count(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk, int64_t n,
+              uint32_t *cnt) {
+  if (n <= 0) return ASL_OK;
+  hipLaunchKernelGGL(inv_count_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
+                     order, pos_blk, n, cnt);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk,
+             const uint16_t *pos_loc, int64_t n, const uint2 *ent, uint32_t *cursor,
+             uint16_t *p_loc, float *p_val) {
+  if (n <= 0) return ASL_OK;
+  hipLaunchKernelGGL(inv_fill_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
+                     order, pos_blk, pos_loc, n, ent, cursor, p_loc, p_val);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
 }  // namespace asl

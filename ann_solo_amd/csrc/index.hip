@@ -86,6 +86,12 @@ struct asl_index {
   DevBuf<int32_t> tile_nnz;
   int nnz_stride = 0;
   bool has_sparse = false;
+  // dimension-major postings for flat_inv_scan (IVF-Flat): blocks of FI_BLK vectors
+  DevBuf<int32_t> blk_offsets;   // [nlist + 1] first block of each list
+  DevBuf<uint2> inv_ent;         // [nblocks * d] (first posting, postings) of (block, dimension)
+  DevBuf<uint16_t> inv_loc;      // postings: local vector index
+  DevBuf<float> inv_val;         // postings: value
+  bool has_inv = false;
   int scan_variant = 0;  // 0 = auto (v2 when supported), 1 = force v1
   int unordered = 0;  // 1: search rows = exact top-k as a set, unspecified order (no final sort); 2: rows of packed keys
   bool lists_dirty = true;
@@ -314,6 +320,51 @@ static int build_lists(asl_index *ix) {
       ASL_TRY(sync_stream());
       ix->has_sparse = true;
     }
+    // dimension-major postings (the default IVF-Flat scan)
+    ix->has_inv = false;
+    if (h_max > 0 && (size_t)h_max * 8 < (size_t)ix->d) {
+      std::vector<int32_t> blk_off((size_t)ix->nlist + 1, 0), pos_blk((size_t)n);
+      std::vector<uint16_t> pos_loc((size_t)n);
+      for (int l = 0; l < ix->nlist; l++)
+        blk_off[(size_t)l + 1] =
+            blk_off[(size_t)l] + (off[(size_t)l + 1] - off[(size_t)l] + FI_BLK - 1) / FI_BLK;
+      for (int l = 0; l < ix->nlist; l++)
+        for (int32_t i = off[(size_t)l]; i < off[(size_t)l + 1]; i++) {
+          const int32_t r = i - off[(size_t)l];
+          pos_blk[(size_t)i] = blk_off[(size_t)l] + r / FI_BLK;
+          pos_loc[(size_t)i] = (uint16_t)(r % FI_BLK);
+        }
+      const size_t nblk = (size_t)std::max<int32_t>(blk_off[(size_t)ix->nlist], 1);
+      const size_t ncell = nblk * (size_t)ix->d;
+      DevBuf<int32_t> pos_blk_dev;
+      DevBuf<uint16_t> pos_loc_dev;
+      DevBuf<uint32_t> cnt_dev;
+      ASL_TRY(pos_blk_dev.upload(pos_blk.data(), (size_t)n));
+      ASL_TRY(pos_loc_dev.upload(pos_loc.data(), (size_t)n));
+      ASL_TRY(cnt_dev.reserve(ncell));
+      HIP_TRY(hipMemsetAsync(cnt_dev.p, 0, ncell * 4, stream()));
+      ASL_TRY(inv_count(ix->vecs.p, ix->d, order.p, pos_blk_dev.p, n, cnt_dev.p));
+      std::vector<uint32_t> h_cnt(ncell);
+      ASL_TRY(cnt_dev.download(h_cnt.data(), ncell));
+      ASL_TRY(sync_stream());
+      std::vector<uint2> h_ent(ncell);
+      uint64_t run = 0;
+      for (size_t c = 0; c < ncell; c++) {
+        h_ent[c] = make_uint2((uint32_t)run, h_cnt[c]);
+        run += h_cnt[c];
+      }
+      if (run < (1ull << 32)) {     // 32-bit posting offsets
+        ASL_TRY(ix->blk_offsets.upload(blk_off.data(), blk_off.size()));
+        ASL_TRY(ix->inv_ent.upload(h_ent.data(), ncell));
+        ASL_TRY(ix->inv_loc.reserve((size_t)std::max<uint64_t>(run, 1)));
+        ASL_TRY(ix->inv_val.reserve((size_t)std::max<uint64_t>(run, 1)));
+        HIP_TRY(hipMemsetAsync(cnt_dev.p, 0, ncell * 4, stream()));
+        ASL_TRY(inv_fill(ix->vecs.p, ix->d, order.p, pos_blk_dev.p, pos_loc_dev.p, n, ix->inv_ent.p,
+                         cnt_dev.p, ix->inv_loc.p, ix->inv_val.p));
+        ASL_TRY(sync_stream());
+        ix->has_inv = true;
+      }
+    }
   }
   ASL_TRY(sync_stream());
   ix->lists_dirty = false;
@@ -361,9 +412,17 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
       ASL_TRY(coarse_search(ix, xq, nq, nprobe));
       ASL_TRY(build_lists(ix));
-      if (ix->has_sparse && (ix->scan_variant & 0xff) != 1 &&
-          flat_sparse_supported(d, k, nprobe, ix->nnz_stride)) {
-        {
+      // variant 0: dimension-major postings; 2: sparse tiles; 1: dense GEMM + masked top-k
+      const bool use_inv = ix->has_inv && (ix->scan_variant & 0xff) == 0 &&
+                           flat_inv_supported(d, k, nprobe);
+      if (use_inv || (ix->has_sparse && (ix->scan_variant & 0xff) != 1 &&
+                      flat_sparse_supported(d, k, nprobe, ix->nnz_stride))) {
+        if (use_inv) {
+          ProfScope ps("scan");
+          ASL_TRY(flat_inv_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
+                                ix->blk_offsets.p, ix->inv_ent.p, ix->inv_loc.p, ix->inv_val.p,
+                                ix->ids.p, k, D, I64, I32, set_mode || ix->unordered == 1));
+        } else {
           ProfScope ps("scan");
           ASL_TRY(flat_sparse_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
                                    ix->tile_offsets.p, ix->idx_tiled.p, ix->val_tiled.p,

@@ -43,3 +43,14 @@ perm[blk] = order
 print('sorted, one XCD per sorted range: %.2f ms' % timed(vec[perm].contiguous(), cD[perm].contiguous(), cI[perm].contiguous()))
 rnd = torch.randperm(n, device=dev)
 print('random order        : %.2f ms' % timed(vec[rnd].contiguous(), cD[rnd].contiguous(), cI[rnd].contiguous()))
+
+# longest-first: workgroups are dispatched in blockIdx order, so the short queries fill the tail
+offs = idx.lists()[0]
+sizes = torch.as_tensor(offs[1:] - offs[:-1], device=dev).float()
+load = sizes[cI.long().clamp_min(0)].sum(1)
+lpt = load.argsort(descending=True)
+print('longest first       : %.2f ms' % timed(vec[lpt].contiguous(), cD[lpt].contiguous(), cI[lpt].contiguous()))
+spt = load.argsort()
+print('shortest first      : %.2f ms' % timed(vec[spt].contiguous(), cD[spt].contiguous(), cI[spt].contiguous()))
+print('batch order again   : %.2f ms' % timed(vec, cD, cI))
+print('load: mean %.0f  min %.0f  max %.0f vectors/query' % (load.mean(), load.min(), load.max()))
