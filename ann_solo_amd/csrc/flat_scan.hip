@@ -10,6 +10,8 @@
 // the accumulator unchanged), to the fp32-MFMA GEMM and to the oracle. 300 B/vector
 // instead of 3 200 (fp32) / 1 600 (FAISS-GPU fp16): ~10x less HBM traffic, exact results.
 // Top-k: hist_topk.hpp (no sorting while streaming).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "hist_topk.hpp"
 #include "ivf_kernels.hpp"
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ blk_offsets,
     const uint2 *__restrict__ ent, const uint16_t *__restrict__ p_loc,
     const float *__restrict__ p_val, const int32_t *__restrict__ ids, int k,
-    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode) {
+    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode, int dbg) {
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *s_acc = reinterpret_cast<float *>(smem + TopK::lds_bytes());      // [FI_NW][FI_BLK]
@@ -287,6 +289,22 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
     }
     __syncthreads();
     const int nent = min(FI_CHUNK, total - c0);
+    {
+      // The eight waves of a round meet at a barrier, so a round costs its LARGEST block:
+      // order the blocks by size (rank by counting) and every round gets eight alike.
+      FiUnit mine;
+      int rank = 0;
+      if (tid < nent) {
+        mine = table[tid];
+        for (int o = 0; o < nent; ++o) {
+          const int nbo = table[o].nb;
+          rank += (nbo > mine.nb) || (nbo == mine.nb && o < tid);
+        }
+      }
+      __syncthreads();
+      if (tid < nent) table[rank] = mine;
+      __syncthreads();
+    }
     for (int r0 = 0; r0 < nent; r0 += FI_NW) {
       const int i = r0 + wave;
       int nb = 0, pos0 = 0;
@@ -297,7 +315,7 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
         const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.blk);
         for (int o = lane; o < nb; o += 64) acc[o] = 0.0f;
         const uint2 *erow = ent + (size_t)blk * d;
-        for (int kk0 = 0; kk0 < K; kk0 += 64) {
+        for (int kk0 = 0; kk0 < ((dbg & 1) ? 0 : K); kk0 += 64) {
           const int kk = kk0 + lane;
           uint2 e = make_uint2(0u, 0u);
           float qv = 0.0f;
@@ -318,7 +336,7 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
               qj[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), j));
               cmax = cn[u] > cmax ? cn[u] : cmax;
             }
-            if (cmax == 0) continue;
+            if (cmax == 0 || (dbg & 4)) continue;
             if (cmax <= 64) {     // the usual case: one step per dimension, FI_U loads in flight
               uint32_t loc[FI_U];
               float val[FI_U];
@@ -342,17 +360,39 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
           }
         }
       }
-      // every wave offers its block, one row of 64 per round
-      int nbmax = 0;
+      // Offers. Few accumulators pass the running threshold, so the waves first count their
+      // passing candidates and reserve room for all of them with ONE barrier (bulk_reserve),
+      // then append without synchronising; lockstep rounds of 64 per wave only while the
+      // threshold is still low (first blocks of a query) or ties force exact flushes.
+      bool done = (dbg & 2) != 0;
+      for (int attempt = 0; attempt < 2 && !done; ++attempt) {
+        int cnt = 0;
+        for (int v = lane; v - lane < nb; v += 64)
+          cnt += __popcll(__ballot(v < nb && top.passes(acc[v])));
+        const int st = top.bulk_reserve(cnt, attempt == 0);
+        if (st < 0) break;
+        if (st == 1) {
+          for (int v = lane; v - lane < nb; v += 64) {
+            const bool valid = v < nb;
+            const float score = valid ? acc[v] : 0.0f;
+            if (__ballot(valid && top.passes(score)))     // wave-uniform
+              top.offer(valid, score, (uint32_t)(pos0 + v));
+          }
+          done = true;
+        }
+      }
+      if (!done) {
+        int nbmax = 0;
 #pragma unroll
-      for (int w = 0; w < FI_NW; ++w) nbmax = max(nbmax, r0 + w < nent ? table[r0 + w].nb : 0);
-      for (int r = 0; r * 64 < nbmax; ++r) {
-        top.begin_round();
-        const int v = r * 64 + lane;
-        const bool valid = v < nb;
-        const float score = valid ? acc[v] : 0.0f;
-        const bool take = top.offer(valid, score, (uint32_t)(pos0 + v));
-        top.end_round(__popcll(__ballot(take)));
+        for (int w = 0; w < FI_NW; ++w) nbmax = max(nbmax, r0 + w < nent ? table[r0 + w].nb : 0);
+        for (int r = 0; r * 64 < nbmax; ++r) {
+          top.begin_round();
+          const int v = r * 64 + lane;
+          const bool valid = v < nb;
+          const float score = valid ? acc[v] : 0.0f;
+          const bool take = top.offer(valid, score, (uint32_t)(pos0 + v));
+          top.end_round(__popcll(__ballot(take)));
+        }
       }
     }
     __syncthreads();
@@ -383,7 +423,7 @@ int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int n
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(flat_inv_scan_kernel, dim3(nq), dim3(FI_NT), lds, stream(), xq, d, coarse_I,
                      nprobe, list_offsets, blk_offsets, ent, p_loc, p_val, ids, k, D, I64, I32,
-                     set_mode);
+                     set_mode, getenv("ASL_FI_DBG") ? atoi(getenv("ASL_FI_DBG")) : 0);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
