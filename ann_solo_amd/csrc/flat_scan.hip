@@ -204,7 +204,10 @@ int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t
 // stored entries in those dimensions can contribute. So every inverted list is cut into blocks
 // of FI_BLK vectors and each block keeps, per dimension, the postings (local vector index
 // u16, value f32) of the vectors that are non-zero there -- an inverted file inside the
-// inverted file. A wave takes one (query, block): it zeroes the block's accumulators in LDS
+// inverted file. Storage: one segment per (block, dimension), its c values followed by its c
+// local indices (6c bytes, padded to a 4-byte word), and a table of segment starts in words
+// (c = 2 * words / 3): the scan is bound by the number of DRAM sectors it touches, and a
+// dimension costs one table entry + one ~100-byte segment. A wave takes one (query, block): it zeroes the block's accumulators in LDS
 // and walks the query's non-zero dimensions in ASCENDING order, acc[loc] = fmaf(q_d, val,
 // acc[loc]) over that dimension's postings (a vector occurs at most once per dimension, so
 // the lanes of one step never collide, and steps of one wave reach LDS in program order).
@@ -226,8 +229,8 @@ struct FiUnit {
 __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
     const float *__restrict__ xq, int d, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ blk_offsets,
-    const uint2 *__restrict__ ent, const uint16_t *__restrict__ p_loc,
-    const float *__restrict__ p_val, const int32_t *__restrict__ ids, int k,
+    const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_data,
+    const int32_t *__restrict__ ids, int k,
     float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode, int dbg) {
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -314,13 +317,15 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
         pos0 = __builtin_amdgcn_readfirstlane(u.pos0);
         const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.blk);
         for (int o = lane; o < nb; o += 64) acc[o] = 0.0f;
-        const uint2 *erow = ent + (size_t)blk * d;
+        const uint32_t *erow = seg_start + (size_t)blk * d;
         for (int kk0 = 0; kk0 < ((dbg & 1) ? 0 : K); kk0 += 64) {
           const int kk = kk0 + lane;
           uint2 e = make_uint2(0u, 0u);
           float qv = 0.0f;
           if (kk < K) {
-            e = erow[s_nzd[kk]];
+            const uint32_t dim = s_nzd[kk];
+            const uint32_t w0 = erow[dim], w1 = erow[dim + 1];
+            e = make_uint2(w0, (2u * (w1 - w0)) / 3u);      // first word, postings
             qv = s_nzv[kk];
           }
           const int n = min(64, K - kk0);
@@ -343,8 +348,10 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
 #pragma unroll
               for (int u = 0; u < FI_U; ++u) {
                 const bool on = (uint32_t)lane < cn[u];
-                loc[u] = on ? (uint32_t)p_loc[st[u] + lane] : 0u;
-                val[u] = on ? p_val[st[u] + lane] : 0.0f;
+                val[u] = on ? reinterpret_cast<const float *>(seg_data)[st[u] + lane] : 0.0f;
+                loc[u] = on ? (uint32_t)reinterpret_cast<const uint16_t *>(seg_data)
+                                  [2 * (size_t)(st[u] + cn[u]) + lane]
+                            : 0u;
               }
 #pragma unroll
               for (int u = 0; u < FI_U; ++u)
@@ -353,8 +360,10 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
 #pragma unroll
               for (int u = 0; u < FI_U; ++u)
                 for (uint32_t o = lane; o < cn[u]; o += 64) {
-                  const uint32_t l = p_loc[st[u] + o];
-                  acc[l] = __builtin_fmaf(qj[u], p_val[st[u] + o], acc[l]);
+                  const uint32_t l =
+                      reinterpret_cast<const uint16_t *>(seg_data)[2 * (size_t)(st[u] + cn[u]) + o];
+                  acc[l] = __builtin_fmaf(qj[u], reinterpret_cast<const float *>(seg_data)[st[u] + o],
+                                          acc[l]);
                 }
             }
           }
@@ -410,9 +419,9 @@ bool flat_inv_supported(int d, int k, int nprobe) {
 }
 
 int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
-                  const int32_t *list_offsets, const int32_t *blk_offsets, const uint2 *ent,
-                  const uint16_t *p_loc, const float *p_val, const int32_t *ids, int k, float *D,
-                  int64_t *I64, int32_t *I32, int set_mode) {
+                  const int32_t *list_offsets, const int32_t *blk_offsets,
+                  const uint32_t *seg_start, const uint32_t *seg_data, const int32_t *ids, int k,
+                  float *D, int64_t *I64, int32_t *I32, int set_mode) {
   if (nq <= 0) return ASL_OK;
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   const size_t lds = TopK::lds_bytes() + (size_t)FI_NW * FI_BLK * 4 + (size_t)((d + 3) & ~3) * 4 +
@@ -422,7 +431,7 @@ int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int n
     HIP_TRY(hipFuncSetAttribute((const void *)flat_inv_scan_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(flat_inv_scan_kernel, dim3(nq), dim3(FI_NT), lds, stream(), xq, d, coarse_I,
-                     nprobe, list_offsets, blk_offsets, ent, p_loc, p_val, ids, k, D, I64, I32,
+                     nprobe, list_offsets, blk_offsets, seg_start, seg_data, ids, k, D, I64, I32,
                      set_mode, getenv("ASL_FI_DBG") ? atoi(getenv("ASL_FI_DBG")) : 0);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
@@ -447,8 +456,8 @@ __global__ void inv_fill_kernel(const float *__restrict__ vecs, int d,
                                 const int32_t *__restrict__ order,
                                 const int32_t *__restrict__ pos_blk,
                                 const uint16_t *__restrict__ pos_loc, int64_t n,
-                                const uint2 *__restrict__ ent, uint32_t *__restrict__ cursor,
-                                uint16_t *__restrict__ p_loc, float *__restrict__ p_val) {
+                                const uint32_t *__restrict__ seg_start,
+                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ seg_data) {
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
@@ -458,9 +467,11 @@ __global__ void inv_fill_kernel(const float *__restrict__ vecs, int d,
   for (int j = lane; j < d; j += 64) {
     const float x = row[j];
     if (x != 0.0f) {
-      const uint32_t p = ent[b + j].x + atomicAdd(&cursor[b + j], 1u);
-      p_loc[p] = loc;
-      p_val[p] = x;
+      const uint32_t w0 = seg_start[b + j];
+      const uint32_t c = (2u * (seg_start[b + j + 1] - w0)) / 3u;
+      const uint32_t p = atomicAdd(&cursor[b + j], 1u);     // any order inside a segment
+      reinterpret_cast<float *>(seg_data)[w0 + p] = x;
+      reinterpret_cast<uint16_t *>(seg_data)[2 * (size_t)(w0 + c) + p] = loc;
     }
   }
 }
@@ -475,11 +486,11 @@ int inv_count(const float *vecs, int d, const int32_t *order, const int32_t *pos
 }
 
 int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk,
-             const uint16_t *pos_loc, int64_t n, const uint2 *ent, uint32_t *cursor,
-             uint16_t *p_loc, float *p_val) {
+             const uint16_t *pos_loc, int64_t n, const uint32_t *seg_start, uint32_t *cursor,
+             uint32_t *seg_data) {
   if (n <= 0) return ASL_OK;
   hipLaunchKernelGGL(inv_fill_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
-                     order, pos_blk, pos_loc, n, ent, cursor, p_loc, p_val);
+                     order, pos_blk, pos_loc, n, seg_start, cursor, seg_data);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }

@@ -153,10 +153,18 @@ struct HistTopK {
       ++round_no;
       return 1;
     }
-    if (!may_compact) return -1;
+    if (!may_compact) return -1;   // (the buffer was compacted by the previous call: a lockstep round fits)
+    // same steps as end_round: compact; if ties defeat the buckets, exact flushes from now on
+    // (the lockstep rounds the caller falls back to need ROUND_VECS free slots)
     fill = compact();
+    if (fill > CAP - ROUND_VECS) {
+      sort_mode = true;
+      tk.slot_ids = slot_ids;
+      tk.conv_from = 0;
+      fill = tk.flush(tid);
+    }
     refresh_threshold();
-    return fill > CAP - ROUND_VECS ? -1 : 0;
+    return sort_mode ? -1 : 0;
   }
 
   __device__ __forceinline__ void update_bstar() {

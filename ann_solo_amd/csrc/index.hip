@@ -88,9 +88,8 @@ struct asl_index {
   bool has_sparse = false;
   // dimension-major postings for flat_inv_scan (IVF-Flat): blocks of FI_BLK vectors
   DevBuf<int32_t> blk_offsets;   // [nlist + 1] first block of each list
-  DevBuf<uint2> inv_ent;         // [nblocks * d] (first posting, postings) of (block, dimension)
-  DevBuf<uint16_t> inv_loc;      // postings: local vector index
-  DevBuf<float> inv_val;         // postings: value
+  DevBuf<uint32_t> inv_start;    // [nblocks * d + 1] first 4-byte word of the segment of (block, dimension)
+  DevBuf<uint32_t> inv_data;     // segments: c values (f32) then c local vector indices (u16), padded to a word
   bool has_inv = false;
   int scan_variant = 0;  // 0 = auto (v2 when supported), 1 = force v1
   int unordered = 0;  // 1: search rows = exact top-k as a set, unspecified order (no final sort); 2: rows of packed keys
@@ -347,20 +346,22 @@ static int build_lists(asl_index *ix) {
       std::vector<uint32_t> h_cnt(ncell);
       ASL_TRY(cnt_dev.download(h_cnt.data(), ncell));
       ASL_TRY(sync_stream());
-      std::vector<uint2> h_ent(ncell);
+      // segment of a cell with c postings: c floats + c u16 = (3c + 1) / 2 words
+      std::vector<uint32_t> h_start(ncell + 1);
       uint64_t run = 0;
       for (size_t c = 0; c < ncell; c++) {
-        h_ent[c] = make_uint2((uint32_t)run, h_cnt[c]);
-        run += h_cnt[c];
+        h_start[c] = (uint32_t)run;
+        run += (3ull * h_cnt[c] + 1ull) / 2ull;
       }
-      if (run < (1ull << 32)) {     // 32-bit posting offsets
+      h_start[ncell] = (uint32_t)run;
+      if (run < (1ull << 32)) {     // 32-bit word offsets (16 GB of postings)
         ASL_TRY(ix->blk_offsets.upload(blk_off.data(), blk_off.size()));
-        ASL_TRY(ix->inv_ent.upload(h_ent.data(), ncell));
-        ASL_TRY(ix->inv_loc.reserve((size_t)std::max<uint64_t>(run, 1)));
-        ASL_TRY(ix->inv_val.reserve((size_t)std::max<uint64_t>(run, 1)));
+        ASL_TRY(ix->inv_start.upload(h_start.data(), ncell + 1));
+        ASL_TRY(ix->inv_data.reserve((size_t)std::max<uint64_t>(run, 1)));
+        HIP_TRY(hipMemsetAsync(ix->inv_data.p, 0, (size_t)std::max<uint64_t>(run, 1) * 4, stream()));
         HIP_TRY(hipMemsetAsync(cnt_dev.p, 0, ncell * 4, stream()));
-        ASL_TRY(inv_fill(ix->vecs.p, ix->d, order.p, pos_blk_dev.p, pos_loc_dev.p, n, ix->inv_ent.p,
-                         cnt_dev.p, ix->inv_loc.p, ix->inv_val.p));
+        ASL_TRY(inv_fill(ix->vecs.p, ix->d, order.p, pos_blk_dev.p, pos_loc_dev.p, n,
+                         ix->inv_start.p, cnt_dev.p, ix->inv_data.p));
         ASL_TRY(sync_stream());
         ix->has_inv = true;
       }
@@ -420,7 +421,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
         if (use_inv) {
           ProfScope ps("scan");
           ASL_TRY(flat_inv_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
-                                ix->blk_offsets.p, ix->inv_ent.p, ix->inv_loc.p, ix->inv_val.p,
+                                ix->blk_offsets.p, ix->inv_start.p, ix->inv_data.p,
                                 ix->ids.p, k, D, I64, I32, set_mode || ix->unordered == 1));
         } else {
           ProfScope ps("scan");

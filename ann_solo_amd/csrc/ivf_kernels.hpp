@@ -59,14 +59,14 @@ int flat_sparse_scan(const float *xq, int nq, int d, const int32_t *coarse_I, in
 constexpr int FI_BLK = 768;
 bool flat_inv_supported(int d, int k, int nprobe);
 int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
-                  const int32_t *list_offsets, const int32_t *blk_offsets, const uint2 *ent,
-                  const uint16_t *p_loc, const float *p_val, const int32_t *ids, int k, float *D,
-                  int64_t *I64, int32_t *I32, int set_mode);
+                  const int32_t *list_offsets, const int32_t *blk_offsets,
+                  const uint32_t *seg_start, const uint32_t *seg_data, const int32_t *ids, int k,
+                  float *D, int64_t *I64, int32_t *I32, int set_mode);
 int inv_count(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk, int64_t n,
               uint32_t *cnt);
 int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk,
-             const uint16_t *pos_loc, int64_t n, const uint2 *ent, uint32_t *cursor,
-             uint16_t *p_loc, float *p_val);
+             const uint16_t *pos_loc, int64_t n, const uint32_t *seg_start, uint32_t *cursor,
+             uint32_t *seg_data);
 int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_max_dev);
 int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t *dst_slot,
                    const int32_t *ids, int64_t n, int64_t ntiles, int nnz_stride,

@@ -280,16 +280,47 @@ def test_ivfflat_search_identical_to_oracle(O, vecs, trained):
     off, ids, v = idx.lists()
     assert np.array_equal(off, ivf.list_offsets) and np.array_equal(ids, ivf.ids)
     assert np.array_equal(v, ivf.payload)
-    for k, nprobe in ((1024, 8), (10, 2), (1024, 16)):
-        idx.nprobe = nprobe
-        D, I = idx.search(xq, k)
-        Do, Io = ivf.search(xq, k, nprobe)
-        assert np.array_equal(I, Io)
-        assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    # scan variants: 0 = per-dimension postings (default), 2 = sparse tiles, 1 = dense GEMM
+    for variant in (0, 2, 1):
+        idx.set_scan_variant(variant)
+        for k, nprobe in ((1024, 8), (10, 2), (1024, 16)):
+            idx.nprobe = nprobe
+            D, I = idx.search(xq, k)
+            Do, Io = ivf.search(xq, k, nprobe)
+            assert np.array_equal(I, Io), (variant, k, nprobe)
+            assert np.array_equal(D.view(np.uint32), Do.view(np.uint32)), (variant, k, nprobe)
+    idx.set_scan_variant(0)
     # nprobe == nlist is exact search
     idx.nprobe = 16
     _, I = idx.search(xq, 50)
     assert np.array_equal(I, O.flat_search(xb, xq, 50)[1])
+
+
+def test_ivfflat_postings_scan_many_small_lists():
+    """The postings scan where the candidate set only just exceeds the key buffer and the
+    threshold bucket is crowded (small scores, k = 1024): bulk offers have to fall back to
+    compaction + exact flushes without losing a key. Must equal the dense formulation, for
+    ordered rows and for the unordered set mode."""
+    import torch
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    lib, aux = synthetic.make_library(9000, seed=20240807, device='cpu')
+    sl = SpectralLibrary(lib, config=Config(index='ivfflat', kmeans_niter=10))
+    for z in (2, 3, 4):
+        q, _ = synthetic.make_queries(lib, aux, 200, seed=110 + z, charge=z)
+        idx = sl._get_ann_index(z)
+        vec = sl._encode(q.to('cuda'))
+        for _ in range(3):      # the failure this guards against was a race
+            idx.set_scan_variant(0)
+            D0, I0 = idx.search(vec, 1024)
+            idx.set_unordered(1)
+            Du, Iu = idx.search(vec, 1024)
+            idx.set_unordered(0)
+            idx.set_scan_variant(1)
+            D1, I1 = idx.search(vec, 1024)
+            assert torch.equal(I0, I1) and torch.equal(D0, D1)
+            assert torch.equal(Iu.sort(1).values, I1.sort(1).values)
+        idx.set_scan_variant(0)
 
 
 def test_sharded_search_merges_to_unsharded(O, vecs, trained):
