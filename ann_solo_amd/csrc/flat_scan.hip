@@ -1,5 +1,7 @@
 // flat_scan.hip -- exact IVF-Flat list scan over SPARSE inverted lists (replaces the scan
 // inside FAISS IndexIVFFlat.search, /root/reference/src/ann_solo/spectral_library.py:443-444).
+// Two generations: 64-vector sparse tiles (first half of this file; scan variant 2 and k > 1280)
+// and per-dimension postings (second half; the default).
 //
 // A hashed spectrum vector has at most ~50 non-zeros out of 800 (one per peak), so the
 // lists store (index u16, value f32) pairs instead of 3 200-byte dense rows: 64-vector
