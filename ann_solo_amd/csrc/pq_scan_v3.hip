@@ -22,7 +22,6 @@
 
 namespace asl {
 
-constexpr int V3_NT = 256;
 constexpr int V3_CHUNK = 256;   // tile-table entries per chunk
 
 // LDS tile-table entry, 8 bytes: tile index (26 bits: ids are int32, so an index holds fewer
