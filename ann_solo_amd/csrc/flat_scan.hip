@@ -219,7 +219,10 @@ int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t
 // (50 of 800 dimensions) and 1/4 of its lane-steps. Then all waves offer their accumulators
 // to the workgroup's histogram top-k, vectors with score 0 included (they are candidates of
 // the dense scan too).
-constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CAP = 2048, FI_CHUNK = 128, FI_U = 4;
+#ifndef FI_U_
+#define FI_U_ 8
+#endif
+constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CAP = 2048, FI_CHUNK = 128, FI_U = FI_U_;
 
 struct FiUnit {
   uint32_t blk;   // block index into the per-dimension table
@@ -344,24 +347,24 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
               cmax = cn[u] > cmax ? cn[u] : cmax;
             }
             if (cmax == 0 || (dbg & 4)) continue;
-            if (cmax <= 64) {     // the usual case: one step per dimension, FI_U loads in flight
-              uint32_t loc[FI_U];
-              float val[FI_U];
+            // the first 64 postings of FI_U dimensions are loaded together ...
+            uint32_t loc[FI_U];
+            float val[FI_U];
 #pragma unroll
-              for (int u = 0; u < FI_U; ++u) {
-                const bool on = (uint32_t)lane < cn[u];
-                val[u] = on ? reinterpret_cast<const float *>(seg_data)[st[u] + lane] : 0.0f;
-                loc[u] = on ? (uint32_t)reinterpret_cast<const uint16_t *>(seg_data)
-                                  [2 * (size_t)(st[u] + cn[u]) + lane]
-                            : 0u;
-              }
+            for (int u = 0; u < FI_U; ++u) {
+              const bool on = (uint32_t)lane < cn[u];
+              val[u] = on ? reinterpret_cast<const float *>(seg_data)[st[u] + lane] : 0.0f;
+              loc[u] = on ? (uint32_t)reinterpret_cast<const uint16_t *>(seg_data)
+                                [2 * (size_t)(st[u] + cn[u]) + lane]
+                          : 0u;
+            }
+            // ... and applied dimension by dimension; a dimension with more postings than
+            // lanes (rare) finishes its remaining rows before the next dimension starts
 #pragma unroll
-              for (int u = 0; u < FI_U; ++u)
-                if ((uint32_t)lane < cn[u]) acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);
-            } else {              // a dimension with more postings than lanes: strictly in order
-#pragma unroll
-              for (int u = 0; u < FI_U; ++u)
-                for (uint32_t o = lane; o < cn[u]; o += 64) {
+            for (int u = 0; u < FI_U; ++u) {
+              if ((uint32_t)lane < cn[u]) acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);
+              if (cn[u] > 64u)      // wave-uniform
+                for (uint32_t o = 64u + lane; o < cn[u]; o += 64) {
                   const uint32_t l =
                       reinterpret_cast<const uint16_t *>(seg_data)[2 * (size_t)(st[u] + cn[u]) + o];
                   acc[l] = __builtin_fmaf(qj[u], reinterpret_cast<const float *>(seg_data)[st[u] + o],
