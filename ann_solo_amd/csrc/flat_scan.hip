@@ -236,7 +236,7 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ blk_offsets,
     const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_data,
     const int32_t *__restrict__ ids, int k,
-    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode, int dbg) {
+    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode) {
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *s_acc = reinterpret_cast<float *>(smem + TopK::lds_bytes());      // [FI_NW][FI_BLK]
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
         const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.blk);
         for (int o = lane; o < nb; o += 64) acc[o] = 0.0f;
         const uint32_t *erow = seg_start + (size_t)blk * d;
-        for (int kk0 = 0; kk0 < ((dbg & 1) ? 0 : K); kk0 += 64) {
+        for (int kk0 = 0; kk0 < K; kk0 += 64) {
           const int kk = kk0 + lane;
           uint2 e = make_uint2(0u, 0u);
           float qv = 0.0f;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
               qj[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), j));
               cmax = cn[u] > cmax ? cn[u] : cmax;
             }
-            if (cmax == 0 || (dbg & 4)) continue;
+            if (cmax == 0) continue;
             // the first 64 postings of FI_U dimensions are loaded together ...
             uint32_t loc[FI_U];
             float val[FI_U];
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
       // passing candidates and reserve room for all of them with ONE barrier (bulk_reserve),
       // then append without synchronising; lockstep rounds of 64 per wave only while the
       // threshold is still low (first blocks of a query) or ties force exact flushes.
-      bool done = (dbg & 2) != 0;
+      bool done = false;
       for (int attempt = 0; attempt < 2 && !done; ++attempt) {
         int cnt = 0;
         for (int v = lane; v - lane < nb; v += 64)
@@ -437,7 +437,7 @@ int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int n
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(flat_inv_scan_kernel, dim3(nq), dim3(FI_NT), lds, stream(), xq, d, coarse_I,
                      nprobe, list_offsets, blk_offsets, seg_start, seg_data, ids, k, D, I64, I32,
-                     set_mode, getenv("ASL_FI_DBG") ? atoi(getenv("ASL_FI_DBG")) : 0);
+                     set_mode);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
