@@ -323,6 +323,41 @@ def test_ivfflat_postings_scan_many_small_lists():
         idx.set_scan_variant(0)
 
 
+@pytest.mark.parametrize('d,nnz,nlist', [(800, 90, 4), (96, 10, 3), (130, 16, 7)])
+def test_ivfflat_postings_scan_shapes(d, nnz, nlist):
+    """Postings scan outside the bench's shape: queries with more than 64 non-zero
+    dimensions, lists longer than one 768-vector block, dimensions with more postings than
+    lanes, d not a multiple of 4, an empty list. Must equal the dense GEMM formulation bit for
+    bit (scores) and id for id."""
+    import torch
+    from ann_solo_amd import faiss_compat as faiss
+    g = torch.Generator().manual_seed(1000 + d)
+    n, nq = 5000, 300
+
+    def sparse_rows(m):
+        x = torch.zeros(m, d)
+        for i in range(m):
+            cols = torch.randperm(d, generator=g)[:nnz]
+            x[i, cols] = torch.rand(nnz, generator=g) + 0.05
+        return torch.nn.functional.normalize(x, dim=1)
+    xb, xq = sparse_rows(n), sparse_rows(nq)
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(d), d, nlist)
+    cen = xb[:nlist].clone()
+    cen[-1] = -cen[0]                      # a centroid nothing is assigned to: an empty list
+    idx.set_trained(cen.numpy())
+    idx.add(xb.numpy())
+    off = idx.lists()[0]
+    assert (np.diff(off) == 0).any() and (np.diff(off) > 768).any()
+    for k, nprobe in ((1024, nlist), (100, 2)):
+        idx.nprobe = nprobe
+        out = {}
+        for variant in (0, 1):
+            idx.set_scan_variant(variant)
+            out[variant] = idx.search(xq.numpy(), k)
+        assert np.array_equal(out[0][1], out[1][1])
+        assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+
+
 def test_sharded_search_merges_to_unsharded(O, vecs, trained):
     from ann_solo_amd import faiss_compat as faiss
     xb, xq = vecs
