@@ -38,6 +38,57 @@ def test_two_rank_sharded_bench_path(degree):
         assert d['config']['parallelism'] == 'replicas x2' and d['alt_layouts'] is None
 
 
+_RCCL_WORLD1 = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2], RANK='0', WORLD_SIZE='1')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+from ann_solo_amd import synthetic
+from ann_solo_amd.spectral_library import Config, SpectralLibrary
+from ann_solo_amd.distributed import (HipShardBackend, exchange_keys, exchange_partials,
+                                      _all_gather_rows, sharded_search_batch)
+dev = torch.device('cuda', 0)
+# the collectives exactly as the sharded search issues them (RCCL, its own stream, async)
+K = torch.arange(6 * 5, dtype=torch.int64, device=dev).view(6, 5)
+Ko, works, keep = exchange_keys(K, 1)
+for w in works: w.wait()
+assert torch.equal(Ko.view(6, 5), K)
+D = torch.rand(6, 5, device=dev); I = torch.arange(30, device=dev).view(6, 5)
+Do, Io, works, keep = exchange_partials(D, I, 1, async_op=True)
+for w in works: w.wait()
+assert torch.equal(Do.view(6, 5), D) and torch.equal(Io.view(6, 5), I)
+g, w = _all_gather_rows(D, 1, async_op=True); w.wait()
+assert torch.equal(g, D)
+# the whole chunked pipeline over RCCL at world 1 == the unsharded search
+lib, aux = synthetic.make_library(20000, seed=5, device=dev, charges=(2,), charge_p=(1.0,))
+cfg = Config(num_list=64, num_probe=16, num_candidates=256, index=sys.argv[3], pq_m=32,
+             kmeans_niter=4, mode='ann', batch_size=512)
+sl = SpectralLibrary(lib, config=cfg, device=dev)
+q, _ = synthetic.make_queries(lib, aux, 512, seed=6, open_range=300.0, charge=2)
+ref = sl._search_batch(q, 2, 'open', device_out=True)
+sl._get_ann_index(2).shard(0, 1)
+be = HipShardBackend(sl, 2, 'open')
+got = sharded_search_batch(be, q, device_out=True, _force_exchange=True)
+assert torch.equal(got.best_row, ref.best_row) and torch.equal(got.best_score, ref.best_score)
+dist.destroy_process_group()
+print('rccl-world1-ok')
+'''
+
+
+@pytest.mark.parametrize('index', ['ivfpq', 'ivfflat'])
+def test_rccl_collectives_at_world_one(index, tmp_path):
+    """The RCCL code path itself (all_to_all_single / all_gather_into_tensor on device
+    tensors, async handles, the chunked overlap) cannot be run with two ranks on one GPU; at
+    world size 1 every call is still issued through RCCL exactly as in a multi-GPU job."""
+    script = tmp_path / 'rccl1.py'
+    script.write_text(_RCCL_WORLD1)
+    out = subprocess.run([sys.executable, str(script), ROOT, '29531' if index == 'ivfpq' else '29532',
+                          index], capture_output=True, text=True, timeout=600)
+    assert 'rccl-world1-ok' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
 def test_search_preassigned_equals_search():
     import torch
     from ann_solo_amd import synthetic
