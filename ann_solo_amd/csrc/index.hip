@@ -411,7 +411,12 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
     if (ivf) {
       nprobe = std::max(1, std::min(nprobe, ix->nlist));
       if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
-      ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+      if (!pre_I) {
+        ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+      } else {  // search_preassigned: adopt the caller's probe lists (coarse scores are unused)
+        ASL_TRY(ix->coarse_I.reserve((size_t)nq * nprobe));
+        HIP_TRY(hipMemcpyAsync(ix->coarse_I.p, pre_I, (size_t)nq * nprobe * 4, hipMemcpyDeviceToDevice, stream()));
+      }
       ASL_TRY(build_lists(ix));
       // variant 0: dimension-major postings; 2: sparse tiles; 1: dense GEMM + masked top-k
       const bool use_inv = ix->has_inv && (ix->scan_variant & 0xff) == 0 &&
@@ -904,8 +909,8 @@ int asl_index_search_preassigned(asl_index_t *ix, int32_t nq, const float *xq, i
                                  int32_t nprobe, const float *coarse_D,
                                  const int32_t *coarse_I, float *D, int64_t *I) {
   clear_error();
-  if (!ix || ix->kind != ASL_INDEX_IVFPQ)
-    return fail(ASL_ERR_INVALID, "search_preassigned: IVF-PQ index required");
+  if (!ix || ix->kind == ASL_INDEX_FLAT)
+    return fail(ASL_ERR_INVALID, "search_preassigned: IVF index required");
   if (nq <= 0) return ASL_OK;
   if (!xq || !I || !coarse_D || !coarse_I) return fail(ASL_ERR_INVALID, "search_preassigned: null argument");
   if (nprobe < 1 || nprobe > ix->nlist) return fail(ASL_ERR_INVALID, "search_preassigned: nprobe outside 1..nlist");

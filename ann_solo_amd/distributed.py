@@ -113,8 +113,6 @@ class HipShardBackend:
     supports_preassigned = True
 
     def coarse(self, vectors: torch.Tensor):
-        if self.index.info().kind != 2:
-            return None
         return self.index.coarse(vectors, self.sl._num_probe)
 
     def shard_search_preassigned(self, vectors, coarse_D, coarse_I):

@@ -144,7 +144,8 @@ int asl_lpt_owner(int32_t nlist, const int64_t *sizes, int32_t world, int32_t *o
  * answer supplied by the caller (coarse_D / coarse_I [nq, nprobe], as asl_index_coarse
  * emits; -1 entries are skipped). Used by the sharded search: every rank quantises only
  * its own slice of the batch, the probe lists are all-gathered, and each rank scans its
- * own inverted lists for the whole batch. IVF-PQ only. */
+ * own inverted lists for the whole batch. IVF-PQ and IVF-Flat (which ignores coarse_D: its
+ * scores do not contain the coarse term). */
 int asl_index_search_preassigned(asl_index_t *idx, int32_t nq, const float *xq, int32_t k,
                                  int32_t nprobe, const float *coarse_D,
                                  const int32_t *coarse_I, float *D, int64_t *I);
