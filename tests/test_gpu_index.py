@@ -359,6 +359,18 @@ def test_ivfflat_postings_scan_shapes(d, nnz, nlist):
         assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
 
 
+def test_ivfflat_scan_kernels_fuzz():
+    """scripts/fuzz_flat.py: random shapes, sparsity, k, nprobe, duplicate-heavy data --
+    postings and sparse-tile scans equal the dense formulation (ordered rows bit for bit,
+    unordered rows as sets)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'fuzz_flat.py'), '40', '5'],
+                         capture_output=True, text=True, timeout=600)
+    assert '40 trials, 0 mismatches' in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
 def test_sharded_search_merges_to_unsharded(O, vecs, trained):
     from ann_solo_amd import faiss_compat as faiss
     xb, xq = vecs
