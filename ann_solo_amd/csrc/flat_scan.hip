@@ -1,7 +1,7 @@
 // flat_scan.hip -- exact IVF-Flat list scan over SPARSE inverted lists (replaces the scan
 // inside FAISS IndexIVFFlat.search, /root/reference/src/ann_solo/spectral_library.py:443-444).
-// Two generations: 64-vector sparse tiles (first half of this file; scan variant 2 and k > 1280)
-// and per-dimension postings (second half; the default).
+// Two generations: 64-vector sparse tiles (first half of this file; scan variant 2) and
+// per-dimension postings (second half; the default).
 //
 // A hashed spectrum vector has at most ~50 non-zeros out of 800 (one per peak), so the
 // lists store (index u16, value f32) pairs instead of 3 200-byte dense rows: 64-vector
@@ -222,7 +222,7 @@ int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t
 #ifndef FI_U_
 #define FI_U_ 8
 #endif
-constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CAP = 2048, FI_CHUNK = 128, FI_U = FI_U_;
+constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = 128, FI_U = FI_U_;
 
 struct FiUnit {
   uint32_t blk;   // block index into the per-dimension table
@@ -231,7 +231,9 @@ struct FiUnit {
   int32_t pad;
 };
 
-__global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
+// FI_CAP: key buffer of the top-k (2048: k <= 1280, three workgroups per CU; 4096: k <= 3328, two)
+template <int FI_CAP>
+__global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_kernel(
     const float *__restrict__ xq, int d, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ blk_offsets,
     const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_data,
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
     }
     __syncthreads();
   }
-  if (set_mode)   // unordered exact top-k; the accumulators are dead: scratch
+  if (set_mode && (size_t)FI_CAP * 8 <= (size_t)FI_NW * FI_BLK * 4)   // unordered exact top-k; the accumulators are dead: scratch
     top.finish_set(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
                    I32 ? I32 + (size_t)q * k : nullptr, reinterpret_cast<u64 *>(s_acc));
   else
@@ -420,7 +422,27 @@ __global__ __launch_bounds__(FI_NT, 6) void flat_inv_scan_kernel(
 }
 
 bool flat_inv_supported(int d, int k, int nprobe) {
-  return d <= 4096 && nprobe <= FI_NT && k >= 1 && k + FI_NT + 256 <= FI_CAP;
+  return d <= 4096 && nprobe <= FI_NT && k >= 1 && k + FI_NT + 256 <= 4096;
+}
+
+template <int FI_CAP>
+static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
+                           const int32_t *list_offsets, const int32_t *blk_offsets,
+                           const uint32_t *seg_start, const uint32_t *seg_data,
+                           const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32,
+                           int set_mode) {
+  using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
+  const size_t lds = TopK::lds_bytes() + (size_t)FI_NW * FI_BLK * 4 + (size_t)((d + 3) & ~3) * 4 +
+                     (size_t)FI_CHUNK * sizeof(FiUnit) + 64 + (size_t)((d + 7) & ~7) * 2;
+  if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "flat scan: d=%d does not fit LDS", d);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void *)flat_inv_scan_kernel<FI_CAP>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(flat_inv_scan_kernel<FI_CAP>, dim3(nq), dim3(FI_NT), lds, stream(), xq, d,
+                     coarse_I, nprobe, list_offsets, blk_offsets, seg_start, seg_data, ids, k, D,
+                     I64, I32, set_mode);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
 }
 
 int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
@@ -428,18 +450,11 @@ int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int n
                   const uint32_t *seg_start, const uint32_t *seg_data, const int32_t *ids, int k,
                   float *D, int64_t *I64, int32_t *I32, int set_mode) {
   if (nq <= 0) return ASL_OK;
-  using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
-  const size_t lds = TopK::lds_bytes() + (size_t)FI_NW * FI_BLK * 4 + (size_t)((d + 3) & ~3) * 4 +
-                     (size_t)FI_CHUNK * sizeof(FiUnit) + 64 + (size_t)((d + 7) & ~7) * 2;
-  if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "flat scan: d=%d does not fit LDS", d);
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)flat_inv_scan_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(flat_inv_scan_kernel, dim3(nq), dim3(FI_NT), lds, stream(), xq, d, coarse_I,
-                     nprobe, list_offsets, blk_offsets, seg_start, seg_data, ids, k, D, I64, I32,
-                     set_mode);
-  ASL_CHECK_LAUNCH();
-  return ASL_OK;
+  if (k + FI_NT + 256 <= 2048)
+    return launch_flat_inv<2048>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, seg_start,
+                                 seg_data, ids, k, D, I64, I32, set_mode);
+  return launch_flat_inv<4096>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, seg_start,
+                               seg_data, ids, k, D, I64, I32, set_mode);
 }
 
 // ---- building the postings from dense rows. pos_blk / pos_loc: block and local index of

@@ -93,7 +93,7 @@ int asl_index_set_niter(asl_index_t *idx, int32_t niter);
  * measurements): 0 = automatic (tiled sub-quantiser-per-lane kernel with histogram top-k
  * when m = 32, 8 bits, nprobe <= 256), 1 = generic lane-per-vector kernel, 2 = tiled kernel
  * with sort-based top-k, 3 / 4 = tiled + histogram top-k with a 2048- / 4096-key buffer.
- * IVF-Flat: 0 = per-dimension postings inside every list (k <= 1280; sparse data), 2 = sparse
+ * IVF-Flat: 0 = per-dimension postings inside every list (sparse data), 2 = sparse
  * 64-vector tiles, 1 = dense GEMM + masked top-k.
  * Bits 8+ are measurement knobs of the kernels (results invalid when set). */
 int asl_index_set_scan_variant(asl_index_t *idx, int32_t variant);

@@ -17,7 +17,7 @@ for t in range(trials):
     n = int(rng.integers(200, 20000))
     nlist = int(rng.integers(1, 64))
     nprobe = int(rng.integers(1, nlist + 1))
-    k = int(rng.integers(1, 1281))
+    k = int(rng.integers(1, 2049))
     nq = int(rng.integers(1, 700))
     dup = rng.random() < 0.3          # many identical vectors: ties everywhere
 

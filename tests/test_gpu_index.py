@@ -348,7 +348,7 @@ def test_ivfflat_postings_scan_shapes(d, nnz, nlist):
     idx.add(xb.numpy())
     off = idx.lists()[0]
     assert (np.diff(off) == 0).any() and (np.diff(off) > 768).any()
-    # k > 1280 leaves the postings kernel's key buffer: sparse tiles up to 1536, then dense
+    # k > 1280: the postings kernel with the 4096-key buffer
     for k, nprobe in ((1024, nlist), (100, 2), (1500, nlist), (2000, nlist)):
         idx.nprobe = nprobe
         out = {}
