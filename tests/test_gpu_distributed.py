@@ -14,16 +14,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('degree', [0, 1])
-def test_two_rank_sharded_bench_path(degree):
+@pytest.mark.parametrize('degree,index', [(0, 'ivfpq'), (1, 'ivfpq'), (0, 'ivfflat')])
+def test_two_rank_sharded_bench_path(degree, index):
     """degree 0 = lists sharded over both ranks; degree 1 = two replicas (no exchange)"""
     env = dict(os.environ, ASL_BENCH_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', str(29517 + degree),
+           '--master-addr', '127.0.0.1', '--master-port',
+           str(29517 + degree + (5 if index == 'ivfflat' else 0)),
            os.path.join(ROOT, 'bench.py'),
            '--gpus', '2', '--steps', '1', '--warmup', '1', '--library-size', '60000', '--nlist',
            '256', '--niter', '4', '--batch', '1024', '--recall-queries', '64',
-           '--shard-degree', str(degree)]
+           '--shard-degree', str(degree), '--index', index]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     line = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert line, out.stderr[-2000:]
