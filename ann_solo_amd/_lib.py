@@ -44,7 +44,7 @@ class AslProcessParams(C.Structure):
     _fields_ = [('min_mz', C.c_double), ('max_mz', C.c_double), ('remove_precursor', C.c_int32),
                 ('remove_precursor_tolerance', C.c_double), ('min_intensity', C.c_double),
                 ('max_peaks', C.c_int32), ('scaling', C.c_int32), ('min_peaks', C.c_int32),
-                ('min_mz_range', C.c_double)]
+                ('min_mz_range', C.c_double), ('round_mz', C.c_int32), ('resolution', C.c_int32)]
 
 
 class AslIndexInfo(C.Structure):

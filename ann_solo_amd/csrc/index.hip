@@ -6,7 +6,9 @@
 //
 // Training restates FAISS' Clustering (Lloyd iterations, assignment by the
 // quantiser's metric, mean update, empty-cluster split with eps = 1/1024, at most
-// 256 points per centroid) with a library-local RNG; it is deterministic and
+// 256 points per centroid; SPHERICAL -- centroids L2-renormalised every iteration -- for
+// the inner-product coarse quantiser, as FAISS' IndexIVF sets cp.spherical for
+// METRIC_INNER_PRODUCT) with a library-local RNG; it is deterministic and
 // bit-identical to oracle/asl_oracle.c:orc_kmeans for the same seed.
 #include <algorithm>
 #include <cmath>
@@ -144,6 +146,10 @@ static int kmeans_device(asl_index *ix, const float *x, int64_t n, int64_t ld, i
     ASL_TRY(rows_dev.upload(pick.data(), (size_t)k));
     ASL_TRY(gather_rows_f32(xt, ldt, rows_dev.p, k, d, cent_dev, d));
   }
+  // FAISS IndexIVF: cp.spherical = true for METRIC_INNER_PRODUCT -> post_process_centroids
+  // renormalises after the initialisation and after every iteration (oracle: orc_kmeans)
+  const bool spherical = !l2;
+  if (spherical) ASL_TRY(renorm_rows(cent_dev, k, d));
   DevBuf<int32_t> assign, order, offsets;
   ASL_TRY(assign.reserve((size_t)nt));
   ASL_TRY(order.reserve((size_t)nt));
@@ -204,6 +210,7 @@ static int kmeans_device(asl_index *ix, const float *x, int64_t n, int64_t ld, i
       HIP_TRY(hipMemcpyAsync(cent_dev, h_cent.data(), h_cent.size() * 4, hipMemcpyHostToDevice, stream()));
       ASL_TRY(sync_stream());
     }
+    if (spherical) ASL_TRY(renorm_rows(cent_dev, k, d));
   }
   ASL_TRY(sync_stream());
   return ASL_OK;

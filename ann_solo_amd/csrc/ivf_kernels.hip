@@ -429,6 +429,29 @@ int centroid_update(const float *x, int64_t ld, int d, int k, const int32_t *ord
   return ASL_OK;
 }
 
+// Spherical k-means (FAISS cp.spherical for inner-product indexes): rows with a non-zero
+// norm are rescaled to unit L2 length. Canonical chain: ascending fmaf from +0, sqrtf, IEEE
+// divide (the encoder's norm) -- one lane walks the chain, the block divides.
+__global__ __launch_bounds__(256) void renorm_rows_kernel(float *__restrict__ c, int d) {
+  __shared__ float s_nrm;
+  float *row = c + (size_t)blockIdx.x * d;
+  if (threadIdx.x == 0) {
+    float acc = 0.0f;
+    for (int j = 0; j < d; ++j) acc = __builtin_fmaf(row[j], row[j], acc);
+    s_nrm = acc > 0.0f ? __builtin_sqrtf(acc) : 0.0f;
+  }
+  __syncthreads();
+  const float nrm = s_nrm;
+  if (nrm > 0.0f)
+    for (int j = threadIdx.x; j < d; j += 256) row[j] = row[j] / nrm;
+}
+int renorm_rows(float *c, int k, int d) {
+  if (k <= 0) return ASL_OK;
+  hipLaunchKernelGGL(renorm_rows_kernel, dim3(k), dim3(256), 0, stream(), c, d);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
 // ------------------------------------------------------------------ L2 assignment (PQ)
 // x: [n, ld] (sub-vector view, dsub <= 32), cb: [ksub, dsub]. Chain
 // acc = fmaf(x-c, x-c, acc) ascending, arg-min with lowest-index ties.

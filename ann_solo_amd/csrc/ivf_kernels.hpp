@@ -23,6 +23,7 @@ int gather_rows_f32(const float *src, int64_t ld_src, const int64_t *rows, int64
 int gather_rows_u8(const uint8_t *src, const int32_t *rows, int64_t n, int m, uint8_t *dst);
 int centroid_update(const float *x, int64_t ld, int d, int k, const int32_t *order,
                     const int32_t *offsets, float *centroids);
+int renorm_rows(float *c, int k, int d);
 int l2_assign(const float *x, int64_t ld, int64_t n, int dsub, const float *cb, int ksub,
               int32_t *assign);
 int residual(const float *x, const int32_t *assign, const float *centroids, int64_t n, int d,

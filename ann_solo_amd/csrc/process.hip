@@ -1,6 +1,6 @@
 // process.hip -- batched peak preprocessing (replaces process_spectrum,
 // /root/reference/src/ann_solo/spectrum.py:57-119, i.e. the spectrum_utils 0.3.x calls
-// set_mz_range / remove_precursor_peak / filter_intensity / scale_intensity + L2 norm and the
+// set_mz_range / round / remove_precursor_peak / filter_intensity / scale_intensity + L2 norm and the
 // validity checks of spectrum.py:13-36). PARITY UNPINNED: spectrum_utils is an
 // un-vendored dependency; the kernel is bit-identical to oracle/orc_process_spectrum.
 //
@@ -18,8 +18,18 @@ constexpr int PS_NT = 256, PS_MAXN = 4096;
 
 struct ProcParams {
   double min_mz, max_mz, rp_tol, min_intensity, min_mz_range;
-  int remove_precursor, max_peaks, scaling, min_peaks;
+  int remove_precursor, max_peaks, scaling, min_peaks, resolution;
 };
+
+// MsmsSpectrum.round's m/z rounding (numba np.round_ on a float: evaluated in double, ties to
+// even, stored as float32) -- oracle: orc_round_mz
+__device__ __forceinline__ float round_mz(float mz, int decimals) {
+  double p = 1.0;
+  const int a = decimals < 0 ? -decimals : decimals;
+  for (int i = 0; i < a; ++i) p *= 10.0;
+  const double x = (double)mz;
+  return (float)(decimals >= 0 ? rint(x * p) / p : rint(x / p) * p);
+}
 
 __device__ __forceinline__ bool wg_valid(const float *mz, const uint8_t *keep, int n, int tid,
                                          int *s3 /* cnt, first, last */, int min_peaks,
@@ -49,6 +59,9 @@ __device__ __forceinline__ bool wg_valid(const float *mz, const uint8_t *keep, i
   return ok;
 }
 
+// ROUND: config.resolution is set -- the spectrum is staged in LDS, its m/z rounded and peaks
+// with equal rounded m/z merged (spectrum.py:84-85) before the remaining steps run on the copy.
+template <bool ROUND>
 __global__ __launch_bounds__(PS_NT) void process_kernel(
     DevPeaks raw, ProcParams P, float *__restrict__ out_mz, float *__restrict__ out_int,
     int32_t *__restrict__ out_src, int32_t *__restrict__ out_count,
@@ -58,6 +71,9 @@ __global__ __launch_bounds__(PS_NT) void process_kernel(
   float *val = reinterpret_cast<float *>(keys + PS_MAXN);          // [PS_MAXN]
   uint8_t *keep = reinterpret_cast<uint8_t *>(val + PS_MAXN);      // [PS_MAXN]
   int *ctl = reinterpret_cast<int *>(keep + PS_MAXN);              // 16 ints
+  float *w_mz = reinterpret_cast<float *>(ctl + 16);               // ROUND only: [PS_MAXN] x 3
+  float *w_int = w_mz + PS_MAXN;
+  int *w_src = reinterpret_cast<int *>(w_int + PS_MAXN);
   const int s = blockIdx.x, tid = threadIdx.x;
   const int o = raw.offsets[s];
   int n = raw.offsets[s + 1] - o;
@@ -88,6 +104,42 @@ __global__ __launch_bounds__(PS_NT) void process_kernel(
   if (!wg_valid(mz, keep, n, tid, ctl, P.min_peaks, P.min_mz_range)) {
     bail();
     return;
+  }
+  if (ROUND) {
+    int *head = reinterpret_cast<int *>(val);   // scratch: val is not live yet
+    for (int i = tid; i < n; i += PS_NT) {
+      w_mz[i] = keep[i] ? round_mz(mz[i], P.resolution) : mz[i];
+      w_int[i] = inten[i];
+      w_src[i] = i;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += PS_NT)
+      head[i] = keep[i] && (i == 0 || !keep[i - 1] || w_mz[i - 1] != w_mz[i]);
+    __syncthreads();
+    for (int i = tid; i < n; i += PS_NT) {
+      if (!head[i]) continue;
+      int best = i;
+      float sum = w_int[i], bv = w_int[i];
+      for (int j = i + 1; j < n && keep[j] && w_mz[j] == w_mz[i]; ++j) {
+        const float v = w_int[j];
+        sum += v;
+        if (v > bv) {
+          bv = v;
+          best = j;
+        }
+      }
+      w_int[i] = sum;    // only this head reads its group's entries
+      w_src[i] = best;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += PS_NT) keep[i] = (uint8_t)head[i];
+    __syncthreads();
+    mz = w_mz;
+    inten = w_int;
+    if (!wg_valid(mz, keep, n, tid, ctl, P.min_peaks, P.min_mz_range)) {
+      bail();
+      return;
+    }
   }
   if (P.remove_precursor) {
     const double adduct = 1.0072766;
@@ -159,7 +211,7 @@ __global__ __launch_bounds__(PS_NT) void process_kernel(
     const int i = tid * PER + u;
     if (i < n && keep[i]) {
       out_mz[(size_t)s * P.max_peaks + pos] = mz[i];
-      out_src[(size_t)s * P.max_peaks + pos] = i;
+      out_src[(size_t)s * P.max_peaks + pos] = ROUND ? w_src[i] : i;
       c_val[pos] = val[i];
       ++pos;
     }
@@ -215,15 +267,23 @@ extern "C" int asl_process_batch(const asl_peaks_t *raw, const asl_process_param
   DevBuf<int> status;
   ASL_TRY(status.reserve(1));
   HIP_TRY(hipMemsetAsync(status.p, 0, sizeof(int), stream()));
+  if (p->round_mz && (p->resolution < -6 || p->resolution > 12))
+    return fail(ASL_ERR_INVALID, "process_batch: resolution must be in -6..12 decimals");
   ProcParams P{p->min_mz, p->max_mz, p->remove_precursor_tolerance, p->min_intensity,
-               p->min_mz_range, p->remove_precursor, p->max_peaks, p->scaling, p->min_peaks};
-  const size_t lds = (size_t)PS_MAXN * (8 + 4 + 1) + 64;
-  HIP_TRY(hipFuncSetAttribute((const void *)process_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+               p->min_mz_range, p->remove_precursor, p->max_peaks, p->scaling, p->min_peaks,
+               p->resolution};
+  const bool round = p->round_mz != 0;
+  const size_t lds = (size_t)PS_MAXN * (8 + 4 + 1) + 64 + (round ? (size_t)PS_MAXN * 12 : 0);
+  const void *fn = round ? (const void *)process_kernel<true> : (const void *)process_kernel<false>;
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   {
     ProfScope ps("process");
-    hipLaunchKernelGGL(process_kernel, dim3(n), dim3(PS_NT), lds, stream(), R.dev, P, o_mz.d,
-                       o_int.d, o_src.d, o_cnt.d, o_val.d, status.p);
+    if (round)
+      hipLaunchKernelGGL(process_kernel<true>, dim3(n), dim3(PS_NT), lds, stream(), R.dev, P,
+                         o_mz.d, o_int.d, o_src.d, o_cnt.d, o_val.d, status.p);
+    else
+      hipLaunchKernelGGL(process_kernel<false>, dim3(n), dim3(PS_NT), lds, stream(), R.dev, P,
+                         o_mz.d, o_int.d, o_src.d, o_cnt.d, o_val.d, status.p);
     ASL_CHECK_LAUNCH();
   }
   ASL_TRY(o_mz.finish());

@@ -91,13 +91,13 @@ def process_spectra(raw, is_library: bool, config=None, device='cuda'):
     scaling = g('scaling', 'rank')
     scaling = {'rank': 1, 'sqrt': 2, 'root': 2, None: 0}[scaling]
     max_peaks = g('max_peaks_used_library', 50) if is_library else g('max_peaks_used', 50)
-    if g('resolution', None) is not None:
-        raise NotImplementedError('config.resolution (m/z rounding) is not implemented on the device')
+    resolution = g('resolution', None)
     P = _lib.AslProcessParams(float(g('min_mz', 11)), float(g('max_mz', 2010)),
                               int(bool(g('remove_precursor', False))),
                               float(g('remove_precursor_tolerance', 0.0)),
                               float(g('min_intensity', 0.01)), int(max_peaks), scaling,
-                              int(g('min_peaks', 10)), float(g('min_mz_range', 250.0)))
+                              int(g('min_peaks', 10)), float(g('min_mz_range', 250.0)),
+                              int(resolution is not None), int(resolution or 0))
     r = raw.to(device).contiguous()
     n = r.n
     dev = r.mz.device

@@ -190,11 +190,13 @@ int asl_rescore_batch(const asl_peaks_t *queries, const asl_peaks_t *library,
 
 /* ------------------------------------------------------------------ peak preprocessing
  * Replaces process_spectrum (src/ann_solo/spectrum.py:57-119: spectrum_utils set_mz_range,
- * remove_precursor_peak(tol,'Da',2), filter_intensity, scale_intensity, L2 norm, and the
- * validity checks of :13-36), batched. Raw peaks ascending in m/z, <= 4096 per spectrum.
- * Outputs are padded to max_peaks per spectrum: out_mz / out_intensity / out_src
- * [n, max_peaks] (out_src = index of the kept peak inside its raw spectrum, may be NULL),
- * out_count[n], out_valid[n] (is_valid). scaling: 0 none, 1 rank, 2 root. */
+ * round(resolution,'sum'), remove_precursor_peak(tol,'Da',2), filter_intensity,
+ * scale_intensity, L2 norm, and the validity checks of :13-36), batched. Raw peaks ascending
+ * in m/z, <= 4096 per spectrum. Outputs are padded to max_peaks per spectrum: out_mz /
+ * out_intensity / out_src [n, max_peaks] (out_src = index of the kept peak inside its raw
+ * spectrum -- after rounding: of the most intense of the merged peaks, whose annotation
+ * survives --, may be NULL), out_count[n], out_valid[n] (is_valid).
+ * scaling: 0 none, 1 rank, 2 root. */
 typedef struct {
   double min_mz, max_mz;              /* config.min_mz / max_mz (inclusive) */
   int32_t remove_precursor;           /* config.remove_precursor */
@@ -204,6 +206,8 @@ typedef struct {
   int32_t scaling;
   int32_t min_peaks;                  /* config.min_peaks */
   double min_mz_range;                /* config.min_mz_range */
+  int32_t round_mz;                   /* config.resolution is not None (spectrum.py:84) */
+  int32_t resolution;                 /* config.resolution: decimals of MsmsSpectrum.round */
 } asl_process_params_t;
 int asl_process_batch(const asl_peaks_t *raw, const asl_process_params_t *params,
                       float *out_mz, float *out_intensity, int32_t *out_src,

@@ -182,17 +182,62 @@ static int spectrum_ok(const float *mz, const uint8_t *keep, int32_t n, int min_
   return cnt >= min_peaks && cnt > 0 && (double)(mz[last] - mz[first]) >= min_range;
 }
 
-int orc_process_spectrum(const float *mz, const float *intensity, int32_t n, double precursor_mz,
-                         int32_t precursor_charge, const orc_process_params_t *p,
-                         float *out_mz, float *out_int, int32_t *out_src, int32_t *n_out) {
+/* spectrum_utils 0.3.x MsmsSpectrum.round(decimals, 'sum') (spectrum.py:84-85). The library
+ * function is numba-compiled: np.round_ on a float is evaluated in double --
+ * rint(x * 10^d) / 10^d for d >= 0, rint(x / 10^-d) * 10^-d for d < 0, ties to even -- and
+ * stored back as float32. Peaks whose rounded m/z coincide are merged: intensity = sequential
+ * float32 sum in m/z order, annotation (here: the source index) = that of the most intense
+ * merged peak, first on ties (np.argmax). */
+float orc_round_mz(float mz, int32_t decimals) {
+  double x = (double)mz, p = 1.0;
+  int32_t a = decimals < 0 ? -decimals : decimals;
+  for (int32_t i = 0; i < a; i++) p *= 10.0;
+  double y = decimals >= 0 ? rint(x * p) / p : rint(x / p) * p;
+  return (float)y;
+}
+
+int orc_process_spectrum(const float *mz_in, const float *intensity_in, int32_t n,
+                         double precursor_mz, int32_t precursor_charge,
+                         const orc_process_params_t *p, float *out_mz, float *out_int,
+                         int32_t *out_src, int32_t *n_out) {
   *n_out = 0;
   if (n <= 0) return 0;
   uint8_t *keep = (uint8_t *)malloc((size_t)n);
+  float *mz = (float *)malloc(sizeof(float) * (size_t)n);
+  float *intensity = (float *)malloc(sizeof(float) * (size_t)n);
+  int32_t *src = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  orc_pk_t *pk = NULL;
+  float *val = NULL;
+  int ok = 0;
+  memcpy(mz, mz_in, sizeof(float) * (size_t)n);
+  memcpy(intensity, intensity_in, sizeof(float) * (size_t)n);
+  for (int32_t i = 0; i < n; i++) src[i] = i;
   /* spectrum.py:79 set_mz_range: inclusive on both sides */
   for (int32_t i = 0; i < n; i++) keep[i] = (double)mz[i] >= p->min_mz && (double)mz[i] <= p->max_mz;
-  if (!spectrum_ok(mz, keep, n, p->min_peaks, p->min_mz_range)) {
-    free(keep);
-    return 0;
+  if (!spectrum_ok(mz, keep, n, p->min_peaks, p->min_mz_range)) goto done;
+  /* spectrum.py:84-85 round(resolution, 'sum') */
+  if (p->round_mz) {
+    for (int32_t i = 0; i < n; i++)
+      if (keep[i]) mz[i] = orc_round_mz(mz[i], p->resolution);
+    int32_t i = 0;
+    while (i < n) {
+      if (!keep[i]) {
+        i++;
+        continue;
+      }
+      int32_t j = i + 1, best = i;
+      float sum = intensity[i];
+      while (j < n && keep[j] && mz[j] == mz[i]) {
+        sum += intensity[j];
+        if (intensity[j] > intensity[best]) best = j;
+        keep[j] = 0;
+        j++;
+      }
+      intensity[i] = sum;
+      src[i] = best;
+      i = j;
+    }
+    if (!spectrum_ok(mz, keep, n, p->min_peaks, p->min_mz_range)) goto done;
   }
   /* spectrum.py:90-92 remove_precursor_peak(tol, 'Da', 2) */
   if (p->remove_precursor) {
@@ -204,13 +249,10 @@ int orc_process_spectrum(const float *mz, const float *intensity, int32_t n, dou
         for (int32_t i = 0; i < n; i++)
           if (keep[i] && fabs((double)mz[i] - rm) <= p->remove_precursor_tolerance) keep[i] = 0;
       }
-    if (!spectrum_ok(mz, keep, n, p->min_peaks, p->min_mz_range)) {
-      free(keep);
-      return 0;
-    }
+    if (!spectrum_ok(mz, keep, n, p->min_peaks, p->min_mz_range)) goto done;
   }
   /* spectrum.py:97-99 filter_intensity: strictly above min_intensity * max, top max_peaks */
-  orc_pk_t *pk = (orc_pk_t *)malloc(sizeof(orc_pk_t) * (size_t)n);
+  pk = (orc_pk_t *)malloc(sizeof(orc_pk_t) * (size_t)n);
   int m = 0;
   for (int32_t i = 0; i < n; i++)
     if (keep[i]) {
@@ -227,13 +269,9 @@ int orc_process_spectrum(const float *mz, const float *intensity, int32_t n, dou
       keep[pk[r].idx] = 1;
       kept++;
     }
-  if (!spectrum_ok(mz, keep, n, p->min_peaks, p->min_mz_range)) {
-    free(keep);
-    free(pk);
-    return 0;
-  }
+  if (!spectrum_ok(mz, keep, n, p->min_peaks, p->min_mz_range)) goto done;
   /* spectrum.py:104-110 scale_intensity; :112 L2 norm (canonical ascending fmaf chain) */
-  float *val = (float *)calloc((size_t)n, sizeof(float));
+  val = (float *)calloc((size_t)n, sizeof(float));
   for (int r = 0; r < kept; r++) {
     int32_t i = pk[r].idx;
     if (p->scaling == 1)
@@ -252,14 +290,19 @@ int orc_process_spectrum(const float *mz, const float *intensity, int32_t n, dou
     if (keep[i]) {
       out_mz[o] = mz[i];
       out_int[o] = val[i] / nrm;
-      out_src[o] = i;
+      out_src[o] = src[i];
       o++;
     }
   *n_out = o;
+  ok = 1;
+done:
   free(val);
   free(keep);
   free(pk);
-  return 1;
+  free(mz);
+  free(intensity);
+  free(src);
+  return ok;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -601,8 +644,32 @@ void orc_assign(const float *x, int64_t n, int32_t d, const float *centroids, in
   }
 }
 
+/* FAISS ClusteringParameters.spherical (post_process_centroids -> fvec_renorm_L2): every
+ * centroid with a non-zero norm is rescaled to unit L2 length. Canonical arithmetic of this
+ * build: ascending-index fmaf chain, sqrtf, IEEE divide -- the encoder's norm. */
+static void renorm_rows(float *c, int32_t k, int32_t d) {
+  for (int32_t i = 0; i < k; i++) {
+    float *ci = c + (size_t)i * d;
+    float acc = 0.0f;
+    for (int32_t j = 0; j < d; j++) acc = fmaf(ci[j], ci[j], acc);
+    if (acc > 0.0f) {
+      float nrm = sqrtf(acc);
+      for (int32_t j = 0; j < d; j++) ci[j] = ci[j] / nrm;
+    }
+  }
+}
+
+/* Lloyd k-means as FAISS' Clustering::train runs it (published algorithm; FAISS itself is
+ * absent here): subsample to max_ppc points per centroid, k random training points as the
+ * initial centroids, then niter x { assign by the quantiser's metric, mean update,
+ * split_clusters for empty clusters (eps = 1/1024), post_process_centroids }.
+ * metric == ORC_METRIC_IP implies SPHERICAL k-means: FAISS' IndexIVF constructor sets
+ * cp.spherical = true for METRIC_INNER_PRODUCT (the reference builds exactly such an index,
+ * src/ann_solo/spectral_library.py:174-178), so the centroids are L2-renormalised after the
+ * initialisation and after every iteration. The PQ sub-quantisers (L2) are not spherical. */
 void orc_kmeans(const float *x, int64_t n, int32_t d, int32_t k, int32_t niter,
                 uint64_t seed, int metric, int32_t max_ppc, float *centroids) {
+  const int spherical = metric == ORC_METRIC_IP;
   /* subsample to k*max_ppc points in permutation order */
   int64_t nt = n;
   const float *xt = x;
@@ -626,6 +693,7 @@ void orc_kmeans(const float *x, int64_t n, int32_t d, int32_t k, int32_t niter,
              sizeof(float) * (size_t)d);
     free(perm);
   }
+  if (spherical) renorm_rows(centroids, k, d);
   int32_t *assign = (int32_t *)malloc(sizeof(int32_t) * (size_t)nt);
   float *hassign = (float *)malloc(sizeof(float) * (size_t)k);
   uint64_t rng = seed + 2;
@@ -670,6 +738,7 @@ void orc_kmeans(const float *x, int64_t n, int32_t d, int32_t k, int32_t niter,
       hassign[ci] = floorf(hassign[cj] / 2);
       hassign[cj] -= hassign[ci];
     }
+    if (spherical) renorm_rows(centroids, k, d);
   }
   free(assign);
   free(hassign);

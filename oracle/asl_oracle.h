@@ -75,7 +75,10 @@ typedef struct {
   int32_t scaling;
   int32_t min_peaks;
   double min_mz_range;
+  int32_t round_mz;   /* config.resolution is not None (spectrum.py:84) */
+  int32_t resolution; /* decimals of MsmsSpectrum.round */
 } orc_process_params_t;
+float orc_round_mz(float mz, int32_t decimals);
 int orc_process_spectrum(const float *mz, const float *intensity, int32_t n, double precursor_mz,
                          int32_t precursor_charge, const orc_process_params_t *p,
                          float *out_mz, float *out_int, int32_t *out_src, int32_t *n_out);

@@ -147,16 +147,18 @@ class OrcProcessParams(C.Structure):
     _fields_ = [('min_mz', C.c_double), ('max_mz', C.c_double), ('remove_precursor', C.c_int32),
                 ('remove_precursor_tolerance', C.c_double), ('min_intensity', C.c_double),
                 ('max_peaks', C.c_int32), ('scaling', C.c_int32), ('min_peaks', C.c_int32),
-                ('min_mz_range', C.c_double)]
+                ('min_mz_range', C.c_double), ('round_mz', C.c_int32), ('resolution', C.c_int32)]
 
 
 def process_spectrum(mz, intensity, precursor_mz, precursor_charge, min_mz=11, max_mz=2010,
                      remove_precursor=False, remove_precursor_tolerance=0.0, min_intensity=0.01,
-                     max_peaks=50, scaling='rank', min_peaks=10, min_mz_range=250.0):
+                     max_peaks=50, scaling='rank', min_peaks=10, min_mz_range=250.0,
+                     resolution=None):
     mz, intensity = _c(mz, np.float32), _c(intensity, np.float32)
     P = OrcProcessParams(min_mz, max_mz, int(remove_precursor), remove_precursor_tolerance,
                          min_intensity, max_peaks, {'rank': 1, 'root': 2, 'sqrt': 2, None: 0}[scaling],
-                         min_peaks, min_mz_range)
+                         min_peaks, min_mz_range, int(resolution is not None),
+                         int(resolution or 0))
     om, oi = np.zeros(max_peaks, np.float32), np.zeros(max_peaks, np.float32)
     src = np.zeros(max_peaks, np.int32)
     n = C.c_int32()

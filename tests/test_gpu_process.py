@@ -33,6 +33,10 @@ def _raw_pack(rng, n_spec, sizes):
     dict(scaling='sqrt', max_peaks_used=30),
     dict(remove_precursor=True, remove_precursor_tolerance=1.5, min_intensity=0.05),
     dict(scaling=None, min_peaks=3, min_mz_range=10.0, max_peaks_used=150),
+    dict(resolution=0),                                                 # spectrum.py:84-85
+    dict(resolution=1, remove_precursor=True, remove_precursor_tolerance=1.5, scaling='sqrt'),
+    dict(resolution=-1, scaling=None, max_peaks_used=80),
+    dict(resolution=3),
 ])
 def test_process_matches_oracle(O, cfg):
     from types import SimpleNamespace
@@ -50,7 +54,7 @@ def test_process_matches_oracle(O, cfg):
             mz[sl], it[sl], pmz[s], pz[s], 11, 2010, cfg.get('remove_precursor', False),
             cfg.get('remove_precursor_tolerance', 0.0), cfg.get('min_intensity', 0.01),
             cfg.get('max_peaks_used', 50), cfg.get('scaling', 'rank'), cfg.get('min_peaks', 10),
-            cfg.get('min_mz_range', 250.0))
+            cfg.get('min_mz_range', 250.0), cfg.get('resolution'))
         assert bool(valid[s]) == ok, s
         got = slice(oo[s], oo[s + 1])
         if not ok:

@@ -101,6 +101,25 @@ def test_kmeans_is_deterministic_and_finite(O, vecs):
     assert sorted(p.tolist()) == list(range(1000))
 
 
+def test_ip_kmeans_is_spherical_l2_is_not(O, vecs):
+    """FAISS' IndexIVF sets cp.spherical = true for METRIC_INNER_PRODUCT (the reference's index,
+    spectral_library.py:174-178): centroids are L2-renormalised after every iteration. The PQ
+    sub-quantisers train with L2 and stay plain means."""
+    xb, _ = vecs
+    c = O.kmeans(xb, 16, 5, 7, 0, 256)                       # metric 0 = inner product
+    assert np.allclose(np.linalg.norm(c.astype(np.float64), axis=1), 1.0, atol=2e-7)
+    # a centroid is the renormalised mean of its cluster (last iteration's assignment)
+    prev = O.kmeans(xb, 16, 4, 7, 0, 256)
+    a = np.argmax(xb @ prev.T, axis=1)
+    for j in range(16):
+        m = xb[a == j].astype(np.float64).mean(0)
+        if (a == j).any():
+            assert np.allclose(c[j], m / np.linalg.norm(m), atol=1e-5)
+    sub = np.ascontiguousarray(xb[:, :25])
+    c2 = O.kmeans(sub, 16, 5, 7, 1, 0)                       # metric 1 = L2: means, not unit vectors
+    assert np.abs(np.linalg.norm(c2, axis=1) - 1).max() > 1e-3
+
+
 def test_precursor_window_formulae(O):
     """spectral_library.py:421-427 in float64 on (float64 query, float32 library)."""
     rng = np.random.default_rng(0)

@@ -8,7 +8,7 @@ import pytest
 
 def _numpy_process(mz, it, pmz, pz, min_mz=11, max_mz=2010, remove_precursor=False, rp_tol=0.0,
                    min_intensity=0.01, max_peaks=50, scaling='rank', min_peaks=10,
-                   min_mz_range=250.0):
+                   min_mz_range=250.0, resolution=None):
     def valid(m):                                            # spectrum.py:13-36
         return len(m) >= min_peaks and len(m) > 0 and float(m[-1] - m[0]) >= min_mz_range
     idx = np.arange(len(mz))
@@ -16,6 +16,19 @@ def _numpy_process(mz, it, pmz, pz, min_mz=11, max_mz=2010, remove_precursor=Fal
     mz, it, idx = mz[keep], it[keep], idx[keep]
     if not valid(mz):
         return False, None, None, None
+    if resolution is not None:                               # spectrum.py:84-85 round(d, 'sum')
+        rmz = np.round(mz.astype(np.float64), resolution).astype(np.float32)
+        uniq, first, inv = np.unique(rmz, return_index=True, return_inverse=True)
+        it_sum = np.zeros(len(uniq), np.float32)
+        best = first.copy()
+        for j in range(len(rmz)):                            # sequential float32 sum, first argmax
+            g = inv[j]
+            it_sum[g] = np.float32(it_sum[g] + it[j])
+            if it[j] > it[best[g]]:
+                best[g] = j
+        mz, it, idx = uniq, it_sum, idx[best]
+        if not valid(mz):
+            return False, None, None, None
     if remove_precursor:
         neutral = (pmz - 1.0072766) * pz
         rm = np.array([(neutral + iso) / c + 1.0072766 for c in range(pz, 0, -1)
@@ -49,6 +62,10 @@ def _numpy_process(mz, it, pmz, pz, min_mz=11, max_mz=2010, remove_precursor=Fal
     dict(scaling='sqrt', max_peaks=30),
     dict(remove_precursor=True, rp_tol=1.5, min_intensity=0.05),
     dict(scaling=None, min_peaks=3, min_mz_range=10.0, max_peaks=150),
+    dict(resolution=0),
+    dict(resolution=1, remove_precursor=True, rp_tol=1.5, scaling='sqrt'),
+    dict(resolution=-1, scaling=None, max_peaks=80),
+    dict(resolution=3),
 ])
 def test_oracle_process_matches_numpy_formulation(O, cfg):
     rng = np.random.default_rng(11)
@@ -63,7 +80,7 @@ def test_oracle_process_matches_numpy_formulation(O, cfg):
         ok, om, oi, src = O.process_spectrum(
             mz, it, pmz, pz, 11, 2010, cfg.get('remove_precursor', False), cfg.get('rp_tol', 0.0),
             cfg.get('min_intensity', 0.01), cfg.get('max_peaks', 50), cfg.get('scaling', 'rank'),
-            cfg.get('min_peaks', 10), cfg.get('min_mz_range', 250.0))
+            cfg.get('min_peaks', 10), cfg.get('min_mz_range', 250.0), cfg.get('resolution'))
         ok2, m2, i2, s2 = _numpy_process(mz, it, pmz, pz, **cfg)
         assert ok == ok2, s
         if not ok:
@@ -89,6 +106,16 @@ def test_oracle_process_documented_behaviour(O):
     assert (np.diff(src) > 0).all()                                       # m/z order preserved
     # too few peaks / too narrow a range -> invalid
     assert not O.process_spectrum(mz[:6], it[:6], 700.0, 2)[0]
+    # resolution: peaks that round to the same m/z are merged, intensities summed, the
+    # annotation (source index) of the most intense one survives (spectrum.py:84-85)
+    mz3 = np.sort(np.concatenate([np.linspace(100, 1900, 30), [500.2, 500.4, 499.6]])).astype(np.float32)
+    it3 = np.ones(len(mz3), np.float32)
+    it3[np.searchsorted(mz3, np.float32(500.2))] = 7.0
+    ok, om, oi, src = O.process_spectrum(mz3, it3, 700.0, 2, scaling=None, resolution=0)
+    assert ok and (om == np.round(om)).all() and len(np.unique(om)) == len(om)
+    at = int(np.nonzero(om == 500.0)[0][0])
+    assert src[at] == np.searchsorted(mz3, np.float32(500.2))
+    assert np.isclose(oi[at] / oi.min(), 9.0)                             # 1 + 7 + 1
     narrow = np.linspace(500, 600, 40).astype(np.float32)
     assert not O.process_spectrum(narrow, np.ones(40, np.float32), 700.0, 2)[0]
     # precursor removal: peaks within tol of (M + iso)/c + proton for c = z..1, iso = 0..2
