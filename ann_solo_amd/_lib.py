@@ -22,6 +22,9 @@ c_u8p = C.POINTER(C.c_uint8)
 c_u32p = C.POINTER(C.c_uint32)
 
 
+TK_MAX_K = 2048      # largest k / nprobe of the LDS top-k (csrc/ivf_kernels.hpp)
+
+
 class AnnSoloMiError(RuntimeError):
     pass
 
@@ -65,7 +68,7 @@ EXPORTS = [
     'asl_index_pq_lut', 'asl_rescore_batch', 'asl_library_create', 'asl_library_free',
     'asl_library_size', 'asl_search_batch', 'asl_window_candidates', 'asl_profile_enable',
     'asl_profile_reset', 'asl_profile_get', 'asl_profile_scanned_vectors',
-    'asl_rescore_knn', 'asl_lpt_owner', 'asl_index_set_scan_variant', 'asl_index_search_preassigned', 'asl_process_batch',
+    'asl_rescore_knn', 'asl_lpt_owner', 'asl_index_supports_keys', 'asl_index_set_scan_variant', 'asl_index_search_preassigned', 'asl_process_batch',
     'asl_ssm_features_batch', 'asl_index_set_unordered', 'asl_topk_merge_keys',
 ]
 

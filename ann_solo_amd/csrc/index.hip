@@ -297,6 +297,7 @@ static int build_lists(asl_index *ix) {
     ix->has_tiles = true;
   }
   ix->has_sparse = false;
+  ix->has_inv = false;
   if (ix->kind == ASL_INDEX_IVFFLAT && n > 0 && ix->d <= 65535) {
     DevBuf<int32_t> nnz, nnz_max;
     ASL_TRY(nnz.reserve((size_t)n));
@@ -327,7 +328,6 @@ static int build_lists(asl_index *ix) {
       ix->has_sparse = true;
     }
     // dimension-major postings (the default IVF-Flat scan)
-    ix->has_inv = false;
     if (h_max > 0 && (size_t)h_max * 8 < (size_t)ix->d) {
       std::vector<int32_t> blk_off((size_t)ix->nlist + 1, 0), pos_blk((size_t)n);
       std::vector<uint16_t> pos_loc((size_t)n);
@@ -578,9 +578,28 @@ int asl_index_set_unordered(asl_index_t *ix, int32_t unordered) {
 }
 
 int asl_index_set_scan_variant(asl_index_t *ix, int32_t variant) {
+  clear_error();
   if (!ix || variant < 0) return fail(ASL_ERR_INVALID, "set_scan_variant");
+#ifndef ASL_ENABLE_DBG
+  // bits 8+ are measurement knobs of the scan kernels (results invalid when set): accepted
+  // only by the instrumented build of scripts/ab_*.sh (EXTRA=-DASL_ENABLE_DBG)
+  if (variant > 4)
+    return fail(ASL_ERR_INVALID, "set_scan_variant: %d is not a kernel id (0..4); measurement "
+                "bits need a library built with -DASL_ENABLE_DBG", variant);
+#endif
   ix->scan_variant = variant;
   return ASL_OK;
+}
+
+// 1 when asl_index_search_preassigned can emit packed 64-bit keys (unordered mode 2) for this
+// index at (k, nprobe): the predicate index_search_device applies, for callers that must
+// choose the exchange format up front (ann_solo_amd/distributed.py).
+int asl_index_supports_keys(const asl_index_t *ix, int32_t k, int32_t nprobe) {
+  if (!ix || ix->kind != ASL_INDEX_IVFPQ) return 0;
+  const int sv = ix->scan_variant & 0xff;
+  nprobe = std::max(1, std::min(nprobe, ix->nlist));
+  return ix->pq_m == 32 && ix->ksub == 256 && sv != 1 && sv != 2 &&
+         pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe) && k + 768 <= TK_MAX_K;
 }
 
 int asl_index_set_niter(asl_index_t *ix, int32_t niter) {
@@ -1052,6 +1071,38 @@ asl_index_t *asl_index_load(const char *path) {
     fail(ASL_ERR_IO, "load: %s is not an annsolo_mi index", path);
     return nullptr;
   }
+  {  // never trust a file: every count below sizes a host vector or a device allocation
+    const char *bad = nullptr;
+    const bool ivf = h.kind == ASL_INDEX_IVFFLAT || h.kind == ASL_INDEX_IVFPQ;
+    if (h.version != 1) bad = "unsupported version";
+    else if (h.kind < ASL_INDEX_FLAT || h.kind > ASL_INDEX_IVFPQ) bad = "unknown index kind";
+    else if (h.d <= 0 || h.d > (1 << 20)) bad = "bad dimension";
+    else if (ivf && (h.nlist <= 0 || h.nlist > (1 << 24))) bad = "bad nlist";
+    else if (h.kind == ASL_INDEX_IVFPQ &&
+             (!(h.pq_m == 4 || h.pq_m == 8 || h.pq_m == 16 || h.pq_m == 32 || h.pq_m == 64) ||
+              h.d % h.pq_m != 0 || h.pq_bits < 1 || h.pq_bits > 8)) bad = "bad product quantiser";
+    else if (h.n_store < 0 || h.ntotal < h.n_store || h.ntotal >= ((int64_t)1 << 31)) bad = "bad vector counts";
+    else if (h.niter < 0 || (h.trained != 0 && h.trained != 1) || (h.has_vids != 0 && h.has_vids != 1)) bad = "bad flags";
+    else if (h.shard_world < 1 || h.shard_rank < 0 || h.shard_rank >= h.shard_world) bad = "bad shard fields";
+    else if (!h.trained && h.n_store > 0 && ivf) bad = "vectors in an untrained index";
+    if (!bad) {  // the payload must be exactly what the header announces
+      const uint64_t ksub = h.kind == ASL_INDEX_IVFPQ ? (1ull << h.pq_bits) : 0;
+      uint64_t want = sizeof h;
+      if (h.trained && ivf) want += (uint64_t)h.nlist * h.d * 4;
+      if (h.trained && h.kind == ASL_INDEX_IVFPQ) want += (uint64_t)h.pq_m * ksub * (uint64_t)(h.d / h.pq_m) * 4;
+      if (ivf) want += (uint64_t)h.n_store * 4;
+      if (h.has_vids) want += (uint64_t)h.n_store * 4;
+      want += h.kind == ASL_INDEX_IVFPQ ? (uint64_t)h.n_store * h.pq_m : (uint64_t)h.n_store * h.d * 4;
+      const long here = ftell(f);
+      if (fseek(f, 0, SEEK_END) != 0 || (uint64_t)ftell(f) != want) bad = "file size does not match the header";
+      fseek(f, here, SEEK_SET);
+    }
+    if (bad) {
+      fclose(f);
+      fail(ASL_ERR_IO, "load: %s: %s", path, bad);
+      return nullptr;
+    }
+  }
   asl_index *ix = new asl_index();
   ix->d = h.d;
   ix->nlist = h.nlist;
@@ -1092,6 +1143,23 @@ asl_index_t *asl_index_load(const char *path) {
   else
     slurp(ix->vecs, n * ix->d);
   fclose(f);
+  if (ok && ix->n_store > 0 && (ix->kind != ASL_INDEX_FLAT || ix->has_vids)) {
+    // list assignments / global ids index host and device arrays later: range-check them now
+    std::vector<int32_t> tmp((size_t)ix->n_store);
+    if (ix->kind != ASL_INDEX_FLAT) {
+      ok = hipMemcpy(tmp.data(), ix->vlist.p, tmp.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+      for (size_t i = 0; ok && i < tmp.size(); i++) ok = tmp[i] >= 0 && tmp[i] < ix->nlist;
+    }
+    if (ok && ix->has_vids) {
+      ok = hipMemcpy(tmp.data(), ix->vids.p, tmp.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+      for (size_t i = 0; ok && i < tmp.size(); i++) ok = tmp[i] >= 0 && (int64_t)tmp[i] < ix->ntotal;
+    }
+    if (!ok) {
+      delete ix;
+      fail(ASL_ERR_IO, "load: %s holds list or id entries out of range", path);
+      return nullptr;
+    }
+  }
   if (!ok) {
     delete ix;
     fail(ASL_ERR_IO, "load: %s is truncated or unreadable", path);

@@ -874,8 +874,13 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
     int64_t avg = total_slots / (nq > 0 ? nq : 1);
     int ysplit = 1;
     if (nq < 2048 && avg > 4096) ysplit = (int)std::min<int64_t>(64, cdiv(avg, 4096));
-    static const bool force_v1 = getenv("ASL_RESCORE_V1") != nullptr;  // A/B knob
+#ifdef ASL_ENABLE_DBG   // A/B and ablation knobs: instrumented builds only (scripts/ab_*.sh, pmc_rescore.sh)
+    static const bool force_v1 = getenv("ASL_RESCORE_V1") != nullptr;
     static const int rs_dbg = getenv("ASL_RESCORE_DBG") ? atoi(getenv("ASL_RESCORE_DBG")) : 0;
+#else
+    constexpr bool force_v1 = false;
+    constexpr int rs_dbg = 0;
+#endif
     if (!force_v1) {
       // hash kernel, then the binary-search kernel on whatever it deferred (its blocks
       // return at once for queries with nothing deferred)

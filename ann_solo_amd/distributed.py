@@ -97,7 +97,9 @@ class HipShardBackend:
         self.charge = charge
         self.mode = mode
         self.part = spectral_library.partitions[charge]
-        self.index = spectral_library._get_ann_index(charge)
+        # charges too rare for an ANN index (and brute-force mode) only ever run window searches
+        self.index = (spectral_library._get_ann_index(charge)
+                      if charge in spectral_library._ann_filenames else None)
         self.device = spectral_library.device
         self.k = spectral_library._num_candidates
 
@@ -126,7 +128,11 @@ class HipShardBackend:
     # packed 8-byte hits for the exchange (instead of 4-byte score + 8-byte id)
     @property
     def supports_keys(self):
-        return self.index.info().kind == 2 and self.k + 256 + 512 <= 2048
+        """Packed-key rows exist only in the tiled IVF-PQ scan (index.hip: m = 32, 8-bit codes,
+        automatic scan variant, nprobe within the tiled kernel's limit, k + 768 <= 2048); every
+        other configuration exchanges (D, I) rows."""
+        return bool(_lib.lib().asl_index_supports_keys(self.index._h, int(self.k),
+                                                       int(self.sl._num_probe)))
 
     def shard_search_keys(self, vectors, coarse_D, coarse_I):
         return self.index.search_preassigned_keys(vectors, self.k, coarse_D, coarse_I)
@@ -139,14 +145,21 @@ class HipShardBackend:
         from . import faiss_compat
         return faiss_compat.topk_merge(Ds, Is)
 
-    def rescore_knn(self, queries: PackedSpectra, knn: torch.Tensor, device_out=False):
+    def window_search(self, queries: PackedSpectra, mode: str, pm_stride=None):
+        """Precursor-window search of the rank's own queries against the replicated peak store
+        (cascade level 1, and charges without an ANN index): no exchange at all."""
+        return self.sl._search_batch_local(queries, self.charge, mode, device_out=True,
+                                           pm_stride=pm_stride)
+
+    def rescore_knn(self, queries: PackedSpectra, knn: torch.Tensor, device_out=False,
+                    pm_stride=None):
         from .spectral_library import BatchResult
         from .spectrum import get_dim, HASH_SEED
         sl, cfg = self.sl, self.sl.config
         tol_val, tol_mode = sl._tolerance(self.mode)
         q = queries.to(self.device).contiguous()
         nq = q.n
-        stride = q.max_peaks()
+        stride = pm_stride or q.max_peaks()
         if device_out:
             mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=self.device)
             best_row, best_score = mk((nq,), torch.int32), mk((nq,), torch.float64)
@@ -258,7 +271,8 @@ def _concat_results(parts):
 
 
 def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, device_out=False,
-                         chunks: Optional[int] = None, _force_exchange: bool = False):
+                         chunks: Optional[int] = None, _force_exchange: bool = False,
+                         pm_stride: Optional[int] = None, check_sizes: bool = False):
     """One batch: ``queries_local`` is this rank's equally sized slice of the global
     batch. Returns the BatchResult of the local slice (library rows are global).
 
@@ -267,10 +281,23 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     being scanned; merge and rescoring of piece c are issued after the scan of piece c+1, so
     the last piece's exchange hides behind the rescoring of the one before."""
     world = dist.get_world_size(group)
+    if queries_local.n == 0:
+        # every rank must bring the same, non-zero number of queries (the collectives below are
+        # fixed-shape); callers with ragged batches pad -- see sharded_cascade_batch
+        raise ValueError('sharded_search_batch: empty local slice (pad ragged batches)')
+    if check_sizes and world > 1:
+        t = torch.tensor([queries_local.n, -queries_local.n], dtype=torch.int64)
+        if dist.get_backend(group) == 'nccl':
+            t = t.to(queries_local.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        if int(t[0]) != -int(t[1]):
+            raise ValueError('sharded_search_batch: ranks hold slices of different sizes')
+    # one peak-match table width for every chunk of the slice
+    kw = {'pm_stride': pm_stride or queries_local.max_peaks()}
     vec = backend.encode(queries_local)
     if world == 1 and not _force_exchange:   # (_force_exchange: tests drive the collectives at world 1)
         D, I = backend.shard_search(vec)
-        return backend.rescore_knn(queries_local, I, device_out)
+        return backend.rescore_knn(queries_local, I, device_out, **kw)
     n_local = vec.shape[0]
     # the gather of the hashed vectors travels while the coarse quantiser runs on the own slice
     allvec, w_vec = _all_gather_rows(vec, world, group, async_op=True)
@@ -298,7 +325,7 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
             knn = backend.merge(payload[0].contiguous(), payload[1].contiguous())[1]
         sub = queries_local if (lo, hi) == (0, n_local) else queries_local.select(
             torch.arange(lo, hi, device=queries_local.device))
-        results.append(backend.rescore_knn(sub, knn, device_out))
+        results.append(backend.rescore_knn(sub, knn, device_out, **kw))
 
     for c in range(chunks):
         lo, hi = bounds[c], bounds[c + 1]
@@ -321,3 +348,61 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
         pending = nxt
     finish(pending)
     return _concat_results(results)
+
+
+# ---------------------------------------------------------------------------- cascade batches
+_RESULT_FIELDS = ('best_row', 'best_score', 'n_candidates', 'pm_count', 'pm_pairs')
+
+
+def _result_field(res, name):
+    v = res[name] if isinstance(res, dict) else getattr(res, name)
+    if torch.is_tensor(v):
+        return v
+    v = np.ascontiguousarray(v)
+    return torch.from_numpy(v.view(np.int32) if v.dtype == np.uint32 else v)   # no u32 collectives
+
+
+def sharded_cascade_batch(backend, queries: PackedSpectra, mode: str, use_ann: bool, group=None):
+    """One batch of one cascade level on ``world`` ranks (configs[4]: the second, open pass of
+    the cascade over the list-sharded library; reference: ``_search_cascade`` ->
+    ``_search_batch``, /root/reference/src/ann_solo/spectral_library.py:301-317,328-370).
+
+    Every rank holds the SAME ``queries`` (the whole batch -- each process reads the query
+    file, as the reference's single process does) and answers for its own contiguous slice of
+    ``ceil(n / world)`` rows; a ragged tail is padded by repeating the last query, and the
+    padding rows are dropped after the gather:
+
+      * ``use_ann`` (open search on a charge with an ANN index): ``sharded_search_batch`` --
+        the list-sharded scan + exchange + merge, then rescoring of the own slice;
+      * otherwise (standard search, brute-force mode, charges too rare for an index): the
+        precursor-window search is data-parallel over the queries against the replicated
+        peak store -- no data-path collective.
+
+    The per-query results of all slices are all-gathered (about 0.5 KB per query), so every
+    rank continues the cascade (FDR filter, remaining queries) on identical data, exactly as a
+    single process would. Returns a ``BatchResult`` (numpy) of ``queries.n`` rows."""
+    from .spectral_library import BatchResult
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = queries.n
+    if n == 0:
+        raise ValueError('sharded_cascade_batch: empty batch')
+    n_local = -(-n // world)
+    rows = torch.arange(rank * n_local, (rank + 1) * n_local).clamp_(max=n - 1)
+    q_loc = queries.select(rows.to(queries.device))
+    stride = queries.max_peaks()
+    if use_ann:
+        res = sharded_search_batch(backend, q_loc, group=group, device_out=True, pm_stride=stride)
+    else:
+        res = backend.window_search(q_loc, mode, pm_stride=stride)
+    out = {}
+    for name in _RESULT_FIELDS:
+        t = _result_field(res, name)
+        if name == 'pm_pairs' and t.shape[1] != stride:      # a backend that ignored pm_stride
+            p = torch.zeros((t.shape[0], stride, 2), dtype=t.dtype, device=t.device)
+            p[:, :min(stride, t.shape[1])] = t[:, :stride]
+            t = p
+        out[name] = _all_gather_rows(t, world, group)[:n].cpu().numpy()
+    pm = out['pm_pairs']
+    return BatchResult(out['best_row'], out['best_score'], out['n_candidates'], out['pm_count'],
+                       pm.view(np.uint32) if pm.dtype == np.int32 else pm, None)

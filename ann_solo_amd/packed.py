@@ -115,13 +115,16 @@ class PackedSpectra:
     #   precursor_mz f64[n] | precursor_charge u8[n]
     # keyed by the SHA-1 hyper-parameter hash the reference keeps in its .spcfg file
     # (reader.py: config hash check) -- a store written under other settings is rejected.
-    def save(self, path: str, hyperparameter_hash: str = '') -> None:
+    def save(self, path: str, hyperparameter_hash: str = '', extra: Optional[dict] = None) -> None:
         o, mz, it, chg, pmz, pz = self.numpy()
         if pz.size and (pz.min() < 0 or pz.max() > 255):
             raise ValueError('precursor charge outside 0..255')
         ids = None if self.identifiers is None else [
             i if isinstance(i, (str, type(None))) else int(i) for i in self.identifiers]
-        meta = json.dumps({'hash': hyperparameter_hash, 'identifiers': ids}).encode('utf-8')
+        meta = {'hash': hyperparameter_hash, 'identifiers': ids}
+        if extra is not None:
+            meta['extra'] = extra
+        meta = json.dumps(meta).encode('utf-8')
         with open(path, 'wb') as f:
             f.write(STORE_MAGIC)
             f.write(struct.pack('<QQI', self.n, int(mz.shape[0]), len(meta)))
@@ -132,7 +135,7 @@ class PackedSpectra:
 
     @staticmethod
     def load(path: str, hyperparameter_hash: Optional[str] = None,
-             device='cpu') -> 'PackedSpectra':
+             device='cpu', return_meta: bool = False) -> 'PackedSpectra':
         """Read a store; if ``hyperparameter_hash`` is given it must match the one the store
         was written under (``ValueError`` otherwise, the reference's ``is_recreated`` case)."""
         with open(path, 'rb') as f:
@@ -152,7 +155,8 @@ class PackedSpectra:
             chg, pmz, pz = rd(P, 'u1'), rd(n, '<f8'), rd(n, 'u1')
         if n and (o[0] != 0 or o[-1] != P or (np.diff(o) < 0).any()):
             raise ValueError(f'{path}: corrupt offsets')
-        return PackedSpectra.from_numpy(o, mz, it, chg, pmz, pz, device, meta.get('identifiers'))
+        pack = PackedSpectra.from_numpy(o, mz, it, chg, pmz, pz, device, meta.get('identifiers'))
+        return (pack, meta) if return_meta else pack
 
     @staticmethod
     def from_spectra(spectra, device='cpu') -> 'PackedSpectra':

@@ -1,17 +1,20 @@
 """Search engine -- host-side mirror of the hot-path half of the reference's
 ``ann_solo/spectral_library.py`` (``SpectralLibrary`` :27-500).
 
-What is mirrored (same names, same meaning): ``_get_hyperparameter_hash`` (:118-131),
-``_create_ann_indexes`` (:133-183), ``_get_ann_index`` (:457-500), ``_search_batch``
-(:328-370), ``_get_library_candidates`` (:372-455), ``_search_cascade`` batching
-(:301-317) and ``shutdown`` (:185-191). What is different by design: the library is a
-packed, HBM-resident peak store per precursor charge instead of per-spectrum HDF5
-reads, and a whole batch runs through ``asl_search_batch`` in one device pipeline
-(encode -> IVF top-k -> precursor post-filter -> shifted-dot best match).
+What is mirrored (same names, same meaning): the constructor (:46-116: ``SpectralLibrary(
+filename)`` over a ``SpectralLibraryReader``, kept as ``_library_reader``),
+``_get_hyperparameter_hash`` (:118-131), ``_create_ann_indexes`` (:133-183), ``search`` /
+``_search_cascade`` (:193-326), ``_search_batch`` (:328-370), ``_get_library_candidates``
+(:372-455), ``_get_ann_index`` (:457-500) and ``shutdown`` (:185-191). What is different by
+design: the library is a packed, HBM-resident peak store per precursor charge (built once
+through the reader's surface, ``library_store.py``) instead of per-spectrum HDF5 reads, a
+whole batch runs through ``asl_search_batch`` in one device pipeline (encode -> IVF top-k ->
+precursor post-filter -> shifted-dot best match), and with ``enable_sharding`` every batch of
+both cascade levels runs over the ranks of one node (``distributed.py``).
 
-File parsing, FDR/mokapot scoring and mzTab writing stay with the reference
-(out of scope); ``search_charge_batches`` yields exactly the
-``(query, library_match, peak_matches)`` triples ``_search_batch`` yields there.
+File parsing, FDR/mokapot scoring stay with the reference (out of scope): the
+library/query readers and the scorer are injected (defaults: the reference's own
+``ann_solo.reader`` when it is importable).
 """
 import ctypes as C
 import hashlib
@@ -19,6 +22,7 @@ import json
 import logging
 import os
 from dataclasses import dataclass, field
+from types import SimpleNamespace
 from typing import Dict, Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -99,64 +103,169 @@ class BatchResult:
         return self.pm_pairs[i, :self.pm_count[i]].astype(np.int64)
 
 
+INDEX_EXT = '.idxmi'      # own container; the reference's FAISS files keep '.idxann' untouched
+
+
+def _reference_reader_factory(filename: str, config_hash: str):
+    """Default library reader: the reference's own ``SpectralLibraryReader`` (reader.py:40-116)
+    when the ``ann_solo`` package is installed next to this one."""
+    try:
+        from ann_solo import reader as ref_reader          # noqa: the reference package
+    except Exception as e:                                   # faiss/h5py/... missing
+        raise ImportError(
+            'SpectralLibrary(filename) needs a library reader: install the reference package '
+            '(ann_solo.reader.SpectralLibraryReader) or pass reader_factory=') from e
+    return ref_reader.SpectralLibraryReader(filename, config_hash)
+
+
+def _reference_query_reader(filename: str):
+    try:
+        from ann_solo import reader as ref_reader
+    except Exception as e:
+        raise ImportError('search(query_filename) needs a query reader: install the reference '
+                          'package (ann_solo.reader.read_query_file) or pass query_reader=') from e
+    return ref_reader.read_query_file(filename)
+
+
 class SpectralLibrary:
     _hyperparameters = ['min_mz', 'max_mz', 'bin_size', 'hash_len', 'num_list']
 
-    def __init__(self, library: PackedSpectra, identifiers=None, config: Config = None,
+    def __init__(self, library, identifiers=None, config: Config = None,
                  valid: Optional[np.ndarray] = None, index_dir: Optional[str] = None,
-                 basename: str = 'library', device='cuda'):
-        """``library``: all library spectra, already processed (``process_spectrum``);
-        ``identifiers``: library ids (default: row numbers); ``valid``: is_valid flags.
-        ANN indexes are built for every charge with >= num_list spectra
-        (spectral_library.py:100-104) and cached as ``<base>_<hash7>_<charge>.idxann``
-        under ``index_dir`` when given (:98-108)."""
+                 basename: Optional[str] = None, device='cuda', reader_factory=None,
+                 query_reader=None, score_ssms=None, annotation_alignment: str = 'peaks'):
+        """``library`` is one of
+
+        * a file name -- the reference's call, ``SpectralLibrary(filename)``
+          (spectral_library.py:46-116): ``reader_factory(filename, hyper_hash)`` (default: the
+          reference's ``SpectralLibraryReader``) opens it, the packed store and the ANN indexes
+          are cached next to it as ``<library>_<hash7>.spstore`` / ``<library>_<hash7>_<charge>
+          .idxmi``;
+        * a reader object with the reference reader's surface (``spec_info``,
+          ``read_all_spectra()``, optional ``is_recreated`` / ``get_version()`` / ``close()``);
+        * a ``PackedSpectra`` of already processed library spectra (``identifiers``: library
+          ids, default row numbers; ``valid``: is_valid flags).
+
+        ANN indexes are built for every charge with >= num_list spectra (:100-104) and cached
+        under ``index_dir`` when one is known (:98-108). ``query_reader(filename)`` (default: the
+        reference's ``read_query_file``) and ``score_ssms(ssms, mode)`` (stands for
+        ``utils.score_ssms``, :319-326) serve ``search(query_filename)``.
+        ``annotation_alignment='snapshot'`` reproduces the snapshot's use of RAW-peak
+        annotations on processed library peaks (reader.py:243-245; see library_store.py)."""
         self.config = config or Config()
         self.device = torch.device(device)
         cfg = self.config
-        if cfg.num_candidates > 2048 or cfg.num_probe > 2048:
-            # FAISS-GPU clamps both to 1024 (:76-87); this implementation's LDS top-k holds 2048
-            logging.warning('Using num_candidates/num_probe <= 2048 (maximum supported)')
-            cfg.num_candidates = min(cfg.num_candidates, 2048)
-            cfg.num_probe = min(cfg.num_probe, 2048)
-        self._num_probe = cfg.num_probe
-        self._num_candidates = cfg.num_candidates
+        k_max = _lib.TK_MAX_K
+        if cfg.num_probe > k_max:
+            # the reference clamps both to 1024 on the GPU (FAISS-GPU's limit, :76-87); this
+            # implementation's LDS top-k holds 2048 -- same warning, the larger limit
+            logging.warning('Using num_probe=%d (maximum supported value on the GPU), %d was '
+                            'supplied', k_max, cfg.num_probe)
+        if cfg.num_candidates > k_max:
+            logging.warning('Using num_candidates=%d (maximum supported value on the GPU), %d '
+                            'was supplied', k_max, cfg.num_candidates)
+        self._num_probe = min(cfg.num_probe, k_max)
+        self._num_candidates = min(cfg.num_candidates, k_max)
         self._use_gpu = True
         self._ann_filenames: Dict[int, str] = {}
         self._current_index: Tuple[Optional[int], Optional[faiss.Index]] = (None, None)
-        self._index_dir = index_dir
-        self._basename = basename
+        self._query_reader = query_reader or _reference_query_reader
+        self._score_ssms = score_ssms
+        self._dist = None
+        self._library_reader = None
+        self.library_meta: Optional[Dict[int, list]] = None
         self.partitions: Dict[int, ChargePartition] = {}
+        verify_file_existence = True
+        if isinstance(library, PackedSpectra):
+            self._index_dir = index_dir
+            self._basename = basename or 'library'
+            self._init_from_packed(library, identifiers, valid)
+        else:
+            from . import library_store as ls
+            if isinstance(library, (str, os.PathLike)):
+                filename = os.fspath(library)
+                self._library_reader = (reader_factory or _reference_reader_factory)(
+                    filename, self._get_hyperparameter_hash())
+            else:
+                self._library_reader = library
+                filename = getattr(library, '_filename', None) or cfg.spectral_library_filename
+            if filename:
+                stem = os.path.splitext(filename)[0]
+                self._index_dir = index_dir if index_dir is not None else (os.path.dirname(stem) or '.')
+                self._basename = basename or os.path.basename(stem)
+            else:
+                self._index_dir, self._basename = index_dir, basename or 'library'
+            if getattr(self._library_reader, 'is_recreated', False):
+                logging.warning('ANN indexes were created using non-compatible settings')
+                verify_file_existence = False
+            key = ls.store_hash(cfg, self._get_hyperparameter_hash(), annotation_alignment)
+            path = None if self._index_dir is None else os.path.join(
+                self._index_dir, f'{self._basename}_{key[:7]}{ls.STORE_EXT}')
+            store = ls.load_or_build_library_store(self._library_reader, cfg, self.device, path,
+                                                   key, annotation_alignment)
+            self.library_meta = store.meta
+            for z, (a, b) in store.ranges.items():
+                rows = torch.arange(a, b)
+                info = self._library_reader.spec_info['charge'][z]
+                self._add_partition(int(z), store.spectra.select(rows), np.asarray(info['id']),
+                                    store.valid[a:b],
+                                    np.asarray(info['precursor_mz'], np.float32))
+        if cfg.mode == 'ann':
+            create = []
+            for z in sorted(self.partitions):
+                if len(self.partitions[z].ids) < cfg.num_list:
+                    continue          # infrequent charge: brute force (spectral_library.py:102-104)
+                base = f'{self._basename}_{self._get_index_hash()[:7]}'
+                self._ann_filenames[z] = os.path.join(self._index_dir or '', f'{base}_{z}{INDEX_EXT}')
+                if (self._index_dir is None or not verify_file_existence or
+                        not os.path.isfile(self._ann_filenames[z])):
+                    if self._index_dir is not None:
+                        logging.warning('Missing ANN index for charge %d', z)
+                    create.append(z)
+            if create:
+                self._create_ann_indexes(create)
+
+    def _init_from_packed(self, library: PackedSpectra, identifiers, valid) -> None:
         n = library.n
         ids = np.arange(n) if identifiers is None else np.asarray(identifiers)
         pz = library.precursor_charge.cpu().numpy()
         valid = np.ones(n, bool) if valid is None else np.asarray(valid, bool)
         for z in np.unique(pz):
             rows = np.nonzero(pz == z)[0]
-            part = library.select(torch.as_tensor(rows)).to(self.device).contiguous()
+            self._add_partition(int(z), library.select(torch.as_tensor(rows)), ids[rows],
+                                valid[rows], None)
+
+    def _add_partition(self, z: int, spectra: PackedSpectra, ids, valid, pmz32) -> None:
+        part = spectra.to(self.device).contiguous()
+        if pmz32 is None:       # spec_info stores the precursor m/z column as float32 (reader.py:186-189)
             pmz32 = part.precursor_mz.cpu().numpy().astype(np.float32)
-            v = np.ascontiguousarray(valid[rows].astype(np.uint8))
-            h = _lib.lib().asl_library_create(C.byref(_lib.peaks_struct(part)), _lib.ptr(pmz32),
-                                              _lib.ptr(v))
-            if not h:
-                _lib.check(-1)
-            self.partitions[int(z)] = ChargePartition(int(z), ids[rows], pmz32, part,
-                                                      C.c_void_p(h))
-        if cfg.mode == 'ann':
-            create = []
-            for z in sorted(self.partitions):
-                if len(self.partitions[z].ids) < cfg.num_list:
-                    continue          # infrequent charge: brute force (spectral_library.py:102-104)
-                base = f'{self._basename}_{self._get_hyperparameter_hash()[:7]}'
-                self._ann_filenames[z] = os.path.join(index_dir or '', f'{base}_{z}.idxann')
-                if index_dir is None or not os.path.isfile(self._ann_filenames[z]):
-                    create.append(z)
-            if create:
-                self._create_ann_indexes(create)
+        pmz32 = np.ascontiguousarray(pmz32, np.float32)
+        v = np.ascontiguousarray(np.asarray(valid).astype(np.uint8))
+        h = _lib.lib().asl_library_create(C.byref(_lib.peaks_struct(part)), _lib.ptr(pmz32),
+                                          _lib.ptr(v))
+        if not h:
+            _lib.check(-1)
+        self.partitions[z] = ChargePartition(z, np.asarray(ids), pmz32, part, C.c_void_p(h))
 
     # ------------------------------------------------------------------ reference mirrors
     def _get_hyperparameter_hash(self) -> str:
         b = json.dumps({hp: self.config[hp] for hp in self._hyperparameters}).encode('utf-8')
         return hashlib.sha1(b).hexdigest()
+
+    def _get_index_hash(self) -> str:
+        """Hash in the cached index file names: the reference's five hyper-parameters for its
+        own configuration (IVF-Flat, FAISS' default 25 iterations and seed 1234 -- same 7 hex
+        digits as the reference's ``.idxann`` name); any additive option of this implementation
+        (index kind, PQ shape, trainer settings) is hashed in as well, so switching it can never
+        pick up a stale file."""
+        cfg = self.config
+        if cfg.index == 'ivfflat' and cfg.kmeans_niter == 25 and cfg.seed == 1234:
+            return self._get_hyperparameter_hash()
+        d = {hp: cfg[hp] for hp in self._hyperparameters}
+        d.update(index=cfg.index, kmeans_niter=cfg.kmeans_niter, seed=cfg.seed)
+        if cfg.index == 'ivfpq':
+            d.update(pq_m=cfg.pq_m, pq_bits=cfg.pq_bits)
+        return hashlib.sha1(json.dumps(d).encode('utf-8')).hexdigest()
 
     def _encode(self, spectra: PackedSpectra) -> torch.Tensor:
         cfg = self.config
@@ -186,15 +295,69 @@ class SpectralLibrary:
             part.index = ann_index
             del vectors
 
+    def _index_matches(self, idx: faiss.Index, part: ChargePartition) -> bool:
+        cfg, i = self.config, idx.info()
+        kind = 2 if cfg.index == 'ivfpq' else 1
+        return (i.kind == kind and i.d == cfg.hash_len and i.nlist == cfg.num_list and
+                i.ntotal == len(part.ids) and bool(i.trained) and i.shard_world == 1 and
+                (kind != 2 or (i.pq_m == cfg.pq_m and i.pq_ksub == (1 << cfg.pq_bits))))
+
     def _get_ann_index(self, charge: int) -> faiss.Index:
         part = self.partitions[charge]
         if part.index is None:
-            part.index = faiss.read_index(self._ann_filenames[charge])
+            idx = None
+            try:
+                idx = faiss.read_index(self._ann_filenames[charge])
+            except _lib.AnnSoloMiError as e:
+                logging.warning('ANN index %s unreadable (%s): rebuilding',
+                                self._ann_filenames[charge], e)
+            if idx is not None and not self._index_matches(idx, part):
+                # e.g. another library under the same base name: out-of-range ids would be
+                # dropped silently by the rescoring bounds check -- never search a stale index
+                logging.warning('ANN index %s does not match the library/configuration: '
+                                'rebuilding', self._ann_filenames[charge])
+                idx = None
+            if idx is None:
+                self._create_ann_indexes([charge])
+            else:
+                part.index = idx
+            d = self._dist
+            if d is not None and d.world > 1:
+                part.index.shard(d.rank, d.world)
         part.index.nprobe = self._num_probe
         self._current_index = charge, part.index
         return part.index
 
+    # ------------------------------------------------------------------ multi-GPU
+    def enable_sharding(self, group=None) -> None:
+        """List-shard every ANN index over the ranks of ``group`` (default: all ranks of the
+        initialised ``torch.distributed`` job) -- SURVEY.md 8(e). From here on every batch of
+        both cascade levels runs on all ranks (``distributed.sharded_cascade_batch``): the open
+        search scans this rank's inverted lists for the whole batch and exchanges per-shard
+        top-k, the standard search is data-parallel over the queries; every rank ends up with
+        the results of the whole batch. Every rank must call ``search`` with the same queries."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if self._dist is not None and self._dist.world > 1:
+            raise RuntimeError('enable_sharding: the indexes are sharded already')
+        self._dist = SimpleNamespace(group=group, world=world, rank=rank, backends={})
+        if world > 1:
+            for part in self.partitions.values():
+                if part.index is not None:
+                    part.index.shard(rank, world)
+
+    def _shard_backend(self, charge: int, mode: str):
+        from .distributed import HipShardBackend
+        key = (charge, mode)
+        if key not in self._dist.backends:
+            self._dist.backends[key] = HipShardBackend(self, charge, mode)
+        return self._dist.backends[key]
+
     def shutdown(self) -> None:
+        reader = getattr(self, '_library_reader', None)
+        if reader is not None and hasattr(reader, 'close'):
+            reader.close()                       # spectral_library.py:189
         for part in self.partitions.values():
             if part.handle:
                 _lib.lib().asl_library_free(part.handle)
@@ -209,10 +372,32 @@ class SpectralLibrary:
             return cfg.precursor_tolerance_mass_open, cfg.precursor_tolerance_mode_open
         raise ValueError('Unknown search mode')
 
+    def _uses_ann(self, charge: int, mode: str) -> bool:
+        return self.config.mode == 'ann' and mode == 'open' and charge in self._ann_filenames
+
     def _search_batch(self, queries: PackedSpectra, charge: int, mode: str,
                       want_knn: bool = False, device_out: bool = False) -> Optional[BatchResult]:
-        """One batch of same-charge, processed query spectra through the device hot path.
-        Returns None when the library has no spectra of that charge (:411-412)."""
+        """One batch of same-charge, processed query spectra (spectral_library.py:328-370):
+        through the device hot path of this GPU, or -- after ``enable_sharding`` on more than
+        one rank -- over all ranks. Returns None when the library has no spectra of that charge
+        (:411-412)."""
+        d = getattr(self, '_dist', None)
+        if d is None or d.world == 1:
+            return self._search_batch_local(queries, charge, mode, want_knn, device_out)
+        tol_val, tol_mode = self._tolerance(mode)
+        if tol_mode not in ('Da', 'ppm'):
+            raise ValueError('Unknown precursor tolerance mode')
+        if charge not in self.partitions or queries.n == 0:
+            return None if charge not in self.partitions else self._search_batch_local(
+                queries, charge, mode)
+        from .distributed import sharded_cascade_batch
+        return sharded_cascade_batch(self._shard_backend(charge, mode), queries, mode,
+                                     self._uses_ann(charge, mode), d.group)
+
+    def _search_batch_local(self, queries: PackedSpectra, charge: int, mode: str,
+                            want_knn: bool = False, device_out: bool = False,
+                            pm_stride: Optional[int] = None) -> Optional[BatchResult]:
+        """One batch on this GPU alone (the index must not be sharded for open searches)."""
         tol_val, tol_mode = self._tolerance(mode)
         if tol_mode not in ('Da', 'ppm'):
             raise ValueError('Unknown precursor tolerance mode')
@@ -220,12 +405,12 @@ class SpectralLibrary:
             return None
         cfg = self.config
         part = self.partitions[charge]
-        use_ann = cfg.mode == 'ann' and mode == 'open' and charge in self._ann_filenames
+        use_ann = self._uses_ann(charge, mode)
         idx = self._get_ann_index(charge) if use_ann else None
         q = queries.to(self.device).contiguous()
         nq = q.n
         k = self._num_candidates
-        stride = q.max_peaks()
+        stride = pm_stride or q.max_peaks()
         xp = torch if device_out else np
         kw = dict(device=self.device) if device_out else {}
         mk = (lambda shape, dt: torch.empty(shape, dtype=dt, **kw)) if device_out else \
@@ -293,8 +478,32 @@ class SpectralLibrary:
                                float(res.best_score[i]))
 
     # ------------------------------------------------------------------ cascade driver
-    def search(self, query_spectra: Dict[int, PackedSpectra], query_meta: Dict[int, list],
-               library_meta: Dict[int, list], score_ssms=None) -> list:
+    def search(self, query, query_meta: Optional[Dict[int, list]] = None,
+               library_meta: Optional[Dict[int, list]] = None, score_ssms=None) -> list:
+        """``SpectralLibrary.search(query_filename)`` (spectral_library.py:193-262): identify all
+        spectra of a query file. ``query`` is a file name (read by the injected ``query_reader``,
+        default the reference's ``read_query_file``), an iterable of query spectrum objects
+        (``identifier, precursor_mz, precursor_charge`` -- None: tried at 2 and 3, :213-223 --
+        ``mz, intensity``, optional ``retention_time, index``), or the packed form of
+        ``search_packed``. Queries are preprocessed in batches on the device, low-quality ones
+        dropped (:225-228). Returns the identifications as SSM records with the attributes
+        ``writer.write_mztab`` consumes (writer.py:129-148)."""
+        if isinstance(query, dict):
+            return self.search_packed(query, query_meta, library_meta, score_ssms)
+        from .library_store import pack_queries
+        if isinstance(query, (str, os.PathLike)):
+            logging.info('Process file %s', query)
+            query = self._query_reader(os.fspath(query))
+        query_spectra, qmeta = pack_queries(query, self.config, self.device)
+        lmeta = library_meta if library_meta is not None else self.library_meta
+        if lmeta is None:
+            raise ValueError('search(): no library metadata (library built from a PackedSpectra); '
+                             'pass library_meta=')
+        return self.search_packed(query_spectra, qmeta, lmeta,
+                                  score_ssms or getattr(self, '_score_ssms', None))
+
+    def search_packed(self, query_spectra: Dict[int, PackedSpectra], query_meta: Dict[int, list],
+                      library_meta: Dict[int, list], score_ssms=None) -> list:
         """``SpectralLibrary.search`` (spectral_library.py:193-262) over packed, already
         processed query spectra split by precursor charge (the file parsing and
         ``process_spectrum`` filtering of :207-228 happen before; queries of unknown charge
@@ -331,10 +540,12 @@ class SpectralLibrary:
         ``_search_batch``; per query identifier the FIRST match is kept (the reference compares
         ``search_engine_score`` values that are still NaN at this point, :312-316, so a later
         duplicate never replaces an earlier one)."""
+        import time
         from .spectrum_similarity import ssm_features
         from .writer import ssms_from_batch
         ssms = {}
         bs = self.config.batch_size
+        t_level, n_in = time.perf_counter(), sum(len(r) for r in rows_by_charge.values())
         for charge, rows in rows_by_charge.items():
             for b0 in range(0, len(rows), bs):
                 sel = rows[b0:b0 + bs]
@@ -354,6 +565,10 @@ class SpectralLibrary:
                     if ssm.query_identifier not in ssms:
                         ssms[ssm.query_identifier] = ssm
         out = list(ssms.values())
+        acc = getattr(self, 'level_seconds', None)
+        if acc is not None:       # bench.py: wall time, queries in, SSMs out of every cascade level
+            sec, a, b = acc.get(mode, (0.0, 0, 0))
+            acc[mode] = (sec + time.perf_counter() - t_level, a + n_in, b + len(out))
         if score_ssms is not None:
             return list(score_ssms(out, mode))
         for ssm in out:        # no scorer: cosine (spectrum_similarity.py:81-106), accepted

@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_SCANNED_VECTOR = 36  # 32-B PQ code + 4-B id
+BYTES_PER_CODE = 32            # the codes-only variant SURVEY.md 8(d) asks to report too
 
 
 def log(*a):
@@ -51,7 +52,16 @@ def main():
     ap.add_argument('--niter', type=int, default=25)
     ap.add_argument('--open-da', type=float, default=500.0)
     ap.add_argument('--scan-variant', type=int, default=0, help='0 auto (tiled v2), 1 generic v1')
-    ap.add_argument('--recall-queries', type=int, default=256)
+    ap.add_argument('--recall-queries', type=int, default=2048)
+    ap.add_argument('--workload', default='batch', choices=['batch', 'cascade'],
+                    help="'batch' (default): BASELINE configs[2]/[3], one 16 384-query open-search "
+                         "batch per step; 'cascade': configs[4], standard search -> FDR gate -> "
+                         "open search of the unidentified remainder over the same library")
+    ap.add_argument('--cascade-batches', type=int, default=4,
+                    help='cascade workload: query batches per GPU in one pass')
+    ap.add_argument('--accept-cosine', type=float, default=0.7,
+                    help='cascade workload: stand-in for the mokapot/FDR gate between the levels '
+                         '(utils.score_ssms is out of scope): accept an SSM when its cosine >= this')
     ap.add_argument('--shard-degree', type=int, default=0,
                     help='N > 1: ranks per shard group (lists sharded inside a group, groups are '
                          'replicas); 0 = N, the fully list-sharded layout of the north star; '
@@ -112,6 +122,13 @@ def main():
         log(f'[bench] library {lib.n} spectra, {lib.mz.numel()} peaks; index {args.index} '
             f'nlist={args.nlist} built in {time.time() - t_build:.1f}s')
 
+    if args.workload == 'cascade':
+        run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # ---- queries: world * batch, identical on every rank, each rank owns one slice
     q_all, truth = synthetic.make_queries(lib, aux, world * args.batch, seed=42,
                                           open_range=args.open_da, charge=charge)
@@ -133,18 +150,38 @@ def main():
         _, Ie = flat.search(sl._encode(qs), args.k)
         del flat
         knn = r.knn
-        inter = 0
-        for i in range(nr):     # set intersection per query on the device
-            inter += int(torch.isin(knn[i][knn[i] >= 0], Ie[i]).sum())
+
+        def overlap(A):         # sum over queries of |A_i & Exact_i| (sets, on the device)
+            return sum(int(torch.isin(A[i][A[i] >= 0], Ie[i]).sum()) for i in range(nr))
         src = src_local[:nr]
         hit = (knn == src.unsqueeze(1)).any(1)
         mod = mod_local[:nr]
         top1 = (r.best_row.to(torch.int64) == src)
+        rec = overlap(knn) / float(nr * args.k)
         recall = {'queries': nr, 'k': args.k,
-                  'recall_at_k_vs_exact_ip': inter / float(nr * args.k),
+                  'recall_at_k_vs_exact_ip': rec,
                   'hit_at_k_source_spectrum': float(hit.float().mean()),
                   'hit_at_k_modified_only': float(hit[mod].float().mean()) if mod.any() else None,
                   'top1_is_source_spectrum': float(top1.float().mean())}
+        if args.index == 'ivfpq':
+            # SURVEY.md 8(d) operating point: IVF-Flat over the SAME coarse quantiser and nprobe =
+            # exact scores inside the probed lists, the ceiling of this index geometry
+            fl = faiss.IndexIVFFlat(faiss.IndexFlatIP(cfg.hash_len), cfg.hash_len, args.nlist)
+            fl.set_trained(idx.centroids())
+            vec = sl._encode(part.spectra)
+            fl.add(vec)
+            del vec
+            fl.nprobe = args.nprobe
+            _, If = fl.search(sl._encode(qs), args.k)
+            del fl
+            rf = overlap(If) / float(nr * args.k)
+            recall.update({'ivfflat_same_geometry_recall_at_k': rf,
+                           'ratio_to_ivfflat': rec / rf if rf > 0 else None,
+                           'ivfflat_hit_at_k_source_spectrum':
+                               float((If == src.unsqueeze(1)).any(1).float().mean()),
+                           'fixed_recall_criterion': 'recall@k >= 0.95 x IVF-Flat(nlist, nprobe) '
+                                                     '(SURVEY.md 8d)',
+                           'meets_criterion': bool(rf > 0 and rec / rf >= 0.95)})
         torch.cuda.empty_cache()
 
     def barrier():
@@ -235,15 +272,26 @@ def main():
             per_vec = BYTES_PER_SCANNED_VECTOR if args.index == 'ivfpq' else 4 * cfg.hash_len
             bytes_per_launch = scanned / scan['launches'] * per_vec
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(args, world)
             roofline = {'bound': 'hbm', 'kernel': 'pq_scan_v3_kernel' if args.index == 'ivfpq'
                         else 'flat_inv_scan_kernel (dense-row bytes per SURVEY 8d; reads ~1/40 of them)',
                         'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(achieved / HBM_PEAK_GBS, 5),
-                        'traffic': pmc_traffic(args, world),
+                        'bytes_per_vector': per_vec,
+                        'traffic': traffic, 'traffic_source': traffic_src,
                         'avg_launch_ms': round(avg_ms, 4),
                         'algorithmic_bytes_per_launch': int(bytes_per_launch),
                         'vectors_scanned_per_query': round(scanned / args.steps /
                                                            (degree * args.batch), 1)}
+            if args.index == 'ivfpq':
+                # the ids are read for survivors only: SURVEY.md 8(d)'s "ids implicit" variant
+                codes = achieved * BYTES_PER_CODE / BYTES_PER_SCANNED_VECTOR
+                roofline['achieved_codes_only'] = round(codes, 2)
+                roofline['frac_codes_only'] = round(codes / HBM_PEAK_GBS, 5)
+                if traffic:
+                    roofline['achieved_measured_traffic'] = round(traffic / (avg_ms * 1e-3) / 1e9, 2)
+                    roofline['frac_measured_traffic'] = round(
+                        traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         # post-path step of the same batch, outside the timed region: the 33 SSM similarity
         # features of every best match (utils._compute_ssm_features), one kernel launch
         from ann_solo_amd.spectrum_similarity import ssm_features
@@ -291,21 +339,156 @@ def main():
         dist.destroy_process_group()
 
 
+class _LibraryMeta:
+    """``library_meta[charge]`` for a synthetic library: row r on demand instead of millions of
+    dictionaries (the writer reads identifier / peptide / precursor_mz / is_decoy)."""
+
+    def __init__(self, ids, pmz):
+        self.ids, self.pmz = ids, pmz
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, r):
+        return {'identifier': int(self.ids[r]), 'peptide': f'SYNTH{int(self.ids[r])}K',
+                'precursor_mz': float(self.pmz[r]), 'is_decoy': False}
+
+
+def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
+    """BASELINE configs[4]: the reference's two-level cascade (spectral_library.py:237-259) --
+    standard search (20 ppm window, no ANN) of every query, a gate standing for the mokapot FDR
+    filter, then the open search (ANN + +-open Da window, shifted dot) of the unidentified
+    remainder -- through ``SpectralLibrary.search`` (host SSM assembly included). With N > 1 the
+    library's IVF lists are sharded over the ranks (``enable_sharding``): level 1 is data-parallel
+    over the queries, level 2 is the list-sharded search. One "step" = one pass over
+    ``cascade_batches`` x 16 384 queries per GPU."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from ann_solo_amd import synthetic
+    part = sl.partitions[charge]
+    nq = world * args.cascade_batches * args.batch
+    q, truth = synthetic.make_queries(lib, aux, nq, seed=42, open_range=args.open_da, charge=charge)
+    q = q.contiguous()
+    pmz = q.precursor_mz.cpu().numpy()
+    qmeta = {charge: [dict(identifier=f'scan={i}', index=i, retention_time=0.0,
+                           precursor_charge=charge, precursor_mz=float(pmz[i])) for i in range(nq)]}
+    lmeta = {charge: _LibraryMeta(part.ids, part.precursor_mz)}
+    thr = args.accept_cosine
+
+    def gate(ssms, mode):           # stands for utils.score_ssms (mokapot, out of scope)
+        for s in ssms:
+            s.q = 0.0 if s.search_engine_score >= thr else 1.0
+        return ssms
+
+    def sub(n):
+        rows = torch.arange(n, device=dev)
+        return {charge: q.select(rows)}, {charge: qmeta[charge][:n]}
+    key = lambda ids: sorted((s.query_identifier, int(s.library_identifier), s.search_engine_score,
+                              s.q) for s in ids)
+    check = None
+    if world > 1:                   # the same queries through one GPU, before the index is sharded
+        ns = min(2 * args.batch // 8 + 37, nq)          # ragged against batch and world
+        qs, qm = sub(ns)
+        ref = key(sl.search(qs, qm, lmeta, score_ssms=gate))
+        sl.enable_sharding()
+        got = key(sl.search(qs, qm, lmeta, score_ssms=gate))
+        flag = torch.tensor([int(ref == got)], device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        check = {'queries': ns, 'sharded_cascade_equals_unsharded': bool(flag.item())}
+    for _ in range(args.warmup):
+        qs, qm = sub(min(nq, 2 * args.batch))
+        sl.search(qs, qm, lmeta, score_ssms=gate)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    L = _lib_handle()
+    L.asl_profile_enable(1)
+    L.asl_profile_reset()
+    sl.level_seconds = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids = sl.search({charge: q}, qmeta, lmeta, score_ssms=gate)
+    barrier()
+    el = time.perf_counter() - t0
+    L.asl_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank != 0:
+        return
+    stages = {}
+    for name in ('encode', 'coarse_gemm', 'coarse_select', 'scan', 'filter', 'rescore',
+                 'rescore_matches'):
+        ms, n = C.c_double(), C.c_int64()
+        L.asl_profile_get(name.encode(), C.byref(ms), C.byref(n))
+        stages[name] = round(ms.value / args.steps, 3)
+    src = truth['source_row'].cpu().numpy()
+    by = {s.query_identifier: s for s in ids}
+    correct = sum(int(by[f'scan={i}'].library_identifier) == int(part.ids[src[i]])
+                  for i in range(nq) if f'scan={i}' in by)
+    lv = {}
+    for mode, (sec, n_in, n_out) in sl.level_seconds.items():
+        lv[mode] = {'queries_in_per_step': n_in // args.steps, 'ssms_out_per_step': n_out // args.steps,
+                    'seconds_per_step': round(sec / args.steps, 4),
+                    'spectra_per_s': round(n_in / sec, 1) if sec > 0 else None}
+    out = {
+        'metric': 'query spectra/sec + recall@k vs brute-force, open-mod search on MassIVE-KB',
+        'value': round(nq * args.steps / el, 2), 'unit': 'query spectra/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(el / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'configs[4]: cascade over a MassIVE-KB-scale synthetic library '
+                               f'({args.library_size} spectra): standard search 20 ppm -> gate '
+                               f'(cosine >= {thr:g}, stands for the mokapot FDR filter) -> open search '
+                               f'+-{args.open_da:g} Da of the remainder, {args.index} nlist={args.nlist} '
+                               f'nprobe={args.nprobe} k={args.k}, shifted dot; host SSM assembly included',
+                   'queries_per_gpu': args.cascade_batches * args.batch, 'batch': args.batch,
+                   'parallelism': 'single' if world == 1 else
+                   f'level 1 query-parallel x{world}, level 2 ivf-list-shard x{world}'},
+        'levels': lv,
+        'identifications': {'total': len(ids), 'source_spectrum_identified': correct,
+                            'queries': nq},
+        'cascade_check': check,
+        'device_stages_ms_per_step': stages,
+    }
+    print(json.dumps(out), flush=True)
+
+
+def _lib_handle():
+    from ann_solo_amd import _lib
+    return _lib.lib()
+
+
+PMC_TRAFFIC_FILE = 'profiles/r02_pmc_traffic.json'
+
+
 def pmc_traffic(args, world):
-    """HBM-side bytes per scan launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in
-    its own run, scripts/pmc.sh; FETCH_SIZE is in KiB and reads 1/2 of a wide coalesced stream
-    on gfx950, MI355X_MICROARCH.md). Only valid for the exact default workload; else null."""
+    """(bytes, source): HBM-side bytes per scan launch from the COMMITTED PMC pass of this build
+    (rocprofv3 --pmc FETCH_SIZE in its own run, scripts/pmc.sh; FETCH_SIZE is in KiB and reads 1/2
+    of a wide coalesced stream on gfx950, MI355X_MICROARCH.md) -- a constant read from a file, not
+    measured by this run (counters cannot be collected from inside the process); the JSON says so
+    in `traffic_source`. Only for the exact default workload; else (None, reason)."""
     default = (world == 1 and args.library_size == 2_100_000 and args.nlist == 4096 and
                args.nprobe == 128 and args.k == 1024 and args.batch == 16384 and
-               args.index == 'ivfpq' and args.scan_variant == 0)
-    path = os.path.join(ROOT, 'profiles', 'r01_v10_pmc_traffic.json')
-    if not default or not os.path.exists(path):
-        return None
+               args.index == 'ivfpq' and args.scan_variant == 0 and args.niter == 25)
+    path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
+    if not default:
+        return None, 'not the default workload: no committed PMC pass applies'
+    if not os.path.exists(path):
+        return None, f'{PMC_TRAFFIC_FILE} missing'
     try:
         with open(path) as f:
-            return int(json.load(f)['scan_hbm_bytes_per_launch'])
-    except Exception:
-        return None
+            d = json.load(f)
+        return int(d['scan_hbm_bytes_per_launch']), (
+            f"{PMC_TRAFFIC_FILE} (committed rocprofv3 --pmc FETCH_SIZE pass of this build, x2 gfx950 "
+            f"correction; not measured in this run)")
+    except Exception as e:
+        return None, f'{PMC_TRAFFIC_FILE} unreadable: {e}'
 
 
 def cpu_baseline(args, sl, part, idx, q, res, charge, cfg):
@@ -345,13 +528,26 @@ def cpu_baseline(args, sl, part, idx, q, res, charge, cfg):
     t_all, r_all = run(n_all, cores)
     best_row = res.best_row[:n_all].cpu().numpy()
     best_score = res.best_score[:n_all].cpu().numpy()
+    # candidate id sets at bench size: the GPU's k nearest ids of the same queries (sorted rows)
+    g = sl._search_batch(q.select(torch.arange(n_all, device=q.device)), charge, 'open',
+                         want_knn=True)
+    knn_gpu, knn_cpu = np.sort(g.knn, axis=1), np.sort(r_all['knn_I'], axis=1)
+    rows_equal = (knn_gpu == knn_cpu).all(axis=1)
     parity = {'queries': n_all,
+              'knn_id_sets_equal': bool(rows_equal.all()),
+              'knn_rows_differing': int((~rows_equal).sum()),
+              'knn_ids_compared': int(knn_gpu.size),
               'best_row_equal': bool(np.array_equal(best_row, r_all['best_row'])),
               'best_score_max_abs_diff': float(np.abs(best_score - r_all['best_score']).max())}
+    try:                       # time FAISS' own CPU index when it is installed
+        import faiss as _faiss   # noqa: F401
+        faiss_note = 'importable (not timed: wire IndexIVFPQ here)'
+    except Exception:
+        faiss_note = 'unavailable'
     log(f'[bench] cpu baseline: {n_all} queries on {cores} threads in {t_all:.2f}s, '
         f'single core {per_q * 1e3:.2f} ms/query (setup {time.time() - t0:.1f}s)')
     return {'value': round(n_all / t_all, 2), 'unit': 'query spectra/s', 'cores': cores,
-            'kind': 'port',
+            'kind': 'port', 'faiss': faiss_note,
             'sample': f'{n_all} queries of the same batch, same index, all {cores} host threads '
                       f'(OpenMP over queries)',
             'single_core_value': round(1.0 / per_q, 2),

@@ -95,7 +95,8 @@ int asl_index_set_niter(asl_index_t *idx, int32_t niter);
  * with sort-based top-k, 3 / 4 = tiled + histogram top-k with a 2048- / 4096-key buffer.
  * IVF-Flat: 0 = per-dimension postings inside every list (sparse data), 2 = sparse
  * 64-vector tiles, 1 = dense GEMM + masked top-k.
- * Bits 8+ are measurement knobs of the kernels (results invalid when set). */
+ * Values above 4 are rejected: the kernels' measurement bits (8+) exist only in a library built
+ * with -DASL_ENABLE_DBG (scripts/ab_*.sh). */
 int asl_index_set_scan_variant(asl_index_t *idx, int32_t variant);
 
 /* Introspection, used by the parity tests and by multi-GPU sharding. Sizes via
@@ -132,6 +133,10 @@ int asl_index_set_unordered(asl_index_t *idx, int32_t mode);
 int asl_topk_merge_keys(int32_t S, int32_t nq, int32_t k, const int64_t *Ks, float *D, int64_t *I,
                         int32_t unordered);
 int asl_index_shard(asl_index_t *idx, int32_t rank, int32_t world);
+/* 1 if asl_index_search_preassigned can emit packed keys (unordered mode 2) for this index at
+ * (k, nprobe) -- the tiled IVF-PQ scan: m = 32, 8-bit codes, automatic scan variant, nprobe
+ * within the tiled kernel's limit, k + 768 <= 2048 --, else 0 (exchange (D, I) rows then). */
+int asl_index_supports_keys(const asl_index_t *idx, int32_t k, int32_t nprobe);
 /* list -> owner rank map of the balancing above, for inspection. */
 int asl_index_shard_map(const asl_index_t *idx, int32_t world, int32_t *owner /* [nlist] */);
 

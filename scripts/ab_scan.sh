@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs the instrumented library: make -C ann_solo_amd/csrc clean all EXTRA=-DASL_ENABLE_DBG
 # A/B of the PQ scan kernel with measurement knobs (scan-variant = kernel | dbg<<8):
 #   dbg bit 1: no top-k appends, 2: no LUT build, 4: no ADC, 8: no code loads
 cd "$(dirname "$0")/.."

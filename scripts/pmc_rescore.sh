@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs the instrumented library: make -C ann_solo_amd/csrc clean all EXTRA=-DASL_ENABLE_DBG
 # VALU/SALU instruction counts of the rescoring kernel under its measurement knobs.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

@@ -1,5 +1,6 @@
 """Measurement helper: per-workgroup phase durations of pq_scan_v3 (dbg bit 32), for the
-unsharded index and for shard 0 of W.   python scripts/scan_phases.py [W] [variant]"""
+unsharded index and for shard 0 of W. Needs the instrumented library
+(make -C ann_solo_amd/csrc clean all EXTRA=-DASL_ENABLE_DBG).   python scripts/scan_phases.py [W] [variant]"""
 import os
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))

@@ -14,6 +14,7 @@ class OracleShardBackend:
         self.charge, self.k, self.nprobe = charge, k, nprobe
         self.prec_tol, self.prec_mode = prec_tol, prec_mode
         self.frag_tol, self.allow_shift = frag_tol, allow_shift
+        self.window_tol = {'std': (20.0, 'ppm'), 'open': (prec_tol, prec_mode)}
         nlist = len(centroids)
         sizes = np.bincount(assign, minlength=nlist)
         owner = owner_fn(sizes, world)
@@ -42,16 +43,121 @@ class OracleShardBackend:
         D, I = O.topk_merge(Ds.numpy(), Is.numpy())
         return torch.from_numpy(D), torch.from_numpy(I)
 
-    def rescore_knn(self, queries, knn, device_out=False):
+    def _window_ok(self, q_pmz, tol, mode):
+        """spectral_library.py:421-427 in float64 over the float32 library column."""
+        l = self.pmz32.astype(np.float64)
+        if mode == 'Da':
+            return np.abs(q_pmz - l) * self.charge <= tol
+        return np.abs(q_pmz - l) / l * 10 ** 6 <= tol
+
+    def _best(self, Q, cands, pm_stride):
+        n = Q.n
+        stride = pm_stride or max(1, int(np.diff(Q.offsets).max()))
+        out = dict(best_row=np.full(n, -1, np.int32), best_score=np.zeros(n),
+                   n_candidates=np.zeros(n, np.int32), pm_count=np.zeros(n, np.int32),
+                   pm_pairs=np.zeros((n, stride, 2), np.uint32))
+        for i, cand in enumerate(cands):
+            out['n_candidates'][i] = len(cand)
+            if len(cand) == 0:
+                continue
+            b, s, m = O.best_match(Q, i, self.L, cand, self.frag_tol, self.allow_shift)
+            if b >= 0:
+                out['best_row'][i], out['best_score'][i] = cand[b], s
+                out['pm_count'][i] = len(m)
+                out['pm_pairs'][i, :len(m)] = m
+        return out
+
+    def rescore_knn(self, queries, knn, device_out=False, pm_stride=None):
         Q = O.Spectra(*queries.numpy())
         knn = knn.numpy()
-        best_row = np.full(Q.n, -1, np.int32)
-        best_score = np.zeros(Q.n)
+        cands = []
         for i in range(Q.n):
-            cand = np.sort(np.array([r for r in knn[i] if r >= 0 and O.precursor_ok(
-                Q.precursor_mz[i], self.pmz32[r], self.charge, self.prec_tol, self.prec_mode)],
-                np.int64))
-            b, s, _ = O.best_match(Q, i, self.L, cand, self.frag_tol, self.allow_shift)
-            if b >= 0:
-                best_row[i], best_score[i] = cand[b], s
-        return dict(best_row=best_row, best_score=best_score, knn=knn)
+            ok = self._window_ok(Q.precursor_mz[i], self.prec_tol, self.prec_mode)
+            r = knn[i][knn[i] >= 0]
+            cands.append(np.sort(r[ok[r]]).astype(np.int64))
+        out = self._best(Q, cands, pm_stride)
+        out['knn'] = knn
+        return out
+
+    def window_search(self, queries, mode, pm_stride=None, tol=None):
+        """Window-only search (cascade level 1 / charges without an index)."""
+        Q = O.Spectra(*queries.numpy())
+        tol_val, tol_mode = tol if tol is not None else self.window_tol[mode]
+        cands = [np.nonzero(self._window_ok(Q.precursor_mz[i], tol_val, tol_mode))[0]
+                 .astype(np.int64) for i in range(Q.n)]
+        return self._best(Q, cands, pm_stride)
+
+
+# ---------------------------------------------------------------------------- cascade on CPU
+from types import SimpleNamespace                                    # noqa: E402
+
+from ann_solo_amd.spectral_library import BatchResult, Config, SpectralLibrary   # noqa: E402
+
+
+def oracle_cosines(q, lib_spectra, rows, pm_pairs, pm_count, *a):
+    """Stand-in for the device ``ssm_features`` (column 0 = cosine over the peak matches,
+    spectrum_similarity.py:81-106); the other columns are not used by the cascade."""
+    qo, _, qi, *_ = q.numpy()
+    lo, _, li, *_ = lib_spectra.numpy()
+    out = np.full((q.n, 33), np.nan)
+    for i in range(q.n):
+        r = int(rows[i])
+        if r < 0:
+            continue
+        pm = np.asarray(pm_pairs[i][:int(pm_count[i])]).astype(np.int64)
+        out[i, 0] = float(np.sum(qi[qo[i] + pm[:, 0]].astype(np.float32) *
+                                 li[lo[r] + pm[:, 1]].astype(np.float32), dtype=np.float32))
+    return out
+
+
+class OracleSpectralLibrary(SpectralLibrary):
+    """``SpectralLibrary`` whose device calls are answered by the oracle: the cascade driver,
+    the batching and the multi-rank dispatch are the product's own code."""
+
+    def __init__(self, parts, config, k, nprobe, world=1, rank=0, group=None):
+        # parts: {charge: dict(lib_np, pmz32, centroids, assign, payload, codebooks) or window-only}
+        self.config = config
+        self.device = torch.device('cpu')
+        self._num_candidates, self._num_probe = k, nprobe
+        self._ann_filenames = {z: 'oracle' for z, p in parts.items() if p.get('centroids') is not None}
+        self._dist = None if world == 1 else SimpleNamespace(group=group, world=world, rank=rank,
+                                                             backends={})
+        self.partitions, self._full, self._shard = {}, {}, {}
+        from ann_solo_amd.distributed import lpt_owner
+        from ann_solo_amd.packed import PackedSpectra
+        for z, p in parts.items():
+            self.partitions[z] = SimpleNamespace(spectra=PackedSpectra.from_numpy(*p['lib_np']),
+                                                 ids=np.arange(len(p['pmz32'])))
+            if z in self._ann_filenames:
+                mk = lambda r, w: OracleShardBackend(
+                    p['lib_np'], p['pmz32'], p['centroids'], p['assign'], p['payload'],
+                    p.get('codebooks'), r, w, z, k, nprobe, config.precursor_tolerance_mass_open,
+                    config.precursor_tolerance_mode_open, config.fragment_mz_tolerance,
+                    config.allow_peak_shifts, lpt_owner)
+                self._full[z] = mk(0, 1)
+                self._shard[z] = mk(rank, world)
+            else:                       # window-only partition: a backend without an index
+                be = OracleShardBackend.__new__(OracleShardBackend)
+                be.L, be.pmz32, be.charge = O.Spectra(*p['lib_np']), p['pmz32'], z
+                be.frag_tol, be.allow_shift = config.fragment_mz_tolerance, config.allow_peak_shifts
+                be.window_tol = {'std': (20.0, 'ppm'), 'open': (config.precursor_tolerance_mass_open,
+                                                                config.precursor_tolerance_mode_open)}
+                self._full[z] = self._shard[z] = be
+        for be in list(self._full.values()) + list(self._shard.values()):
+            be.window_tol['std'] = (config.precursor_tolerance_mass, config.precursor_tolerance_mode)
+
+    def _shard_backend(self, charge, mode):
+        return self._shard[charge]
+
+    def _search_batch_local(self, queries, charge, mode, want_knn=False, device_out=False,
+                            pm_stride=None):
+        if charge not in self.partitions:
+            return None
+        be = self._full[charge]
+        if self._uses_ann(charge, mode):
+            _, I = be.full.search(be.encode(queries).numpy(), self._num_candidates, self._num_probe)
+            r = be.rescore_knn(queries, torch.from_numpy(I), pm_stride=pm_stride)
+        else:
+            r = be.window_search(queries, mode, pm_stride=pm_stride)
+        return BatchResult(r['best_row'], r['best_score'], r['n_candidates'], r['pm_count'],
+                           r['pm_pairs'], r.get('knn'))

@@ -139,3 +139,80 @@ def test_lpt_owner_rule():
     assert max(loads) - min(loads) <= sizes.max()
     assert lpt_owner(sizes, 1).tolist() == [0] * 6
     assert lpt_owner(np.zeros(0, np.int64), 4).tolist() == []
+
+
+# ------------------------------------------------------------------ configs[4]: the cascade
+def _cascade_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import oracle_py as O
+    from oracle_backend import OracleSpectralLibrary, oracle_cosines
+    from ann_solo_amd import synthetic, spectrum_similarity
+    from ann_solo_amd.spectral_library import Config
+    spectrum_similarity.ssm_features = oracle_cosines
+    lib, aux = synthetic.make_library(1400, seed=95, device='cpu', charges=(2, 3),
+                                      charge_p=(0.8, 0.2))
+    cfg = Config(batch_size=16, precursor_tolerance_mass_open=300.0,
+                 precursor_tolerance_mode_open='Da', fdr=0.01)
+    parts, qs, qmeta, lmeta = {}, {}, {}, {}
+    pz = lib.precursor_charge.numpy()
+    n_q = {2: 37, 3: 5}                                   # ragged against batch 16 and 2 ranks
+    for z in (2, 3):
+        rows = np.nonzero(pz == z)[0]
+        sub = lib.select(torch.as_tensor(rows))
+        lib_np = sub.numpy()
+        p = dict(lib_np=lib_np, pmz32=lib_np[4].astype(np.float32))
+        if z == 2:                                        # charge 3: too rare for an index
+            xb = O.encode_batch(lib_np[1], lib_np[2], lib_np[0], 10.96, 0.04, 800)
+            cen = O.kmeans(xb, 8, 4, 1234, 0, 256)
+            a = O.assign(xb, cen, 0)
+            cb = O.pq_train(xb, cen, 8, 16, 4, 1241)
+            p.update(centroids=cen, assign=a, codebooks=cb, payload=O.pq_encode(xb, cen, a, cb))
+        parts[z] = p
+        q, _ = synthetic.make_queries(lib, aux, n_q[z], seed=96 + z, charge=z, open_range=300.0)
+        qs[z] = q
+        qmeta[z] = [dict(identifier=f'scan={100 * z + i}', index=100 * z + i, precursor_charge=z,
+                         precursor_mz=float(q.precursor_mz[i])) for i in range(q.n)]
+        lmeta[z] = [dict(identifier=int(1000 * z + r), peptide=f'PEP{z}x{r}K',
+                         precursor_mz=float(pm)) for r, pm in enumerate(p['pmz32'])]
+    qmeta[3][1]['identifier'] = qmeta[2][4]['identifier']   # unknown charge: one id, tried twice
+
+    def scorer(ssms, mode):                # stands for utils.score_ssms: deterministic q-values
+        for s in ssms:
+            s.q = 0.001 if s.search_engine_score > 0.6 else 0.5
+        return ssms
+    one = OracleSpectralLibrary(parts, cfg, 64, 4)
+    ref = one.search(qs, qmeta, lmeta, score_ssms=scorer)
+    many = OracleSpectralLibrary(parts, cfg, 64, 4, world, rank)
+    got = many.search(qs, qmeta, lmeta, score_ssms=scorer)
+    key = lambda s: (s.query_identifier, s.library_identifier, s.charge, s.search_engine_score,
+                     s.q, s.peak_matches.tolist())
+    same = sorted(map(key, ref)) == sorted(map(key, got))
+    n_std = sum(s.q < cfg.fdr for s in ref)
+    # the second level really ran sharded: shard 0 and shard 1 own different lists
+    owners = set(many._shard[2].owner.tolist())
+    with open(os.path.join(out_dir, f'rank{rank}.txt'), 'w') as f:
+        f.write(f'{int(same)} {len(ref)} {n_std} {len(owners)}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_cascade_equals_unsharded(tmp_path):
+    """configs[4] on CPU: standard search (data-parallel window search) -> FDR gate -> open search
+    of the remainder over the list-sharded index, ragged batches, a charge without an index and
+    a duplicated identifier -- identical identifications on every rank and to one process
+    (reference: spectral_library.py:237-259, 301-317)."""
+    world = 2
+    mp.spawn(_cascade_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    seen = []
+    for r in range(world):
+        same, n, n_std, owners = open(os.path.join(tmp_path, f'rank{r}.txt')).read().split()
+        assert same == '1' and owners == '2'
+        assert int(n) >= 35 and 5 < int(n_std) < int(n)       # both cascade levels contributed
+        seen.append((n, n_std))
+    assert seen[0] == seen[1]

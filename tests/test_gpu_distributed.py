@@ -39,6 +39,50 @@ def test_two_rank_sharded_bench_path(degree, index):
         assert d['config']['parallelism'] == 'replicas x2' and d['alt_layouts'] is None
 
 
+@pytest.mark.parametrize('index', ['ivfpq', 'ivfflat'])
+def test_two_rank_sharded_cascade(index):
+    """configs[4] through the real engine on two ranks sharing GPU 0 (host-side collectives):
+    standard search data-parallel over the queries, open search over the list-sharded index;
+    the identifications must equal the one-GPU cascade's (bench.py --workload cascade)."""
+    env = dict(os.environ, ASL_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29541' if index == 'ivfpq' else '29542',
+           os.path.join(ROOT, 'bench.py'), '--workload', 'cascade',
+           '--gpus', '2', '--steps', '1', '--warmup', '1', '--library-size', '60000', '--nlist',
+           '256', '--niter', '4', '--batch', '1024', '--cascade-batches', '2', '--index', index]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert line, out.stderr[-3000:]
+    d = json.loads(line[-1])
+    assert d['n_gpus'] == 2 and d['config']['workload'].startswith('configs[4]')
+    assert d['cascade_check']['sharded_cascade_equals_unsharded'] is True
+    lv = d['levels']
+    assert lv['std']['queries_in_per_step'] == 4096
+    assert 0 < lv['open']['queries_in_per_step'] < 4096              # only the remainder
+    ident = d['identifications']
+    assert ident['source_spectrum_identified'] > 0.6 * ident['queries']
+    assert d['value'] > 0
+
+
+def test_sharded_exchange_falls_back_without_packed_keys():
+    """packed-key rows exist only in the tiled m = 32 / 8-bit scan; every other
+    IVF-PQ shape must exchange (D, I) rows instead of failing."""
+    import torch
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.distributed import HipShardBackend
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    lib, aux = synthetic.make_library(5000, seed=79, device='cpu', charges=(2,), charge_p=(1.0,))
+    for kw, want in ((dict(pq_m=32), True), (dict(pq_m=16), False), (dict(pq_m=32, pq_bits=6), False)):
+        sl = SpectralLibrary(lib, config=Config(num_list=32, num_probe=8, num_candidates=200,
+                                                index='ivfpq', kmeans_niter=3, **kw))
+        be = HipShardBackend(sl, 2, 'open')
+        assert be.supports_keys is want, kw
+        sl.shutdown()
+    sl = SpectralLibrary(lib, config=Config(num_list=32, num_probe=8, num_candidates=1500,
+                                            index='ivfpq', kmeans_niter=3))
+    assert HipShardBackend(sl, 2, 'open').supports_keys is False      # k + 768 > 2048
+
+
 _RCCL_WORLD1 = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
@@ -71,8 +115,28 @@ q, _ = synthetic.make_queries(lib, aux, 512, seed=6, open_range=300.0, charge=2)
 ref = sl._search_batch(q, 2, 'open', device_out=True)
 sl._get_ann_index(2).shard(0, 1)
 be = HipShardBackend(sl, 2, 'open')
-got = sharded_search_batch(be, q, device_out=True, _force_exchange=True)
+got = sharded_search_batch(be, q, device_out=True, _force_exchange=True, check_sizes=True)
 assert torch.equal(got.best_row, ref.best_row) and torch.equal(got.best_score, ref.best_score)
+if sys.argv[3] == 'ivfpq':      # a PQ shape without packed keys takes the (D, I) exchange
+    cfg16 = Config(num_list=64, num_probe=16, num_candidates=256, index='ivfpq', pq_m=16,
+                   kmeans_niter=4, mode='ann', batch_size=512)
+    s16 = SpectralLibrary(lib, config=cfg16, device=dev)
+    ref16 = s16._search_batch(q, 2, 'open', device_out=True)
+    s16._get_ann_index(2).shard(0, 1)
+    be16 = HipShardBackend(s16, 2, 'open')
+    assert not be16.supports_keys
+    got16 = sharded_search_batch(be16, q, device_out=True, _force_exchange=True)
+    assert torch.equal(got16.best_row, ref16.best_row) and torch.equal(got16.best_score, ref16.best_score)
+    # the cascade entry point at world 1: ragged batch, both levels
+    from ann_solo_amd.distributed import sharded_cascade_batch
+    q37 = q.select(torch.arange(37, device=q.device))
+    for mode, ann in (('open', True), ('std', False)):
+        a = sharded_cascade_batch(be, q37, mode, ann)
+        sl2 = sl._search_batch_local(q37, 2, mode) if mode == 'std' else None
+        if sl2 is not None:
+            assert (a.best_row == sl2.best_row).all() and (a.best_score == sl2.best_score).all()
+        else:
+            assert (a.best_row == ref.best_row[:37].cpu().numpy()).all()
 dist.destroy_process_group()
 print('rccl-world1-ok')
 '''

@@ -22,7 +22,7 @@ def world():
     dev = torch.device('cuda', 0)
     lib, aux = synthetic.make_library(N_LIB, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
     cfg = Config(num_list=4096, num_probe=128, num_candidates=1024, index='ivfpq', pq_m=32,
-                 kmeans_niter=2, precursor_tolerance_mass_open=500.0,
+                 kmeans_niter=25, precursor_tolerance_mass_open=500.0,   # the bench's index
                  precursor_tolerance_mode_open='Da', batch_size=16384, seed=1234)
     sl = SpectralLibrary(lib, config=cfg, device=dev)
     q, truth = synthetic.make_queries(lib, aux, 2048, seed=42, open_range=500.0, charge=2)
@@ -71,7 +71,7 @@ def test_three_shards_merge_to_the_unsharded_result(world, tmp_path):
     idx = sl._get_ann_index(2)
     vec = sl._encode(q)[:1024].contiguous()
     D, I = idx.search(vec, 1024)
-    path = os.path.join(tmp_path, 'full_abc1234_2.idxann')
+    path = os.path.join(tmp_path, 'full_abc1234_2.idxmi')
     faiss.write_index(idx, path)
     owner = idx.shard_map(3)
     assert set(owner.tolist()) == {0, 1, 2}
@@ -115,4 +115,93 @@ def test_fused_search_winners_equal_the_oracle_on_a_sample(world, O):
         assert res.peak_matches(int(i)).tolist() == m.tolist()
     src = truth['source_row'].cpu().numpy()
     unmod = ~truth['is_modified'].cpu().numpy()
-    assert (res.best_row[unmod] == src[unmod]).mean() > 0.75          # kmeans_niter = 2: coarse but sane
+    assert (res.best_row[unmod] == src[unmod]).mean() > 0.75
+
+
+def _candidate_pack(O, part_np, cand):
+    o, mz, it, chg, pmz, pz = part_np
+    off = np.concatenate([[0], np.cumsum(o[cand + 1] - o[cand])])
+    sel = np.concatenate([np.arange(o[r], o[r + 1]) for r in cand]) if len(cand) else np.zeros(0, np.int64)
+    return O.Spectra(off, mz[sel], it[sel], chg[sel], pmz[cand], pz[cand])
+
+
+def test_knn_id_sets_equal_the_oracle_at_bench_size(world, O):
+    """The bench's own index (25 k-means iterations): the k = 1024 neighbour ids AND scores of
+    sampled queries equal the oracle's IVF-PQ search over the same lists, row for row."""
+    sl, q, _ = world
+    idx = sl._get_ann_index(2)
+    off, ids, codes = idx.lists()
+    info = idx.info()
+    ivf = O.HostIVF.__new__(O.HostIVF)
+    ivf.centroids, ivf.nlist, ivf.d = idx.centroids(), info.nlist, info.d
+    ivf.list_offsets, ivf.ids, ivf.payload, ivf.codebooks, ivf.kind = off, ids, codes, idx.codebooks(), 1
+    rows = np.arange(0, q.n, 16)                                      # 128 sampled queries
+    vec = sl._encode(q)[rows].contiguous()
+    D, I = idx.search(vec, 1024)
+    Do, Io = ivf.search(vec.cpu().numpy(), 1024, 128)
+    assert np.array_equal(I.cpu().numpy(), Io)
+    assert np.array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
+
+
+def test_cascade_std_then_open_on_the_remainder(world, O):
+    """configs[4] at full size on one GPU (spectral_library.py:237-259): the standard search
+    identifies what a 20 ppm window can, the gate keeps confident SSMs, the open search runs on
+    the rest only; sampled winners of both levels equal the oracle."""
+    import torch
+    sl, q, truth = world
+    part = sl.partitions[2]
+    part_np = part.spectra.to('cpu').numpy()
+    n = q.n
+    pmzq = q.precursor_mz.cpu().numpy()
+    qmeta = {2: [dict(identifier=f'scan={i}', index=i, precursor_charge=2, precursor_mz=float(pmzq[i]))
+                 for i in range(n)]}
+
+    class Meta:
+        def __getitem__(self, r):
+            return dict(identifier=int(r), peptide=f'P{r}K', precursor_mz=float(part.precursor_mz[r]))
+    seen = {}
+
+    def gate(ssms, mode):
+        seen[mode] = [s.query_identifier for s in ssms]
+        for s in ssms:
+            s.q = 0.0 if s.search_engine_score >= 0.7 else 1.0
+        return ssms
+    ids = sl.search({2: q}, qmeta, {2: Meta()}, score_ssms=gate)
+    by = {s.query_identifier: s for s in ids}
+    std = sl._search_batch(q, 2, 'std')
+    opn = sl._search_batch(q, 2, 'open')
+    cos = {}
+    kept_std = 0
+    for i in range(n):
+        s = by.get(f'scan={i}')
+        if s is None:
+            assert opn.best_row[i] < 0
+            continue
+        if s.q == 0.0 and std.best_row[i] >= 0 and f'scan={i}' not in seen['open']:
+            assert s.library_identifier == std.best_row[i]            # kept from level 1
+            kept_std += 1
+        else:
+            assert f'scan={i}' in seen['open'] and s.library_identifier == opn.best_row[i]
+    assert len(seen['std']) == int((std.best_row >= 0).sum())
+    assert kept_std > 0.3 * n and len(seen['open']) == n - kept_std   # level 2 saw only the remainder
+    # sampled oracle parity of both levels
+    Q = O.Spectra(*q.numpy())
+    lib_pmz = part.precursor_mz.astype(np.float64)
+    for i in range(0, n, 40):
+        want = np.nonzero(np.abs(pmzq[i] - lib_pmz) / lib_pmz * 10 ** 6 <= 20.0)[0].astype(np.int64)
+        assert std.n_candidates[i] == len(want)
+        if len(want) == 0:
+            assert std.best_row[i] == -1
+            continue
+        b, sc, m = O.best_match(Q, i, _candidate_pack(O, part_np, want),
+                                np.arange(len(want), dtype=np.int64), 0.02, True)
+        if b < 0:
+            assert std.best_row[i] == -1
+        else:
+            assert std.best_row[i] == want[b] and std.best_score[i] == sc
+            assert std.peak_matches(i).tolist() == m.tolist()
+    src = truth['source_row'].cpu().numpy()
+    unmod = ~truth['is_modified'].cpu().numpy()
+    right = np.array([int(by[f'scan={i}'].library_identifier) == src[i] if f'scan={i}' in by else False
+                      for i in range(n)])
+    assert right[unmod].mean() > 0.9 and right.mean() > 0.75

@@ -435,7 +435,7 @@ def test_save_load_roundtrip(tmp_path, vecs, pq_index):
     idx, _ = pq_index
     idx.nprobe = 8
     D, I = idx.search(xq, 200)
-    p = os.path.join(tmp_path, 'lib_abc1234_2.idxann')
+    p = os.path.join(tmp_path, 'lib_abc1234_2.idxmi')
     faiss.write_index(idx, p)
     idx2 = faiss.read_index(p)
     idx2.nprobe = 8
@@ -445,7 +445,7 @@ def test_save_load_roundtrip(tmp_path, vecs, pq_index):
     idx2.reset()
     assert idx2.ntotal == 0
     with pytest.raises(Exception):
-        faiss.read_index(os.path.join(tmp_path, 'missing.idxann'))
+        faiss.read_index(os.path.join(tmp_path, 'missing.idxmi'))
 
 
 def test_error_behaviour(vecs):

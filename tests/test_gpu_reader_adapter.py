@@ -1,0 +1,197 @@
+"""The reference's engine surface on the device path: ``SpectralLibrary(
+filename | reader)``, ``._library_reader``, ``.search(query_filename | spectra)`` returning SSM
+records the mzTab writer consumes, ``.shutdown()`` -- spectral_library.py:46-116,193-262,
+ann_solo.py:78-83 -- driven through a reader with the reference reader's surface."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fake_reader import FakeReader, FakeSpectrum, Annotation   # noqa: E402
+
+
+def _objects(pack, chg_as_annotation=True, ids=None, peptide=True):
+    """PackedSpectra of processed synthetic spectra -> RAW-looking spectrum objects: intensities
+    are blown up again so that process_spectrum has something to do (rank scaling is invariant
+    under monotone maps)."""
+    o, mz, it, chg, pmz, pz = pack.to('cpu').numpy()
+    out = []
+    for i in range(pack.n):
+        sl = slice(o[i], o[i + 1])
+        ann = [Annotation(int(c)) if c else None for c in chg[sl]] if chg_as_annotation else None
+        out.append(FakeSpectrum(ids[i] if ids is not None else i, float(pmz[i]), int(pz[i]), mz[sl],
+                                np.exp(6.0 * it[sl]), ann, f'PEP{i}K' if peptide else None,
+                                is_decoy=(i % 9 == 0), retention_time=0.5 * i, index=i))
+    return out
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from ann_solo_amd import synthetic
+    lib, aux = synthetic.make_library(6000, seed=31, device='cpu', charges=(2, 3), charge_p=(0.7, 0.3))
+    q, truth = synthetic.make_queries(lib, aux, 400, seed=32, open_range=300.0)
+    return lib, aux, q, truth
+
+
+def test_filename_constructor_search_and_caches(setup, tmp_path, monkeypatch):
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary, INDEX_EXT
+    from ann_solo_amd.writer import write_mztab
+    lib, aux, q, truth = setup
+    lib_objs = _objects(lib)
+    rng = np.random.default_rng(1)
+    order = rng.permutation(len(lib_objs))               # file order != identifier order
+    fn = str(tmp_path / 'human.splib')
+    made = []
+
+    def factory(filename, config_hash):
+        r = FakeReader([lib_objs[i] for i in order], filename)
+        r.config_hash = config_hash
+        made.append(r)
+        return r
+    cfg = Config(num_list=32, num_probe=16, num_candidates=512, index='ivfpq', kmeans_niter=4,
+                 batch_size=128, query_filename=str(tmp_path / 'q.mgf'), spectral_library_filename=fn)
+    q_objs = _objects(q, chg_as_annotation=False, ids=[f'scan={i}' for i in range(q.n)])
+    for i in range(0, q.n, 10):
+        q_objs[i].precursor_charge = None                # unknown charge: tried at 2 and 3
+    sl = SpectralLibrary(fn, config=cfg, reader_factory=factory, query_reader=lambda f: iter(q_objs))
+    assert sl._library_reader is made[0] and made[0].config_hash == sl._get_hyperparameter_hash()
+    assert made[0].reads == 1
+    h7 = sl._get_index_hash()[:7]
+    files = sorted(os.listdir(tmp_path))
+    assert [f for f in files if f.endswith(INDEX_EXT)] == [f'human_{h7}_{z}{INDEX_EXT}' for z in (2, 3)]
+    assert len([f for f in files if f.endswith('.spstore')]) == 1
+    # row r of a partition is spec_info id[r]; processing the blown-up peaks gives back the library
+    for z, part in sl.partitions.items():
+        assert part.ids.tolist() == made[0].spec_info['charge'][z]['id'].tolist()
+        assert np.array_equal(part.precursor_mz, made[0].spec_info['charge'][z]['precursor_mz'])
+        o, mz, it, chg, *_ = part.spectra.to('cpu').numpy()
+        lo, lmz, lit, lchg, *_ = lib.numpy()
+        for r in (0, 7, len(part.ids) - 1):
+            src = int(part.ids[r])
+            assert np.array_equal(mz[o[r]:o[r + 1]], lmz[lo[src]:lo[src + 1]])
+            assert np.allclose(it[o[r]:o[r + 1]], lit[lo[src]:lo[src + 1]], rtol=1e-6)
+            assert np.array_equal(chg[o[r]:o[r + 1]], lchg[lo[src]:lo[src + 1]])
+
+    def scorer(ssms, mode):
+        for s in ssms:
+            s.q = 0.001 if s.search_engine_score > 0.6 else 0.5
+        return ssms
+    ids = sl.search(cfg.query_filename, score_ssms=scorer)
+    by = {s.query_identifier: s for s in ids}
+    assert len(by) == len(ids) > 0.8 * q.n
+    # the same identifications as the packed path over the same processed spectra
+    packed_lib = SpectralLibrary(lib, config=cfg)
+    src = truth['source_row'].numpy()
+    right = 0
+    for z in (2, 3):
+        rows = np.nonzero(q.precursor_charge.numpy() == z)[0]
+        std = packed_lib._search_batch(q.select(torch.as_tensor(rows)), z, 'std')
+        opn = packed_lib._search_batch(q.select(torch.as_tensor(rows)), z, 'open')
+        zrows = np.nonzero(lib.precursor_charge.numpy() == z)[0]
+        for j, i in enumerate(rows):
+            s = by.get(f'scan={i}')
+            if s is None or s.charge != z:
+                continue
+            cand = {int(zrows[r]) for r in (std.best_row[j], opn.best_row[j]) if r >= 0}
+            assert int(s.library_identifier) in cand
+            assert s.sequence == f'PEP{int(s.library_identifier)}K'
+            assert s.is_decoy == (int(s.library_identifier) % 9 == 0)
+            assert s.retention_time == 0.5 * i and s.query_index == i
+            right += int(s.library_identifier) == src[i]
+    assert right > 0.6 * q.n
+    monkeypatch.chdir(tmp_path)
+    out = write_mztab(ids, 'out', cfg, sl._library_reader.get_version())
+    rows = [l.split('\t') for l in open(out) if l.startswith('PSM')]
+    assert len(rows) == len(ids) and all(len(r) == 22 for r in rows)
+    sl.shutdown()
+    assert made[0].closed
+    # a second engine over the same files: store and indexes come from the caches
+    sl2 = SpectralLibrary(fn, config=cfg, reader_factory=factory, query_reader=lambda f: iter(q_objs))
+    assert made[1].reads == 0
+    ids2 = sl2.search(iter(q_objs), score_ssms=scorer)               # an iterable works as well
+    assert sorted((s.query_identifier, s.library_identifier, s.search_engine_score) for s in ids2) == \
+        sorted((s.query_identifier, s.library_identifier, s.search_engine_score) for s in ids)
+    sl2.shutdown()
+    # a recreated reader (reader.py:161) invalidates both caches, as the reference rebuilds its indexes
+    t_idx = os.path.getmtime(sl._ann_filenames[2])
+
+    def recreated(filename, config_hash):
+        r = factory(filename, config_hash)
+        r.is_recreated = True
+        return r
+    sl3 = SpectralLibrary(fn, config=cfg, reader_factory=recreated)
+    assert made[2].reads == 1 and os.path.getmtime(sl3._ann_filenames[2]) >= t_idx
+    sl3.shutdown()
+
+
+def test_stale_or_foreign_index_cache_is_rebuilt(setup, tmp_path):
+    """the cached index must match kind / d / nlist / PQ shape / ntotal; additive
+    options are part of the file name; a foreign file is never searched."""
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    from ann_solo_amd import synthetic
+    lib, aux, q, _ = setup
+    base = dict(num_list=32, num_probe=16, num_candidates=256, kmeans_niter=4)
+    a = SpectralLibrary(lib, config=Config(index='ivfpq', **base), index_dir=str(tmp_path), basename='lib')
+    b = SpectralLibrary(lib, config=Config(index='ivfflat', **base), index_dir=str(tmp_path), basename='lib')
+    c = SpectralLibrary(lib, config=Config(index='ivfpq', pq_m=16, **base), index_dir=str(tmp_path), basename='lib')
+    names = {os.path.basename(x._ann_filenames[2]) for x in (a, b, c)}
+    assert len(names) == 3                                            # no sharing across options
+    # reference configuration keeps the reference's five-key hash in the name
+    d = SpectralLibrary(lib, config=Config(index='ivfflat', num_list=32, num_probe=16), basename='lib')
+    assert d._get_index_hash() == d._get_hyperparameter_hash()
+    # another library under the same base name: ntotal differs -> rebuilt, results are its own
+    small, aux2 = synthetic.make_library(3000, seed=33, device='cpu', charges=(2,), charge_p=(1.0,))
+    e = SpectralLibrary(small, config=Config(index='ivfpq', **base), index_dir=str(tmp_path), basename='lib')
+    for p in e.partitions.values():
+        p.index = None
+    q2, _ = synthetic.make_queries(small, aux2, 64, seed=34, charge=2)
+    r = e._search_batch(q2, 2, 'open')
+    fresh = SpectralLibrary(small, config=Config(index='ivfpq', **base))
+    r0 = fresh._search_batch(q2, 2, 'open')
+    assert np.array_equal(r.best_row, r0.best_row) and e._get_ann_index(2).ntotal == small.n
+    # garbage and truncated files
+    path = e._ann_filenames[2]
+    blob = open(path, 'rb').read()
+    for bad in (b'IwFl' + b'\\0' * 64, blob[:len(blob) // 2], blob[:40] + b'\\xff' * 8 + blob[48:]):
+        open(path, 'wb').write(bad)
+        e.partitions[2].index = None
+        r = e._search_batch(q2, 2, 'open')
+        assert np.array_equal(r.best_row, r0.best_row)
+
+
+def test_corrupt_index_files_are_rejected(tmp_path):
+    """asl_index_load validates the header, the payload size and the list / id ranges."""
+    import struct
+    from ann_solo_amd import faiss_compat as faiss
+    from ann_solo_amd._lib import AnnSoloMiError
+    rng = np.random.default_rng(0)
+    x = rng.random((600, 64), dtype=np.float32)
+    idx = faiss.IndexIVFPQ(faiss.IndexFlatIP(64), 64, 8, 16, 8)
+    idx.set_niter(2)
+    idx.train(x)
+    idx.add(x)
+    p = str(tmp_path / 'a.idxmi')
+    faiss.write_index(idx, p)
+    good = open(p, 'rb').read()
+    assert faiss.read_index(p).ntotal == 600
+
+    def patched(off, fmt, val):
+        b = bytearray(good)
+        b[off:off + struct.calcsize(fmt)] = struct.pack(fmt, val)
+        return bytes(b)
+    # header: magic[8] version d nlist kind pq_m pq_bits niter trained | ntotal n_store | ...
+    cases = {'version': patched(8, '<i', 7), 'd': patched(12, '<i', -5), 'nlist': patched(16, '<i', 0),
+             'kind': patched(20, '<i', 9), 'pq_m': patched(24, '<i', 0), 'pq_bits': patched(28, '<i', 12),
+             'n_store': patched(48, '<q', 1 << 40), 'truncated': good[:-100], 'padded': good + b'x'}
+    # a list assignment outside [0, nlist): first vlist entry follows centroids + codebooks
+    vl = 72 + 8 * 64 * 4 + 16 * 256 * 4 * 4
+    cases['vlist'] = patched(vl, '<i', 8)
+    for name, blob in cases.items():
+        q = str(tmp_path / f'{name}.idxmi')
+        open(q, 'wb').write(blob)
+        with pytest.raises(AnnSoloMiError):
+            faiss.read_index(q)

@@ -122,7 +122,7 @@ def test_index_cache_files(tmp_path, world):
     a = SpectralLibrary(lib, config=cfg, index_dir=str(tmp_path), basename='lib')
     h7 = a._get_hyperparameter_hash()[:7]
     files = sorted(os.listdir(tmp_path))
-    assert files == [f'lib_{h7}_{z}.idxann' for z in (2, 3, 4)]
+    assert files == [f'lib_{h7}_{z}.idxmi' for z in (2, 3, 4)]
     for p in a.partitions.values():
         p.index = None                     # force a reload from the cache files
     from ann_solo_amd import synthetic
