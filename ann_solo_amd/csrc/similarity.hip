@@ -523,9 +523,88 @@ __global__ __launch_bounds__(64 * SIM_WAVES) void ssm_features_kernel(
     for (int k = 0; k < ASL_SSM_NFEAT; k++) o[k] = f[k];
 }
 
+// Column 0 alone (the cosine the cascade uses as its default search-engine score,
+// spectrum_similarity.py:81-106 / utils.py:407): one wave per SSM, the same lane-strided
+// double accumulation and wave tree sum as cosine_of() above, so the value has the bits of
+// features[:, 0]; no LDS staging, no peak-count limit. 33x less work per SSM.
+__global__ __launch_bounds__(256) void ssm_cosine_kernel(
+    DevPeaks Qs, DevPeaks L, const int32_t *__restrict__ lib_rows,
+    const uint32_t *__restrict__ pm_pairs, const int32_t *__restrict__ pm_count, int pm_stride,
+    double *__restrict__ out, int *status) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + wave;
+  if (q >= Qs.n) return;
+  const long long row = lib_rows[q];
+  if (row < 0 || row >= L.n) {
+    if (lane == 0) out[q] = NAN;
+    return;
+  }
+  const int qo = Qs.offsets[q], lo = L.offsets[row];
+  const int nq = Qs.offsets[q + 1] - qo, nl = L.offsets[row + 1] - lo;
+  int n = pm_count[q];
+  if (n > pm_stride) n = pm_stride;
+  const uint32_t *pm = pm_pairs + (size_t)q * pm_stride * 2;
+  double d = 0.0;
+  bool bad = false;
+  for (int i = lane; i < n; i += 64) {
+    const uint32_t a = pm[2 * i], b = pm[2 * i + 1];
+    if (a >= (uint32_t)nq || b >= (uint32_t)nl) {
+      bad = true;
+      continue;
+    }
+    d += (double)Qs.intensity[qo + a] * (double)L.intensity[lo + b];
+  }
+  if (__ballot(bad)) {
+    if (lane == 0) {
+      atomicOr(status, 2);
+      out[q] = NAN;
+    }
+    return;
+  }
+  d = wsum(d);
+  if (lane == 0) out[q] = n ? d : 0.0;
+}
+
 }  // namespace asl
 
 using namespace asl;
+
+extern "C" int asl_ssm_cosine_batch(const asl_peaks_t *queries, const asl_peaks_t *library,
+                                    const int32_t *lib_rows, const uint32_t *pm_pairs,
+                                    const int32_t *pm_count, int32_t pm_stride, double *cosine) {
+  clear_error();
+  if (!queries || !library || !lib_rows || !pm_count || !cosine)
+    return fail(ASL_ERR_INVALID, "ssm_cosine: null argument");
+  const int nq = queries->n;
+  if (nq == 0) return ASL_OK;
+  if (pm_stride <= 0 || !pm_pairs) return fail(ASL_ERR_INVALID, "ssm_cosine: pm_pairs/pm_stride");
+  ASL_TRY(ensure_device());
+  PeaksStage Q, L;
+  ASL_TRY(Q.init(queries));
+  ASL_TRY(L.init(library));
+  In<int32_t> rows, cnt;
+  In<uint32_t> pairs;
+  Out<double> o;
+  ASL_TRY(rows.init(lib_rows, nq));
+  ASL_TRY(cnt.init(pm_count, nq));
+  ASL_TRY(pairs.init(pm_pairs, (size_t)nq * pm_stride * 2));
+  ASL_TRY(o.init(cosine, (size_t)nq));
+  DevBuf<int> status;
+  ASL_TRY(status.reserve(1));
+  HIP_TRY(hipMemsetAsync(status.p, 0, sizeof(int), stream()));
+  {
+    ProfScope ps("ssm_cosine");
+    hipLaunchKernelGGL(ssm_cosine_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, stream(),
+                       Q.dev, L.dev, rows.d, pairs.d, cnt.d, pm_stride, o.d, status.p);
+    ASL_CHECK_LAUNCH();
+  }
+  int st = 0;
+  HIP_TRY(hipMemcpyAsync(&st, status.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+  ASL_TRY(o.finish());
+  ASL_TRY(sync_stream());
+  if (st & 2) return fail(ASL_ERR_INVALID, "ssm_cosine: a peak match index is out of range");
+  return ASL_OK;
+}
 
 extern "C" int asl_ssm_features_batch(const asl_peaks_t *queries, const asl_peaks_t *library,
                                       const int32_t *lib_rows, const uint32_t *pm_pairs,

@@ -4,8 +4,9 @@ ranks of one node, one process per GPU, ``torch.distributed`` over RCCL/xGMI.
 The reference has no distributed code at all; this is the north star's
 addition. Per batch and charge partition:
 
-  1. every rank encodes ITS slice of the query batch (HIP encoder) and the hashed
-     vectors are all-gathered (nq x 800 fp32 per rank -- small);
+  1. the PEAKS of every rank's slice of the query batch are all-gathered as fixed-width rows
+     (~0.5 KB per query; the hashed vector would be 3.2 KB) and every rank hashes all
+     queries itself (HIP encoder);
   2. every rank searches its own inverted lists for ALL queries: coarse quantiser is
      replicated (identical probe lists everywhere, bit-exact fp32 MFMA chain), the
      PQ/flat scan touches only locally owned lists -> per-shard top-k;
@@ -244,6 +245,52 @@ def _all_gather_rows(x: torch.Tensor, world: int, group=None, async_op: bool = F
     return (out, None) if async_op else out
 
 
+PEAK_ROW_ALIGN = 16      # fixed row width of the peak exchange = max peaks rounded up to this
+
+
+def _peak_row_width(queries: PackedSpectra) -> int:
+    """Width every rank derives WITHOUT communication: processed queries hold at most
+    ``max_peaks_used`` (default 50) peaks (spectrum.py:97-99), so 64 covers the reference's
+    configuration; wider spectra widen the row in steps of PEAK_ROW_ALIGN. Ranks must agree --
+    they do whenever their slices come from the same preprocessing."""
+    m = max(queries.max_peaks(), 50)
+    return -(-m // PEAK_ROW_ALIGN) * PEAK_ROW_ALIGN
+
+
+def _all_gather_peaks(queries: PackedSpectra, world: int, group=None):
+    """All-gather of the local queries' peaks as fixed-width rows [n, 2 W + 1] of 4-byte words
+    (W m/z values, W intensities, the peak count). Returns (gathered [world * n, 2 W + 1], work)."""
+    W = _peak_row_width(queries)
+    dev = queries.device
+    n = queries.n
+    off = queries.offsets.to(torch.int64)
+    cnt = (off[1:] - off[:-1])
+    slot = torch.arange(W, device=dev).unsqueeze(0)
+    have = slot < cnt.unsqueeze(1)
+    pos = (off[:-1].unsqueeze(1) + slot).clamp_(max=max(int(queries.mz.numel()) - 1, 0))
+    buf = torch.zeros((n, 2 * W + 1), dtype=torch.float32, device=dev)
+    if queries.mz.numel():
+        buf[:, :W] = torch.where(have, queries.mz[pos], buf[:, :W])
+        buf[:, W:2 * W] = torch.where(have, queries.intensity[pos], buf[:, W:2 * W])
+    buf[:, 2 * W] = cnt.to(torch.int32).view(torch.float32)          # bit pattern, not a value
+    return _all_gather_rows(buf, world, group, async_op=True)
+
+
+def _unpack_peaks(rows: torch.Tensor, like: PackedSpectra) -> PackedSpectra:
+    """Fixed-width peak rows -> PackedSpectra (peaks only: what the encoder reads)."""
+    W = (rows.shape[1] - 1) // 2
+    n = rows.shape[0]
+    dev = rows.device
+    cnt = rows[:, 2 * W].contiguous().view(torch.int32).to(torch.int64)
+    have = torch.arange(W, device=dev).unsqueeze(0) < cnt.unsqueeze(1)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = torch.cumsum(cnt, 0)
+    return PackedSpectra(offsets.to(torch.int32), rows[:, :W][have], rows[:, W:2 * W][have],
+                         torch.zeros(int(offsets[-1]), dtype=torch.uint8, device=dev),
+                         torch.zeros(n, dtype=torch.float64, device=dev),
+                         torch.zeros(n, dtype=torch.int32, device=dev))
+
+
 def _concat_results(parts):
     """Concatenate per-chunk results (``BatchResult`` of the HIP backend or the dictionaries of
     a test backend) along the query axis; peak-match tables are padded to the widest chunk."""
@@ -299,13 +346,19 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
         D, I = backend.shard_search(vec)
         return backend.rescore_knn(queries_local, I, device_out, **kw)
     n_local = vec.shape[0]
-    # the gather of the hashed vectors travels while the coarse quantiser runs on the own slice
-    allvec, w_vec = _all_gather_rows(vec, world, group, async_op=True)
+    # every rank needs the hashed vectors of ALL queries for its shard scan. A query is <= ~50
+    # peaks (8 B each) but 800 floats once hashed, so the PEAKS travel (fixed-width rows,
+    # ~0.5 KB per query instead of 3.2 KB) while the coarse quantiser runs on the own slice, and
+    # every rank hashes the foreign queries itself (encode: ~6 us per 1000 queries)
+    packed, w_vec = _all_gather_peaks(queries_local, world, group)
     co = backend.coarse(vec) if getattr(backend, 'supports_preassigned', False) else None
     if co is not None:
         cD, cI = _all_gather_rows(co[0], world, group), _all_gather_rows(co[1], world, group)
     if w_vec is not None:
         w_vec.wait()
+    allvec = backend.encode(_unpack_peaks(packed, queries_local))
+    rank = dist.get_rank(group)
+    allvec[rank * n_local:(rank + 1) * n_local] = vec      # (same bits; skips nothing, documents intent)
     if chunks is None:
         chunks = 4 if dist.get_backend(group) == 'nccl' else 2
     chunks = max(1, min(chunks, n_local))

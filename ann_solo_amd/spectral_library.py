@@ -503,75 +503,232 @@ class SpectralLibrary:
                                   score_ssms or getattr(self, '_score_ssms', None))
 
     def search_packed(self, query_spectra: Dict[int, PackedSpectra], query_meta: Dict[int, list],
-                      library_meta: Dict[int, list], score_ssms=None) -> list:
+                      library_meta: Dict[int, list], score_ssms=None) -> 'SSMTable':
         """``SpectralLibrary.search`` (spectral_library.py:193-262) over packed, already
         processed query spectra split by precursor charge (the file parsing and
         ``process_spectrum`` filtering of :207-228 happen before; queries of unknown charge
-        are entered once per candidate charge with the same identifier).
+        are entered once per candidate charge with the same identifier; inside one charge set
+        identifiers are unique).
 
         ``query_meta[charge][i]`` / ``library_meta[charge][row]``: mappings with the reference's
-        attribute names (see ``writer.ssms_from_batch``). ``score_ssms(ssms, mode)`` stands
-        for ``utils.score_ssms`` (:319-326, mokapot -- out of scope): it assigns
-        ``search_engine_score`` / ``q`` and returns the SSMs to keep; default: cosine as the
-        score, q = 0 (everything accepted). Returns the list of identifications (one per
-        query identifier), ready for ``writer.write_mztab``."""
+        attribute names (see ``writer.ssms_from_batch``). ``score_ssms`` stands for
+        ``utils.score_ssms`` (:319-326, mokapot -- out of scope): called as ``score_ssms(ssms,
+        mode)`` with a list of SSM records it assigns ``search_engine_score`` / ``q`` and
+        returns the SSMs to keep; a callable with the attribute ``columnar = True`` receives the
+        ``SSMTable`` itself instead, writes ``table.q`` (and ``table.score``) and may return a
+        keep-mask -- no per-SSM Python objects on the search path. Default: cosine as the score,
+        q = 0 (everything accepted).
+
+        Returns the identifications (one per query identifier) as an ``SSMTable``: a sequence
+        of SSM records materialised on access (``len``, iteration, indexing), ready for
+        ``writer.write_mztab``; its columns (``charge, qrow, lib_row, score, q``) are there for
+        consumers that do not want 10^5 Python objects."""
         cfg = self.config
-        identifications = {}
         do_cascade_open = (cfg.precursor_tolerance_mass_open is not None and
                            cfg.precursor_tolerance_mode_open is not None)
-        remaining = {z: list(range(q.n)) for z, q in query_spectra.items()}
-        # cascade level 1: standard search (:238-245)
-        for ssm in self._search_cascade(query_spectra, query_meta, library_meta, remaining, 'std',
-                                        score_ssms):
-            if not do_cascade_open or ssm.q < cfg.fdr:
-                identifications[ssm.query_identifier] = ssm
-        if do_cascade_open:
-            # cascade level 2: open search on the queries not identified so far (:249-259)
-            remaining = {z: [i for i in rows if query_meta[z][i]['identifier'] not in identifications]
-                         for z, rows in remaining.items()}
-            for ssm in self._search_cascade(query_spectra, query_meta, library_meta, remaining,
-                                            'open', score_ssms):
-                identifications[ssm.query_identifier] = ssm
-        return list(identifications.values())
+        uid = _query_uids(query_meta, list(query_spectra))
+        remaining = {z: np.arange(q.n, dtype=np.int64) for z, q in query_spectra.items()}
+        # cascade level 1: standard search (:238-245); with a second level only the confident
+        # identifications are retained
+        t1 = self._search_cascade(query_spectra, query_meta, library_meta, remaining, 'std',
+                                  score_ssms, uid)
+        if not do_cascade_open:
+            return t1
+        t1 = t1.take(t1.q < cfg.fdr)
+        # cascade level 2: open search on the queries not identified so far (:249-259)
+        if uid is None:
+            for z in remaining:
+                done = np.zeros(len(remaining[z]), bool)
+                done[t1.qrow[t1.charge == z]] = True
+                remaining[z] = remaining[z][~done]
+        else:
+            found = t1.uids(uid)
+            remaining = {z: rows[~np.isin(uid[z][rows], found)] for z, rows in remaining.items()}
+        t2 = self._search_cascade(query_spectra, query_meta, library_meta, remaining, 'open',
+                                  score_ssms, uid)
+        return SSMTable.concat([t1, t2])
 
     def _search_cascade(self, query_spectra, query_meta, library_meta, rows_by_charge, mode,
-                        score_ssms=None) -> list:
+                        score_ssms=None, uid=None) -> 'SSMTable':
         """One cascade level (:264-326): batches of ``batch_size`` same-charge queries through
         ``_search_batch``; per query identifier the FIRST match is kept (the reference compares
         ``search_engine_score`` values that are still NaN at this point, :312-316, so a later
-        duplicate never replaces an earlier one)."""
+        duplicate never replaces an earlier one). Host work is per batch, not per query."""
         import time
-        from .spectrum_similarity import ssm_features
-        from .writer import ssms_from_batch
-        ssms = {}
+        from . import spectrum_similarity
         bs = self.config.batch_size
-        t_level, n_in = time.perf_counter(), sum(len(r) for r in rows_by_charge.values())
+        t_level = time.perf_counter()
+        n_in = sum(len(r) for r in rows_by_charge.values())
+        table = SSMTable(query_meta, library_meta)
         for charge, rows in rows_by_charge.items():
+            rows = np.asarray(rows, np.int64)
+            qs = query_spectra[charge]
             for b0 in range(0, len(rows), bs):
                 sel = rows[b0:b0 + bs]
-                if not sel:
+                if len(sel) == 0:
                     continue
-                q = query_spectra[charge].select(torch.as_tensor(sel, dtype=torch.int64))
-                res = self._search_batch(q, charge, mode)
+                whole = len(sel) == qs.n and sel[0] == 0 and sel[-1] == qs.n - 1
+                q = (qs if whole else qs.select(torch.as_tensor(sel))).to(self.device)
+                res = self._search_batch(q, charge, mode, device_out=True)
                 if res is None:
                     continue
                 part = self.partitions[charge]
-                cos = ssm_features(q.to(self.device), part.spectra, res.best_row, res.pm_pairs,
-                                   res.pm_count, self.config.min_mz, self.config.max_mz,
-                                   self.config.bin_size)[:, 0]
-                cos = cos.detach().cpu().numpy() if hasattr(cos, 'detach') else cos
-                qm = [query_meta[charge][i] for i in sel]
-                for ssm in ssms_from_batch(res, qm, library_meta[charge], scores=cos):
-                    if ssm.query_identifier not in ssms:
-                        ssms[ssm.query_identifier] = ssm
-        out = list(ssms.values())
+                # default search-engine score: the cosine over the winner's peak matches
+                cos = spectrum_similarity.ssm_cosine(q, part.spectra, res.best_row, res.pm_pairs,
+                                                     res.pm_count)
+                table.add_batch(charge, sel, _to_np(res.best_row), _to_np(cos), res)
+        if uid is not None:
+            table = table.first_per_uid(uid)
         acc = getattr(self, 'level_seconds', None)
         if acc is not None:       # bench.py: wall time, queries in, SSMs out of every cascade level
+            torch.cuda.synchronize() if self.device.type == 'cuda' else None
             sec, a, b = acc.get(mode, (0.0, 0, 0))
-            acc[mode] = (sec + time.perf_counter() - t_level, a + n_in, b + len(out))
-        if score_ssms is not None:
-            return list(score_ssms(out, mode))
-        for ssm in out:        # no scorer: cosine (spectrum_similarity.py:81-106), accepted
-            ssm.q = 0.0
+            acc[mode] = (sec + time.perf_counter() - t_level, a + n_in, b + len(table))
+        if score_ssms is None:    # no scorer: cosine (spectrum_similarity.py:81-106), accepted
+            table.q[:] = 0.0
+            return table
+        if getattr(score_ssms, 'columnar', False):
+            keep = score_ssms(table, mode)
+            return table if keep is None else table.take(np.asarray(keep))
+        objs = table.materialize()
+        for i, o in enumerate(objs):
+            o._row = i
+        kept = list(score_ssms(objs, mode))
+        out = table.take(np.asarray([o._row for o in kept], np.int64))
+        out.score = np.asarray([o.search_engine_score for o in kept], np.float64)
+        out.q = np.asarray([o.q for o in kept], np.float64)
         return out
 
+
+def _to_np(a):
+    return a.detach().cpu().numpy() if hasattr(a, 'detach') else np.asarray(a)
+
+
+def _query_uids(query_meta, charges) -> Optional[Dict[int, np.ndarray]]:
+    """Integer id per query identifier, shared across the charge sets -- or None when there is
+    a single set (identifiers are unique inside a set, so nothing can collide)."""
+    if len(charges) <= 1:
+        return None
+    table: Dict = {}
+    out = {}
+    for z in charges:
+        out[z] = np.fromiter((table.setdefault(m['identifier'], len(table)) for m in query_meta[z]),
+                             np.int64, len(query_meta[z]))
+    return out
+
+
+class SSMTable:
+    """Spectrum-spectrum matches of a cascade level / the identifications of a search, columnar:
+    ``charge``, ``qrow`` (row inside ``query_spectra[charge]``), ``lib_row`` (row inside the
+    charge partition), ``score`` (search_engine_score), ``q``. Behaves as a sequence of the
+    reference's SSM records (``writer.SpectrumSpectrumMatch``: the attributes writer.py:129-148
+    reads), built on access from the query / library metadata and the peak matches the device
+    emitted (kept per batch, fetched from the device when first needed)."""
+
+    def __init__(self, query_meta, library_meta):
+        self.query_meta, self.library_meta = query_meta, library_meta
+        self.charge = np.zeros(0, np.int32)
+        self.qrow = np.zeros(0, np.int64)
+        self.lib_row = np.zeros(0, np.int32)
+        self.score = np.zeros(0, np.float64)
+        self.q = np.zeros(0, np.float64)
+        self.batch = np.zeros(0, np.int32)       # index into _batches
+        self.pos = np.zeros(0, np.int32)         # row inside that batch
+        self._batches: list = []
+        self._pending: list = []
+
+    def add_batch(self, charge, qrows, best_row, score, res) -> None:
+        hit = np.nonzero(best_row >= 0)[0]       # queries without a candidate: no SSM (:359)
+        b = len(self._batches)
+        self._batches.append(res)
+        self._pending.append((np.full(len(hit), charge, np.int32), np.asarray(qrows, np.int64)[hit],
+                              best_row[hit].astype(np.int32), np.asarray(score, np.float64)[hit],
+                              np.full(len(hit), b, np.int32), hit.astype(np.int32)))
+        self._flush()
+
+    def _flush(self):
+        if not self._pending:
+            return
+        cols = list(zip(*self._pending))
+        self._pending = []
+        cat = lambda old, new: np.concatenate([old] + list(new))
+        self.charge, self.qrow = cat(self.charge, cols[0]), cat(self.qrow, cols[1])
+        self.lib_row, self.score = cat(self.lib_row, cols[2]), cat(self.score, cols[3])
+        self.batch, self.pos = cat(self.batch, cols[4]), cat(self.pos, cols[5])
+        self.q = np.concatenate([self.q, np.full(len(self.charge) - len(self.q), np.nan)])
+
+    def __len__(self):
+        return len(self.charge)
+
+    def take(self, sel) -> 'SSMTable':
+        """Rows ``sel`` (boolean mask or indices, order kept); shares the per-batch storage."""
+        sel = np.asarray(sel)
+        idx = np.nonzero(sel)[0] if sel.dtype == bool else sel.astype(np.int64)
+        out = SSMTable(self.query_meta, self.library_meta)
+        out._batches = self._batches
+        for name in ('charge', 'qrow', 'lib_row', 'score', 'q', 'batch', 'pos'):
+            setattr(out, name, getattr(self, name)[idx])
+        return out
+
+    @staticmethod
+    def concat(tables) -> 'SSMTable':
+        out = SSMTable(tables[0].query_meta, tables[0].library_meta)
+        shift = 0
+        for t in tables:
+            out._batches = out._batches + t._batches
+            for name in ('charge', 'qrow', 'lib_row', 'score', 'q', 'pos'):
+                setattr(out, name, np.concatenate([getattr(out, name), getattr(t, name)]))
+            out.batch = np.concatenate([out.batch, t.batch + shift])
+            shift += len(t._batches)
+        return out
+
+    def uids(self, uid) -> np.ndarray:
+        out = np.zeros(len(self), np.int64)
+        for z in np.unique(self.charge):
+            m = self.charge == z
+            out[m] = uid[int(z)][self.qrow[m]]
+        return out
+
+    def first_per_uid(self, uid) -> 'SSMTable':
+        u = self.uids(uid)
+        _, first = np.unique(u, return_index=True)
+        return self if len(first) == len(u) else self.take(np.sort(first))
+
+    def identifiers(self) -> list:
+        return [self.query_meta[int(z)][int(r)]['identifier'] for z, r in zip(self.charge, self.qrow)]
+
+    def library_identifiers(self, partitions) -> np.ndarray:
+        """Library identifiers of the matches (``partitions``: ``SpectralLibrary.partitions``)."""
+        out = np.empty(len(self), dtype=object)
+        for z in np.unique(self.charge):
+            m = self.charge == z
+            out[m] = partitions[int(z)].ids[self.lib_row[m]]
+        return out
+
+    def _peak_matches(self, i) -> np.ndarray:
+        b = self._batches[int(self.batch[i])]
+        if not isinstance(b, tuple):             # first access: one device -> host copy per batch
+            b = (_to_np(b.pm_count), _to_np(b.pm_pairs))
+            self._batches[int(self.batch[i])] = b
+        p = int(self.pos[i])
+        return b[1][p, :b[0][p]].astype(np.int64)
+
+    def __getitem__(self, i):
+        from .writer import SpectrumSpectrumMatch
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        z = int(self.charge[i])
+        qm, lm = self.query_meta[z][int(self.qrow[i])], self.library_meta[z][int(self.lib_row[i])]
+        return SpectrumSpectrumMatch(
+            lm['peptide'], qm['identifier'], qm['index'], lm['identifier'],
+            qm.get('retention_time'), qm['precursor_charge'], qm['precursor_mz'],
+            lm['precursor_mz'], lm.get('is_decoy', False), float(self.score[i]), float(self.q[i]),
+            self._peak_matches(i))
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def materialize(self) -> list:
+        return list(self)

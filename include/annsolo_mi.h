@@ -243,6 +243,15 @@ int asl_ssm_features_batch(const asl_peaks_t *queries, const asl_peaks_t *librar
                            double min_mz, double max_mz, double bin_size, int32_t top,
                            double *features /* [nq, ASL_SSM_NFEAT] */);
 
+/* features[:, 0] alone -- the cosine over the peak matches (spectrum_similarity.py:81-106), the
+ * cascade's default search-engine score (utils.py:407) -- with the same bits as column 0 of
+ * asl_ssm_features_batch; rows with lib_rows[i] < 0 are NaN. */
+int asl_ssm_cosine_batch(const asl_peaks_t *queries, const asl_peaks_t *library,
+                         const int32_t *lib_rows /* [nq] */,
+                         const uint32_t *pm_pairs /* [nq, pm_stride, 2] */,
+                         const int32_t *pm_count /* [nq] */, int32_t pm_stride,
+                         double *cosine /* [nq] */);
+
 /* ------------------------------------------------------------------ hot path
  * One batch of same-charge queries through
  *   SpectralLibrary._search_batch / _get_library_candidates

@@ -94,19 +94,19 @@ from types import SimpleNamespace                                    # noqa: E40
 from ann_solo_amd.spectral_library import BatchResult, Config, SpectralLibrary   # noqa: E402
 
 
-def oracle_cosines(q, lib_spectra, rows, pm_pairs, pm_count, *a):
-    """Stand-in for the device ``ssm_features`` (column 0 = cosine over the peak matches,
-    spectrum_similarity.py:81-106); the other columns are not used by the cascade."""
+def oracle_cosines(q, lib_spectra, rows, pm_pairs, pm_count):
+    """Stand-in for the device ``ssm_cosine`` (the cosine over the peak matches,
+    spectrum_similarity.py:81-106)."""
     qo, _, qi, *_ = q.numpy()
     lo, _, li, *_ = lib_spectra.numpy()
-    out = np.full((q.n, 33), np.nan)
+    out = np.full(q.n, np.nan)
     for i in range(q.n):
         r = int(rows[i])
         if r < 0:
             continue
         pm = np.asarray(pm_pairs[i][:int(pm_count[i])]).astype(np.int64)
-        out[i, 0] = float(np.sum(qi[qo[i] + pm[:, 0]].astype(np.float32) *
-                                 li[lo[r] + pm[:, 1]].astype(np.float32), dtype=np.float32))
+        out[i] = float(np.sum(qi[qo[i] + pm[:, 0]].astype(np.float64) *
+                              li[lo[r] + pm[:, 1]].astype(np.float64)))
     return out
 
 

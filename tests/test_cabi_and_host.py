@@ -190,8 +190,8 @@ def test_search_cascade_control_flow(monkeypatch):
     sl.config = Config(batch_size=4)
     sl.device = torch.device('cpu')
     sl.partitions = {2: SimpleNamespace(spectra=lib), 3: SimpleNamespace(spectra=lib)}
-    monkeypatch.setattr(spectrum_similarity, 'ssm_features',
-                        lambda q, l, rows, pairs, cnt, *a: np.tile(np.linspace(0.5, 0.9, 33), (q.n, 1)))
+    monkeypatch.setattr(spectrum_similarity, 'ssm_cosine',
+                        lambda q, l, rows, pairs, cnt: np.full(q.n, 0.5))
     from ann_solo_amd.packed import PackedSpectra
     mk = lambda pm, z: PackedSpectra.from_numpy(np.arange(len(pm) + 1) * 2, np.tile([100., 200.], len(pm)),
                                                 np.tile([.6, .8], len(pm)), None, pm, np.full(len(pm), z))

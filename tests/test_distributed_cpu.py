@@ -154,7 +154,7 @@ def _cascade_worker(rank, world, port, out_dir):
     from oracle_backend import OracleSpectralLibrary, oracle_cosines
     from ann_solo_amd import synthetic, spectrum_similarity
     from ann_solo_amd.spectral_library import Config
-    spectrum_similarity.ssm_features = oracle_cosines
+    spectrum_similarity.ssm_cosine = oracle_cosines
     lib, aux = synthetic.make_library(1400, seed=95, device='cpu', charges=(2, 3),
                                       charge_p=(0.8, 0.2))
     cfg = Config(batch_size=16, precursor_tolerance_mass_open=300.0,

@@ -83,26 +83,33 @@ def test_filename_constructor_search_and_caches(setup, tmp_path, monkeypatch):
     ids = sl.search(cfg.query_filename, score_ssms=scorer)
     by = {s.query_identifier: s for s in ids}
     assert len(by) == len(ids) > 0.8 * q.n
-    # the same identifications as the packed path over the same processed spectra
+    # search(filename) == the packed driver over the adapter's own query packing
+    from ann_solo_amd.library_store import pack_queries
+    qs, qm = pack_queries(iter(q_objs), cfg, 'cuda')
+    again = sl.search(qs, qm, sl.library_meta, score_ssms=scorer)
+    ssm_key = lambda s: (s.query_identifier, s.library_identifier, s.charge, s.search_engine_score, s.q)
+    assert sorted(map(ssm_key, again)) == sorted(map(ssm_key, ids))
+    # level 1 is an exact window search, independent of the index: SSMs kept from it equal the
+    # standard search of an engine built straight from the processed library pack
     packed_lib = SpectralLibrary(lib, config=cfg)
     src = truth['source_row'].numpy()
-    right = 0
-    for z in (2, 3):
-        rows = np.nonzero(q.precursor_charge.numpy() == z)[0]
-        std = packed_lib._search_batch(q.select(torch.as_tensor(rows)), z, 'std')
-        opn = packed_lib._search_batch(q.select(torch.as_tensor(rows)), z, 'open')
+    right = kept = 0
+    for z in qs:
+        std = packed_lib._search_batch(qs[z], z, 'std')
         zrows = np.nonzero(lib.precursor_charge.numpy() == z)[0]
-        for j, i in enumerate(rows):
-            s = by.get(f'scan={i}')
+        for j, m in enumerate(qm[z]):
+            s = by.get(m['identifier'])
             if s is None or s.charge != z:
                 continue
-            cand = {int(zrows[r]) for r in (std.best_row[j], opn.best_row[j]) if r >= 0}
-            assert int(s.library_identifier) in cand
+            i = int(m['identifier'].split('=')[1])
+            if s.q < cfg.fdr:                                     # kept from the standard search
+                assert std.best_row[j] >= 0 and int(s.library_identifier) == int(zrows[std.best_row[j]])
+                kept += 1
             assert s.sequence == f'PEP{int(s.library_identifier)}K'
             assert s.is_decoy == (int(s.library_identifier) % 9 == 0)
             assert s.retention_time == 0.5 * i and s.query_index == i
             right += int(s.library_identifier) == src[i]
-    assert right > 0.6 * q.n
+    assert kept > 0.25 * q.n and right > 0.6 * q.n
     monkeypatch.chdir(tmp_path)
     out = write_mztab(ids, 'out', cfg, sl._library_reader.get_version())
     rows = [l.split('\t') for l in open(out) if l.startswith('PSM')]
