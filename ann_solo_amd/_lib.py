@@ -32,7 +32,8 @@ class AnnSoloMiError(RuntimeError):
 class AslPeaks(C.Structure):
     _fields_ = [('n', C.c_int32), ('offsets', C.c_void_p), ('mz', C.c_void_p),
                 ('intensity', C.c_void_p), ('charge', C.c_void_p),
-                ('precursor_mz', C.c_void_p), ('precursor_charge', C.c_void_p)]
+                ('precursor_mz', C.c_void_p), ('precursor_charge', C.c_void_p),
+                ('n_peaks', C.c_int64)]
 
 
 class AslSearchParams(C.Structure):
@@ -59,7 +60,7 @@ class AslIndexInfo(C.Structure):
 
 EXPORTS = [
     'asl_last_error', 'asl_version', 'asl_get_num_gpus', 'asl_set_device', 'asl_set_stream',
-    'asl_synchronize', 'asl_get_dim', 'asl_hash_idx', 'asl_encode_batch', 'asl_index_create',
+    'asl_synchronize', 'asl_set_pipeline', 'asl_get_dim', 'asl_hash_idx', 'asl_encode_batch', 'asl_index_create',
     'asl_index_free', 'asl_index_train', 'asl_index_add', 'asl_index_search',
     'asl_index_reset', 'asl_index_ntotal', 'asl_index_is_trained', 'asl_index_save',
     'asl_index_load', 'asl_index_set_niter', 'asl_index_info', 'asl_index_get_centroids',
@@ -209,4 +210,8 @@ def peaks_struct(p) -> AslPeaks:
     else:
         arrs = p
         n = len(p[0]) - 1
-    return AslPeaks(n, *[ptr(a) for a in arrs])
+    # a pack's peak arrays are exactly sized (offsets[n] == len(mz)): telling the library spares
+    # it the read-back of offsets[n] from the device (a stream synchronisation per call)
+    mz = arrs[1]
+    n_peaks = int(mz.numel()) if hasattr(mz, 'numel') else int(len(mz))
+    return AslPeaks(n, *[ptr(a) for a in arrs], n_peaks)

@@ -21,7 +21,16 @@ void clear_error() { g_err.clear(); }
 
 hipStream_t stream() { return g_stream; }
 
+static Pipeline g_pipe;
+static int ensure_device_raw();
 int ensure_device() {
+  ASL_TRY(ensure_device_raw());
+  // batches of the two-stream pipeline still in flight use the handles' scratch buffers: any
+  // other entry point first waits for them (and reports their deferred status)
+  if (g_pipe.inflight && !g_pipe.in_call) ASL_TRY(pipeline_drain());
+  return ASL_OK;
+}
+static int ensure_device_raw() {
   static int state = 0;  // 0 unknown, 1 ok, -1 none
   if (state == 0) {
     int n = 0;
@@ -49,6 +58,42 @@ bool is_device_ptr(const void *p) {
 int sync_stream() {
   HIP_TRY(hipStreamSynchronize(g_stream));
   return ASL_OK;
+}
+
+StreamScope::StreamScope(hipStream_t s) : prev(g_stream) { g_stream = s; }
+StreamScope::~StreamScope() { g_stream = prev; }
+
+Pipeline &pipeline() { return g_pipe; }
+
+int pipeline_init() {
+  Pipeline &p = g_pipe;
+  if (p.A) return ASL_OK;
+  // non-blocking: no implicit ordering against the null stream (the caller's, PyTorch's) --
+  // the ordering that matters is expressed with events
+  HIP_TRY(hipStreamCreateWithFlags(&p.A, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&p.B, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&p.ev_in, hipEventDisableTiming));
+  for (int i = 0; i < 2; i++) {
+    HIP_TRY(hipEventCreateWithFlags(&p.ev_front[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p.ev_scan[i], hipEventDisableTiming));
+  }
+  HIP_TRY(hipMalloc((void **)&p.status, sizeof(int)));
+  HIP_TRY(hipMemset(p.status, 0, sizeof(int)));
+  return ASL_OK;
+}
+
+int rescore_status_error(int status_bits);
+
+int pipeline_drain() {
+  Pipeline &p = g_pipe;
+  if (!p.inflight) return ASL_OK;
+  p.inflight = false;
+  HIP_TRY(hipStreamSynchronize(p.A));
+  HIP_TRY(hipStreamSynchronize(p.B));
+  int st = 0;
+  HIP_TRY(hipMemcpy(&st, p.status, sizeof(int), hipMemcpyDeviceToHost));
+  if (st) HIP_TRY(hipMemset(p.status, 0, sizeof(int)));
+  return rescore_status_error(st);
 }
 
 // ---------------------------------------------------------------- profiling
@@ -141,8 +186,17 @@ int asl_set_stream(void *s) {
 }
 
 int asl_synchronize(void) {
-  ASL_TRY(ensure_device());
+  clear_error();
+  ASL_TRY(ensure_device());   // drains the pipeline (deferred status of its batches)
   return sync_stream();
+}
+
+int asl_set_pipeline(int on) {
+  clear_error();
+  ASL_TRY(ensure_device());
+  if (on) ASL_TRY(pipeline_init());
+  g_pipe.on = on != 0;
+  return ASL_OK;
 }
 
 int asl_profile_enable(int on) {
@@ -193,7 +247,10 @@ int PeaksStage::init(const asl_peaks_t *p) {
   if (!p->offsets || !p->precursor_mz || !p->precursor_charge)
     return fail(ASL_ERR_INVALID, "peaks: offsets/precursor arrays are required");
   int32_t last = 0;
-  if (is_device_ptr(p->offsets)) {
+  if (p->n_peaks > 0) {          // the caller knows offsets[n]: no read-back, no synchronisation
+    if (p->n_peaks > 0x7fffffffLL) return fail(ASL_ERR_INVALID, "peaks: more than 2^31-1 peaks");
+    last = (int32_t)p->n_peaks;
+  } else if (is_device_ptr(p->offsets)) {
     HIP_TRY(hipMemcpyAsync(&last, p->offsets + p->n, sizeof(int32_t), hipMemcpyDeviceToHost,
                            stream()));
     ASL_TRY(sync_stream());
@@ -217,6 +274,12 @@ int PeaksStage::init(const asl_peaks_t *p) {
   dev.precursor_mz = pmz.d;
   dev.precursor_charge = pcharge.d;
   return ASL_OK;
+}
+
+bool peaks_on_device(const asl_peaks_t *p) {
+  return p && is_device_ptr(p->offsets) && is_device_ptr(p->mz) && is_device_ptr(p->intensity) &&
+         is_device_ptr(p->precursor_mz) && is_device_ptr(p->precursor_charge) &&
+         (!p->charge || is_device_ptr(p->charge));
 }
 
 }  // namespace asl

@@ -136,6 +136,28 @@ struct Out {
 
 int sync_stream();
 
+// Work issued inside the scope goes to `s` (every kernel launch reads stream()).
+struct StreamScope {
+  hipStream_t prev;
+  explicit StreamScope(hipStream_t s);
+  ~StreamScope();
+};
+
+// Two-stream software pipeline of asl_search_batch (asl_set_pipeline): stream A runs the
+// MFMA-bound front of batch i+1 (encode, coarse GEMM, coarse select) while stream B runs the
+// scan + rescoring of batch i. Buffers that cross the streams exist twice (by parity).
+struct Pipeline {
+  bool on = false, inflight = false, in_call = false;
+  hipStream_t A = nullptr, B = nullptr;
+  hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_scan[2] = {nullptr, nullptr};
+  bool scan_recorded[2] = {false, false};
+  int parity = 0;
+  int *status = nullptr;   // sticky rescoring flags of the batches in flight
+};
+Pipeline &pipeline();
+int pipeline_init();
+int pipeline_drain();   // waits for A and B; reports the sticky status of the drained batches
+
 // Stage timers (HIP events on the library's stream).
 struct ProfScope {
   int slot = -1;
@@ -166,5 +188,6 @@ struct PeaksStage {  // stages an asl_peaks_t whose arrays may be on the host
   DevPeaks dev;
   int init(const asl_peaks_t *p);
 };
+bool peaks_on_device(const asl_peaks_t *p);
 
 }  // namespace asl

@@ -380,10 +380,15 @@ static int build_lists(asl_index *ix) {
 }
 
 // coarse quantiser: top-nprobe centroids by inner product -> ix->coarse_D / coarse_I
-static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe) {
+static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe,
+                         float *out_D = nullptr, int32_t *out_I = nullptr) {
   const int nlist = ix->nlist, d = ix->d;
-  ASL_TRY(ix->coarse_D.reserve((size_t)nq * nprobe));
-  ASL_TRY(ix->coarse_I.reserve((size_t)nq * nprobe));
+  if (!out_D) {
+    ASL_TRY(ix->coarse_D.reserve((size_t)nq * nprobe));
+    ASL_TRY(ix->coarse_I.reserve((size_t)nq * nprobe));
+    out_D = ix->coarse_D.p;
+    out_I = ix->coarse_I.p;
+  }
   int rows = (int)std::min<int64_t>(nq, std::max<int64_t>(1, (int64_t)(SCORE_CHUNK_BYTES / ((size_t)nlist * 4))));
   ASL_TRY(ix->ws_scores.reserve((size_t)rows * nlist));
   for (int r0 = 0; r0 < nq; r0 += rows) {
@@ -395,8 +400,7 @@ static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe) {
     {
       ProfScope ps("coarse_select");
       ASL_TRY(row_topk(ix->ws_scores.p, nlist, m, nlist, nprobe, nullptr, 0, nullptr, nullptr, 0,
-                       ix->coarse_D.p + (size_t)r0 * nprobe, nullptr,
-                       ix->coarse_I.p + (size_t)r0 * nprobe, nprobe));
+                       out_D + (size_t)r0 * nprobe, nullptr, out_I + (size_t)r0 * nprobe, nprobe));
     }
   }
   return ASL_OK;
@@ -528,6 +532,20 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
 }
 
 int index_dim(const asl_index *ix) { return ix->d; }
+
+// The two halves of an IVF search for the two-stream pipeline (search.hip): the coarse
+// quantiser into caller-owned buffers, then index_search_device with those as pre_D / pre_I.
+int index_nprobe(const asl_index *ix, int nprobe) {
+  return ix->kind == ASL_INDEX_FLAT ? 0 : std::max(1, std::min(nprobe, ix->nlist));
+}
+int index_prepare(asl_index *ix) {   // everything that may allocate or synchronise, up front
+  if (!ix->trained) return fail(ASL_ERR_STATE, "search: index is not trained");
+  return ix->kind == ASL_INDEX_FLAT ? ASL_OK : build_lists(ix);
+}
+int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, float *out_D,
+                        int32_t *out_I) {
+  return coarse_search(ix, xq, nq, nprobe, out_D, out_I);
+}
 
 }  // namespace asl
 

@@ -839,6 +839,8 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_matches_kernel(
   if (best_row && lane == 0) best_row[q] = (int32_t)row;
   if (row < 0) {
     if (pm_count && lane == 0) pm_count[q] = 0;
+    if (pm_pairs)   // rows are fully defined: zero beyond the matches (callers may pass raw memory)
+      for (int t = lane; t < 2 * pm_stride; t += 64) pm_pairs[(size_t)q * pm_stride * 2 + t] = 0u;
     return;
   }
   if (!pm_count && !pm_pairs) return;
@@ -853,6 +855,9 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_matches_kernel(
   wave_sync();
   cnt_tmp = s_cnt[wave];
   if (pm_count && lane == 0) pm_count[q] = cnt_tmp;
+  if (pm_pairs)
+    for (int t = 2 * (cnt_tmp < pm_stride ? cnt_tmp : pm_stride) + lane; t < 2 * pm_stride; t += 64)
+      pm_pairs[(size_t)q * pm_stride * 2 + t] = 0u;
 }
 
 // Host driver shared by asl_rescore_batch and asl_search_batch. All pointers are
@@ -863,11 +868,11 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
                    double *pair_score, long long *best_slot, int32_t *best_cand,
                    int32_t *best_row, double *best_score, int32_t *n_valid,
                    int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride, int *status,
-                   const PrecFilter &filter) {
+                   const PrecFilter &filter, bool clear_status) {
   const int nq = Q.n;
   if (nq == 0) return ASL_OK;
   CandView cv{rows64, rows32, cand_offsets, stride, filter};
-  HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), stream()));
+  if (clear_status) HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), stream()));
   {
     ProfScope ps("rescore");
     // split long candidate lists over blockIdx.y when there are few queries
@@ -915,6 +920,14 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
                        allow_shift, pm_count, pm_pairs, pm_stride, best_row, status);
     ASL_CHECK_LAUNCH();
   }
+  return ASL_OK;
+}
+
+int rescore_status_error(int st) {
+  if (st & RS_STATUS_PEAKS)
+    return fail(ASL_ERR_CAPACITY, "rescore: a spectrum has more than %d peaks", RS_MAXP);
+  if (st & RS_STATUS_MATCHES)
+    return fail(ASL_ERR_CAPACITY, "rescore: a pair generated more than %d peak matches", RS_MCAP);
   return ASL_OK;
 }
 

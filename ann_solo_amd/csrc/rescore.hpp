@@ -52,7 +52,8 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
                    double *pair_score, long long *best_slot, int32_t *best_cand,
                    int32_t *best_row, double *best_score, int32_t *n_valid,
                    int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride, int *status,
-                   const PrecFilter &filter = PrecFilter());
-int rescore_check_status(const int *status_dev);
+                   const PrecFilter &filter = PrecFilter(), bool clear_status = true);
+int rescore_check_status(const int *status_dev);   // reads the flags back: synchronises
+int rescore_status_error(int status_bits);         // ASL_OK or the error the flags stand for
 
 }  // namespace asl

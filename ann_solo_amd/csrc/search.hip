@@ -24,6 +24,10 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
                         int64_t *I64, int32_t *I32, const float *pre_D, const int32_t *pre_I,
                         bool set_mode);
 int index_dim(const asl_index *ix);
+int index_nprobe(const asl_index *ix, int nprobe);
+int index_prepare(asl_index *ix);
+int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, float *out_D,
+                        int32_t *out_I);
 // Window [lo,hi) of each query inside the precursor-sorted library.
 __global__ void window_range_kernel(const double *__restrict__ q_pmz, int nq,
                                     const float *__restrict__ sorted_pmz, int n, int charge,
@@ -83,6 +87,9 @@ struct asl_library {
   // scratch
   DevBuf<float> qvec;
   DevBuf<int32_t> knn, cand, lo, cnt, woff;
+  // buffers that cross the two streams of the pipeline, by batch parity
+  DevBuf<float> p_qvec[2], p_cD[2];
+  DevBuf<int32_t> p_cI[2];
   DevBuf<double> pair_score;
   DevBuf<long long> best_slot;
   DevBuf<int> status;
@@ -291,6 +298,73 @@ int asl_rescore_knn(asl_library_t *L, const asl_peaks_t *queries, const asl_sear
   return rescore_check_status(L->status.p);
 }
 
+// asl_search_batch in pipeline mode (asl_set_pipeline): nothing here waits for the device.
+//   stream A: encode -> coarse GEMM -> coarse select        (MFMA-bound, ~1.1 ms of a 16 384 batch)
+//   stream B: list scan -> filter + rescoring -> peak matches (VALU / fabric bound, ~8.5 ms)
+// so the front of batch i+1 runs under the scan of batch i. Buffers written by A and read by B
+// (hashed queries, probe lists) exist twice; A re-uses a pair only after B's scan of the batch
+// that read it (ev_scan). Everything else is touched by one stream only. Errors the kernels
+// flag are sticky and reported by the next call that drains (asl_synchronize or any other
+// entry point).
+static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peaks_t *queries,
+                                  const asl_search_params_t *P, int32_t *best_row,
+                                  double *best_score, int32_t *n_cand, int32_t *pm_count,
+                                  uint32_t *pm_pairs, int32_t pm_stride, int64_t *knn_I) {
+  Pipeline &pp = pipeline();
+  struct InCall {
+    Pipeline &p;
+    explicit InCall(Pipeline &q) : p(q) { p.in_call = true; }
+    ~InCall() { p.in_call = false; }
+  } guard(pp);
+  const int nq = queries->n, k = P->k, d = index_dim(idx);
+  const int nprobe = index_nprobe(idx, P->nprobe);
+  PeaksStage Q;
+  ASL_TRY(Q.init(queries));   // device pointers + known peak count: no copy, no wait
+  const int par = pp.parity;
+  // allocations first (growing a buffer synchronises the device: only ever on the first batches)
+  ASL_TRY(index_prepare(idx));
+  ASL_TRY(L->p_qvec[par].reserve((size_t)nq * d));
+  ASL_TRY(L->p_cD[par].reserve((size_t)nq * nprobe));
+  ASL_TRY(L->p_cI[par].reserve((size_t)nq * nprobe));
+  ASL_TRY(L->knn.reserve((size_t)nq * k));
+  ASL_TRY(L->pair_score.reserve((size_t)nq * k));
+  ASL_TRY(L->best_slot.reserve((size_t)nq));
+  pp.parity ^= 1;
+  // the caller's stream produced the inputs (and owns the output memory) up to here
+  HIP_TRY(hipEventRecord(pp.ev_in, stream()));
+  HIP_TRY(hipStreamWaitEvent(pp.A, pp.ev_in, 0));
+  HIP_TRY(hipStreamWaitEvent(pp.B, pp.ev_in, 0));
+  pp.inflight = true;
+  {
+    StreamScope on_a(pp.A);
+    if (pp.scan_recorded[par]) HIP_TRY(hipStreamWaitEvent(pp.A, pp.ev_scan[par], 0));
+    ASL_TRY(encode_device(Q.dev.mz, Q.dev.intensity, Q.dev.offsets, nq, P->min_bound, P->bin_size,
+                          d, P->hash_seed, 1, L->p_qvec[par].p));
+    ASL_TRY(index_coarse_device(idx, nq, L->p_qvec[par].p, nprobe, L->p_cD[par].p, L->p_cI[par].p));
+    HIP_TRY(hipEventRecord(pp.ev_front[par], pp.A));
+  }
+  {
+    StreamScope on_b(pp.B);
+    HIP_TRY(hipStreamWaitEvent(pp.B, pp.ev_front[par], 0));
+    ASL_TRY(index_search_device(idx, nq, L->p_qvec[par].p, k, nprobe, nullptr, knn_I, L->knn.p,
+                                L->p_cD[par].p, L->p_cI[par].p, knn_I == nullptr));
+    HIP_TRY(hipEventRecord(pp.ev_scan[par], pp.B));
+    pp.scan_recorded[par] = true;
+    PrecFilter flt;
+    flt.lib_pmz = L->pmz32.p;
+    flt.valid = L->has_valid ? L->valid.p : nullptr;
+    flt.meta = L->meta.p;
+    flt.tol = P->precursor_tol;
+    flt.mode = P->precursor_mode;
+    flt.charge = P->charge;
+    ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->knn.p, nullptr, k, (int64_t)nq * k,
+                           P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
+                           L->best_slot.p, nullptr, best_row, best_score, n_cand, pm_count,
+                           pm_pairs, pm_stride, pp.status, flt, /*clear_status=*/false));
+  }
+  return ASL_OK;
+}
+
 int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *queries,
                      const asl_search_params_t *P, int32_t *best_row, double *best_score,
                      int32_t *n_cand, int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride,
@@ -301,6 +375,24 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
   if (nq == 0) return ASL_OK;
   if (pm_pairs && pm_stride <= 0) return fail(ASL_ERR_INVALID, "search_batch: pm_stride");
   if (P->use_ann && !idx) return fail(ASL_ERR_INVALID, "search_batch: use_ann needs an index");
+  if (P->use_ann && P->k <= 0) return fail(ASL_ERR_INVALID, "search_batch: k must be positive");
+  {
+    // pipeline mode applies to ANN batches whose arguments all live on the device (nothing to
+    // stage, nothing to copy back) and whose peak count the caller supplied; anything else takes
+    // the synchronous path below, after the batches in flight have drained
+    Pipeline &pp = pipeline();
+    auto dev_or_null = [](const void *p) { return !p || is_device_ptr(p); };
+    if (pp.on && P->use_ann && queries->n_peaks > 0 && peaks_on_device(queries) &&
+        is_device_ptr(best_row) && is_device_ptr(best_score) && dev_or_null(n_cand) &&
+        dev_or_null(pm_count) && dev_or_null(pm_pairs) && dev_or_null(knn_I)) {
+      pp.in_call = true;                    // do not drain: this call joins the pipeline
+      const int rc = ensure_device();
+      pp.in_call = false;
+      ASL_TRY(rc);
+      return search_batch_pipelined(L, idx, queries, P, best_row, best_score, n_cand, pm_count,
+                                    pm_pairs, pm_stride, knn_I);
+    }
+  }
   ASL_TRY(ensure_device());
   PeaksStage Q;
   ASL_TRY(Q.init(queries));

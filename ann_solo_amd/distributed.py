@@ -165,11 +165,11 @@ class HipShardBackend:
             mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=self.device)
             best_row, best_score = mk((nq,), torch.int32), mk((nq,), torch.float64)
             n_cand, pm_count = mk((nq,), torch.int32), mk((nq,), torch.int32)
-            pm_pairs = torch.zeros((nq, stride, 2), dtype=torch.int32, device=self.device)
+            pm_pairs = torch.empty((nq, stride, 2), dtype=torch.int32, device=self.device)
         else:
             best_row, best_score = np.empty(nq, np.int32), np.empty(nq, np.float64)
             n_cand, pm_count = np.empty(nq, np.int32), np.empty(nq, np.int32)
-            pm_pairs = np.zeros((nq, stride, 2), np.uint32)
+            pm_pairs = np.empty((nq, stride, 2), np.uint32)
         _, min_bound, _ = get_dim(cfg.min_mz, cfg.max_mz, cfg.bin_size)
         P = _lib.AslSearchParams(min_bound, cfg.bin_size, HASH_SEED, self.k, sl._num_probe,
                                  self.charge, float(tol_val), 0 if tol_mode == 'Da' else 1,

@@ -347,6 +347,16 @@ class SpectralLibrary:
                 if part.index is not None:
                     part.index.shard(rank, world)
 
+    def set_pipeline(self, on: bool = True) -> None:
+        """Two-stream software pipeline of the device hot path (``asl_set_pipeline``): with
+        ``device_out=True`` an open-search ``_search_batch`` returns without waiting, and the
+        encoder + coarse quantiser of the next batch run under the list scan of this one.
+        Results are valid after ``synchronize()``; values are bit-identical either way."""
+        _lib.check(_lib.lib().asl_set_pipeline(int(bool(on))))
+
+    def synchronize(self) -> None:
+        _lib.check(_lib.lib().asl_synchronize())
+
     def _shard_backend(self, charge: int, mode: str):
         from .distributed import HipShardBackend
         key = (charge, mode)
@@ -419,8 +429,9 @@ class SpectralLibrary:
         best_score = mk((nq,), xp.float64)
         n_cand = mk((nq,), xp.int32)
         pm_count = mk((nq,), xp.int32)
-        pm_pairs = (torch.zeros((nq, stride, 2), dtype=torch.int32, **kw) if device_out
-                    else np.zeros((nq, stride, 2), np.uint32))
+        # (the kernel writes every slot: matches first, zeros beyond pm_count)
+        pm_pairs = (torch.empty((nq, stride, 2), dtype=torch.int32, **kw) if device_out
+                    else np.empty((nq, stride, 2), np.uint32))
         knn = mk((nq, k), xp.int64) if (want_knn and use_ann) else None
         _, min_bound, _ = get_dim(cfg.min_mz, cfg.max_mz, cfg.bin_size)
         P = _lib.AslSearchParams(min_bound, cfg.bin_size, HASH_SEED, k, self._num_probe, charge,

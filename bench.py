@@ -53,6 +53,9 @@ def main():
     ap.add_argument('--open-da', type=float, default=500.0)
     ap.add_argument('--scan-variant', type=int, default=0, help='0 auto (tiled v2), 1 generic v1')
     ap.add_argument('--recall-queries', type=int, default=2048)
+    ap.add_argument('--no-pipeline', action='store_true',
+                    help='run the stages of consecutive batches strictly one after the other '
+                         '(default: two-stream software pipeline, asl_set_pipeline)')
     ap.add_argument('--workload', default='batch', choices=['batch', 'cascade'],
                     help="'batch' (default): BASELINE configs[2]/[3], one 16 384-query open-search "
                          "batch per step; 'cascade': configs[4], standard search -> FDR gate -> "
@@ -245,12 +248,19 @@ def main():
         step = unsharded_step
 
     L = _lib.lib()
+    # consecutive steps are independent batches: the encoder + coarse quantiser of step i+1 run
+    # on one stream under the list scan of step i on another (bit-identical results)
+    pipelined = not args.no_pipeline and degree == 1
+    sl.set_pipeline(pipelined)
     for _ in range(args.warmup):
         step()
+    sl.synchronize()
     L.asl_profile_enable(1)
     L.asl_profile_reset()
     elapsed, res = timed(step, args.steps)
+    sl.synchronize()            # reports any error a pipelined batch deferred
     L.asl_profile_enable(0)
+    sl.set_pipeline(False)
 
     stages = {}
     for name in ('encode', 'coarse_gemm', 'coarse_select', 'scan', 'filter', 'rescore',
@@ -325,6 +335,9 @@ def main():
                        (f'ivf-list-shard x{degree}' if degree == world else
                         f'replicas x{world}' if degree == 1 else
                         f'ivf-list-shard x{degree} in {world // degree} replica groups')},
+            'pipeline': {'two_stream': pipelined,
+                         'note': 'stage times overlap across consecutive steps when true: their '
+                                 'sum exceeds ms_per_step'},
             'recall': recall,
             'shard_check': shard_check,
             'alt_layouts': alt,

@@ -52,7 +52,18 @@ int asl_get_num_gpus(void);
 int asl_set_device(int device);
 /* hipStream_t to issue work on (NULL = default stream). */
 int asl_set_stream(void *hip_stream);
+/* Waits for all work issued by the library, including batches of the pipeline below, and
+ * reports any error those batches deferred. */
 int asl_synchronize(void);
+/* Two-stream software pipeline for asl_search_batch (off by default). When on, a call with
+ * use_ann = 1 whose arrays ALL live on the device and whose queries->n_peaks is set returns
+ * without waiting: the encoder and the coarse quantiser of that batch run on one internal stream,
+ * list scan + rescoring on another, so the MFMA-bound front of batch i+1 executes under the scan
+ * of batch i. Contract in this mode: inputs must stay untouched and outputs are valid only after
+ * asl_synchronize() (or a device-wide synchronisation); capacity errors the kernels flag are
+ * reported by that call instead. Any other entry point first waits for the batches in flight.
+ * Results are bit-identical to the synchronous path. */
+int asl_set_pipeline(int on);
 
 /* ------------------------------------------------------------------ encoder
  * Replaces spectrum_to_vector / get_dim / hash_idx, src/ann_solo/spectrum.py:122-214
@@ -178,6 +189,8 @@ typedef struct {
   const uint8_t *charge;           /* [offsets[n]] or NULL (all 0) */
   const double *precursor_mz;      /* [n] */
   const int32_t *precursor_charge; /* [n] */
+  int64_t n_peaks;                 /* offsets[n] when the caller knows it, else 0: device-resident
+                                      offsets are then read back (one stream synchronisation) */
 } asl_peaks_t;
 
 /* Candidates of query q are library rows cand_rows[cand_offsets[q] .. cand_offsets[q+1]).
@@ -186,7 +199,8 @@ typedef struct {
  *                 wins, SpectrumMatch.cpp:118), -1 if the list has no valid entry
  *   best_score[q] SpectrumMatcher::dot score (double)
  *   pm_count[q]   number of matched peak pairs of the winner
- *   pm_pairs      [nq, pm_stride, 2] (query_peak, candidate_peak) in greedy order */
+ *   pm_pairs      [nq, pm_stride, 2] (query_peak, candidate_peak) in greedy order, zero beyond
+ *                 pm_count[q] (asl_search_batch / asl_rescore_knn write every slot) */
 int asl_rescore_batch(const asl_peaks_t *queries, const asl_peaks_t *library,
                       const int64_t *cand_rows, const int32_t *cand_offsets,
                       double fragment_mz_tolerance, int allow_shift, int32_t *best_cand,

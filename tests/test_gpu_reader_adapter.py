@@ -89,27 +89,31 @@ def test_filename_constructor_search_and_caches(setup, tmp_path, monkeypatch):
     again = sl.search(qs, qm, sl.library_meta, score_ssms=scorer)
     ssm_key = lambda s: (s.query_identifier, s.library_identifier, s.charge, s.search_engine_score, s.q)
     assert sorted(map(ssm_key, again)) == sorted(map(ssm_key, ids))
-    # level 1 is an exact window search, independent of the index: SSMs kept from it equal the
-    # standard search of an engine built straight from the processed library pack
+    # the standard search is an exact window search, independent of the index and of the row
+    # order: the adapter engine (rows in file order) and an engine built straight from the
+    # processed library pack name the same library spectra with the same scores
     packed_lib = SpectralLibrary(lib, config=cfg)
     src = truth['source_row'].numpy()
-    right = kept = 0
+    right = n_std = 0
     for z in qs:
-        std = packed_lib._search_batch(qs[z], z, 'std')
+        std_a = sl._search_batch(qs[z], z, 'std')
+        std_p = packed_lib._search_batch(qs[z], z, 'std')
         zrows = np.nonzero(lib.precursor_charge.numpy() == z)[0]
+        ids_a = np.where(std_a.best_row >= 0, sl.partitions[z].ids[std_a.best_row.clip(0)], -1)
+        ids_p = np.where(std_p.best_row >= 0, zrows[std_p.best_row.clip(0)], -1)
+        assert np.array_equal(ids_a, ids_p) and np.array_equal(std_a.best_score, std_p.best_score)
+        assert np.array_equal(std_a.n_candidates, std_p.n_candidates)
+        n_std += int((ids_a >= 0).sum())
         for j, m in enumerate(qm[z]):
             s = by.get(m['identifier'])
             if s is None or s.charge != z:
                 continue
             i = int(m['identifier'].split('=')[1])
-            if s.q < cfg.fdr:                                     # kept from the standard search
-                assert std.best_row[j] >= 0 and int(s.library_identifier) == int(zrows[std.best_row[j]])
-                kept += 1
             assert s.sequence == f'PEP{int(s.library_identifier)}K'
             assert s.is_decoy == (int(s.library_identifier) % 9 == 0)
             assert s.retention_time == 0.5 * i and s.query_index == i
             right += int(s.library_identifier) == src[i]
-    assert kept > 0.25 * q.n and right > 0.6 * q.n
+    assert n_std > 0.25 * q.n and right > 0.6 * q.n
     monkeypatch.chdir(tmp_path)
     out = write_mztab(ids, 'out', cfg, sl._library_reader.get_version())
     rows = [l.split('\t') for l in open(out) if l.startswith('PSM')]
