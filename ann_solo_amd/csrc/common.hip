@@ -72,10 +72,12 @@ int pipeline_init() {
   // the ordering that matters is expressed with events
   HIP_TRY(hipStreamCreateWithFlags(&p.A, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&p.B, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&p.C, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&p.ev_in, hipEventDisableTiming));
   for (int i = 0; i < 2; i++) {
     HIP_TRY(hipEventCreateWithFlags(&p.ev_front[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p.ev_scan[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p.ev_resc[i], hipEventDisableTiming));
   }
   HIP_TRY(hipMalloc((void **)&p.status, sizeof(int)));
   HIP_TRY(hipMemset(p.status, 0, sizeof(int)));
@@ -90,6 +92,7 @@ int pipeline_drain() {
   p.inflight = false;
   HIP_TRY(hipStreamSynchronize(p.A));
   HIP_TRY(hipStreamSynchronize(p.B));
+  HIP_TRY(hipStreamSynchronize(p.C));
   int st = 0;
   HIP_TRY(hipMemcpy(&st, p.status, sizeof(int), hipMemcpyDeviceToHost));
   if (st) HIP_TRY(hipMemset(p.status, 0, sizeof(int)));

@@ -143,14 +143,15 @@ struct StreamScope {
   ~StreamScope();
 };
 
-// Two-stream software pipeline of asl_search_batch (asl_set_pipeline): stream A runs the
-// MFMA-bound front of batch i+1 (encode, coarse GEMM, coarse select) while stream B runs the
-// scan + rescoring of batch i. Buffers that cross the streams exist twice (by parity).
+// Software pipeline of asl_search_batch over three streams (asl_set_pipeline): A runs the
+// MFMA-bound front of batch i+2 (encode, coarse GEMM, coarse select), B the list scan of batch
+// i+1, C the filter + rescoring of batch i. Buffers that cross streams exist twice (by parity).
 struct Pipeline {
   bool on = false, inflight = false, in_call = false;
-  hipStream_t A = nullptr, B = nullptr;
-  hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_scan[2] = {nullptr, nullptr};
-  bool scan_recorded[2] = {false, false};
+  hipStream_t A = nullptr, B = nullptr, C = nullptr;
+  hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_scan[2] = {nullptr, nullptr},
+             ev_resc[2] = {nullptr, nullptr};
+  bool scan_recorded[2] = {false, false}, resc_recorded[2] = {false, false};
   int parity = 0;
   int *status = nullptr;   // sticky rescoring flags of the batches in flight
 };

@@ -28,6 +28,9 @@
 namespace asl {
 
 constexpr int RS_WAVES = 4;
+#ifndef RS_OCC
+#define RS_OCC 7   // waves per SIMD the hash kernel is built for (A/B: -DRS_OCC=6)
+#endif
 constexpr int RS_MAXP = 256;   // peaks per spectrum the kernels accept
 constexpr int RS_MCAP = 512;   // generated peak matches per pair the kernels accept
 
@@ -607,7 +610,7 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
 // are compiled with those facts folded in (each open "is this pointer null" question is a
 // wave-uniform predicate held in scalar registers across the hot loops); 0 = any shape.
 template <bool KNOBS, int FORM>
-__global__ __launch_bounds__(64 * RS_WAVES, 7) void rescore_score_v2_kernel(
+__global__ __launch_bounds__(64 * RS_WAVES, RS_OCC) void rescore_score_v2_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
     double *__restrict__ pair_score, int *__restrict__ q_defer, int *status, int dbg_arg) {
   const int dbg = KNOBS ? dbg_arg : 0;

@@ -89,7 +89,7 @@ struct asl_library {
   DevBuf<int32_t> knn, cand, lo, cnt, woff;
   // buffers that cross the two streams of the pipeline, by batch parity
   DevBuf<float> p_qvec[2], p_cD[2];
-  DevBuf<int32_t> p_cI[2];
+  DevBuf<int32_t> p_cI[2], p_knn[2];
   DevBuf<double> pair_score;
   DevBuf<long long> best_slot;
   DevBuf<int> status;
@@ -299,13 +299,15 @@ int asl_rescore_knn(asl_library_t *L, const asl_peaks_t *queries, const asl_sear
 }
 
 // asl_search_batch in pipeline mode (asl_set_pipeline): nothing here waits for the device.
-//   stream A: encode -> coarse GEMM -> coarse select        (MFMA-bound, ~1.1 ms of a 16 384 batch)
-//   stream B: list scan -> filter + rescoring -> peak matches (VALU / fabric bound, ~8.5 ms)
-// so the front of batch i+1 runs under the scan of batch i. Buffers written by A and read by B
-// (hashed queries, probe lists) exist twice; A re-uses a pair only after B's scan of the batch
-// that read it (ev_scan). Everything else is touched by one stream only. Errors the kernels
-// flag are sticky and reported by the next call that drains (asl_synchronize or any other
-// entry point).
+//   stream A: encode -> coarse GEMM -> coarse select          (MFMA-bound, ~1.1 ms of a 16 384 batch)
+//   stream B: list scan                                       (fabric / VALU bound, ~6.3 ms)
+//   stream C: filter + rescoring -> peak matches of the winners (latency / VALU bound, ~2.2 ms)
+// so the front of batch i+2 and the rescoring of batch i run under the scan of batch i+1.
+// Buffers written by one stream and read by the next (hashed queries + probe lists: A -> B;
+// neighbour ids: B -> C) exist twice; the producer re-uses a pair only after the consumer of
+// the batch that read it has finished (ev_scan / ev_resc). Everything else is touched by one
+// stream only. Errors the kernels flag are sticky and reported by the next call that drains
+// (asl_synchronize or any other entry point).
 static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peaks_t *queries,
                                   const asl_search_params_t *P, int32_t *best_row,
                                   double *best_score, int32_t *n_cand, int32_t *pm_count,
@@ -326,7 +328,7 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
   ASL_TRY(L->p_qvec[par].reserve((size_t)nq * d));
   ASL_TRY(L->p_cD[par].reserve((size_t)nq * nprobe));
   ASL_TRY(L->p_cI[par].reserve((size_t)nq * nprobe));
-  ASL_TRY(L->knn.reserve((size_t)nq * k));
+  ASL_TRY(L->p_knn[par].reserve((size_t)nq * k));
   ASL_TRY(L->pair_score.reserve((size_t)nq * k));
   ASL_TRY(L->best_slot.reserve((size_t)nq));
   pp.parity ^= 1;
@@ -334,6 +336,7 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
   HIP_TRY(hipEventRecord(pp.ev_in, stream()));
   HIP_TRY(hipStreamWaitEvent(pp.A, pp.ev_in, 0));
   HIP_TRY(hipStreamWaitEvent(pp.B, pp.ev_in, 0));
+  HIP_TRY(hipStreamWaitEvent(pp.C, pp.ev_in, 0));
   pp.inflight = true;
   {
     StreamScope on_a(pp.A);
@@ -346,10 +349,16 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
   {
     StreamScope on_b(pp.B);
     HIP_TRY(hipStreamWaitEvent(pp.B, pp.ev_front[par], 0));
-    ASL_TRY(index_search_device(idx, nq, L->p_qvec[par].p, k, nprobe, nullptr, knn_I, L->knn.p,
-                                L->p_cD[par].p, L->p_cI[par].p, knn_I == nullptr));
+    if (pp.resc_recorded[par]) HIP_TRY(hipStreamWaitEvent(pp.B, pp.ev_resc[par], 0));
+    ASL_TRY(index_search_device(idx, nq, L->p_qvec[par].p, k, nprobe, nullptr, knn_I,
+                                L->p_knn[par].p, L->p_cD[par].p, L->p_cI[par].p,
+                                knn_I == nullptr));
     HIP_TRY(hipEventRecord(pp.ev_scan[par], pp.B));
     pp.scan_recorded[par] = true;
+  }
+  {
+    StreamScope on_c(pp.C);
+    HIP_TRY(hipStreamWaitEvent(pp.C, pp.ev_scan[par], 0));
     PrecFilter flt;
     flt.lib_pmz = L->pmz32.p;
     flt.valid = L->has_valid ? L->valid.p : nullptr;
@@ -357,10 +366,12 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
     flt.tol = P->precursor_tol;
     flt.mode = P->precursor_mode;
     flt.charge = P->charge;
-    ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->knn.p, nullptr, k, (int64_t)nq * k,
+    ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->p_knn[par].p, nullptr, k, (int64_t)nq * k,
                            P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
                            L->best_slot.p, nullptr, best_row, best_score, n_cand, pm_count,
                            pm_pairs, pm_stride, pp.status, flt, /*clear_status=*/false));
+    HIP_TRY(hipEventRecord(pp.ev_resc[par], pp.C));
+    pp.resc_recorded[par] = true;
   }
   return ASL_OK;
 }
