@@ -197,8 +197,10 @@ int asl_synchronize(void) {
 int asl_set_pipeline(int on) {
   clear_error();
   ASL_TRY(ensure_device());
+  if (on < 0 || on > 3) return fail(ASL_ERR_INVALID, "set_pipeline: 0 (off), 1 / 2 (two streams) or 3");
   if (on) ASL_TRY(pipeline_init());
   g_pipe.on = on != 0;
+  g_pipe.streams = on == 3 ? 3 : 2;
   return ASL_OK;
 }
 

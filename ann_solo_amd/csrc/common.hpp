@@ -148,6 +148,7 @@ struct StreamScope {
 // i+1, C the filter + rescoring of batch i. Buffers that cross streams exist twice (by parity).
 struct Pipeline {
   bool on = false, inflight = false, in_call = false;
+  int streams = 2;   // 2: front | scan + rescoring; 3: front | scan | rescoring
   hipStream_t A = nullptr, B = nullptr, C = nullptr;
   hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_scan[2] = {nullptr, nullptr},
              ev_resc[2] = {nullptr, nullptr};

@@ -301,8 +301,9 @@ int asl_rescore_knn(asl_library_t *L, const asl_peaks_t *queries, const asl_sear
 // asl_search_batch in pipeline mode (asl_set_pipeline): nothing here waits for the device.
 //   stream A: encode -> coarse GEMM -> coarse select          (MFMA-bound, ~1.1 ms of a 16 384 batch)
 //   stream B: list scan                                       (fabric / VALU bound, ~6.3 ms)
-//   stream C: filter + rescoring -> peak matches of the winners (latency / VALU bound, ~2.2 ms)
-// so the front of batch i+2 and the rescoring of batch i run under the scan of batch i+1.
+//   stream C (three-stream mode; else B): filter + rescoring -> peak matches (VALU bound, ~2.2 ms)
+// so the front of the next batch (and in three-stream mode the rescoring of the previous one)
+// runs under the scan of this one.
 // Buffers written by one stream and read by the next (hashed queries + probe lists: A -> B;
 // neighbour ids: B -> C) exist twice; the producer re-uses a pair only after the consumer of
 // the batch that read it has finished (ev_scan / ev_resc). Everything else is touched by one
@@ -357,8 +358,11 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
     pp.scan_recorded[par] = true;
   }
   {
-    StreamScope on_c(pp.C);
-    HIP_TRY(hipStreamWaitEvent(pp.C, pp.ev_scan[par], 0));
+    // measured (profiles/r02_pipeline_ab.txt): scan and rescoring are both VALU-limited, so a
+    // third stream only makes them share the CUs -- the default keeps rescoring behind its scan
+    hipStream_t sc = pp.streams == 3 ? pp.C : pp.B;
+    StreamScope on_c(sc);
+    HIP_TRY(hipStreamWaitEvent(sc, pp.ev_scan[par], 0));
     PrecFilter flt;
     flt.lib_pmz = L->pmz32.p;
     flt.valid = L->has_valid ? L->valid.p : nullptr;
@@ -370,7 +374,7 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
                            P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
                            L->best_slot.p, nullptr, best_row, best_score, n_cand, pm_count,
                            pm_pairs, pm_stride, pp.status, flt, /*clear_status=*/false));
-    HIP_TRY(hipEventRecord(pp.ev_resc[par], pp.C));
+    HIP_TRY(hipEventRecord(pp.ev_resc[par], sc));
     pp.resc_recorded[par] = true;
   }
   return ASL_OK;

@@ -347,12 +347,12 @@ class SpectralLibrary:
                 if part.index is not None:
                     part.index.shard(rank, world)
 
-    def set_pipeline(self, on: bool = True) -> None:
+    def set_pipeline(self, on=True) -> None:
         """Two-stream software pipeline of the device hot path (``asl_set_pipeline``): with
         ``device_out=True`` an open-search ``_search_batch`` returns without waiting, and the
         encoder + coarse quantiser of the next batch run under the list scan of this one.
         Results are valid after ``synchronize()``; values are bit-identical either way."""
-        _lib.check(_lib.lib().asl_set_pipeline(int(bool(on))))
+        _lib.check(_lib.lib().asl_set_pipeline(int(on)))       # True/1: two streams, 3: three
 
     def synchronize(self) -> None:
         _lib.check(_lib.lib().asl_synchronize())

@@ -335,7 +335,7 @@ def main():
                        (f'ivf-list-shard x{degree}' if degree == world else
                         f'replicas x{world}' if degree == 1 else
                         f'ivf-list-shard x{degree} in {world // degree} replica groups')},
-            'pipeline': {'streams': 3 if pipelined else 1,
+            'pipeline': {'streams': 2 if pipelined else 1,
                          'note': 'stage times overlap across consecutive steps when true: their '
                                  'sum exceeds ms_per_step'},
             'recall': recall,

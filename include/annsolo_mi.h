@@ -55,11 +55,12 @@ int asl_set_stream(void *hip_stream);
 /* Waits for all work issued by the library, including batches of the pipeline below, and
  * reports any error those batches deferred. */
 int asl_synchronize(void);
-/* Software pipeline for asl_search_batch over three internal streams (off by default). When
- * on, a call with use_ann = 1 whose arrays ALL live on the device and whose queries->n_peaks is
- * set returns without waiting: the encoder and the coarse quantiser of that batch run on one
- * stream, the list scan on a second, filter + rescoring on a third, so the MFMA-bound front of
- * batch i+2 and the rescoring of batch i execute under the scan of batch i+1. Contract in this mode: inputs must stay untouched and outputs are valid only after
+/* Software pipeline for asl_search_batch over internal streams (mode 0 = off, the default).
+ * When on, a call with use_ann = 1 whose arrays ALL live on the device and whose
+ * queries->n_peaks is set returns without waiting. Mode 1 (= 2): the encoder and the coarse
+ * quantiser of a batch run on one stream, list scan + rescoring on a second, so the MFMA-bound
+ * front of batch i+1 executes under the scan of batch i. Mode 3 moves filter + rescoring to a
+ * third stream (measured no faster on MI355X: both compete for the vector ALUs). Contract in this mode: inputs must stay untouched and outputs are valid only after
  * asl_synchronize() (or a device-wide synchronisation); capacity errors the kernels flag are
  * reported by that call instead. Any other entry point first waits for the batches in flight.
  * Results are bit-identical to the synchronous path. */

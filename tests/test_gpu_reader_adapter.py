@@ -101,7 +101,8 @@ def test_filename_constructor_search_and_caches(setup, tmp_path, monkeypatch):
         zrows = np.nonzero(lib.precursor_charge.numpy() == z)[0]
         ids_a = np.where(std_a.best_row >= 0, sl.partitions[z].ids[std_a.best_row.clip(0)], -1)
         ids_p = np.where(std_p.best_row >= 0, zrows[std_p.best_row.clip(0)], -1)
-        assert np.array_equal(std_a.best_score, std_p.best_score)
+        # (the adapter's library went through process_spectrum again: intensities agree to 1e-6)
+        assert np.allclose(std_a.best_score, std_p.best_score, rtol=1e-5, atol=1e-7)
         assert np.array_equal(std_a.n_candidates, std_p.n_candidates)
         # equal scores go to the lowest library ROW, and the two engines order their rows
         # differently: identical spectra in the synthetic library may swap places
