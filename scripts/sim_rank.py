@@ -43,8 +43,9 @@ def timed(fn, reps=3):
     return (time.perf_counter() - t0) / reps * 1e3, out
 
 
-t_enc, vec = timed(lambda: be.encode(q))
-t_coarse, _ = timed(lambda: be.coarse(vec))
+t_enc, _ = timed(lambda: be.encode(q_all))      # every rank hashes ALL queries (peaks travel)
+vec = be.encode(q)
+t_coarse, _ = timed(lambda: be.coarse(vec))     # ... and quantises its own slice
 if index == 'ivfpq':
     t_scan, K = timed(lambda: be.shard_search_keys(allvec, cD, cI))
     Ks = K.view(W, batch, -1).contiguous()
@@ -55,6 +56,6 @@ else:
     t_merge, (_, knn) = timed(lambda: be.merge(Ds, Is))
 t_resc, _ = timed(lambda: be.rescore_knn(q, knn, True))
 tot = t_enc + t_coarse + t_scan + t_merge + t_resc
-print(f'{index} W={W} batch/rank={batch} variant={variant}: encode {t_enc:.2f} coarse {t_coarse:.2f} '
+print(f'{index} W={W} batch/rank={batch} variant={variant}: encode (all {W * batch}) {t_enc:.2f} coarse {t_coarse:.2f} '
       f'shard scan ({W * batch} queries) {t_scan:.2f} merge {t_merge:.2f} rescore {t_resc:.2f} '
       f'| compute per step {tot:.2f} ms (collectives excluded)')
