@@ -221,3 +221,48 @@ def test_search_cascade_control_flow(monkeypatch):
     ids = sl.search(qs, meta, lmeta, score_ssms=scorer)
     assert sum(c[2] for c in calls if c[1] == 'open') == 13      # both charge copies of scan=2 retried
     assert len(ids) == 12 and all(s.q == 0.001 for s in ids)
+
+
+def test_ssm_table_columnar_bookkeeping():
+    """SSMTable (the cascade's columnar result): batches appended, first-wins per identifier,
+    subsets, concatenation and on-demand SSM records with the writer's attributes."""
+    from types import SimpleNamespace
+    from ann_solo_amd.spectral_library import SSMTable, _query_uids
+    qmeta = {2: [dict(identifier=f'scan={i}', index=i, precursor_charge=2, precursor_mz=400. + i)
+                 for i in range(6)],
+             3: [dict(identifier=f'scan={i}', index=i, precursor_charge=3, precursor_mz=300. + i,
+                      retention_time=1.5) for i in (4, 9)]}
+    lmeta = {z: [dict(identifier=100 * z + r, peptide=f'PEP{z}{r}K', precursor_mz=500. + r,
+                      is_decoy=(r == 2)) for r in range(5)] for z in (2, 3)}
+    mk = lambda rows, cnt: SimpleNamespace(
+        pm_count=np.asarray(cnt, np.int32),
+        pm_pairs=np.arange(len(rows) * 3 * 2, dtype=np.uint32).reshape(len(rows), 3, 2))
+    t = SSMTable(qmeta, lmeta)
+    t.add_batch(2, np.array([0, 1, 2]), np.array([4, -1, 2], np.int32), np.array([.9, np.nan, .4]),
+                mk([0, 1, 2], [2, 0, 3]))
+    t.add_batch(2, np.array([3, 4, 5]), np.array([-1, 0, 1], np.int32), np.array([np.nan, .7, .6]),
+                mk([3, 4, 5], [0, 1, 1]))
+    t.add_batch(3, np.array([0, 1]), np.array([3, 3], np.int32), np.array([.8, .5]), mk([0, 1], [1, 2]))
+    assert len(t) == 6 and t.charge.tolist() == [2, 2, 2, 2, 3, 3] and t.qrow.tolist() == [0, 2, 4, 5, 0, 1]
+    assert np.isnan(t.q).all()
+    uid = _query_uids(qmeta, [2, 3])
+    assert _query_uids(qmeta, [2]) is None
+    assert uid[3].tolist() == [uid[2][4], 6]                       # scan=4 is shared, scan=9 is new
+    d = t.first_per_uid(uid)                                        # charge 3's scan=4 loses to charge 2's
+    assert d.identifiers() == ['scan=0', 'scan=2', 'scan=4', 'scan=5', 'scan=9']
+    d.q[:] = [0.0, 0.5, 0.0, 0.5, 0.0]
+    keep = d.take(d.q < 0.01)
+    assert keep.identifiers() == ['scan=0', 'scan=4', 'scan=9'] and keep.lib_row.tolist() == [4, 0, 3]
+    both = SSMTable.concat([keep, d.take(np.array([1]))])
+    assert len(both) == 4 and both.batch.tolist() == [0, 1, 2, 3 + 0]   # second table's batches shifted
+    s = both[1]
+    assert (s.query_identifier, s.library_identifier, s.sequence, s.charge) == ('scan=4', 200, 'PEP20K', 2)
+    assert s.search_engine_score == 0.7 and s.q == 0.0 and s.peak_matches.shape == (1, 2)
+    assert s.peak_matches.tolist() == [[6, 7]]                      # batch 1, row 1 of its pair table
+    last = both[-1]
+    assert last.query_identifier == 'scan=2' and last.is_decoy and last.peak_matches.shape == (3, 2)
+    assert [x.query_identifier for x in both] == both.identifiers()
+    assert both[2].retention_time == 1.5 and both[0].retention_time is None
+    ids = both.library_identifiers({2: SimpleNamespace(ids=np.arange(200, 205)),
+                                    3: SimpleNamespace(ids=np.arange(300, 305))})
+    assert ids.tolist() == [204, 200, 303, 202]

@@ -44,6 +44,40 @@ def test_features_match_goldens_and_oracle(O):
     assert np.array_equal(Fd.cpu().numpy().view(np.uint64), F.view(np.uint64))
 
 
+def test_cosine_kernel_has_the_bits_of_feature_column_0():
+    """asl_ssm_cosine_batch (the cascade's default score, spectrum_similarity.py:81-106) == column
+    0 of the feature kernel bit for bit, on the goldens and on a searched batch, host and device
+    arrays; rows without a match are NaN; the reference test constant 0.44582117 comes out."""
+    import torch
+    from ann_solo_amd import spectrum_similarity as sim
+    g = np.load(os.path.join(HERE, 'golden', 'ssm_features_golden.npz'))
+    qo, lo, po = g['q_offsets'], g['l_offsets'], g['pm_offsets']
+    n = len(qo) - 1
+    cnt = np.diff(po).astype(np.int32)
+    pairs = np.zeros((n, max(1, cnt.max()), 2), np.uint32)
+    for c in range(n):
+        pairs[c, :cnt[c]] = g['pm_pairs'][po[c]:po[c + 1]]
+    Q, L = _pack(qo, g['q_mz'], g['q_intensity']), _pack(lo, g['l_mz'], g['l_intensity'])
+    rows = np.arange(n, dtype=np.int32)
+    rows[::7] = -1
+    F = sim.ssm_features(Q, L, rows, pairs, cnt)
+    c0 = sim.ssm_cosine(Q, L, rows, pairs, cnt)
+    assert np.array_equal(c0.view(np.uint64), F[:, 0].view(np.uint64))
+    assert np.isnan(c0[::7]).all() and np.isfinite(c0[rows >= 0]).all()
+    cd = sim.ssm_cosine(Q.to('cuda'), L.to('cuda'), torch.from_numpy(rows).cuda(),
+                        torch.from_numpy(pairs.view(np.int32)).cuda(), torch.from_numpy(cnt).cuda())
+    assert np.array_equal(cd.cpu().numpy().view(np.uint64), c0.view(np.uint64))
+    kat = np.load(os.path.join(HERE, 'golden', 'similarity_kat.npz'))
+    q_mz, q_int, l_mz, l_int, pm = kat_case(kat, 'partial_match')
+    one = sim.ssm_cosine(_pack([0, len(q_mz)], q_mz, q_int), _pack([0, len(l_mz)], l_mz, l_int),
+                         np.zeros(1, np.int32), np.asarray(pm, np.uint32)[None], np.array([len(pm)], np.int32))
+    assert abs(one[0] - 0.44582117) < 1e-7
+    with pytest.raises(Exception):
+        bad = pairs.copy()
+        bad[1, 0, 0] = 10 ** 6
+        sim.ssm_cosine(Q, L, np.arange(n, dtype=np.int32), bad, cnt)
+
+
 def test_reference_test_constants_through_the_calculator_mirror():
     from ann_solo_amd.spectrum_similarity import SpectrumSimilarityCalculator
     exp = json.load(open(os.path.join(HERE, 'golden', 'similarity_expected.json')))
