@@ -1,4 +1,6 @@
 // common.hip -- error state, stream, pointer classification, stage timers.
+#include <cstdlib>
+
 #include "common.hpp"
 
 #include <mutex>
@@ -70,9 +72,18 @@ int pipeline_init() {
   if (p.A) return ASL_OK;
   // non-blocking: no implicit ordering against the null stream (the caller's, PyTorch's) --
   // the ordering that matters is expressed with events
-  HIP_TRY(hipStreamCreateWithFlags(&p.A, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&p.B, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&p.C, hipStreamNonBlocking));
+  // the scan/rescoring chain (B) is the critical path of a step, the front (A) only has to be
+  // ready one batch ahead: B's workgroups are dispatched first, A's fill what is left
+  int least = 0, greatest = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  const bool flat = getenv("ASL_PIPE_FLAT_PRIORITY") != nullptr;   // A/B knob (measurement)
+  HIP_TRY(hipStreamCreateWithPriority(&p.A, hipStreamNonBlocking, flat ? greatest : least));
+  HIP_TRY(hipStreamCreateWithPriority(&p.B, hipStreamNonBlocking, greatest));
+  if (getenv("ASL_PIPE_SINGLE")) {   // measurement: asynchronous calls, but everything in order on B
+    (void)hipStreamDestroy(p.A);
+    p.A = p.B;
+  }
+  HIP_TRY(hipStreamCreateWithPriority(&p.C, hipStreamNonBlocking, greatest));
   HIP_TRY(hipEventCreateWithFlags(&p.ev_in, hipEventDisableTiming));
   for (int i = 0; i < 2; i++) {
     HIP_TRY(hipEventCreateWithFlags(&p.ev_front[i], hipEventDisableTiming));

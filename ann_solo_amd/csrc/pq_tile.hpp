@@ -22,11 +22,22 @@ __device__ __forceinline__ float dpp_mov(float x) {
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
 }
 
+#ifndef PQT_ADC_V2
+#define PQT_ADC_V2 1   // 0: the round-1 instruction selection (A/B)
+#endif
+
 __device__ __forceinline__ float lut_at(const char *lut_bytes, uint32_t word, int byte_idx,
                                         uint32_t lane_off) {
-  const uint32_t c = (word >> (8 * byte_idx)) & 0xffu;
+  uint32_t c = (word >> (8 * byte_idx)) & 0xffu;
+#if PQT_ADC_V2
+  // keep the byte a value of its own: otherwise byte 0 is rewritten to (word << 7) & 0x7f80 and
+  // costs three VALU instructions (shift, and, add) instead of two (and / bfe, lshl_add)
+  asm volatile("" : "+v"(c));
+#endif
   return *reinterpret_cast<const float *>(lut_bytes + ((c << 7) + lane_off));
 }
+
+typedef float pqt_f2 __attribute__((ext_vector_type(2)));
 
 // 64 ADC sums of one tile: lane l returns the sum of vector l (without the coarse term).
 __device__ __forceinline__ float tile_adc(const char *lut_bytes, const uint4 A, const uint4 B,
@@ -34,9 +45,25 @@ __device__ __forceinline__ float tile_adc(const char *lut_bytes, const uint4 A, 
   float v[16];
   const uint32_t a[4] = {A.x, A.y, A.z, A.w};
   const uint32_t b[4] = {B.x, B.y, B.z, B.w};
+#if PQT_ADC_V2
+  // the 16 first-level sums as 8 packed fp32 adds (v_pk_add_f32: two IEEE adds per instruction,
+  // same bits); the DPP butterflies below have no packed form
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    pqt_f2 x, y;
+    x.x = lut_at(lut_bytes, a[r >> 2], r & 3, offA);
+    x.y = lut_at(lut_bytes, a[(r + 1) >> 2], (r + 1) & 3, offA);
+    y.x = lut_at(lut_bytes, b[r >> 2], r & 3, offB);
+    y.y = lut_at(lut_bytes, b[(r + 1) >> 2], (r + 1) & 3, offB);
+    const pqt_f2 z = x + y;
+    v[r] = z.x;
+    v[r + 1] = z.y;
+  }
+#else
 #pragma unroll
   for (int r = 0; r < 16; ++r)
     v[r] = lut_at(lut_bytes, a[r >> 2], r & 3, offA) + lut_at(lut_bytes, b[r >> 2], r & 3, offB);
+#endif
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = v[r] + dpp_mov<0x140>(v[r ^ 15]);   // row_mirror
 #pragma unroll

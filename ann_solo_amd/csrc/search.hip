@@ -341,6 +341,11 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
   pp.inflight = true;
   {
     StreamScope on_a(pp.A);
+    // The buffers of this parity were last read by the scan of batch i-2: the front of batch i
+    // starts when that scan ends, i.e. it runs under the RESCORING of batch i-2. Measured
+    // (profiles/r02_pipeline_ab.txt): holding it back until the batch has finished, so that it
+    // runs under the next scan instead, is worse -- the scan loses 1.3 ms to a 0.9 ms GEMM
+    // beside it (9.88 ms per step), the rescoring only 0.6 ms (9.35 ms).
     if (pp.scan_recorded[par]) HIP_TRY(hipStreamWaitEvent(pp.A, pp.ev_scan[par], 0));
     ASL_TRY(encode_device(Q.dev.mz, Q.dev.intensity, Q.dev.offsets, nq, P->min_bound, P->bin_size,
                           d, P->hash_seed, 1, L->p_qvec[par].p));

@@ -120,7 +120,8 @@ def test_index_cache_files(tmp_path, world):
     lib, aux, sl = world
     cfg = Config(**sl.config.__dict__)
     a = SpectralLibrary(lib, config=cfg, index_dir=str(tmp_path), basename='lib')
-    h7 = a._get_hyperparameter_hash()[:7]
+    h7 = a._get_index_hash()[:7]        # (== the reference's five-key hash for its own IVF-Flat setup)
+    assert (cfg.index == 'ivfflat') == (a._get_index_hash() == a._get_hyperparameter_hash())
     files = sorted(os.listdir(tmp_path))
     assert files == [f'lib_{h7}_{z}.idxmi' for z in (2, 3, 4)]
     for p in a.partitions.values():

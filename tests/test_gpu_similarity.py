@@ -74,7 +74,8 @@ def test_cosine_kernel_has_the_bits_of_feature_column_0():
     assert abs(one[0] - 0.44582117) < 1e-7
     with pytest.raises(Exception):
         bad = pairs.copy()
-        bad[1, 0, 0] = 10 ** 6
+        c = int(np.nonzero(cnt > 0)[0][0])       # a pair that is actually read
+        bad[c, 0, 0] = 10 ** 6
         sim.ssm_cosine(Q, L, np.arange(n, dtype=np.int32), bad, cnt)
 
 
