@@ -51,7 +51,8 @@ def main():
     ap.add_argument('--pq-m', type=int, default=32)
     ap.add_argument('--niter', type=int, default=25)
     ap.add_argument('--open-da', type=float, default=500.0)
-    ap.add_argument('--scan-variant', type=int, default=0, help='0 auto (tiled v2), 1 generic v1')
+    ap.add_argument('--scan-variant', type=int, default=0,
+                    help='A/B of scan kernels (asl_index_set_scan_variant); 0 = default')
     ap.add_argument('--recall-queries', type=int, default=2048)
     ap.add_argument('--no-pipeline', action='store_true',
                     help='run the stages of consecutive batches strictly one after the other '
@@ -118,8 +119,7 @@ def main():
     sl = SpectralLibrary(lib, config=cfg, device=dev)
     part = sl.partitions[charge]
     idx = sl._get_ann_index(charge)
-    if args.index == 'ivfpq':
-        idx.set_scan_variant(args.scan_variant)
+    idx.set_scan_variant(args.scan_variant)
     torch.cuda.synchronize()
     if rank == 0:
         log(f'[bench] library {lib.n} spectra, {lib.mz.numel()} peaks; index {args.index} '
