@@ -430,23 +430,15 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       }
       ASL_TRY(build_lists(ix));
       // variant 0: dimension-major postings; 2: sparse tiles; 1: dense GEMM + masked top-k
-      const bool use_inv = ix->has_inv && ((ix->scan_variant & 0xff) == 0 || (ix->scan_variant & 0xff) == 3) &&
+      const bool use_inv = ix->has_inv && (ix->scan_variant & 0xff) == 0 &&
                            flat_inv_supported(d, k, nprobe);
       if (use_inv || (ix->has_sparse && (ix->scan_variant & 0xff) != 1 &&
                       flat_sparse_supported(d, k, nprobe, ix->nnz_stride))) {
         if (use_inv) {
           ProfScope ps("scan");
-          // variant 3: block-major pass over the same postings (unsharded indexes; a shard's
-          // head lists are too short to give it a threshold)
-          int redo = 1;
-          if ((ix->scan_variant & 0xff) == 3 && ix->shard_world == 1 && flat_bm_supported(d, k, nprobe))
-            ASL_TRY(flat_bm_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->nlist, ix->list_offsets.p,
-                                 ix->blk_offsets.p, ix->inv_start.p, ix->inv_data.p, ix->ids.p, k,
-                                 D, I64, I32, &redo));
-          if (redo)
-            ASL_TRY(flat_inv_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
-                                  ix->blk_offsets.p, ix->inv_start.p, ix->inv_data.p,
-                                  ix->ids.p, k, D, I64, I32, set_mode || ix->unordered == 1));
+          ASL_TRY(flat_inv_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
+                                ix->blk_offsets.p, ix->inv_start.p, ix->inv_data.p,
+                                ix->ids.p, k, D, I64, I32, set_mode || ix->unordered == 1));
         } else {
           ProfScope ps("scan");
           ASL_TRY(flat_sparse_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,

@@ -63,13 +63,6 @@ int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int n
                   const int32_t *list_offsets, const int32_t *blk_offsets,
                   const uint32_t *seg_start, const uint32_t *seg_data, const int32_t *ids, int k,
                   float *D, int64_t *I64, int32_t *I32, int set_mode);
-// block-major exact IVF-Flat over the same postings (flat_bm_scan.hip); *fell_back = 1: nothing
-// was written, redo the batch with flat_inv_scan
-bool flat_bm_supported(int d, int k, int nprobe);
-int flat_bm_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe, int nlist,
-                 const int32_t *list_offsets, const int32_t *blk_offsets,
-                 const uint32_t *seg_start, const uint32_t *seg_data, const int32_t *ids, int k,
-                 float *D, int64_t *I64, int32_t *I32, int *fell_back);
 int inv_count(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk, int64_t n,
               uint32_t *cnt);
 int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk,
