@@ -546,6 +546,10 @@ int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, floa
                         int32_t *out_I) {
   return coarse_search(ix, xq, nq, nprobe, out_D, out_I);
 }
+int index_shard_world(const asl_index *ix, int *rank) {
+  if (rank) *rank = ix->shard_rank;
+  return ix->kind == ASL_INDEX_FLAT ? 0 : ix->shard_world;
+}
 
 }  // namespace asl
 

@@ -1,0 +1,148 @@
+// sharded.hip -- the list-sharded IVF search behind the C ABI, over an RCCL communicator the
+// CALLER owns (asl_index_shard(idx, rank, world, rcclComm)). The Python
+// engine drives the same exchange through torch.distributed (ann_solo_amd/distributed.py); this
+// entry point is for hosts that bind the C ABI directly.
+//
+// RCCL is not linked: the ncclXxx entry points are resolved at first use from the process
+// (a host that created a communicator has RCCL loaded already -- e.g. PyTorch's bundled copy) and
+// only then from librccl.so.1, so the library never drags a second RCCL into the process.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.hpp"
+#include "ivf_kernels.hpp"
+
+struct asl_index;
+
+namespace asl {
+int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
+                        int64_t *I64, int32_t *I32, const float *pre_D, const int32_t *pre_I,
+                        bool set_mode);
+int index_dim(const asl_index *ix);
+int index_nprobe(const asl_index *ix, int nprobe);
+int index_prepare(asl_index *ix);
+int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, float *out_D,
+                        int32_t *out_I);
+int index_shard_world(const asl_index *ix, int *rank);
+
+// the few RCCL declarations used (rccl.h: stable since NCCL 2.7)
+typedef void *nccl_comm_t;
+typedef int nccl_result_t;
+constexpr int NCCL_INT32 = 2, NCCL_INT64 = 4, NCCL_FLOAT32 = 7;
+struct Rccl {
+  nccl_result_t (*AllGather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
+  nccl_result_t (*Send)(const void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  nccl_result_t (*Recv)(void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  nccl_result_t (*GroupStart)() = nullptr;
+  nccl_result_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(nccl_result_t) = nullptr;
+  bool ok = false;
+};
+
+static Rccl &rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r;
+  tried = true;
+  // 1. ASL_RCCL_LIB (explicit path); 2. whatever RCCL the process exposes globally; 3. an
+  // instance that is loaded already under the usual soname; 4. a fresh load
+  void *h = nullptr;
+  if (const char *path = getenv("ASL_RCCL_LIB")) h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+  if (!h && dlsym(RTLD_DEFAULT, "ncclAllGather")) h = RTLD_DEFAULT;
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return r;
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+  r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend"));
+  r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(h, "ncclRecv"));
+  r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+  r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  r.ok = r.AllGather && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
+  return r;
+}
+
+#define RCCL_TRY(expr)                                                                        \
+  do {                                                                                        \
+    nccl_result_t r_ = (expr);                                                                \
+    if (r_ != 0)                                                                              \
+      return fail(ASL_ERR_HIP, "%s: %s", #expr, R.GetErrorString ? R.GetErrorString(r_) : "RCCL error"); \
+  } while (0)
+
+}  // namespace asl
+
+using namespace asl;
+
+// Every rank calls this with ITS nq queries (the same nq on every rank, device pointers) after
+// asl_index_shard(idx, rank, world) on an index holding the same vectors everywhere:
+//   all-gather of the hashed queries -> coarse quantiser on the own slice, probe lists
+//   all-gathered -> scan of the local inverted lists for all world x nq queries (exact top-k
+//   sets) -> all-to-all of the per-shard rows (grouped send/recv: direct peer copies over xGMI)
+//   -> k-way merge under (score desc, id asc).
+// D / I [nq, k]: identical to what the unsharded index returns for these queries.
+extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_t nq,
+                                        const float *xq, int32_t k, int32_t nprobe, float *D,
+                                        int64_t *I) {
+  clear_error();
+  if (!ix || !rccl_comm || !xq || !I) return fail(ASL_ERR_INVALID, "search_sharded: null argument");
+  if (nq <= 0) return fail(ASL_ERR_INVALID, "search_sharded: every rank must bring nq > 0 queries");
+  if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search_sharded: k=%d outside 1..%d", k, TK_MAX_K);
+  ASL_TRY(ensure_device());
+  int rank = 0;
+  const int world = index_shard_world(ix, &rank);
+  if (world < 1) return fail(ASL_ERR_STATE, "search_sharded: call asl_index_shard first");
+  if (!is_device_ptr(xq) || !is_device_ptr(I) || (D && !is_device_ptr(D)))
+    return fail(ASL_ERR_INVALID, "search_sharded: queries and results must be device memory");
+  Rccl &R = rccl();
+  if (!R.ok) return fail(ASL_ERR_STATE, "search_sharded: RCCL (librccl.so.1) is not available in this process");
+  const int d = index_dim(ix);
+  const int np = index_nprobe(ix, nprobe);
+  if (np <= 0) return fail(ASL_ERR_INVALID, "search_sharded: an IVF index is required");
+  ASL_TRY(index_prepare(ix));
+  const size_t all = (size_t)world * nq;
+  static DevBuf<float> &x_all = *new DevBuf<float>(), &cD = *new DevBuf<float>(),
+                       &cD_all = *new DevBuf<float>(), &Dp = *new DevBuf<float>(),
+                       &Dr = *new DevBuf<float>(), &Dtmp = *new DevBuf<float>();
+  static DevBuf<int32_t> &cI = *new DevBuf<int32_t>(), &cI_all = *new DevBuf<int32_t>();
+  static DevBuf<int64_t> &Ip = *new DevBuf<int64_t>(), &Ir = *new DevBuf<int64_t>();
+  ASL_TRY(x_all.reserve(all * d));
+  ASL_TRY(cD.reserve((size_t)nq * np));
+  ASL_TRY(cI.reserve((size_t)nq * np));
+  ASL_TRY(cD_all.reserve(all * np));
+  ASL_TRY(cI_all.reserve(all * np));
+  ASL_TRY(Dp.reserve(all * k));
+  ASL_TRY(Ip.reserve(all * k));
+  ASL_TRY(Dr.reserve(all * k));
+  ASL_TRY(Ir.reserve(all * k));
+  hipStream_t st = stream();
+  nccl_comm_t comm = rccl_comm;
+  // 1. everybody's queries; the coarse quantiser runs on the own slice meanwhile (same stream:
+  //    RCCL orders itself after it; a second stream would overlap the two)
+  RCCL_TRY(R.AllGather(xq, x_all.p, (size_t)nq * d, NCCL_FLOAT32, comm, st));
+  ASL_TRY(index_coarse_device(ix, nq, xq, np, cD.p, cI.p));
+  RCCL_TRY(R.AllGather(cD.p, cD_all.p, (size_t)nq * np, NCCL_FLOAT32, comm, st));
+  RCCL_TRY(R.AllGather(cI.p, cI_all.p, (size_t)nq * np, NCCL_INT32, comm, st));
+  // 2. the local lists, for all queries (rank-major rows), as exact top-k sets
+  ASL_TRY(index_search_device(ix, (int)all, x_all.p, k, np, Dp.p, Ip.p, nullptr, cD_all.p, cI_all.p, true));
+  // 3. rank r receives the `world` partial rows of its own queries
+  RCCL_TRY(R.GroupStart());
+  for (int r = 0; r < world; ++r) {
+    RCCL_TRY(R.Send(Dp.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_FLOAT32, r, comm, st));
+    RCCL_TRY(R.Recv(Dr.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_FLOAT32, r, comm, st));
+    RCCL_TRY(R.Send(Ip.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_INT64, r, comm, st));
+    RCCL_TRY(R.Recv(Ir.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_INT64, r, comm, st));
+  }
+  RCCL_TRY(R.GroupEnd());
+  // 4. merge
+  float *Dout = D;
+  if (!Dout) {
+    ASL_TRY(Dtmp.reserve((size_t)nq * k));
+    Dout = Dtmp.p;
+  }
+  ASL_TRY(topk_merge(Dr.p, Ir.p, world, nq, k, Dout, I));
+  return ASL_OK;
+}

@@ -145,6 +145,16 @@ int asl_index_set_unordered(asl_index_t *idx, int32_t mode);
 int asl_topk_merge_keys(int32_t S, int32_t nq, int32_t k, const int64_t *Ks, float *D, int64_t *I,
                         int32_t unordered);
 int asl_index_shard(asl_index_t *idx, int32_t rank, int32_t world);
+/* The sharded search itself, for hosts that bind the C ABI directly: every rank
+ * of `rccl_comm` (an ncclComm_t the caller created; one rank per GPU) calls this with ITS nq
+ * queries -- the same nq everywhere, device pointers only -- after asl_index_shard(idx, rank,
+ * world) on an index that was filled identically on every rank. All-gather of the queries and of
+ * the probe lists, scan of the local inverted lists for all world x nq queries, grouped
+ * send/recv of the per-shard top-k (all-to-all), merge: D / I [nq, k] equal the unsharded
+ * index's rows for these queries. Enqueued on the library's stream; RCCL is resolved from the
+ * process at first use (never linked). */
+int asl_index_search_sharded(asl_index_t *idx, void *rccl_comm, int32_t nq, const float *xq,
+                             int32_t k, int32_t nprobe, float *D, int64_t *I);
 /* 1 if asl_index_search_preassigned can emit packed keys (unordered mode 2) for this index at
  * (k, nprobe) -- the tiled IVF-PQ scan: m = 32, 8-bit codes, automatic scan variant, nprobe
  * within the tiled kernel's limit, k + 768 <= 2048 --, else 0 (exchange (D, I) rows then). */

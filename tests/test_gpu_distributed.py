@@ -154,6 +154,63 @@ def test_rccl_collectives_at_world_one(index, tmp_path):
     assert 'rccl-world1-ok' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
 
 
+_RCCL_CABI = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+torch.cuda.set_device(0)
+# the communicator comes from the host application -- here: the RCCL copy PyTorch ships, made
+# visible process-wide so that libannsolo_mi resolves the very same instance
+rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'), mode=C.RTLD_GLOBAL)
+class UID(C.Structure):
+    _fields_ = [('b', C.c_char * 128)]
+uid, comm = UID(), C.c_void_p()
+assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+from ann_solo_amd import _lib, synthetic
+from ann_solo_amd.spectral_library import Config, SpectralLibrary
+dev = torch.device('cuda', 0)
+lib, aux = synthetic.make_library(20000, seed=5, device=dev, charges=(2,), charge_p=(1.0,))
+q, _ = synthetic.make_queries(lib, aux, 300, seed=6, open_range=300.0, charge=2)
+L = _lib.lib()
+for index in ('ivfpq', 'ivfflat'):
+    sl = SpectralLibrary(lib, config=Config(num_list=64, num_probe=16, num_candidates=256, index=index,
+                                            kmeans_niter=4), device=dev)
+    idx = sl._get_ann_index(2)
+    vec = sl._encode(q)
+    idx.nprobe = 16
+    D0, I0 = idx.search(vec, 256)
+    # unsharded handles are refused, then the real thing at world 1
+    D = torch.empty((q.n, 256), dtype=torch.float32, device=dev)
+    I = torch.empty((q.n, 256), dtype=torch.int64, device=dev)
+    idx.shard(0, 1)
+    rc = L.asl_index_search_sharded(idx._h, comm, q.n, _lib.ptr(vec), 256, 16, _lib.ptr(D), _lib.ptr(I))
+    assert rc == 0, L.asl_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(I, I0) and torch.equal(D, D0), index
+    # host pointers and missing communicators are errors, not crashes
+    assert L.asl_index_search_sharded(idx._h, None, q.n, _lib.ptr(vec), 256, 16, _lib.ptr(D), _lib.ptr(I)) < 0
+    host = np.zeros((q.n, 256), np.int64)
+    assert L.asl_index_search_sharded(idx._h, comm, q.n, _lib.ptr(vec), 256, 16, _lib.ptr(D), _lib.ptr(host)) < 0
+    sl.shutdown()
+rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+rccl.ncclCommDestroy(comm)
+print('rccl-cabi-ok')
+'''
+
+
+def test_c_abi_sharded_search_over_a_caller_owned_rccl_communicator(tmp_path):
+    """asl_index_search_sharded (SURVEY.md 8 b2: the rcclComm form of the boundary): RCCL
+    all-gathers + grouped send/recv issued from inside the library on a communicator the host
+    created; at world 1 every collective still goes through RCCL and the result must equal the
+    unsharded search bit for bit."""
+    script = tmp_path / 'rccl_cabi.py'
+    script.write_text(_RCCL_CABI)
+    out = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert 'rccl-cabi-ok' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
 def test_search_preassigned_equals_search():
     import torch
     from ann_solo_amd import synthetic
