@@ -96,6 +96,16 @@ struct asl_index {
   int scan_variant = 0;  // 0 = auto (v2 when supported), 1 = force v1
   int unordered = 0;  // 1: search rows = exact top-k as a set, unspecified order (no final sort); 2: rows of packed keys
   bool lists_dirty = true;
+  // exact re-rank of the IVF-PQ short-list (refine.hip): sparse copies of the added vectors,
+  // add order = global id; kept whole on every shard
+  int refine_k = 0;            // 0 = off; else the short-list size k' (> k) that is re-ranked
+  bool refine_rows = false;    // rows are being stored on add()
+  bool refine_bad = false;     // a vector had more non-zeros than a row holds
+  int64_t r_n = 0;
+  DevBuf<uint16_t> r_dim;
+  DevBuf<float> r_val;
+  DevBuf<uint8_t> r_cnt;
+  DevBuf<int32_t> ws_short;
   // scratch
   DevBuf<float> ws_scores, coarse_D, ws_x;
   DevBuf<int32_t> coarse_I, ws_assign;
@@ -490,6 +500,26 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
     HIP_TRY(hipMemcpyAsync(ix->coarse_D.p, pre_D, (size_t)nq * nprobe * 4, hipMemcpyDeviceToDevice, stream()));
     HIP_TRY(hipMemcpyAsync(ix->coarse_I.p, pre_I, (size_t)nq * nprobe * 4, hipMemcpyDeviceToDevice, stream()));
   }
+  // exact re-rank: the ADC scan returns k' > k candidates as a set, refine.hip keeps the k best
+  const bool refine = ix->refine_k > k && ix->refine_rows && ix->unordered == 0;
+  float *fin_D = D;
+  int64_t *fin_I64 = I64;
+  int32_t *fin_I32 = I32;
+  const int k_out = k;
+  if (refine) {
+    if (ix->refine_bad)
+      return fail(ASL_ERR_CAPACITY, "search: refine is unavailable, a stored vector has more than %d non-zeros",
+                  refine_stride());
+    if (ix->r_n != ix->ntotal)
+      return fail(ASL_ERR_STATE, "search: refine rows cover %lld of %lld vectors (enable refine before add)",
+                  (long long)ix->r_n, (long long)ix->ntotal);
+    k = std::min(ix->refine_k, (int)TK_MAX_K);
+    ASL_TRY(ix->ws_short.reserve((size_t)nq * k));
+    D = nullptr;
+    I64 = nullptr;
+    I32 = ix->ws_short.p;
+    set_mode = true;
+  }
   {
     ProfScope ps("scan");
     const int sv = ix->scan_variant & 0xff;
@@ -527,6 +557,11 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
     // vectors scored by this launch, summed on the device (nothing waits inside a step)
     if (unsigned long long *acc = prof_scanned_dev())
       ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
+  }
+  if (refine) {
+    ProfScope ps("refine");
+    ASL_TRY(refine_topk(xq, nq, d, ix->ws_short.p, nullptr, k, ix->r_dim.p, ix->r_val.p, ix->r_cnt.p, ix->r_n,
+                        k_out, fin_D, fin_I64, fin_I32));
   }
   return ASL_OK;
 }
@@ -692,6 +727,31 @@ int asl_index_add(asl_index_t *ix, int64_t n, const float *x) {
                       ix->ksub, ix->dsub, codes.p));
     ASL_TRY(dev_append(ix->codes_add, (size_t)ix->n_store * ix->pq_m, codes.p, (size_t)n * ix->pq_m));
     ASL_TRY(sync_stream());
+    if (ix->refine_rows) {
+      const size_t S = (size_t)refine_stride(), have = (size_t)ix->r_n, want = have + (size_t)n;
+      auto grow = [&](auto &buf, size_t per) -> int {
+        using T = typename std::remove_reference<decltype(*buf.p)>::type;
+        if (want * per <= buf.cap) return ASL_OK;
+        DevBuf<T> nb;
+        ASL_TRY(nb.reserve(std::max(want * per, buf.cap + buf.cap / 2)));
+        if (have) HIP_TRY(hipMemcpyAsync(nb.p, buf.p, have * per * sizeof(T), hipMemcpyDeviceToDevice, stream()));
+        ASL_TRY(sync_stream());
+        buf = std::move(nb);
+        return ASL_OK;
+      };
+      ASL_TRY(grow(ix->r_dim, S));
+      ASL_TRY(grow(ix->r_val, S));
+      ASL_TRY(grow(ix->r_cnt, 1));
+      DevBuf<int> st;
+      ASL_TRY(st.reserve(1));
+      HIP_TRY(hipMemsetAsync(st.p, 0, sizeof(int), stream()));
+      ASL_TRY(refine_append_rows(dx.d, n, ix->d, ix->r_n, ix->r_dim.p, ix->r_val.p, ix->r_cnt.p, st.p));
+      int h = 0;
+      HIP_TRY(hipMemcpyAsync(&h, st.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+      ASL_TRY(sync_stream());
+      if (h) ix->refine_bad = true;
+      ix->r_n += n;
+    }
   } else {
     ASL_TRY(dev_append(ix->vecs, (size_t)ix->n_store * ix->d, dx.d, (size_t)n * ix->d));
   }
@@ -699,6 +759,46 @@ int asl_index_add(asl_index_t *ix, int64_t n, const float *x) {
   ix->n_store += n;
   ix->ntotal += n;
   ix->lists_dirty = true;
+  return ASL_OK;
+}
+
+int asl_index_set_refine(asl_index_t *ix, int32_t kprime) {
+  clear_error();
+  if (!ix) return fail(ASL_ERR_INVALID, "set_refine: null index");
+  if (ix->kind != ASL_INDEX_IVFPQ) return fail(ASL_ERR_INVALID, "set_refine: an IVF-PQ index is required");
+  if (kprime < 0 || kprime > TK_MAX_K) return fail(ASL_ERR_INVALID, "set_refine: k' must be in 0..%d", TK_MAX_K);
+  if (kprime > 0 && !ix->refine_rows) {
+    if (ix->ntotal > 0)
+      return fail(ASL_ERR_STATE, "set_refine: enable before add() (the exact rows are stored as vectors arrive)");
+    ix->refine_rows = true;
+  }
+  ix->refine_k = kprime;
+  return ASL_OK;
+}
+
+int asl_index_refine(asl_index_t *ix, int32_t nq, const float *xq, int32_t kp, const int64_t *I_in,
+                     int32_t k, float *D, int64_t *I) {
+  clear_error();
+  if (!ix || !xq || !I_in || !I) return fail(ASL_ERR_INVALID, "refine: null argument");
+  if (!ix->refine_rows || ix->r_n != ix->ntotal)
+    return fail(ASL_ERR_STATE, "refine: the index stores no exact rows (asl_index_set_refine before add)");
+  if (ix->refine_bad) return fail(ASL_ERR_CAPACITY, "refine: a stored vector has more than %d non-zeros", refine_stride());
+  if (nq <= 0) return ASL_OK;
+  if (k <= 0 || k > kp || kp > TK_MAX_K) return fail(ASL_ERR_INVALID, "refine: need 0 < k <= k' <= %d", TK_MAX_K);
+  ASL_TRY(ensure_device());
+  In<float> dq;
+  In<int64_t> dI;
+  Out<float> oD;
+  Out<int64_t> oI;
+  ASL_TRY(dq.init(xq, (size_t)nq * ix->d));
+  ASL_TRY(dI.init(I_in, (size_t)nq * kp));
+  ASL_TRY(oD.init(D, (size_t)nq * k));
+  ASL_TRY(oI.init(I, (size_t)nq * k));
+  ASL_TRY(refine_topk(dq.d, nq, ix->d, nullptr, dI.d, kp, ix->r_dim.p, ix->r_val.p, ix->r_cnt.p, ix->r_n,
+                      k, oD.d, oI.d, nullptr));
+  ASL_TRY(oD.finish());
+  ASL_TRY(oI.finish());
+  if (oD.to_host() || oI.to_host() || dq.own.p || dI.own.p) ASL_TRY(sync_stream());
   return ASL_OK;
 }
 
@@ -713,6 +813,8 @@ int asl_index_reset(asl_index_t *ix) {
   ix->ws_scores.release();
   ix->ntotal = 0;
   ix->n_store = 0;
+  ix->r_n = 0;
+  ix->refine_bad = false;
   ix->has_vids = false;
   ix->shard_rank = 0;
   ix->shard_world = 1;
@@ -1050,6 +1152,7 @@ int asl_index_save(const asl_index_t *ix, const char *path) {
   h.shard_rank = ix->shard_rank;
   h.shard_world = ix->shard_world;
   h.has_vids = ix->has_vids;
+  h.pad = ix->refine_rows ? (1 | (ix->refine_k << 1)) : 0;   // exact rows follow the payload
   bool ok = fwrite(&h, sizeof h, 1, f) == 1;
   auto dump = [&](const void *dev, size_t bytes) {
     if (!ok || bytes == 0) return;
@@ -1070,6 +1173,12 @@ int asl_index_save(const asl_index_t *ix, const char *path) {
     dump(ix->codes_add.p, n * ix->pq_m);
   else
     dump(ix->vecs.p, n * ix->d * 4);
+  if (ix->refine_rows) {
+    const size_t rn = (size_t)ix->r_n, S = (size_t)refine_stride();
+    dump(ix->r_cnt.p, rn);
+    dump(ix->r_dim.p, rn * S * 2);
+    dump(ix->r_val.p, rn * S * 4);
+  }
   ok = (fclose(f) == 0) && ok;
   if (!ok) return fail(ASL_ERR_IO, "save: write to %s failed", path);
   return ASL_OK;
@@ -1107,6 +1216,7 @@ asl_index_t *asl_index_load(const char *path) {
     else if (h.niter < 0 || (h.trained != 0 && h.trained != 1) || (h.has_vids != 0 && h.has_vids != 1)) bad = "bad flags";
     else if (h.shard_world < 1 || h.shard_rank < 0 || h.shard_rank >= h.shard_world) bad = "bad shard fields";
     else if (!h.trained && h.n_store > 0 && ivf) bad = "vectors in an untrained index";
+    else if (h.pad < 0 || ((h.pad & 1) && h.kind != ASL_INDEX_IVFPQ) || (h.pad >> 1) > TK_MAX_K) bad = "bad refine fields";
     if (!bad) {  // the payload must be exactly what the header announces
       const uint64_t ksub = h.kind == ASL_INDEX_IVFPQ ? (1ull << h.pq_bits) : 0;
       uint64_t want = sizeof h;
@@ -1115,6 +1225,7 @@ asl_index_t *asl_index_load(const char *path) {
       if (ivf) want += (uint64_t)h.n_store * 4;
       if (h.has_vids) want += (uint64_t)h.n_store * 4;
       want += h.kind == ASL_INDEX_IVFPQ ? (uint64_t)h.n_store * h.pq_m : (uint64_t)h.n_store * h.d * 4;
+      if (h.pad & 1) want += (uint64_t)h.ntotal * (1 + (uint64_t)refine_stride() * 6);
       const long here = ftell(f);
       if (fseek(f, 0, SEEK_END) != 0 || (uint64_t)ftell(f) != want) bad = "file size does not match the header";
       fseek(f, here, SEEK_SET);
@@ -1164,6 +1275,17 @@ asl_index_t *asl_index_load(const char *path) {
     slurp(ix->codes_add, n * ix->pq_m);
   else
     slurp(ix->vecs, n * ix->d);
+  if (h.pad & 1) {
+    const size_t rn = (size_t)ix->ntotal, S = (size_t)refine_stride();
+    ix->refine_rows = true;
+    ix->refine_k = h.pad >> 1;
+    ix->r_n = ix->ntotal;
+    if (rn) {
+      slurp(ix->r_cnt, rn);
+      slurp(ix->r_dim, rn * S);
+      slurp(ix->r_val, rn * S);
+    }
+  }
   fclose(f);
   if (ok && ix->n_store > 0 && (ix->kind != ASL_INDEX_FLAT || ix->has_vids)) {
     // list assignments / global ids index host and device arrays later: range-check them now

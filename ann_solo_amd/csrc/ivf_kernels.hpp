@@ -63,6 +63,13 @@ int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int n
                   const int32_t *list_offsets, const int32_t *blk_offsets,
                   const uint32_t *seg_start, const uint32_t *seg_data, const int32_t *ids, int k,
                   float *D, int64_t *I64, int32_t *I32, int set_mode);
+// exact re-rank of a short-list against sparse stored rows (refine.hip)
+int refine_stride();
+int refine_append_rows(const float *x, int64_t n, int d, int64_t row0, uint16_t *r_dim, float *r_val,
+                       uint8_t *r_cnt, int *status);
+int refine_topk(const float *xq, int nq, int d, const int32_t *I_in, const int64_t *I_in64, int kp,
+                const uint16_t *r_dim, const float *r_val, const uint8_t *r_cnt, int64_t n_rows, int k, float *D,
+                int64_t *I64, int32_t *I32);
 int inv_count(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk, int64_t n,
               uint32_t *cnt);
 int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk,

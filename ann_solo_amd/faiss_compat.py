@@ -181,6 +181,27 @@ class Index:
         _lib.check(_lib.lib().asl_index_pq_lut(self._h, x.shape[0], _lib.ptr(x), _lib.ptr(lut)))
         return lut
 
+    def set_refine(self, kprime: int):
+        """IVF-PQ: re-rank the ``kprime`` best ADC candidates with the exact inner product and
+        return the k best (FAISS ``IndexRefineFlat``); call before ``add``. 0 switches it off."""
+        _lib.check(_lib.lib().asl_index_set_refine(self._h, int(kprime)))
+
+    def refine(self, x, I_in, k):
+        """Exact re-rank of a short-list obtained elsewhere: (D [nq,k], I [nq,k])."""
+        x = _as_f32(x, self.d)
+        nq, kp = I_in.shape
+        if isinstance(x, np.ndarray):
+            I_in = np.ascontiguousarray(I_in, np.int64)
+            D, I = np.empty((nq, k), np.float32), np.empty((nq, k), np.int64)
+        else:
+            import torch
+            I_in = I_in.to(torch.int64).contiguous()
+            D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+        _lib.check(_lib.lib().asl_index_refine(self._h, nq, _lib.ptr(x), int(kp), _lib.ptr(I_in),
+                                               int(k), _lib.ptr(D), _lib.ptr(I)))
+        return D, I
+
     def set_unordered(self, mode=True):
         """Result rows as exact top-k SETS (unspecified order, no final sort). ``mode`` 2 packs
         every hit into one 64-bit key in the id output (see ``search_preassigned_keys``)."""

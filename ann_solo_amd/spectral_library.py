@@ -73,6 +73,7 @@ class Config:
     pq_bits: int = 8
     kmeans_niter: int = 25
     seed: int = 1234
+    refine_k: Optional[int] = None          # IVF-PQ: exact re-rank of the refine_k best ADC candidates
 
     def __getitem__(self, k):
         return getattr(self, k)
@@ -265,6 +266,8 @@ class SpectralLibrary:
         d.update(index=cfg.index, kmeans_niter=cfg.kmeans_niter, seed=cfg.seed)
         if cfg.index == 'ivfpq':
             d.update(pq_m=cfg.pq_m, pq_bits=cfg.pq_bits)
+            if cfg.refine_k:
+                d.update(refine_k=cfg.refine_k)
         return hashlib.sha1(json.dumps(d).encode('utf-8')).hexdigest()
 
     def _encode(self, spectra: PackedSpectra) -> torch.Tensor:
@@ -288,6 +291,8 @@ class SpectralLibrary:
                                                faiss.METRIC_INNER_PRODUCT)
             ann_index.seed = cfg.seed
             ann_index.set_niter(cfg.kmeans_niter)
+            if cfg.index == 'ivfpq' and cfg.refine_k:
+                ann_index.set_refine(cfg.refine_k)
             ann_index.train(vectors)
             ann_index.add(vectors)
             if self._index_dir is not None:

@@ -54,6 +54,9 @@ def main():
     ap.add_argument('--scan-variant', type=int, default=0,
                     help='A/B of scan kernels (asl_index_set_scan_variant); 0 = default')
     ap.add_argument('--recall-queries', type=int, default=2048)
+    ap.add_argument('--refine-k', type=int, default=0,
+                    help="IVF-PQ: exact re-rank of the k' best ADC candidates (asl_index_set_refine); "
+                         '0 = off (the default workload)')
     ap.add_argument('--no-pipeline', action='store_true',
                     help='run the stages of consecutive batches strictly one after the other '
                          '(default: two-stream software pipeline, asl_set_pipeline)')
@@ -115,7 +118,7 @@ def main():
     cfg = Config(num_list=args.nlist, num_probe=args.nprobe, num_candidates=args.k,
                  index=args.index, pq_m=args.pq_m, kmeans_niter=args.niter, mode='ann',
                  precursor_tolerance_mass_open=args.open_da, precursor_tolerance_mode_open='Da',
-                 batch_size=args.batch, seed=1234)
+                 batch_size=args.batch, seed=1234, refine_k=args.refine_k or None)
     sl = SpectralLibrary(lib, config=cfg, device=dev)
     part = sl.partitions[charge]
     idx = sl._get_ann_index(charge)
@@ -263,7 +266,7 @@ def main():
     sl.set_pipeline(False)
 
     stages = {}
-    for name in ('encode', 'coarse_gemm', 'coarse_select', 'scan', 'filter', 'rescore',
+    for name in ('encode', 'coarse_gemm', 'coarse_select', 'scan', 'refine', 'filter', 'rescore',
                  'rescore_matches'):
         ms, n = C.c_double(), C.c_int64()
         L.asl_profile_get(name.encode(), C.byref(ms), C.byref(n))
@@ -326,11 +329,12 @@ def main():
             'config': {'workload': f'configs[2]: MassIVE-KB-scale synthetic library '
                                    f'({args.library_size} spectra, one charge-{charge} partition), '
                                    f'{args.index} m={args.pq_m} nlist={args.nlist} nprobe={args.nprobe} '
-                                   f'k={args.k}, open +-{args.open_da:g} Da, shifted dot, '
+                                   f'k={args.k}{f" (exact re-rank of {args.refine_k})" if args.refine_k else ""}, open +-{args.open_da:g} Da, shifted dot, '
                                    f'fragment tol 0.02 Da',
                        'library_size': args.library_size, 'batch_per_gpu': args.batch,
                        'global_batch': world * args.batch, 'index': args.index,
                        'nlist': args.nlist, 'nprobe': args.nprobe, 'k': args.k,
+                       'refine_k': args.refine_k or None,
                        'parallelism': 'single' if world == 1 else
                        (f'ivf-list-shard x{degree}' if degree == world else
                         f'replicas x{world}' if degree == 1 else

@@ -101,6 +101,16 @@ asl_index_t *asl_index_load(const char *path);
 /* k-means iterations (FAISS ClusteringParameters.niter, default 25) */
 int asl_index_set_niter(asl_index_t *idx, int32_t niter);
 
+/* Exact re-rank of the IVF-PQ short-list (FAISS IndexRefineFlat's role). kprime > 0, set BEFORE
+ * add(): the index also keeps every added vector as a sparse fp32 row (<= 64 non-zeros, 384 B),
+ * and asl_index_search / asl_search_batch with k < kprime let the ADC scan return kprime
+ * candidates, rescore them with the exact inner product and return the k best, (score desc, id
+ * asc) -- for the vectors it reaches, IVF-Flat's scores. kprime = 0 switches the re-rank off (the
+ * rows stay). asl_index_refine re-ranks a short-list obtained elsewhere (e.g. merged shard rows). */
+int asl_index_set_refine(asl_index_t *idx, int32_t kprime);
+int asl_index_refine(asl_index_t *idx, int32_t nq, const float *xq, int32_t kprime,
+                     const int64_t *I_in /* [nq,kprime], -1 = empty */, int32_t k, float *D, int64_t *I);
+
 /* PQ scan kernel selection (all return identical results; the switch exists for A/B
  * measurements): 0 = automatic (tiled sub-quantiser-per-lane kernel with histogram top-k
  * when m = 32, 8 bits, nprobe <= 256), 1 = generic lane-per-vector kernel, 2 = tiled kernel

@@ -584,6 +584,32 @@ void orc_flat_search(const float *xb, int64_t nb, const float *xq, int32_t nq, i
   }
 }
 
+/* FAISS IndexRefineFlat restated: the ids of a short-list (any order, -1 = empty) are rescored
+ * with the exact inner product against the stored vectors and the k best are returned,
+ * (score desc, id asc), -1 / -FLT_MAX padded. */
+void orc_refine(const float *xb, const float *xq, int32_t nq, int32_t d, const int64_t *I_in,
+                int32_t kp, int32_t k, float *D, int64_t *I) {
+#pragma omp parallel
+  {
+    orc_hit_t *heap = (orc_hit_t *)malloc(sizeof(orc_hit_t) * (size_t)(k > 0 ? k : 1));
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)d);
+    float *val = (float *)malloc(sizeof(float) * (size_t)d);
+#pragma omp for schedule(dynamic, 4)
+    for (int32_t q = 0; q < nq; q++) {
+      orc_topk_t t = {heap, 0, k};
+      int nnz = sparsify(xq + (size_t)q * d, d, idx, val);
+      for (int32_t c = 0; c < kp; c++) {
+        int64_t id = I_in[(size_t)q * kp + c];
+        if (id >= 0) topk_push(&t, ip_sparse_q(idx, val, nnz, xb + (size_t)id * d), id);
+      }
+      topk_finish(&t, D + (size_t)q * k, I + (size_t)q * k);
+    }
+    free(heap);
+    free(idx);
+    free(val);
+  }
+}
+
 /* ------------------------------------------------------------------------ */
 /* k-means (FAISS Clustering restated: Lloyd, quantizer-metric assignment,   */
 /* mean update, empty-cluster split with eps = 1/1024)                       */

@@ -112,6 +112,8 @@ void orc_flat_search(const float *xb, int64_t nb, const float *xq, int32_t nq, i
 /* ---- k-means / IVF / PQ (restated FAISS definitions) ------------------- */
 #define ORC_METRIC_IP 0
 #define ORC_METRIC_L2 1
+void orc_refine(const float *xb, const float *xq, int32_t nq, int32_t d, const int64_t *I_in,
+                int32_t kp, int32_t k, float *D, int64_t *I);
 void orc_rand_perm(int64_t n, uint64_t seed, int64_t *perm);
 void orc_kmeans(const float *x, int64_t n, int32_t d, int32_t k, int32_t niter,
                 uint64_t seed, int metric, int32_t max_points_per_centroid,

@@ -365,6 +365,17 @@ class HostIVF:
         return D, I
 
 
+def refine(xb, xq, I_in, k):
+    """Exact re-rank of a short-list (FAISS IndexRefineFlat): (D [nq,k], I [nq,k])."""
+    xb, xq, I_in = _c(xb, np.float32), _c(xq, np.float32), _c(I_in, np.int64)
+    nq, kp = I_in.shape
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    lib().orc_refine(_p(xb, c_f32p), _p(xq, c_f32p), C.c_int32(nq), C.c_int32(xb.shape[1]),
+                     _p(I_in, c_i64p), C.c_int32(kp), C.c_int32(k), _p(D, c_f32p), _p(I, c_i64p))
+    return D, I
+
+
 def topk_merge(Ds, Is):
     Ds, Is = _c(Ds, np.float32), _c(Is, np.int64)
     S, nq, k = Ds.shape

@@ -1,0 +1,118 @@
+"""Exact re-rank of the IVF-PQ short-list (asl_index_set_refine / refine.hip; FAISS
+IndexRefineFlat's role) against the oracle: the ADC scan's k' candidates rescored with the exact
+fp32 inner product, the k best kept -- ids and scores bit for bit, through search(), the fused
+batch, the stand-alone entry and a save/load round trip."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def world(O):
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    lib, aux = synthetic.make_library(60000, seed=51, device='cpu', charges=(2,), charge_p=(1.0,))
+    cfg = Config(num_list=256, num_probe=32, num_candidates=256, index='ivfpq', kmeans_niter=4,
+                 refine_k=1024, precursor_tolerance_mass_open=500.0, precursor_tolerance_mode_open='Da')
+    sl = SpectralLibrary(lib, config=cfg)
+    q, _ = synthetic.make_queries(lib, aux, 400, seed=52, open_range=500.0, charge=2)
+    part = sl.partitions[2]
+    xb = sl._encode(part.spectra).cpu().numpy()
+    xq = sl._encode(q.to('cuda')).cpu().numpy()
+    idx = sl._get_ann_index(2)
+    off, ids, codes = idx.lists()
+    info = idx.info()
+    ivf = O.HostIVF.__new__(O.HostIVF)
+    ivf.centroids, ivf.nlist, ivf.d = idx.centroids(), info.nlist, info.d
+    ivf.list_offsets, ivf.ids, ivf.payload, ivf.codebooks, ivf.kind = off, ids, codes, idx.codebooks(), 1
+    yield sl, q, xb, xq, ivf
+    sl.shutdown()
+
+
+@pytest.mark.parametrize('k,kp', [(256, 1024), (100, 512), (1024, 2048), (1, 300), (512, 513)])
+def test_refined_search_equals_the_oracle(O, world, k, kp):
+    sl, q, xb, xq, ivf = world
+    idx = sl._get_ann_index(2)
+    idx.nprobe = 32
+    idx.set_refine(kp)
+    try:
+        D, I = idx.search(xq, k)
+    finally:
+        idx.set_refine(1024)
+    _, I_short = ivf.search(xq, kp, 32)                   # the ADC short-list (order is irrelevant)
+    Do, Io = O.refine(xb, xq, I_short, k)
+    assert np.array_equal(I, Io)
+    assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    # the scores are the exact inner products (IVF-Flat's numbers), not ADC estimates
+    row = I[7][I[7] >= 0]
+    exact = np.array([O.ip(xq[7], xb[r]) for r in row], np.float32)
+    assert np.array_equal(D[7][:len(row)].view(np.uint32), exact.view(np.uint32))
+
+
+def test_refine_raises_recall_and_costs_no_identifications(O, world):
+    sl, q, xb, xq, ivf = world
+    idx = sl._get_ann_index(2)
+    idx.nprobe = 32
+    k = 256
+    De, Ie = O.flat_search(xb, xq, k)
+    idx.set_refine(0)
+    _, I_pq = idx.search(xq, k)
+    idx.set_refine(1024)
+    _, I_rf = idx.search(xq, k)
+    rec = lambda I: np.mean([len(np.intersect1d(I[i][I[i] >= 0], Ie[i])) / k for i in range(len(Ie))])
+    assert rec(I_rf) > rec(I_pq) + 0.03
+    # the fused batch consumes the refined neighbour list: winners == the oracle's best match over it
+    res = sl._search_batch(q, 2, 'open', want_knn=True)
+    assert np.array_equal(res.knn, I_rf)
+    part = sl.partitions[2]
+    Q, L = O.Spectra(*q.numpy()), O.Spectra(*part.spectra.to('cpu').numpy())
+    for i in range(0, q.n, 25):
+        cand = np.sort(np.array([r for r in res.knn[i] if r >= 0 and O.precursor_ok(
+            float(q.precursor_mz[i]), part.precursor_mz[r], 2, 500.0, 'Da')], np.int64))
+        b, s, _ = O.best_match(Q, i, L, cand, 0.02, True)
+        assert (res.best_row[i] == (cand[b] if b >= 0 else -1)) and (b < 0 or res.best_score[i] == s)
+    assert np.array_equal(sl._search_batch(q, 2, 'open').best_row, res.best_row)
+
+
+def test_standalone_entry_round_trip_and_errors(O, world, tmp_path):
+    from ann_solo_amd import faiss_compat as faiss
+    from ann_solo_amd._lib import AnnSoloMiError
+    sl, q, xb, xq, ivf = world
+    idx = sl._get_ann_index(2)
+    _, I_short = ivf.search(xq, 700, 32)
+    I_short[3, ::5] = -1
+    D, I = idx.refine(xq, I_short, 300)
+    Do, Io = O.refine(xb, xq, I_short, 300)
+    assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    Dd, Id = idx.refine(torch.from_numpy(xq).cuda(), torch.from_numpy(I_short).cuda(), 300)
+    assert np.array_equal(Id.cpu().numpy(), Io)
+    p = str(tmp_path / 'r.idxmi')
+    faiss.write_index(idx, p)
+    back = faiss.read_index(p)
+    back.nprobe = 32
+    idx.nprobe = 32
+    a, b = idx.search(xq, 256), back.search(xq, 256)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    # rows are stored as vectors arrive: enabling afterwards is refused; dense vectors do not fit a row
+    plain = faiss.IndexIVFPQ(faiss.IndexFlatIP(800), 800, 16, 32, 8)
+    plain.set_niter(2)
+    plain.train(xb[:5000])
+    plain.add(xb[:5000])
+    with pytest.raises(AnnSoloMiError):
+        plain.set_refine(512)
+    with pytest.raises(AnnSoloMiError):
+        plain.refine(xq, I_short % 5000, 10)
+    dense = faiss.IndexIVFPQ(faiss.IndexFlatIP(800), 800, 16, 32, 8)
+    dense.set_niter(2)
+    dense.set_refine(512)
+    rng = np.random.default_rng(1)
+    xd = rng.random((4000, 800), dtype=np.float32)
+    dense.train(xd)
+    dense.add(xd)
+    dense.nprobe = 4
+    with pytest.raises(AnnSoloMiError):
+        dense.search(xd[:8], 50)
+    dense.set_refine(0)
+    assert dense.search(xd[:8], 50)[1].shape == (8, 50)
