@@ -357,10 +357,27 @@ class SpectralLibrary:
         ``device_out=True`` an open-search ``_search_batch`` returns without waiting, and the
         encoder + coarse quantiser of the next batch run under the list scan of this one.
         Results are valid after ``synchronize()``; values are bit-identical either way."""
+        self.synchronize()
         _lib.check(_lib.lib().asl_set_pipeline(int(on)))       # True/1: two streams, 3: three
+        self._pipeline_on = bool(on)
 
     def synchronize(self) -> None:
-        _lib.check(_lib.lib().asl_synchronize())
+        """Wait for the batches in flight; their inputs and outputs may be released afterwards."""
+        try:
+            _lib.check(_lib.lib().asl_synchronize())
+        finally:
+            getattr(self, '_inflight', []).clear()
+
+    def _hold(self, *tensors) -> None:
+        """Pipeline mode returns before the device has read the inputs or written the outputs,
+        on streams PyTorch's allocator knows nothing about: a tensor released by the caller could be
+        handed out again (and overwritten) while a kernel still uses it. Every array of a pipelined
+        call is therefore kept alive here until the next synchronisation."""
+        if not hasattr(self, '_inflight'):
+            self._inflight = []
+        self._inflight.append(tensors)
+        if len(self._inflight) >= 32:      # bound what is pinned: waiting here is cheap
+            self.synchronize()
 
     def _shard_backend(self, charge: int, mode: str):
         from .distributed import HipShardBackend
@@ -370,6 +387,8 @@ class SpectralLibrary:
         return self._dist.backends[key]
 
     def shutdown(self) -> None:
+        if getattr(self, '_inflight', None):
+            self.synchronize()
         reader = getattr(self, '_library_reader', None)
         if reader is not None and hasattr(reader, 'close'):
             reader.close()                       # spectral_library.py:189
@@ -447,6 +466,8 @@ class SpectralLibrary:
             part.handle, idx._h if idx is not None else None, C.byref(_lib.peaks_struct(q)),
             C.byref(P), _lib.ptr(best_row), _lib.ptr(best_score), _lib.ptr(n_cand),
             _lib.ptr(pm_count), _lib.ptr(pm_pairs), stride, _lib.ptr(knn)))
+        if device_out and use_ann and getattr(self, '_pipeline_on', False):
+            self._hold(q, best_row, best_score, n_cand, pm_count, pm_pairs, knn)
         return BatchResult(best_row, best_score, n_cand, pm_count, pm_pairs, knn)
 
     def _get_library_candidates(self, queries: PackedSpectra, charge: int, mode: str):

@@ -82,3 +82,31 @@ def test_other_entry_points_wait_for_batches_in_flight(world):
         assert _same(r, ref_open)
     sl.set_pipeline(False)
     assert _same(sl._search_batch(batches[2], 2, 'open', device_out=True), ref_open)
+
+
+def test_callers_may_drop_their_tensors_before_the_batches_finish(world):
+    """The pipeline's streams are invisible to PyTorch's allocator: the engine must keep the
+    arrays of a pipelined call alive itself. Found by scripts/fuzz_paths.py -- a temporary query
+    pack released right after the call was handed out again and overwritten while the kernels
+    of that call were still reading its offsets (memory access fault)."""
+    engines, batches = world
+    sl = engines['ivfpq']
+    sl.set_pipeline(False)
+    ref = [sl._search_batch(q, 2, 'open', device_out=True) for q in batches[:3]]
+    torch.cuda.synchronize()
+    want = [(r.best_row.cpu(), r.best_score.cpu()) for r in ref]
+    host = [q.to('cpu') for q in batches[:3]]
+    sl.set_pipeline(True)
+    got = []
+    for rep in range(4):
+        for i, q in enumerate(host):
+            r = sl._search_batch(q.to('cuda'), 2, 'open', device_out=True)   # temporary device pack
+            got.append((i, r.best_row, r.best_score))
+            del r
+            junk = [torch.full((n,), -7, dtype=torch.int32, device='cuda')     # reuse freed blocks
+                    for n in (q.n + 1, q.mz.numel(), q.mz.numel(), 4 * q.n)]
+            del junk
+    sl.synchronize()
+    for i, row, score in got:
+        assert torch.equal(row.cpu(), want[i][0]) and torch.equal(score.cpu(), want[i][1])
+    sl.set_pipeline(False)
