@@ -1,0 +1,68 @@
+"""Randomised check of list sharding on ONE GPU: an index is saved, loaded W times, each copy
+sharded (asl_index_shard) and searched with the caller's probe lists -- exact top-k sets, packed
+keys when the scan supports them, (D, I) rows otherwise -- and the merge of the W partial results
+must equal the unsharded search bit for bit (ids and scores), for random index kinds, PQ shapes,
+W, nlist, nprobe and k.   python scripts/fuzz_shards.py [seconds] [seed]"""
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+import numpy as np
+import torch
+from ann_solo_amd import _lib, faiss_compat as faiss, synthetic
+from ann_solo_amd.spectral_library import Config, SpectralLibrary
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+t_end = time.time() + budget
+trials = bad = 0
+dev = torch.device('cuda', 0)
+tmp = tempfile.mkdtemp()
+while time.time() < t_end:
+    n = int(rng.choice([3000, 12000, 50000]))
+    nlist = int(rng.choice([8, 32, 128]))
+    nprobe = int(rng.integers(1, nlist + 1))
+    k = int(rng.choice([1, 50, 256, 1024, 1280, 2048]))
+    W = int(rng.choice([2, 3, 4, 8]))
+    index = str(rng.choice(['ivfpq', 'ivfflat']))
+    pq_m = int(rng.choice([16, 32]))
+    nq = int(rng.choice([5, 200, 900]))
+    desc = dict(n=n, nlist=nlist, nprobe=nprobe, k=k, W=W, index=index, pq_m=pq_m, nq=nq)
+    lib, aux = synthetic.make_library(n, seed=int(rng.integers(1, 1 << 30)), device='cpu', charges=(2,),
+                                      charge_p=(1.0,))
+    q, _ = synthetic.make_queries(lib, aux, nq, seed=int(rng.integers(1, 1 << 30)), charge=2)
+    sl = SpectralLibrary(lib, config=Config(num_list=nlist, num_probe=nprobe, num_candidates=k, index=index,
+                                            pq_m=pq_m, kmeans_niter=2), device=dev)
+    idx = sl._get_ann_index(2)
+    idx.nprobe = nprobe
+    vec = sl._encode(q.to(dev))
+    D, I = idx.search(vec, k)
+    cD, cI = idx.coarse(vec, nprobe)
+    path = os.path.join(tmp, 'x.idxmi')
+    faiss.write_index(idx, path)
+    owner = idx.shard_map(W)
+    parts, keys, nloc = [], [], 0
+    use_keys = bool(_lib.lib().asl_index_supports_keys(idx._h, k, nprobe))
+    for r in range(W):
+        sh = faiss.read_index(path)
+        sh.shard(r, W)
+        nloc += sh.info().nlocal
+        if use_keys:
+            keys.append(sh.search_preassigned_keys(vec, k, cD, cI))
+        sh.set_unordered(True)
+        parts.append(sh.search_preassigned(vec, k, cD, cI))
+        del sh
+    Dm, Im = faiss.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    ok = nloc == n and torch.equal(Im, I) and torch.equal(Dm.view(torch.int32), D.view(torch.int32))
+    ok &= set(owner.tolist()) <= set(range(W))
+    if use_keys:
+        Dk, Ik = faiss.topk_merge_keys(torch.stack(keys))
+        ok &= torch.equal(Ik, I) and torch.equal(Dk.view(torch.int32), D.view(torch.int32))
+    trials += 1
+    if not ok:
+        bad += 1
+        print('MISMATCH', desc, flush=True)
+    sl.shutdown()
+print(f'{trials} trials, {bad} mismatches')
