@@ -520,9 +520,20 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
   const uint8_t *s_ch = Wv.c_chg + slot * 64;
   // mass_diff[s] = pmd / s (cpp:26-31): lane (32*half + s) performs its half's (expensive,
   // exact) fp64 division once and parks the quotient in LDS for the other lanes
-  Wv.mdt[lane] = (hl > 0 && hl < S) ? pmd / (double)hl : 0.0;
-  const float inv_w_f = (float)inv_w;
   const int Smax = SA > SB ? SA : SB;
+  {
+    // x / 1 and x / 2 are exact scalings: precursor charges <= 2 (S <= 3) never need the fp64
+    // division sequence (~40 VALU instructions every lane would execute per pair); the branch is
+    // wave-uniform. Identical bits either way.
+    double mdv = 0.0;
+    if (Smax <= 3) {
+      if (hl > 0 && hl < S) mdv = hl == 1 ? pmd : pmd * 0.5;
+    } else if (hl > 0 && hl < S) {
+      mdv = hl == 1 ? pmd : hl == 2 ? pmd * 0.5 : hl == 4 ? pmd * 0.25 : pmd / (double)hl;
+    }
+    Wv.mdt[lane] = mdv;
+  }
+  const float inv_w_f = (float)inv_w;
   const int cmax = cnA > cnB ? cnA : cnB;
   unsigned long long *keys = Wv.keys + half * RS_HC;
   uint32_t *pay = Wv.pay + half * RS_HC;

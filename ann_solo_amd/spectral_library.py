@@ -597,23 +597,38 @@ class SpectralLibrary:
         t_level = time.perf_counter()
         n_in = sum(len(r) for r in rows_by_charge.values())
         table = SSMTable(query_meta, library_meta)
-        for charge, rows in rows_by_charge.items():
-            rows = np.asarray(rows, np.int64)
-            qs = query_spectra[charge]
-            for b0 in range(0, len(rows), bs):
-                sel = rows[b0:b0 + bs]
-                if len(sel) == 0:
-                    continue
-                whole = len(sel) == qs.n and sel[0] == 0 and sel[-1] == qs.n - 1
-                q = (qs if whole else qs.select(torch.as_tensor(sel))).to(self.device)
-                res = self._search_batch(q, charge, mode, device_out=True)
-                if res is None:
-                    continue
-                part = self.partitions[charge]
-                # default search-engine score: the cosine over the winner's peak matches
-                cos = spectrum_similarity.ssm_cosine(q, part.spectra, res.best_row, res.pm_pairs,
-                                                     res.pm_count)
-                table.add_batch(charge, sel, _to_np(res.best_row), _to_np(cos), res)
+        # Phase 1 issues every batch of the level; on one GPU the open-search batches go through
+        # the two-stream pipeline (front of batch i+1 under the scan of batch i, no host wait
+        # between batches). Phase 2, after one synchronisation, scores the winners and files them.
+        d = getattr(self, '_dist', None)
+        piped = (self.device.type == 'cuda' and (d is None or d.world == 1) and
+                 not getattr(self, '_pipeline_on', False) and getattr(self, 'pipeline_cascade', True) and
+                 any(self._uses_ann(z, mode) for z in rows_by_charge))
+        if piped:
+            self.set_pipeline(True)
+        pending = []
+        try:
+            for charge, rows in rows_by_charge.items():
+                rows = np.asarray(rows, np.int64)
+                qs = query_spectra[charge]
+                for b0 in range(0, len(rows), bs):
+                    sel = rows[b0:b0 + bs]
+                    if len(sel) == 0:
+                        continue
+                    whole = len(sel) == qs.n and sel[0] == 0 and sel[-1] == qs.n - 1
+                    q = (qs if whole else qs.select(torch.as_tensor(sel))).to(self.device)
+                    res = self._search_batch(q, charge, mode, device_out=True)
+                    if res is not None:
+                        pending.append((charge, sel, q, res))
+        finally:
+            if piped:
+                self.set_pipeline(False)         # synchronises first
+        for charge, sel, q, res in pending:
+            part = self.partitions[charge]
+            # default search-engine score: the cosine over the winner's peak matches
+            cos = spectrum_similarity.ssm_cosine(q, part.spectra, res.best_row, res.pm_pairs,
+                                                 res.pm_count)
+            table.add_batch(charge, sel, _to_np(res.best_row), _to_np(cos), res)
         if uid is not None:
             table = table.first_per_uid(uid)
         acc = getattr(self, 'level_seconds', None)

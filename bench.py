@@ -385,6 +385,7 @@ def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
     import torch.distributed as dist
     from ann_solo_amd import synthetic
     part = sl.partitions[charge]
+    sl.pipeline_cascade = not args.no_pipeline      # open-search batches through the two-stream pipeline
     nq = world * args.cascade_batches * args.batch
     q, truth = synthetic.make_queries(lib, aux, nq, seed=42, open_range=args.open_da, charge=charge)
     q = q.contiguous()
