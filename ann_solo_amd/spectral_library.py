@@ -21,7 +21,7 @@ import hashlib
 import json
 import logging
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Dict, Iterator, List, Optional, Tuple
 
@@ -569,6 +569,9 @@ class SpectralLibrary:
         # identifications are retained
         t1 = self._search_cascade(query_spectra, query_meta, library_meta, remaining, 'std',
                                   score_ssms, uid)
+        n_identified = int((t1.q < cfg.fdr).sum())
+        # (message parsed by the reference's notebooks: kept verbatim, spectral_library.py:243)
+        logging.info('%d spectra identified after the standard search', n_identified)
         if not do_cascade_open:
             return t1
         t1 = t1.take(t1.q < cfg.fdr)
@@ -583,6 +586,8 @@ class SpectralLibrary:
             remaining = {z: rows[~np.isin(uid[z][rows], found)] for z, rows in remaining.items()}
         t2 = self._search_cascade(query_spectra, query_meta, library_meta, remaining, 'open',
                                   score_ssms, uid)
+        n_identified += int((t2.q < cfg.fdr).sum())
+        logging.info('%d spectra identified after the open search', n_identified)   # :257
         return SSMTable.concat([t1, t2])
 
     def _search_cascade(self, query_spectra, query_meta, library_meta, rows_by_charge, mode,
