@@ -112,15 +112,23 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
   }
   float nrm = 1.0f;
   if (norm) {
+    // ascending-index fmaf chain over the non-zero components (a zero leaves the accumulator
+    // unchanged): the wave finds them 64 at a time with a ballot and every lane walks the same
+    // chain on broadcast values -- ~50 steps instead of hash_len serial LDS reads by one lane
     float acc = 0.0f;
-    if (lane == 0) {
-      for (int i = 0; i < hash_len; ++i) {
-        float v = vec[i];
-        if (v != 0.0f) acc = __builtin_fmaf(v, v, acc);
+    for (int i0 = 0; i0 < hash_len; i0 += 64) {
+      const int i = i0 + lane;
+      const float v = i < hash_len ? vec[i] : 0.0f;
+      unsigned long long m = __ballot(v != 0.0f);
+      while (m) {                       // wave-uniform
+        const int l = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const float x = __builtin_bit_cast(
+            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+        acc = __builtin_fmaf(x, x, acc);
       }
-      acc = __builtin_sqrtf(acc);
     }
-    nrm = __shfl(acc, 0);
+    nrm = __builtin_sqrtf(acc);
   }
   float *row = out + (size_t)spec * hash_len;
   for (int i = lane; i < hash_len; i += 64) row[i] = norm ? vec[i] / nrm : vec[i];
