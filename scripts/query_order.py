@@ -41,6 +41,19 @@ blk = (j % (n // 8)) * 8 + j // (n // 8)       # sorted position j runs as workg
 perm = torch.empty_like(order)
 perm[blk] = order
 print('sorted, one XCD per sorted range: %.2f ms' % timed(vec[perm].contiguous(), cD[perm].contiguous(), cI[perm].contiguous()))
+# canonical probe order: every workgroup walks its lists by ascending list id, so workgroups that
+# run at the same time and share lists read them at about the same moment (L2 hits?)
+sI, so = cI.sort(dim=1)
+sD = cD.gather(1, so)
+print('lists by id, batch order            : %.2f ms' % timed(vec, sD.contiguous(), sI.contiguous()))
+print('lists by id, sorted by top probes   : %.2f ms' % timed(vec[order].contiguous(), sD[order].contiguous(), sI[order].contiguous()))
+print('lists by id, sorted, XCD ranges     : %.2f ms' % timed(vec[perm].contiguous(), sD[perm].contiguous(), sI[perm].contiguous()))
+# similar queries next to each other: order by the centroid the query is closest to, then by score
+key2 = cI[:, 0].long() * 1000000 + (cD[:, 0] * 999999).long().clamp(0, 999999)
+o2 = key2.argsort()
+p2 = torch.empty_like(o2)
+p2[blk] = o2
+print('lists by id, by top-1 list+score, XCD: %.2f ms' % timed(vec[p2].contiguous(), sD[p2].contiguous(), sI[p2].contiguous()))
 rnd = torch.randperm(n, device=dev)
 print('random order        : %.2f ms' % timed(vec[rnd].contiguous(), cD[rnd].contiguous(), cI[rnd].contiguous()))
 
