@@ -61,7 +61,7 @@ class AslIndexInfo(C.Structure):
 EXPORTS = [
     'asl_last_error', 'asl_version', 'asl_get_num_gpus', 'asl_set_device', 'asl_set_stream',
     'asl_synchronize', 'asl_set_pipeline', 'asl_get_dim', 'asl_hash_idx', 'asl_encode_batch', 'asl_index_create',
-    'asl_index_free', 'asl_index_train', 'asl_index_add', 'asl_index_search',
+    'asl_index_free', 'asl_index_train', 'asl_index_add', 'asl_index_add_preassigned', 'asl_index_search',
     'asl_index_reset', 'asl_index_ntotal', 'asl_index_is_trained', 'asl_index_save',
     'asl_index_load', 'asl_index_set_niter', 'asl_index_info', 'asl_index_get_centroids',
     'asl_index_get_codebooks', 'asl_index_set_trained', 'asl_index_get_lists',
@@ -113,6 +113,7 @@ def lib():
         L.asl_index_free.restype = None
         L.asl_index_train.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64]
         L.asl_index_add.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.asl_index_add_preassigned.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.asl_index_search.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p]
         L.asl_index_search_preassigned.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,

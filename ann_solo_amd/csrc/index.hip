@@ -704,7 +704,20 @@ int asl_index_set_trained(asl_index_t *ix, const float *centroids, const float *
   return ASL_OK;
 }
 
-int asl_index_add(asl_index_t *ix, int64_t n, const float *x) {
+static int index_add_impl(asl_index_t *ix, int64_t n, const float *x, const int32_t *lists);
+
+int asl_index_add(asl_index_t *ix, int64_t n, const float *x) { return index_add_impl(ix, n, x, nullptr); }
+
+// add() with the inverted list of every vector supplied by the caller instead of computed by the
+// coarse quantiser: what re-creating an index from its stored inverted lists needs (an imported
+// FAISS file keeps FAISS' own assignments, bit for bit whatever its BLAS rounded).
+int asl_index_add_preassigned(asl_index_t *ix, int64_t n, const float *x, const int32_t *lists) {
+  if (!lists) return fail(ASL_ERR_INVALID, "add_preassigned: null list assignment");
+  if (!ix || ix->kind == ASL_INDEX_FLAT) return fail(ASL_ERR_INVALID, "add_preassigned: an IVF index is required");
+  return index_add_impl(ix, n, x, lists);
+}
+
+static int index_add_impl(asl_index_t *ix, int64_t n, const float *x, const int32_t *lists) {
   clear_error();
   if (!ix) return fail(ASL_ERR_INVALID, "add: null index");
   if (!ix->trained) return fail(ASL_ERR_STATE, "add: index is not trained");
@@ -717,7 +730,18 @@ int asl_index_add(asl_index_t *ix, int64_t n, const float *x) {
   ASL_TRY(dx.init(x, (size_t)n * ix->d));
   if (ix->kind != ASL_INDEX_FLAT) {
     ASL_TRY(ix->ws_assign.reserve((size_t)n));
-    ASL_TRY(assign_ip(ix, dx.d, ix->d, n, ix->centroids.p, ix->nlist, ix->d, ix->ws_assign.p));
+    if (lists) {
+      std::vector<int32_t> h((size_t)n);
+      HIP_TRY(hipMemcpy(h.data(), lists, (size_t)n * 4, hipMemcpyDefault));
+      for (int64_t i = 0; i < n; i++)
+        if (h[(size_t)i] < 0 || h[(size_t)i] >= ix->nlist)
+          return fail(ASL_ERR_INVALID, "add_preassigned: list %d of vector %lld outside 0..%d", h[(size_t)i],
+                      (long long)i, ix->nlist - 1);
+      ASL_TRY(ix->ws_assign.upload(h.data(), (size_t)n));
+      ASL_TRY(sync_stream());
+    } else {
+      ASL_TRY(assign_ip(ix, dx.d, ix->d, n, ix->centroids.p, ix->nlist, ix->d, ix->ws_assign.p));
+    }
     ASL_TRY(dev_append(ix->vlist, (size_t)ix->n_store, ix->ws_assign.p, (size_t)n));
   }
   if (ix->kind == ASL_INDEX_IVFPQ) {

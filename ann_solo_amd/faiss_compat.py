@@ -273,6 +273,135 @@ def read_index(path: str) -> Index:
     return idx
 
 
+# ---------------------------------------------------------------------------- FAISS files
+# FAISS' own on-disk layout of an IndexIVFFlat over an IndexFlatIP / IndexFlatL2 quantiser, as
+# faiss/impl/index_write.cpp (v1.5 .. 1.8) writes it -- the files the reference caches as
+# <library>_<hash7>_<charge>.idxann (spectral_library.py:181). Little endian:
+#   'IwFl' | header | nlist u64 | nprobe u64 | quantiser index | direct map | inverted lists
+#   header    = d i32 | ntotal i64 | 1<<20 i64 | 1<<20 i64 | is_trained u8 | metric i32 (0 IP, 1 L2)
+#   quantiser = 'IxFI' ('IxF2') | header | n_floats u64 | centroids f32[nlist * d]
+#   direct map= type u8 (0 none) | n u64 | i64[n]
+#   lists     = 'ilar' | nlist u64 | code_size u64 (= 4 d) | 'full' | n u64 | sizes u64[nlist]
+#               (or 'sprs' | n u64 | (list, size) u64 pairs) | per non-empty list: codes, ids i64
+# FAISS itself is not installed here, so the layout is restated from its published source and
+# checked by round trips and a byte-level fixture only (tests/test_gpu_faiss_file.py).
+def _fourcc(s):
+    return s.encode('ascii')
+
+
+def write_index_faiss(index: Index, path: str):
+    """Write an IVF-Flat index in FAISS' format (``faiss.read_index`` layout). Row ids are the
+    add-order ids, as FAISS assigns them."""
+    import struct
+    i = index.info()
+    if i.kind != _KIND_IVFFLAT or i.shard_world != 1:
+        raise ValueError('write_index_faiss: an unsharded IVF-Flat index is required')
+    cen = index.centroids()
+    off, ids, vecs = index.lists()
+    hdr = lambda d, n: struct.pack('<iqqqBi', d, n, 1 << 20, 1 << 20, 1, METRIC_INNER_PRODUCT)
+    with open(path, 'wb') as f:
+        f.write(_fourcc('IwFl') + hdr(i.d, i.ntotal) + struct.pack('<QQ', i.nlist, max(1, int(index.nprobe))))
+        f.write(_fourcc('IxFI') + hdr(i.d, i.nlist) + struct.pack('<Q', cen.size))
+        f.write(np.ascontiguousarray(cen, '<f4').tobytes())
+        f.write(struct.pack('<BQ', 0, 0))                                   # no direct map
+        sizes = np.diff(off).astype('<u8')
+        f.write(_fourcc('ilar') + struct.pack('<QQ', i.nlist, 4 * i.d))
+        if int((sizes > 0).sum()) > i.nlist // 2:
+            f.write(_fourcc('full') + struct.pack('<Q', i.nlist) + sizes.tobytes())
+        else:
+            nz = np.nonzero(sizes)[0]
+            pairs = np.stack([nz.astype('<u8'), sizes[nz]], 1)
+            f.write(_fourcc('sprs') + struct.pack('<Q', pairs.size) + pairs.tobytes())
+        for l in range(i.nlist):
+            a, b = int(off[l]), int(off[l + 1])
+            if b > a:
+                f.write(np.ascontiguousarray(vecs[a:b], '<f4').tobytes())
+                f.write(ids[a:b].astype('<i8').tobytes())
+
+
+def read_index_faiss(path: str) -> 'IndexIVFFlat':
+    """Load a FAISS IVF-Flat / inner-product file (e.g. a ``.idxann`` the reference cached):
+    FAISS' centroids and FAISS' own list assignments are kept; ids must be 0..ntotal-1 (what
+    ``index.add`` gives and the reference relies on). Raises ValueError on anything else."""
+    import struct
+    with open(path, 'rb') as f:
+        buf = f.read()
+    pos = [0]
+
+    def take(fmt):
+        v = struct.unpack_from('<' + fmt, buf, pos[0])
+        pos[0] += struct.calcsize('<' + fmt)
+        return v if len(v) > 1 else v[0]
+
+    def cc():
+        v = buf[pos[0]:pos[0] + 4]
+        pos[0] += 4
+        return v
+
+    def arr(dt, count):
+        n = np.dtype(dt).itemsize * count
+        if pos[0] + n > len(buf):
+            raise ValueError(f'{path}: truncated')
+        a = np.frombuffer(buf, dt, count, pos[0])
+        pos[0] += n
+        return a
+    try:
+        if cc() != b'IwFl':
+            raise ValueError(f'{path}: not a FAISS IndexIVFFlat file')
+        d, ntotal, _, _, trained, metric = take('iqqqBi')
+        nlist, nprobe = take('QQ')
+        q4 = cc()
+        if q4 not in (b'IxFI', b'IxF2', b'IxFl') or metric != METRIC_INNER_PRODUCT:
+            raise ValueError(f'{path}: only inner-product IVF-Flat over a flat quantiser is supported')
+        qd, qn, _, _, _, qmetric = take('iqqqBi')
+        nfl = take('Q')
+        if qd != d or qn != nlist or nfl != nlist * d or not trained or d <= 0 or nlist <= 0:
+            raise ValueError(f'{path}: inconsistent quantiser')
+        cen = arr('<f4', nlist * d).reshape(nlist, d)
+        dm_type, dm_n = take('B'), take('Q')
+        arr('<i8', dm_n)
+        if dm_type == 2:                                # hashtable: vector of (id, offset) pairs
+            arr('<i8', 2 * take('Q'))
+        if cc() != b'ilar':
+            raise ValueError(f'{path}: inverted lists are not an ArrayInvertedLists')
+        il_nlist, code_size = take('QQ')
+        if il_nlist != nlist or code_size != 4 * d:
+            raise ValueError(f'{path}: code size {code_size} is not {4 * d} (fp32 IVF-Flat)')
+        lt = cc()
+        sizes = np.zeros(nlist, np.int64)
+        if lt == b'full':
+            sizes[:] = arr('<u8', take('Q'))
+        elif lt == b'sprs':
+            pr = arr('<u8', take('Q')).reshape(-1, 2)
+            sizes[pr[:, 0].astype(np.int64)] = pr[:, 1]
+        else:
+            raise ValueError(f'{path}: unknown list layout {lt!r}')
+        if int(sizes.sum()) != ntotal:
+            raise ValueError(f'{path}: list sizes do not add up to ntotal')
+        x = np.empty((ntotal, d), np.float32)
+        lists = np.empty(ntotal, np.int32)
+        seen = np.zeros(ntotal, bool)
+        for l in range(nlist):
+            n = int(sizes[l])
+            if n == 0:
+                continue
+            codes = arr('<f4', n * d).reshape(n, d)
+            ids = arr('<i8', n)
+            if ids.min() < 0 or ids.max() >= ntotal or seen[ids].any():
+                raise ValueError(f'{path}: ids are not a permutation of 0..ntotal-1')
+            seen[ids] = True
+            x[ids] = codes
+            lists[ids] = l
+    except struct.error as e:
+        raise ValueError(f'{path}: truncated ({e})') from None
+    idx = IndexIVFFlat(IndexFlatIP(d), d, int(nlist), METRIC_INNER_PRODUCT)
+    idx.set_trained(cen)
+    if ntotal:
+        _lib.check(_lib.lib().asl_index_add_preassigned(idx._h, int(ntotal), _lib.ptr(x), _lib.ptr(lists)))
+    idx.nprobe = int(nprobe)
+    return idx
+
+
 def index_cpu_to_gpu(res, device, index, co=None):
     """Indexes of this library are GPU-resident already; kept for call-site parity
     (spectral_library.py:494)."""

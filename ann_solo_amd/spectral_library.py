@@ -134,7 +134,8 @@ class SpectralLibrary:
     def __init__(self, library, identifiers=None, config: Config = None,
                  valid: Optional[np.ndarray] = None, index_dir: Optional[str] = None,
                  basename: Optional[str] = None, device='cuda', reader_factory=None,
-                 query_reader=None, score_ssms=None, annotation_alignment: str = 'peaks'):
+                 query_reader=None, score_ssms=None, annotation_alignment: str = 'peaks',
+                 import_faiss_cache: bool = True):
         """``library`` is one of
 
         * a file name -- the reference's call, ``SpectralLibrary(filename)``
@@ -152,7 +153,10 @@ class SpectralLibrary:
         reference's ``read_query_file``) and ``score_ssms(ssms, mode)`` (stands for
         ``utils.score_ssms``, :319-326) serve ``search(query_filename)``.
         ``annotation_alignment='snapshot'`` reproduces the snapshot's use of RAW-peak
-        annotations on processed library peaks (reader.py:243-245; see library_store.py)."""
+        annotations on processed library peaks (reader.py:243-245; see library_store.py).
+        ``import_faiss_cache``: with the reference's own index type (``index='ivfflat'``) an
+        existing ``<library>_<hash7>_<charge>.idxann`` written by the reference's FAISS is loaded
+        (its centroids and list assignments kept) instead of training a new index."""
         self.config = config or Config()
         self.device = torch.device(device)
         cfg = self.config
@@ -169,6 +173,7 @@ class SpectralLibrary:
         self._num_candidates = min(cfg.num_candidates, k_max)
         self._use_gpu = True
         self._ann_filenames: Dict[int, str] = {}
+        self._faiss_filenames: Dict[int, str] = {}      # reference caches that can be imported
         self._current_index: Tuple[Optional[int], Optional[faiss.Index]] = (None, None)
         self._query_reader = query_reader or _reference_query_reader
         self._score_ssms = score_ssms
@@ -218,8 +223,13 @@ class SpectralLibrary:
                     continue          # infrequent charge: brute force (spectral_library.py:102-104)
                 base = f'{self._basename}_{self._get_index_hash()[:7]}'
                 self._ann_filenames[z] = os.path.join(self._index_dir or '', f'{base}_{z}{INDEX_EXT}')
+                ref = os.path.join(self._index_dir or '', f'{self._basename}_'
+                                   f'{self._get_hyperparameter_hash()[:7]}_{z}.idxann')
+                if (import_faiss_cache and cfg.index == 'ivfflat' and self._index_dir is not None and
+                        verify_file_existence and os.path.isfile(ref)):
+                    self._faiss_filenames[z] = ref
                 if (self._index_dir is None or not verify_file_existence or
-                        not os.path.isfile(self._ann_filenames[z])):
+                        not (os.path.isfile(self._ann_filenames[z]) or z in self._faiss_filenames)):
                     if self._index_dir is not None:
                         logging.warning('Missing ANN index for charge %d', z)
                     create.append(z)
@@ -311,11 +321,21 @@ class SpectralLibrary:
         part = self.partitions[charge]
         if part.index is None:
             idx = None
-            try:
-                idx = faiss.read_index(self._ann_filenames[charge])
-            except _lib.AnnSoloMiError as e:
-                logging.warning('ANN index %s unreadable (%s): rebuilding',
-                                self._ann_filenames[charge], e)
+            imported = False
+            if not os.path.isfile(self._ann_filenames[charge]) and charge in self._faiss_filenames:
+                try:        # the reference's FAISS cache: its centroids, its list assignments
+                    idx = faiss.read_index_faiss(self._faiss_filenames[charge])
+                    imported = True
+                    logging.info('Imported the FAISS index %s', self._faiss_filenames[charge])
+                except (ValueError, OSError, _lib.AnnSoloMiError) as e:
+                    logging.warning('FAISS index %s not usable (%s): building a new index',
+                                    self._faiss_filenames[charge], e)
+            else:
+                try:
+                    idx = faiss.read_index(self._ann_filenames[charge])
+                except _lib.AnnSoloMiError as e:
+                    logging.warning('ANN index %s unreadable (%s): rebuilding',
+                                    self._ann_filenames[charge], e)
             if idx is not None and not self._index_matches(idx, part):
                 # e.g. another library under the same base name: out-of-range ids would be
                 # dropped silently by the rescoring bounds check -- never search a stale index
@@ -326,6 +346,8 @@ class SpectralLibrary:
                 self._create_ann_indexes([charge])
             else:
                 part.index = idx
+                if imported and self._index_dir is not None:     # next time: our own container
+                    faiss.write_index(idx, self._ann_filenames[charge])
             d = self._dist
             if d is not None and d.world > 1:
                 part.index.shard(d.rank, d.world)

@@ -91,6 +91,10 @@ asl_index_t *asl_index_create(int32_t d, int32_t nlist, int32_t kind, int32_t pq
 void asl_index_free(asl_index_t *idx);
 int asl_index_train(asl_index_t *idx, int64_t n, const float *x, uint64_t seed);
 int asl_index_add(asl_index_t *idx, int64_t n, const float *x);
+/* add() with every vector's inverted list given by the caller (lists[n], host or device) instead
+ * of computed by the coarse quantiser: re-creates an index from stored inverted lists, e.g. from
+ * a FAISS .idxann file (faiss_compat.read_index_faiss), keeping the file's own assignments. */
+int asl_index_add_preassigned(asl_index_t *idx, int64_t n, const float *x, const int32_t *lists);
 int asl_index_search(asl_index_t *idx, int32_t nq, const float *xq, int32_t k,
                      int32_t nprobe, float *D, int64_t *I);
 int asl_index_reset(asl_index_t *idx);
