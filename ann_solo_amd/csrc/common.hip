@@ -76,13 +76,19 @@ int pipeline_init() {
   // ready one batch ahead: B's workgroups are dispatched first, A's fill what is left
   int least = 0, greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  const bool flat = getenv("ASL_PIPE_FLAT_PRIORITY") != nullptr;   // A/B knob (measurement)
+#ifdef ASL_ENABLE_DBG   // A/B knobs of profiles/r02_pipeline_ab.txt: instrumented builds only
+  const bool flat = getenv("ASL_PIPE_FLAT_PRIORITY") != nullptr;
+#else
+  const bool flat = false;
+#endif
   HIP_TRY(hipStreamCreateWithPriority(&p.A, hipStreamNonBlocking, flat ? greatest : least));
   HIP_TRY(hipStreamCreateWithPriority(&p.B, hipStreamNonBlocking, greatest));
+#ifdef ASL_ENABLE_DBG
   if (getenv("ASL_PIPE_SINGLE")) {   // measurement: asynchronous calls, but everything in order on B
     (void)hipStreamDestroy(p.A);
     p.A = p.B;
   }
+#endif
   HIP_TRY(hipStreamCreateWithPriority(&p.C, hipStreamNonBlocking, greatest));
   HIP_TRY(hipEventCreateWithFlags(&p.ev_in, hipEventDisableTiming));
   for (int i = 0; i < 2; i++) {
