@@ -74,6 +74,10 @@ class Config:
     kmeans_niter: int = 25
     seed: int = 1234
     refine_k: Optional[int] = None          # IVF-PQ: exact re-rank of the refine_k best ADC candidates
+    # SSM scoring (config.py:158-164). 'none': target-decoy q-values on the cosine (fdr.py).
+    # 'rf' / 'svm' (mokapot models) are not built: pass a ``score_ssms`` callable for those.
+    # None (default here): without a callable every SSM is accepted with q = 0.
+    model: Optional[str] = None
 
     def __getitem__(self, k):
         return getattr(self, k)
@@ -663,6 +667,13 @@ class SpectralLibrary:
             torch.cuda.synchronize() if self.device.type == 'cuda' else None
             sec, a, b = acc.get(mode, (0.0, 0, 0))
             acc[mode] = (sec + time.perf_counter() - t_level, a + n_in, b + len(table))
+        if score_ssms is None and self.config.model is not None:
+            if self.config.model != 'none':
+                raise NotImplementedError(
+                    f"model={self.config.model!r}: the mokapot rf / svm models are outside this "
+                    "library; pass score_ssms= (utils.score_ssms) or use model='none'")
+            from .fdr import CosineTDC
+            score_ssms = CosineTDC(self.config.fdr_min_group_size)
         if score_ssms is None:    # no scorer: cosine (spectrum_similarity.py:81-106), accepted
             table.q[:] = 0.0
             return table
@@ -783,6 +794,32 @@ class SSMTable:
             m = self.charge == z
             out[m] = partitions[int(z)].ids[self.lib_row[m]]
         return out
+
+    def _column(self, meta, rows, name, dtype, default=None) -> np.ndarray:
+        """One metadata attribute of the matches as an array. A metadata container may offer
+        ``column(name, rows)`` (arrays behind it) -- otherwise it is read record by record."""
+        out = np.zeros(len(self), dtype)
+        for z in np.unique(self.charge):
+            m = self.charge == z
+            cont, r = meta[int(z)], rows[m]
+            if hasattr(cont, 'column'):
+                out[m] = cont.column(name, r)
+            elif default is None:
+                out[m] = [cont[int(i)][name] for i in r]
+            else:
+                out[m] = [cont[int(i)].get(name, default) for i in r]
+        return out
+
+    def is_decoy(self) -> np.ndarray:
+        return self._column(self.library_meta, self.lib_row, 'is_decoy', bool, False)
+
+    def mass_diffs(self) -> np.ndarray:
+        """(experimental - library precursor m/z) * query charge, the quantity the reference
+        groups open-search SSMs by (utils.py:227-232)."""
+        exp = self._column(self.query_meta, self.qrow, 'precursor_mz', np.float64)
+        z = self._column(self.query_meta, self.qrow, 'precursor_charge', np.float64)
+        calc = self._column(self.library_meta, self.lib_row, 'precursor_mz', np.float64)
+        return (exp - calc) * z
 
     def _peak_matches(self, i) -> np.ndarray:
         b = self._batches[int(self.batch[i])]

@@ -561,12 +561,91 @@ def gen_rescoring():
     print('rescoring_golden.npz:', len(cases), 'cases,', nlib, 'library spectra')
 
 
+def gen_fdr():
+    """The FDR gate of the cascade without a learned model (utils.score_ssms, model None):
+    (1) ``utils._get_ssm_groups`` run here on seeded mass differences -> fdr_groups_golden.npz;
+    (2) the data of the reference's own test (src/tests/utils_test.py): the 12 cosines and
+    decoy flags its SSMs have, with the q-values the test expects -> fdr_kat.json.
+    utils.py imports mokapot (absent here) and ``spectrum_utils.utils.mass_diff`` at module
+    level without using either in the functions called; bare stand-in modules let it load."""
+    import json
+    import types as _t
+    from unittest import mock
+    sys.modules.setdefault('mokapot', _t.ModuleType('mokapot'))
+    suu = _t.ModuleType('spectrum_utils.utils')
+    suu.mass_diff = lambda a, b, mode_is_da: (a - b) if mode_is_da else (a - b) / b * 1e6
+    sys.modules['spectrum_utils.utils'] = suu
+    sys.modules['spectrum_utils'].utils = suu
+    utils = _load('ann_solo.utils', os.path.join(REF, 'ann_solo/utils.py'))
+    sys.modules['ann_solo'].utils = utils
+    for sub in ('spectrum', 'config', 'spectrum_similarity'):
+        setattr(sys.modules['ann_solo'], sub, sys.modules['ann_solo.' + sub])
+    rng = np.random.default_rng(20241002)
+    mods = np.array([0.0, 0.984016, 15.994915, 79.966331, -17.026549, 42.010565, 14.01565,
+                     57.021464, -18.010565, 27.994915, 1.003355, 2.00671, 21.981943])
+    out = {}
+    case = 0
+    for n in (1, 2, 7, 60, 400, 3000, 8000):
+        for mgs in (1, 5, 20, 100):
+            k = int(rng.integers(1, len(mods) + 1))
+            which = rng.choice(len(mods), k, replace=False)
+            comp = rng.integers(0, k + 1, n)            # k = background
+            md = np.where(comp < k, mods[which[np.minimum(comp, k - 1)]] +
+                          rng.normal(0, rng.choice([0.002, 0.01, 0.05]), n),
+                          rng.uniform(-150, 300, n))
+            if case % 3 == 0:                           # exact duplicates and half-way values
+                md[::5] = np.round(md[::5], 2)
+                md[1::11] = np.floor(md[1::11]) + 0.5
+            ssms = [_t.SimpleNamespace(exp_mass_to_charge=float(v), calc_mass_to_charge=0.0, charge=1)
+                    for v in md]
+            got = np.asarray(utils._get_ssm_groups(ssms, mgs), np.int32)
+            out[f'md_{case}'], out[f'mgs_{case}'], out[f'groups_{case}'] = md, np.int64(mgs), got
+            case += 1
+    out['n_cases'] = np.int64(case)
+    np.savez_compressed(os.path.join(HERE, 'fdr_groups_golden.npz'), **out)
+    print('fdr_groups_golden.npz:', case, 'cases')
+
+    # (2) the SSMs test_score_ssms builds, captured where it hands them to score_ssms
+    sim = sys.modules['ann_solo.spectrum_similarity']
+    captured = {}
+
+    def capture(ssms, fdr, model, *a, **kw):
+        captured['ssms'], captured['fdr'], captured['model'] = ssms, fdr, model
+        raise KeyboardInterrupt
+    t = _load('ref_utils_test', os.path.join(REF, 'tests/utils_test.py'))
+    with mock.patch.object(utils, 'score_ssms', capture):
+        try:
+            t.test_score_ssms()
+        except KeyboardInterrupt:
+            pass
+    with mock.patch('ann_solo.config.config._namespace',
+                    {'min_mz': 11, 'max_mz': 2010, 'bin_size': 0.04}):
+        cos = [float(sim.SpectrumSimilarityCalculator(s).cosine()) for s in captured['ssms']]
+    nan = float('nan')
+    kat = {'source': 'src/tests/utils_test.py:10-80 (test_score_ssms)',
+           'cosine': cos, 'is_decoy': [bool(s.library_spectrum.is_decoy) for s in captured['ssms']],
+           'fdr': captured['fdr'], 'model': captured['model'],
+           # the constants of utils_test.py:60-73
+           'q_expected': [1 / 3, 1 / 3, 1 / 3, nan, nan, 1 / 2, 1 / 2, 1 / 2, nan, nan, 5 / 7, nan]}
+    with open(os.path.join(HERE, 'fdr_kat.json'), 'w') as f:
+        json.dump(kat, f, indent=1)
+    print('fdr_kat.json: cosines', ['%.6f' % c for c in cos])
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('needs /root/reference (build container only)')
+    if sys.argv[1:] == ['fdr']:         # only the FDR fixtures
+        _install_shims()
+        _load('ann_solo.config', os.path.join(REF, 'ann_solo/config.py'))
+        _load('ann_solo.spectrum', os.path.join(REF, 'ann_solo/spectrum.py'))
+        _load('ann_solo.spectrum_similarity', os.path.join(REF, 'ann_solo/spectrum_similarity.py'))
+        gen_fdr()
+        sys.exit(0)
     sp = gen_encoder()
     gen_similarity_kat(sp)
     gen_similarity_expected()
     gen_ssm_features(sp)
     gen_mztab(sp)
     gen_rescoring()
+    gen_fdr()

@@ -185,3 +185,55 @@ def test_search_driver_end_to_end_to_mztab(tmp_path, monkeypatch):
         s = by[r[2]]
         assert r[1] == s.sequence and float(r[8]) == s.search_engine_score and r[20] == str(s.library_identifier)
     sl.shutdown()
+
+
+def test_cascade_with_the_cosine_tdc_gate():
+    """``model='none'`` (reference ``--model none``): both cascade levels gated by target-decoy
+    q-values on the cosine (ann_solo_amd/fdr.py); the open level competes per mass-difference
+    group. Checked against the gate applied by hand to the same levels' SSMs."""
+    import torch
+    from ann_solo_amd import fdr, synthetic
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    lib, aux = synthetic.make_library(6000, seed=81, device='cpu', charges=(2,), charge_p=(1.0,))
+    q, truth = synthetic.make_queries(lib, aux, 900, seed=82, charge=2, open_range=300.0)
+    cfg = Config(num_list=32, num_probe=32, num_candidates=1024, index='ivfpq', kmeans_niter=5,
+                 batch_size=256, model='none', fdr=0.05, fdr_min_group_size=10)
+    sl = SpectralLibrary(lib, config=cfg)
+    rng = np.random.default_rng(7)
+    decoy = rng.random(lib.n) < 0.5                    # half the library flagged as decoys,
+    decoy[truth['source_row'].numpy()] = False         # none of them a query's true source
+    qmeta = {2: [dict(identifier=f'scan={i}', index=i, retention_time=0.0, precursor_charge=2,
+                      precursor_mz=float(q.precursor_mz[i])) for i in range(q.n)]}
+    lmeta = {2: [dict(identifier=int(r), peptide=f'PEPTIDE{r}K', precursor_mz=float(p), is_decoy=bool(decoy[r]))
+                 for r, p in enumerate(sl.partitions[2].precursor_mz)]}
+    ids = sl.search({2: q}, qmeta, lmeta)
+    # by hand: level 1 ungated, then the gate; level 2 on the rest
+    def ungated(table, mode):
+        return None
+    ungated.columnar = True
+    everything = {2: np.arange(q.n)}
+    t1 = sl._search_cascade({2: q}, qmeta, lmeta, everything, 'std', score_ssms=ungated)
+    d1 = decoy[t1.lib_row]
+    q1 = np.where(d1, np.nan, fdr.tdc_qvalues(t1.score, ~d1))
+    keep1 = q1 < cfg.fdr
+    assert 50 < keep1.sum() < len(t1)
+    rest = np.setdiff1d(np.arange(q.n), t1.qrow[keep1])
+    t2 = sl._search_cascade({2: q}, qmeta, lmeta, {2: rest}, 'open', score_ssms=ungated)
+    d2 = decoy[t2.lib_row]
+    md = (np.asarray(q.precursor_mz)[t2.qrow] - sl.partitions[2].precursor_mz[t2.lib_row].astype(np.float64)) * 2
+    g2 = fdr.ssm_groups(md, cfg.fdr_min_group_size)
+    assert len(np.unique(g2)) >= 2
+    q2 = np.full(len(t2), np.nan)
+    for g in np.unique(g2):
+        m = g2 == g
+        q2[m] = np.where(d2[m], np.nan, fdr.tdc_qvalues(t2.score[m], ~d2[m]))
+    np.testing.assert_array_equal(ids.qrow, np.concatenate([t1.qrow[keep1], t2.qrow]))
+    np.testing.assert_array_equal(ids.lib_row, np.concatenate([t1.lib_row[keep1], t2.lib_row]))
+    np.testing.assert_array_equal(ids.q, np.concatenate([q1[keep1], q2]))
+    assert np.isnan(ids.score[decoy[ids.lib_row]]).all() and not np.isnan(ids.score[~decoy[ids.lib_row]]).any()
+    rec = ids[0]
+    assert rec.q == ids.q[0] and rec.is_decoy == bool(decoy[ids.lib_row[0]])
+    with pytest.raises(NotImplementedError):
+        sl.config.model = 'rf'
+        sl.search({2: q}, qmeta, lmeta)
+    sl.shutdown()
