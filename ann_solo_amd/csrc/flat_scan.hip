@@ -207,9 +207,12 @@ int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t
 // of FI_BLK vectors and each block keeps, per dimension, the postings (local vector index
 // u16, value f32) of the vectors that are non-zero there -- an inverted file inside the
 // inverted file. Storage: one segment per (block, dimension), its c values followed by its c
-// local indices (6c bytes, padded to a 4-byte word), and a table of segment starts in words
-// (c = 2 * words / 3): the scan is bound by the number of DRAM sectors it touches, and a
-// dimension costs one table entry + one ~100-byte segment. A wave takes one (query, block): it zeroes the block's accumulators in LDS
+// local indices (6c bytes), and one table word per (block, dimension): the segment's start in
+// 64-byte units from the block's base (high 16 bits) and c (low 16 bits). The scan is bound by
+// the number of 128-byte lines it pulls through L2 (hit rate < 10 %: every (query, block) pair
+// touches its own lines), so segments are PLACED BY LINE: one that fits a line never straddles
+// two, a longer one starts on a line boundary -- a dimension of a 512-vector list (17 postings,
+// 102 bytes) costs one line instead of 1.8, for ~25 % padding. A wave takes one (query, block): it zeroes the block's accumulators in LDS
 // and walks the query's non-zero dimensions in ASCENDING order, acc[loc] = fmaf(q_d, val,
 // acc[loc]) over that dimension's postings (a vector occurs at most once per dimension, so
 // the lanes of one step never collide, and steps of one wave reach LDS in program order).
@@ -223,12 +226,27 @@ int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t
 #define FI_U_ 8
 #endif
 constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = 128, FI_U = FI_U_;
+static_assert(FI_BLK <= 32 * 64, "one bit per row of 64 accumulators in a 32-bit mask");
+#ifndef FI_PHASES
+#define FI_PHASES 0
+#endif
+#if FI_PHASES
+#define FI_T(i)                                   \
+  {                                               \
+    const long long t_now = wall_clock64();       \
+    ph[i] += t_now - t_prev;                      \
+    t_prev = t_now;                               \
+  }
+#else
+#define FI_T(i)
+#endif
+static_assert(64 % FI_U == 0, "a batch of dimensions must not straddle the 64 lanes of a chunk");
 
 struct FiUnit {
   uint32_t blk;   // block index into the per-dimension table
   int32_t pos0;   // list-order position of the block's first vector
   int32_t nb;     // vectors in the block
-  int32_t pad;
+  uint32_t base;  // the block's postings start here, in 64-byte units
 };
 
 // FI_CAP: key buffer of the top-k (2048: k <= 1280, three workgroups per CU; 4096: k <= 3328, two)
@@ -236,8 +254,8 @@ template <int FI_CAP>
 __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_kernel(
     const float *__restrict__ xq, int d, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ blk_offsets,
-    const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_data,
-    const int32_t *__restrict__ ids, int k,
+    const uint32_t *__restrict__ blk_base, const uint32_t *__restrict__ seg_tab,
+    const char *__restrict__ seg_bytes, const int32_t *__restrict__ ids, int k,
     float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode) {
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -248,6 +266,10 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   uint16_t *s_nzd = reinterpret_cast<uint16_t *>(s_misc + 16);             // [d]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
 
+#if FI_PHASES
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_prev = wall_clock64();
+#endif
   // the query's non-zero components, ascending (staged through the accumulator area)
   float *s_q = s_acc;
   for (int i = tid; i < d; i += FI_NT) s_q[i] = xq[(size_t)q * d + i];
@@ -284,6 +306,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   top.init(smem, k, ids, tid);
   float *acc = s_acc + wave * FI_BLK;
 
+  FI_T(0)
   for (int c0 = 0; c0 < total; c0 += FI_CHUNK) {
     {
       const int lo = max(my_pre, c0), hi = min(my_pre + my_nb, c0 + FI_CHUNK);
@@ -293,7 +316,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
         u.blk = (uint32_t)(my_b0 + j);
         u.pos0 = my_pos + j * FI_BLK;
         u.nb = min(FI_BLK, my_len - j * FI_BLK);
-        u.pad = 0;
+        u.base = blk_base[my_b0 + j];
         table[t - c0] = u;
       }
     }
@@ -315,6 +338,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
       if (tid < nent) table[rank] = mine;
       __syncthreads();
     }
+    FI_T(1)
     for (int r0 = 0; r0 < nent; r0 += FI_NW) {
       const int i = r0 + wave;
       int nb = 0, pos0 = 0;
@@ -323,54 +347,55 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
         nb = __builtin_amdgcn_readfirstlane(u.nb);
         pos0 = __builtin_amdgcn_readfirstlane(u.pos0);
         const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.blk);
+        const char *bptr =
+            seg_bytes + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)u.base) * 64;
         for (int o = lane; o < nb; o += 64) acc[o] = 0.0f;
-        const uint32_t *erow = seg_start + (size_t)blk * d;
+        const uint32_t *erow = seg_tab + (size_t)blk * d;
         for (int kk0 = 0; kk0 < K; kk0 += 64) {
           const int kk = kk0 + lane;
           uint2 e = make_uint2(0u, 0u);
           float qv = 0.0f;
           if (kk < K) {
-            const uint32_t dim = s_nzd[kk];
-            const uint32_t w0 = erow[dim], w1 = erow[dim + 1];
-            e = make_uint2(w0, (2u * (w1 - w0)) / 3u);      // first word, postings
+            const uint32_t w = erow[s_nzd[kk]];
+            e = make_uint2((w >> 16) * 64u, w & 0xffffu);   // first byte (from the block's base), postings
             qv = s_nzv[kk];
           }
+#if FI_PHASES
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(e.x), "v"(e.y), "v"(qv));
+          FI_T(2)
+#endif
           const int n = min(64, K - kk0);
+          // lanes past the query's last dimension hold (0, 0) and q = 0: a batch never needs a
+          // tail case (64 % FI_U == 0). The first 64 postings of FI_U dimensions are loaded
+          // together and applied dimension by dimension; a dimension with more postings than
+          // lanes (rare) finishes its remaining rows before the next dimension starts
           for (int j0 = 0; j0 < n; j0 += FI_U) {
-            uint32_t st[FI_U], cn[FI_U];
-            float qj[FI_U];
-            uint32_t cmax = 0;
+            uint32_t st[FI_U], cn[FI_U], loc[FI_U];
+            float qj[FI_U], val[FI_U];
 #pragma unroll
             for (int u = 0; u < FI_U; ++u) {
-              const int j = j0 + u < n ? j0 + u : n - 1;
+              const int j = j0 + u;
               st[u] = (uint32_t)__builtin_amdgcn_readlane((int)e.x, j);
-              cn[u] = j0 + u < n ? (uint32_t)__builtin_amdgcn_readlane((int)e.y, j) : 0u;
+              cn[u] = (uint32_t)__builtin_amdgcn_readlane((int)e.y, j);
               qj[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), j));
-              cmax = cn[u] > cmax ? cn[u] : cmax;
             }
-            if (cmax == 0) continue;
-            // the first 64 postings of FI_U dimensions are loaded together ...
-            uint32_t loc[FI_U];
-            float val[FI_U];
 #pragma unroll
             for (int u = 0; u < FI_U; ++u) {
               const bool on = (uint32_t)lane < cn[u];
-              val[u] = on ? reinterpret_cast<const float *>(seg_data)[st[u] + lane] : 0.0f;
-              loc[u] = on ? (uint32_t)reinterpret_cast<const uint16_t *>(seg_data)
-                                [2 * (size_t)(st[u] + cn[u]) + lane]
+              val[u] = on ? *reinterpret_cast<const float *>(bptr + (st[u] + 4u * lane)) : 0.0f;
+              loc[u] = on ? (uint32_t)*reinterpret_cast<const uint16_t *>(
+                                bptr + (st[u] + 4u * cn[u] + 2u * lane))
                           : 0u;
             }
-            // ... and applied dimension by dimension; a dimension with more postings than
-            // lanes (rare) finishes its remaining rows before the next dimension starts
 #pragma unroll
             for (int u = 0; u < FI_U; ++u) {
               if ((uint32_t)lane < cn[u]) acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);
               if (cn[u] > 64u)      // wave-uniform
                 for (uint32_t o = 64u + lane; o < cn[u]; o += 64) {
-                  const uint32_t l =
-                      reinterpret_cast<const uint16_t *>(seg_data)[2 * (size_t)(st[u] + cn[u]) + o];
-                  acc[l] = __builtin_fmaf(qj[u], reinterpret_cast<const float *>(seg_data)[st[u] + o],
-                                          acc[l]);
+                  const uint32_t l = *reinterpret_cast<const uint16_t *>(
+                      bptr + (st[u] + 4u * cn[u] + 2u * o));
+                  acc[l] = __builtin_fmaf(
+                      qj[u], *reinterpret_cast<const float *>(bptr + (st[u] + 4u * o)), acc[l]);
                 }
             }
           }
@@ -380,19 +405,28 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
       // passing candidates and reserve room for all of them with ONE barrier (bulk_reserve),
       // then append without synchronising; lockstep rounds of 64 per wave only while the
       // threshold is still low (first blocks of a query) or ties force exact flushes.
+      FI_T(3)
       bool done = false;
       for (int attempt = 0; attempt < 2 && !done; ++attempt) {
         int cnt = 0;
-        for (int v = lane; v - lane < nb; v += 64)
-          cnt += __popcll(__ballot(v < nb && top.passes(acc[v])));
+        uint32_t mine = 0;      // bit r: my accumulator of row r (vector 64 r + lane) passes
+        for (int r = 0; r * 64 < nb; ++r) {
+          const int v = r * 64 + lane;
+          const bool p = v < nb && top.passes(acc[v]);
+          mine |= (uint32_t)p << r;
+          cnt += __popcll(__ballot(p));
+        }
+        FI_T(4)
         const int st = top.bulk_reserve(cnt, attempt == 0);
+        FI_T(5)
         if (st < 0) break;
         if (st == 1) {
-          for (int v = lane; v - lane < nb; v += 64) {
-            const bool valid = v < nb;
-            const float score = valid ? acc[v] : 0.0f;
-            if (__ballot(valid && top.passes(score)))     // wave-uniform
-              top.offer(valid, score, (uint32_t)(pos0 + v));
+          for (int r = 0; r * 64 < nb; ++r) {
+            const bool p = (mine >> r) & 1u;
+            if (__ballot(p)) {     // wave-uniform: few rows hold a candidate once the threshold stands
+              const int v = r * 64 + lane;
+              top.offer(p, p ? acc[v] : 0.0f, (uint32_t)(pos0 + v));
+            }
           }
           done = true;
         }
@@ -410,15 +444,29 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
           top.end_round(__popcll(__ballot(take)));
         }
       }
+      FI_T(6)
     }
     __syncthreads();
   }
+  FI_T(1)
+#if FI_PHASES
+  const long long t_fin = wall_clock64();
+#endif
   if (set_mode && (size_t)FI_CAP * 8 <= (size_t)FI_NW * FI_BLK * 4)   // unordered exact top-k; the accumulators are dead: scratch
     top.finish_set(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
                    I32 ? I32 + (size_t)q * k : nullptr, reinterpret_cast<u64 *>(s_acc));
   else
     top.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
                I32 ? I32 + (size_t)q * k : nullptr);
+#if FI_PHASES
+  __syncthreads();
+  if (D && k >= 16 && lane == 0) {     // phase durations (100 MHz ticks) of every wave replace the scores
+    ph[7] = wall_clock64() - t_fin;
+    float *o = D + (size_t)q * k + wave * 8;
+    if (wave * 8 + 8 <= k)
+      for (int i = 0; i < 8; ++i) o[i] = (float)ph[i];
+  }
+#endif
 }
 
 bool flat_inv_supported(int d, int k, int nprobe) {
@@ -428,9 +476,9 @@ bool flat_inv_supported(int d, int k, int nprobe) {
 template <int FI_CAP>
 static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                            const int32_t *list_offsets, const int32_t *blk_offsets,
-                           const uint32_t *seg_start, const uint32_t *seg_data,
-                           const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32,
-                           int set_mode) {
+                           const uint32_t *blk_base, const uint32_t *seg_tab,
+                           const char *seg_bytes, const int32_t *ids, int k, float *D,
+                           int64_t *I64, int32_t *I32, int set_mode) {
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   const size_t lds = TopK::lds_bytes() + (size_t)FI_NW * FI_BLK * 4 + (size_t)((d + 3) & ~3) * 4 +
                      (size_t)FI_CHUNK * sizeof(FiUnit) + 64 + (size_t)((d + 7) & ~7) * 2;
@@ -439,22 +487,44 @@ static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse
     HIP_TRY(hipFuncSetAttribute((const void *)flat_inv_scan_kernel<FI_CAP>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(flat_inv_scan_kernel<FI_CAP>, dim3(nq), dim3(FI_NT), lds, stream(), xq, d,
-                     coarse_I, nprobe, list_offsets, blk_offsets, seg_start, seg_data, ids, k, D,
-                     I64, I32, set_mode);
+                     coarse_I, nprobe, list_offsets, blk_offsets, blk_base, seg_tab, seg_bytes, ids,
+                     k, D, I64, I32, set_mode);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
 
 int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *list_offsets, const int32_t *blk_offsets,
-                  const uint32_t *seg_start, const uint32_t *seg_data, const int32_t *ids, int k,
-                  float *D, int64_t *I64, int32_t *I32, int set_mode) {
+                  const uint32_t *blk_base, const uint32_t *seg_tab, const char *seg_bytes,
+                  const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode) {
   if (nq <= 0) return ASL_OK;
   if (k + FI_NT + 256 <= 2048)
-    return launch_flat_inv<2048>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, seg_start,
-                                 seg_data, ids, k, D, I64, I32, set_mode);
-  return launch_flat_inv<4096>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, seg_start,
-                               seg_data, ids, k, D, I64, I32, set_mode);
+    return launch_flat_inv<2048>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base,
+                                 seg_tab, seg_bytes, ids, k, D, I64, I32, set_mode);
+  return launch_flat_inv<4096>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base,
+                               seg_tab, seg_bytes, ids, k, D, I64, I32, set_mode);
+}
+
+// Placement of a block's segments (counts cnt[0..d) -> table words tab[0..d)); returns the
+// block's size in 64-byte units, or 0 with *ok = false when a start does not fit 16 bits.
+uint32_t inv_place_block(const uint32_t *cnt, int d, uint32_t *tab, bool *ok) {
+  uint32_t pos = 0;     // 64-byte units; even = on a 128-byte line
+  for (int j = 0; j < d; j++) {
+    const uint32_t c = cnt[j];
+    if (c == 0) {
+      tab[j] = 0u;
+      continue;
+    }
+    const uint32_t units = (6u * c + 63u) / 64u;
+    if (units >= 2u && (pos & 1u)) ++pos;     // a full line or more: start on a line
+    if (pos > 0xffffu || c > 0xffffu) {
+      *ok = false;
+      return 0;
+    }
+    tab[j] = (pos << 16) | c;
+    pos += units;
+  }
+  return pos;
 }
 
 // ---- building the postings from dense rows. pos_blk / pos_loc: block and local index of
@@ -476,22 +546,25 @@ __global__ void inv_fill_kernel(const float *__restrict__ vecs, int d,
                                 const int32_t *__restrict__ order,
                                 const int32_t *__restrict__ pos_blk,
                                 const uint16_t *__restrict__ pos_loc, int64_t n,
-                                const uint32_t *__restrict__ seg_start,
-                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ seg_data) {
+                                const uint32_t *__restrict__ blk_base,
+                                const uint32_t *__restrict__ seg_tab,
+                                uint32_t *__restrict__ cursor, char *__restrict__ seg_bytes) {
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
   const float *row = vecs + (size_t)order[i] * d;
   const size_t b = (size_t)pos_blk[i] * d;
+  char *bptr = seg_bytes + (size_t)blk_base[pos_blk[i]] * 64;
   const uint16_t loc = pos_loc[i];
   for (int j = lane; j < d; j += 64) {
     const float x = row[j];
     if (x != 0.0f) {
-      const uint32_t w0 = seg_start[b + j];
-      const uint32_t c = (2u * (seg_start[b + j + 1] - w0)) / 3u;
+      const uint32_t w = seg_tab[b + j];
+      const size_t st = (size_t)(w >> 16) * 64;
+      const uint32_t c = w & 0xffffu;
       const uint32_t p = atomicAdd(&cursor[b + j], 1u);     // any order inside a segment
-      reinterpret_cast<float *>(seg_data)[w0 + p] = x;
-      reinterpret_cast<uint16_t *>(seg_data)[2 * (size_t)(w0 + c) + p] = loc;
+      *reinterpret_cast<float *>(bptr + st + 4 * (size_t)p) = x;
+      *reinterpret_cast<uint16_t *>(bptr + st + 4 * (size_t)c + 2 * (size_t)p) = loc;
     }
   }
 }
@@ -506,11 +579,11 @@ int inv_count(const float *vecs, int d, const int32_t *order, const int32_t *pos
 }
 
 int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk,
-             const uint16_t *pos_loc, int64_t n, const uint32_t *seg_start, uint32_t *cursor,
-             uint32_t *seg_data) {
+             const uint16_t *pos_loc, int64_t n, const uint32_t *blk_base,
+             const uint32_t *seg_tab, uint32_t *cursor, char *seg_bytes) {
   if (n <= 0) return ASL_OK;
   hipLaunchKernelGGL(inv_fill_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
-                     order, pos_blk, pos_loc, n, seg_start, cursor, seg_data);
+                     order, pos_blk, pos_loc, n, blk_base, seg_tab, cursor, seg_bytes);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }

@@ -33,6 +33,16 @@ __device__ __forceinline__ int score_bucket(float s) {
   return (int)t;
 }
 
+// smallest score whose bucket is >= b (1 <= b < HT_NB): score_bucket is monotone, so
+// score_bucket(s) >= b  <=>  s >= bucket_floor(b) for every non-NaN s -- one compare instead of
+// the bucket arithmetic where only the verdict is needed
+__device__ __forceinline__ float bucket_floor(int b) {
+  float s = (float)b / HT_SCALE + HT_LO;
+  while (score_bucket(s) >= b) s = nextafterf(s, -INFINITY);
+  while (score_bucket(s) < b) s = nextafterf(s, INFINITY);
+  return s;
+}
+
 // exclusive prefix sum of one int per thread over a workgroup of NW waves; `part` = NW LDS
 // ints reserved for this call site. Total in `total`.
 template <int NW>
@@ -80,6 +90,7 @@ struct HistTopK {
   // per-round snapshot
   int bstar;
   uint32_t thr_hi;
+  float thr_f;             // bucket_floor(bstar), -inf while bstar == 0
 
   static constexpr size_t lds_bytes() { return (size_t)CAP * 8 + 256 + (size_t)HT_NB * 4; }
 
@@ -102,6 +113,7 @@ struct HistTopK {
     __syncthreads();
     bstar = 0;
     thr_hi = 0;
+    thr_f = -INFINITY;
     return reinterpret_cast<char *>(hist + HT_NB);
   }
 
@@ -111,6 +123,7 @@ struct HistTopK {
   __device__ __forceinline__ void refresh_threshold() {
     thr_hi = (uint32_t)(*thr_p >> 32);
     bstar = ctl[C_BSTAR];
+    thr_f = bstar > 0 ? bucket_floor(bstar) : -INFINITY;
   }
 
   // one candidate per lane; returns true if it was kept (count kept lanes per wave with
@@ -128,9 +141,9 @@ struct HistTopK {
     return false;
   }
 
-  // the test offer() applies, against the current snapshot
+  // the test offer() applies, against the current snapshot (scores are never NaN)
   __device__ __forceinline__ bool passes(float score) const {
-    return sort_mode ? (f2ord(score) >= thr_hi) : (score_bucket(score) >= bstar);
+    return sort_mode ? (f2ord(score) >= thr_hi) : (score >= thr_f);
   }
 
   // Bulk rounds: a wave that holds MANY scored candidates (e.g. a block of accumulators in

@@ -90,8 +90,9 @@ struct asl_index {
   bool has_sparse = false;
   // dimension-major postings for flat_inv_scan (IVF-Flat): blocks of FI_BLK vectors
   DevBuf<int32_t> blk_offsets;   // [nlist + 1] first block of each list
-  DevBuf<uint32_t> inv_start;    // [nblocks * d + 1] first 4-byte word of the segment of (block, dimension)
-  DevBuf<uint32_t> inv_data;     // segments: c values (f32) then c local vector indices (u16), padded to a word
+  DevBuf<uint32_t> blk_base;     // [nblocks] start of the block's postings, 64-byte units
+  DevBuf<uint32_t> inv_tab;      // [nblocks * d] (start from the block's base in 64-byte units) << 16 | postings
+  DevBuf<char> inv_data;         // segments: c values (f32) then c local vector indices (u16), placed by 128-byte line
   bool has_inv = false;
   int scan_variant = 0;  // 0 = auto (v2 when supported), 1 = force v1
   int unordered = 0;  // 1: search rows = exact top-k as a set, unspecified order (no final sort); 2: rows of packed keys
@@ -363,22 +364,25 @@ static int build_lists(asl_index *ix) {
       std::vector<uint32_t> h_cnt(ncell);
       ASL_TRY(cnt_dev.download(h_cnt.data(), ncell));
       ASL_TRY(sync_stream());
-      // segment of a cell with c postings: c floats + c u16 = (3c + 1) / 2 words
-      std::vector<uint32_t> h_start(ncell + 1);
-      uint64_t run = 0;
-      for (size_t c = 0; c < ncell; c++) {
-        h_start[c] = (uint32_t)run;
-        run += (3ull * h_cnt[c] + 1ull) / 2ull;
+      // segments placed block by block (flat_scan.hip: inv_place_block)
+      std::vector<uint32_t> h_tab(ncell), h_base(nblk);
+      uint64_t run = 0;     // 64-byte units
+      bool ok = true;
+      for (size_t b = 0; b < nblk && ok; b++) {
+        h_base[b] = (uint32_t)run;
+        run += inv_place_block(h_cnt.data() + b * (size_t)ix->d, ix->d, h_tab.data() + b * (size_t)ix->d, &ok);
+        run += run & 1ull;      // every block starts on a 128-byte line
       }
-      h_start[ncell] = (uint32_t)run;
-      if (run < (1ull << 32)) {     // 32-bit word offsets (16 GB of postings)
+      if (ok && run < (1ull << 32)) {     // 32-bit unit offsets (256 GB of postings)
+        const size_t bytes = (size_t)std::max<uint64_t>(run, 2) * 64;
         ASL_TRY(ix->blk_offsets.upload(blk_off.data(), blk_off.size()));
-        ASL_TRY(ix->inv_start.upload(h_start.data(), ncell + 1));
-        ASL_TRY(ix->inv_data.reserve((size_t)std::max<uint64_t>(run, 1)));
-        HIP_TRY(hipMemsetAsync(ix->inv_data.p, 0, (size_t)std::max<uint64_t>(run, 1) * 4, stream()));
+        ASL_TRY(ix->blk_base.upload(h_base.data(), nblk));
+        ASL_TRY(ix->inv_tab.upload(h_tab.data(), ncell));
+        ASL_TRY(ix->inv_data.reserve(bytes));
+        HIP_TRY(hipMemsetAsync(ix->inv_data.p, 0, bytes, stream()));
         HIP_TRY(hipMemsetAsync(cnt_dev.p, 0, ncell * 4, stream()));
         ASL_TRY(inv_fill(ix->vecs.p, ix->d, order.p, pos_blk_dev.p, pos_loc_dev.p, n,
-                         ix->inv_start.p, cnt_dev.p, ix->inv_data.p));
+                         ix->blk_base.p, ix->inv_tab.p, cnt_dev.p, ix->inv_data.p));
         ASL_TRY(sync_stream());
         ix->has_inv = true;
       }
@@ -447,7 +451,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
         if (use_inv) {
           ProfScope ps("scan");
           ASL_TRY(flat_inv_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
-                                ix->blk_offsets.p, ix->inv_start.p, ix->inv_data.p,
+                                ix->blk_offsets.p, ix->blk_base.p, ix->inv_tab.p, ix->inv_data.p,
                                 ix->ids.p, k, D, I64, I32, set_mode || ix->unordered == 1));
         } else {
           ProfScope ps("scan");

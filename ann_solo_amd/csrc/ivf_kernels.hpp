@@ -61,8 +61,9 @@ constexpr int FI_BLK = 768;
 bool flat_inv_supported(int d, int k, int nprobe);
 int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *list_offsets, const int32_t *blk_offsets,
-                  const uint32_t *seg_start, const uint32_t *seg_data, const int32_t *ids, int k,
-                  float *D, int64_t *I64, int32_t *I32, int set_mode);
+                  const uint32_t *blk_base, const uint32_t *seg_tab, const char *seg_bytes,
+                  const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode);
+uint32_t inv_place_block(const uint32_t *cnt, int d, uint32_t *tab, bool *ok);
 // exact re-rank of a short-list against sparse stored rows (refine.hip)
 int refine_stride();
 int refine_append_rows(const float *x, int64_t n, int d, int64_t row0, uint16_t *r_dim, float *r_val,
@@ -73,8 +74,8 @@ int refine_topk(const float *xq, int nq, int d, const int32_t *I_in, const int64
 int inv_count(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk, int64_t n,
               uint32_t *cnt);
 int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk,
-             const uint16_t *pos_loc, int64_t n, const uint32_t *seg_start, uint32_t *cursor,
-             uint32_t *seg_data);
+             const uint16_t *pos_loc, int64_t n, const uint32_t *blk_base,
+             const uint32_t *seg_tab, uint32_t *cursor, char *seg_bytes);
 int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_max_dev);
 int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t *dst_slot,
                    const int32_t *ids, int64_t n, int64_t ntiles, int nnz_stride,

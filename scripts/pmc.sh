@@ -7,7 +7,7 @@ tag=$1; shift
 mkdir -p gpurun_out/$tag
 run() {  # name, counters...
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "pq_scan|flat_inv_scan|flat_sparse_scan|rescore_score|gemm_nt|row_topk|row_select" \
+  rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "pq_scan|flat_inv|flat_sparse_scan|rescore_score|gemm_nt|row_topk|row_select" \
      --output-format csv -d /tmp/pmc_$name -o x -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --recall-queries 0 "${BENCH_ARGS[@]}" > /tmp/pmc_$name.log 2>&1
   python3 - "$name" <<'PY' >> gpurun_out/$TAG/summary.txt
 import csv, sys, collections, glob
@@ -35,5 +35,11 @@ BENCH_ARGS=("$@")
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS
 run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES SQ_ACTIVE_INST_SCA
 run tcc FETCH_SIZE
+# (TA_* counters hang the profiler on this pool: not collected)
+if [ -n "$PMC_EXTRA" ]; then
+run l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+run tcp TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum
+run sq3 SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_INSTS_VALU
+fi
 run tcw WRITE_SIZE
 cat gpurun_out/$tag/summary.txt
