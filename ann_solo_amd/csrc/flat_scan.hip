@@ -364,40 +364,79 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(e.x), "v"(e.y), "v"(qv));
           FI_T(2)
 #endif
-          const int n = min(64, K - kk0);
-          // lanes past the query's last dimension hold (0, 0) and q = 0: a batch never needs a
-          // tail case (64 % FI_U == 0). The first 64 postings of FI_U dimensions are loaded
-          // together and applied dimension by dimension; a dimension with more postings than
-          // lanes (rare) finishes its remaining rows before the next dimension starts
-          for (int j0 = 0; j0 < n; j0 += FI_U) {
-            uint32_t st[FI_U], cn[FI_U], loc[FI_U];
+          // The unit of work is a ROW: up to 64 postings of one dimension. A dimension of a
+          // 512-vector list has ~17 postings (one row), but a fragment bin that half the library
+          // shares has hundreds -- a third of the work of a query that holds it -- so rows, not
+          // dimensions, go through the pipeline. Lane j owns dimension j of the chunk (start e.x,
+          // postings e.y, query value qv); rows are numbered in dimension order, and lane r
+          // looks its row up: the dimension whose rows include r (binary search over the
+          // prefix sums, ds_bpermute pulls), then start, count and query value of that
+          // dimension. More than 64 rows in a chunk (dense data): further passes.
+          const uint32_t rows_j = (e.y + 63u) >> 6;
+          uint32_t incl = rows_j;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += t;
+          }
+          const uint32_t pre = incl - rows_j;      // first row of my dimension
+          const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+          for (uint32_t r0 = 0; r0 < R; r0 += 64) {
+            const uint32_t x = r0 + lane;          // my row
+            int lo = 0, hi = 63;                   // the last dimension with pre <= x
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+              const int mid = (lo + hi + 1) >> 1;
+              const uint32_t pm = (uint32_t)__builtin_amdgcn_ds_bpermute(mid << 2, (int)pre);
+              if (pm <= x) lo = mid; else hi = mid - 1;
+            }
+            const uint32_t pj = (uint32_t)__builtin_amdgcn_ds_bpermute(lo << 2, (int)pre);
+            const uint32_t stj = (uint32_t)__builtin_amdgcn_ds_bpermute(lo << 2, (int)e.x);
+            const uint32_t cnj = (uint32_t)__builtin_amdgcn_ds_bpermute(lo << 2, (int)e.y);
+            const float rq = __builtin_bit_cast(
+                float, __builtin_amdgcn_ds_bpermute(lo << 2, __builtin_bit_cast(int, qv)));
+            const uint32_t t = x - pj;             // row inside the dimension
+            const bool live = x < R;
+            const uint32_t rc = live ? min(64u, cnj - 64u * t) : 0u;    // postings in my row
+            const uint32_t rvo = live ? stj + 256u * t : 0u;             // its values ...
+            const uint32_t rlo = live ? stj + 4u * cnj + 128u * t : 0u;  // ... and local indices
+            // Software pipeline over the rows, FI_U deep: row r + FI_U is requested as soon as
+            // row r has been applied, so FI_U - 1 rows are always in flight (loads return in
+            // order: the wait before applying r is "all but the 2 (FI_U - 1) youngest"). Loads
+            // are unconditional -- a lane without a posting repeats the row's last one (same
+            // line, no traffic; rows past the end read the block's first line) -- so no branch
+            // hides them from the wait counters, and the loop runs to a multiple of FI_U
+            // without a tail case. Rows of one dimension touch different vectors; rows of
+            // different dimensions are applied in dimension order: the canonical chain.
+            uint32_t cn[FI_U], loc[FI_U];
             float qj[FI_U], val[FI_U];
+#define FI_FETCH(u, r)                                                                            \
+  {                                                                                               \
+    const uint32_t vo_ = (uint32_t)__builtin_amdgcn_readlane((int)rvo, (r));                      \
+    const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)rlo, (r));                      \
+    cn[u] = (uint32_t)__builtin_amdgcn_readlane((int)rc, (r));                                    \
+    qj[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rq), (r))); \
+    const uint32_t l_ = min((uint32_t)lane, cn[u] - 1u);                                          \
+    val[u] = *reinterpret_cast<const float *>(bptr + (vo_ + 4u * l_));                            \
+    loc[u] = *reinterpret_cast<const uint16_t *>(bptr + (lo_ + 2u * l_));                         \
+  }
+#define FI_APPLY(u) \
+  if ((uint32_t)lane < cn[u]) acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);
+            const int n = (int)min(64u, R - r0);
+            const int n_up = (n + FI_U - 1) & ~(FI_U - 1);
 #pragma unroll
-            for (int u = 0; u < FI_U; ++u) {
-              const int j = j0 + u;
-              st[u] = (uint32_t)__builtin_amdgcn_readlane((int)e.x, j);
-              cn[u] = (uint32_t)__builtin_amdgcn_readlane((int)e.y, j);
-              qj[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), j));
+            for (int u = 0; u < FI_U; ++u) FI_FETCH(u, u)
+            for (int j0 = FI_U; j0 < n_up; j0 += FI_U) {
+#pragma unroll
+              for (int u = 0; u < FI_U; ++u) {
+                FI_APPLY(u)
+                FI_FETCH(u, j0 + u)
+              }
             }
 #pragma unroll
-            for (int u = 0; u < FI_U; ++u) {
-              const bool on = (uint32_t)lane < cn[u];
-              val[u] = on ? *reinterpret_cast<const float *>(bptr + (st[u] + 4u * lane)) : 0.0f;
-              loc[u] = on ? (uint32_t)*reinterpret_cast<const uint16_t *>(
-                                bptr + (st[u] + 4u * cn[u] + 2u * lane))
-                          : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < FI_U; ++u) {
-              if ((uint32_t)lane < cn[u]) acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);
-              if (cn[u] > 64u)      // wave-uniform
-                for (uint32_t o = 64u + lane; o < cn[u]; o += 64) {
-                  const uint32_t l = *reinterpret_cast<const uint16_t *>(
-                      bptr + (st[u] + 4u * cn[u] + 2u * o));
-                  acc[l] = __builtin_fmaf(
-                      qj[u], *reinterpret_cast<const float *>(bptr + (st[u] + 4u * o)), acc[l]);
-                }
-            }
+            for (int u = 0; u < FI_U; ++u) FI_APPLY(u)
+#undef FI_FETCH
+#undef FI_APPLY
           }
         }
       }

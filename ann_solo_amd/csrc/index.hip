@@ -374,7 +374,8 @@ static int build_lists(asl_index *ix) {
         run += run & 1ull;      // every block starts on a 128-byte line
       }
       if (ok && run < (1ull << 32)) {     // 32-bit unit offsets (256 GB of postings)
-        const size_t bytes = (size_t)std::max<uint64_t>(run, 2) * 64;
+        // (+ 512: the scan reads a full wave-width from the start of an empty segment)
+        const size_t bytes = (size_t)std::max<uint64_t>(run, 2) * 64 + 512;
         ASL_TRY(ix->blk_offsets.upload(blk_off.data(), blk_off.size()));
         ASL_TRY(ix->blk_base.upload(h_base.data(), nblk));
         ASL_TRY(ix->inv_tab.upload(h_tab.data(), ncell));
