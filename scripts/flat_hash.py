@@ -1,5 +1,8 @@
+"""Measurement helper: fingerprint of the IVF-Flat results at bench scale (2.1 M library, nlist 4096,
+nprobe 128, k 1024, 16 384 queries) -- two builds of the library must print the same line:
+  ASL_LIB_PATH=build_ab/lib_x.so python scripts/flat_hash.py"""
 import os, sys, hashlib
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch, numpy as np
 from ann_solo_amd import synthetic
 from ann_solo_amd.spectral_library import Config, SpectralLibrary
