@@ -323,24 +323,32 @@ def test_ivfflat_postings_scan_many_small_lists():
         idx.set_scan_variant(0)
 
 
-@pytest.mark.parametrize('d,nnz,nlist', [(800, 90, 4), (96, 10, 3), (130, 16, 7)])
-def test_ivfflat_postings_scan_shapes(d, nnz, nlist):
+@pytest.mark.parametrize('d,nnz,nlist,hot', [(800, 90, 4, 0), (96, 10, 3, 0), (130, 16, 7, 0),
+                                             (800, 70, 4, 4), (400, 30, 5, 2)])
+def test_ivfflat_postings_scan_shapes(d, nnz, nlist, hot):
     """Postings scan outside the bench's shape: queries with more than 64 non-zero
     dimensions, lists longer than one 768-vector block, dimensions with more postings than
-    lanes, d not a multiple of 4, an empty list. Must equal the dense GEMM formulation bit for
-    bit (scores) and id for id."""
+    lanes, d not a multiple of 4, an empty list; ``hot`` dimensions shared by more than half of
+    the vectors and by every query (segments of hundreds of postings: more than 64 rows in a
+    chunk of the row pipeline). Must equal the dense GEMM formulation bit for bit (scores) and
+    id for id."""
     import torch
     from ann_solo_amd import faiss_compat as faiss
     g = torch.Generator().manual_seed(1000 + d)
     n, nq = 5000, 300
 
-    def sparse_rows(m):
+    hot_dims = torch.randperm(d, generator=g)[:hot]
+
+    def sparse_rows(m, p_hot):
         x = torch.zeros(m, d)
         for i in range(m):
             cols = torch.randperm(d, generator=g)[:nnz]
             x[i, cols] = torch.rand(nnz, generator=g) + 0.05
+        if hot:
+            has = torch.rand(m, hot, generator=g) < p_hot
+            x[:, hot_dims] = torch.where(has, torch.rand(m, hot, generator=g) + 0.05, x[:, hot_dims])
         return torch.nn.functional.normalize(x, dim=1)
-    xb, xq = sparse_rows(n), sparse_rows(nq)
+    xb, xq = sparse_rows(n, 0.55), sparse_rows(nq, 1.0)
     idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(d), d, nlist)
     cen = xb[:nlist].clone()
     cen[-1] = -cen[0]                      # a centroid nothing is assigned to: an empty list
