@@ -445,6 +445,16 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
       // then append without synchronising; lockstep rounds of 64 per wave only while the
       // threshold is still low (first blocks of a query) or ties force exact flushes.
       FI_T(3)
+      // the first round of a query: every accumulator of eight blocks would pass (4 k candidates
+      // against a buffer of 2 k) -- the threshold is fixed from a histogram of all of them first
+      const bool cold = c0 == 0 && r0 == 0;     // the same for every wave
+      if (cold) {
+        for (int r = 0; r * 64 < nb; ++r) {
+          const int v = r * 64 + lane;
+          top.cold_count(v < nb, v < nb ? acc[v] : 0.0f);
+        }
+        top.cold_threshold();
+      }
       bool done = false;
       for (int attempt = 0; attempt < 2 && !done; ++attempt) {
         int cnt = 0;
@@ -456,15 +466,18 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
           cnt += __popcll(__ballot(p));
         }
         FI_T(4)
-        const int st = top.bulk_reserve(cnt, attempt == 0);
+        const int st = top.bulk_reserve(cnt, attempt == 0 && !cold);
         FI_T(5)
-        if (st < 0) break;
+        if (st < 0) {
+          if (cold) top.cold_undo();     // a crowded threshold bucket: stream from the empty state
+          break;
+        }
         if (st == 1) {
           for (int r = 0; r * 64 < nb; ++r) {
             const bool p = (mine >> r) & 1u;
             if (__ballot(p)) {     // wave-uniform: few rows hold a candidate once the threshold stands
               const int v = r * 64 + lane;
-              top.offer(p, p ? acc[v] : 0.0f, (uint32_t)(pos0 + v));
+              top.offer(p, p ? acc[v] : 0.0f, (uint32_t)(pos0 + v), cold);
             }
           }
           done = true;

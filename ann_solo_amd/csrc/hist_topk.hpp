@@ -128,17 +128,42 @@ struct HistTopK {
 
   // one candidate per lane; returns true if it was kept (count kept lanes per wave with
   // __ballot and pass the sum to end_round)
-  __device__ __forceinline__ bool offer(bool valid, float score, uint32_t slot) {
+  // counted: the candidate is in the histogram already (cold start below)
+  __device__ __forceinline__ bool offer(bool valid, float score, uint32_t slot, bool counted = false) {
     const uint32_t ob = f2ord(score);
     const int b = score_bucket(score);
     const bool pass = sort_mode ? (ob >= thr_hi) : (b >= bstar);
     if (valid && pass) {
       const int s = atomicAdd(&ctl[C_FILL], 1);
       keys[s] = ((u64)ob << 32) | (u64)slot;
-      if (!sort_mode) atomicAdd(&hist[b], 1);
+      if (!sort_mode && !counted) atomicAdd(&hist[b], 1);
       return true;
     }
     return false;
+  }
+
+  // Cold start of a stream whose first round holds several times k candidates: count ALL of
+  // them in the histogram first (cold_count, every wave, no barrier), then fix the threshold
+  // bucket from the counts (cold_threshold, all threads) and store only the candidates at or
+  // above it, with offer(..., counted = true) -- instead of appending everything 64 per wave at
+  // a time and compacting on the way. Candidates below the bucket leave the histogram again, so
+  // it counts exactly what is stored. If what is left does not fit the buffer (a crowded
+  // threshold bucket), cold_undo() restores the empty state and the caller streams as usual.
+  __device__ __forceinline__ void cold_count(bool valid, float score) {
+    if (valid) atomicAdd(&hist[score_bucket(score)], 1);
+  }
+  __device__ __forceinline__ void cold_threshold() {
+    __syncthreads();
+    update_bstar();
+    refresh_threshold();
+    for (int i = tid; i < bstar; i += NT) hist[i] = 0;
+    __syncthreads();
+  }
+  __device__ __forceinline__ void cold_undo() {
+    for (int i = tid; i < HT_NB; i += NT) hist[i] = 0;
+    if (tid == 0) ctl[C_BSTAR] = 0;
+    __syncthreads();
+    refresh_threshold();
   }
 
   // the test offer() applies, against the current snapshot (scores are never NaN)
