@@ -208,25 +208,26 @@ int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t
 // u16, value f32) of the vectors that are non-zero there -- an inverted file inside the
 // inverted file. Storage: one segment per (block, dimension), its c values followed by its c
 // local indices (6c bytes), and one table word per (block, dimension): the segment's start in
-// 64-byte units from the block's base (high 16 bits) and c (low 16 bits). The scan is bound by
-// the number of 128-byte lines it pulls through L2 (hit rate < 10 %: every (query, block) pair
-// touches its own lines), so segments are PLACED BY LINE: one that fits a line never straddles
-// two, a longer one starts on a line boundary -- a dimension of a 512-vector list (17 postings,
-// 102 bytes) costs one line instead of 1.8, for ~25 % padding. A wave takes one (query, block): it zeroes the block's accumulators in LDS
+// 64-byte units from the block's base (high 16 bits) and c (low 16 bits). Every (query, block)
+// pair touches its own lines (L2 hit rate < 10 %), so segments are PLACED BY LINE: one that
+// fits a 128-byte line never straddles two, a longer one starts on a line boundary -- a
+// dimension of a 512-vector list (17 postings, 102 bytes) costs one line instead of 1.8, for
+// ~25 % padding. A wave takes one (query, block): it zeroes the block's accumulators in LDS
 // and walks the query's non-zero dimensions in ASCENDING order, acc[loc] = fmaf(q_d, val,
 // acc[loc]) over that dimension's postings (a vector occurs at most once per dimension, so
 // the lanes of one step never collide, and steps of one wave reach LDS in program order).
 // Per vector this is the ascending-dimension fp32 chain restricted to the dimensions where
 // both factors are non-zero -- bit-identical to the dense chain, the MFMA GEMM and the oracle
 // (a zero factor leaves the accumulator unchanged) -- at 1/16 of the tile kernel's traffic
-// (50 of 800 dimensions) and 1/4 of its lane-steps. Then all waves offer their accumulators
-// to the workgroup's histogram top-k, vectors with score 0 included (they are candidates of
-// the dense scan too).
+// (50 of 800 dimensions) and 1/4 of its lane-steps. Then the wave offers its accumulators to
+// the workgroup's histogram top-k, vectors with score 0 included (they are candidates of the
+// dense scan too). The eight waves of a workgroup run their blocks independently (blocks are
+// handed out by an LDS counter, appends are one atomic per row of candidates) and meet only
+// when the key buffer is full: see "Offers" below.
 #ifndef FI_U_
 #define FI_U_ 8
 #endif
 constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = 128, FI_U = FI_U_;
-static_assert(FI_BLK <= 32 * 64, "one bit per row of 64 accumulators in a 32-bit mask");
 #ifndef FI_PHASES
 #define FI_PHASES 0
 #endif
@@ -264,6 +265,9 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   FiUnit *table = reinterpret_cast<FiUnit *>(s_nzv + ((d + 3) & ~3));      // [FI_CHUNK]
   int *s_misc = reinterpret_cast<int *>(table + FI_CHUNK);                 // [16]
   uint16_t *s_nzd = reinterpret_cast<uint16_t *>(s_misc + 16);             // [d]
+  volatile int *s_flag = s_misc + 9;      // a wave asks for a sync of the top-k
+  int *s_done = s_misc + 10;              // waves that finished their blocks, summed over the chunks
+  int *s_next = s_misc + 11;              // next block of the chunk to hand out
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
 
 #if FI_PHASES
@@ -298,7 +302,11 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
       }
       base += __popcll(m);
     }
-    if (lane == 0) s_misc[8] = base;
+    if (lane == 0) {
+      s_misc[8] = base;
+      s_misc[9] = 0;      // sync flag
+      s_misc[10] = 0;     // finished waves
+    }
   }
   __syncthreads();
   const int K = s_misc[8];
@@ -306,6 +314,14 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   top.init(smem, k, ids, tid);
   float *acc = s_acc + wave * FI_BLK;
 
+  int chunks_done = 0;
+  auto sync = [&]() {             // raise the flag, meet the other waves, compact
+    if (lane == 0) *s_flag = 1;
+    __syncthreads();
+    if (tid == 0) *s_flag = 0;
+    top.free_sync();
+  };
+  auto sync_wanted = [&]() -> bool { return __builtin_amdgcn_readfirstlane(*s_flag) != 0; };
   FI_T(0)
   for (int c0 = 0; c0 < total; c0 += FI_CHUNK) {
     {
@@ -322,25 +338,14 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
     }
     __syncthreads();
     const int nent = min(FI_CHUNK, total - c0);
-    {
-      // The eight waves of a round meet at a barrier, so a round costs its LARGEST block:
-      // order the blocks by size (rank by counting) and every round gets eight alike.
-      FiUnit mine;
-      int rank = 0;
-      if (tid < nent) {
-        mine = table[tid];
-        for (int o = 0; o < nent; ++o) {
-          const int nbo = table[o].nb;
-          rank += (nbo > mine.nb) || (nbo == mine.nb && o < tid);
-        }
-      }
-      __syncthreads();
-      if (tid < nent) table[rank] = mine;
-      __syncthreads();
-    }
+    // The waves take blocks on their own: the first FI_NW in wave order (the cold start below
+    // needs every wave), then whichever is next (probe order: the lists closest to the query
+    // first, they raise the threshold soonest).
+    if (tid == 0) *s_next = FI_NW;
+    __syncthreads();
     FI_T(1)
-    for (int r0 = 0; r0 < nent; r0 += FI_NW) {
-      const int i = r0 + wave;
+    bool first = true;
+    for (int i = wave;; first = false) {
       int nb = 0, pos0 = 0;
       if (i < nent) {          // wave-uniform
         const FiUnit u = table[i];
@@ -445,9 +450,9 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
       // then append without synchronising; lockstep rounds of 64 per wave only while the
       // threshold is still low (first blocks of a query) or ties force exact flushes.
       FI_T(3)
-      // the first round of a query: every accumulator of eight blocks would pass (4 k candidates
+      // the first blocks of a query: every accumulator of eight blocks would pass (4 k candidates
       // against a buffer of 2 k) -- the threshold is fixed from a histogram of all of them first
-      const bool cold = c0 == 0 && r0 == 0;     // the same for every wave
+      const bool cold = c0 == 0 && first;     // the same for every wave
       if (cold) {
         for (int r = 0; r * 64 < nb; ++r) {
           const int v = r * 64 + lane;
@@ -455,51 +460,46 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
         }
         top.cold_threshold();
       }
-      bool done = false;
-      for (int attempt = 0; attempt < 2 && !done; ++attempt) {
-        int cnt = 0;
-        uint32_t mine = 0;      // bit r: my accumulator of row r (vector 64 r + lane) passes
-        for (int r = 0; r * 64 < nb; ++r) {
-          const int v = r * 64 + lane;
-          const bool p = v < nb && top.passes(acc[v]);
-          mine |= (uint32_t)p << r;
-          cnt += __popcll(__ballot(p));
-        }
-        FI_T(4)
-        const int st = top.bulk_reserve(cnt, attempt == 0 && !cold);
-        FI_T(5)
-        if (st < 0) {
-          if (cold) top.cold_undo();     // a crowded threshold bucket: stream from the empty state
-          break;
-        }
-        if (st == 1) {
-          for (int r = 0; r * 64 < nb; ++r) {
-            const bool p = (mine >> r) & 1u;
-            if (__ballot(p)) {     // wave-uniform: few rows hold a candidate once the threshold stands
-              const int v = r * 64 + lane;
-              top.offer(p, p ? acc[v] : 0.0f, (uint32_t)(pos0 + v), cold);
-            }
-          }
-          done = true;
+      // Offers: a row of accumulators at a time, straight into the key buffer (free_append: one
+      // atomic per row that holds a candidate, no barrier). When the buffer is full the wave
+      // raises the sync flag and waits; every wave looks at the flag between blocks (and in
+      // the wait at the end of the chunk) and joins; then the row is tried again against the
+      // new threshold.
+      for (int r = 0; r * 64 < nb; ++r) {
+        const int v = r * 64 + lane;
+        const float score = v < nb ? acc[v] : 0.0f;
+        for (;;) {
+          const bool p = v < nb && top.passes(score);
+          if (!__ballot(p)) break;                                        // wave-uniform
+          if (top.free_append(p, score, (uint32_t)(pos0 + v), cold)) break;
+          sync();
         }
       }
-      if (!done) {
-        int nbmax = 0;
-#pragma unroll
-        for (int w = 0; w < FI_NW; ++w) nbmax = max(nbmax, r0 + w < nent ? table[r0 + w].nb : 0);
-        for (int r = 0; r * 64 < nbmax; ++r) {
-          top.begin_round();
-          const int v = r * 64 + lane;
-          const bool valid = v < nb;
-          const float score = valid ? acc[v] : 0.0f;
-          const bool take = top.offer(valid, score, (uint32_t)(pos0 + v));
-          top.end_round(__popcll(__ballot(take)));
-        }
-      }
-      FI_T(6)
+      FI_T(4)
+      if (sync_wanted()) sync();
+      FI_T(5)
+      if (i >= nent) break;
+      if (lane == 0) i = atomicAdd(s_next, 1);
+      i = __builtin_amdgcn_readfirstlane(i);
+      if (i >= nent) break;
     }
+    // end of the chunk: wait for the other waves, joining the syncs they ask for
+    if (lane == 0) atomicAdd(s_done, 1);
+    ++chunks_done;
+    for (;;) {
+      if (sync_wanted()) {
+        sync();
+        continue;
+      }
+      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >=
+          FI_NW * chunks_done)
+        break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    FI_T(6)
     __syncthreads();
   }
+  top.free_done();
   FI_T(1)
 #if FI_PHASES
   const long long t_fin = wall_clock64();

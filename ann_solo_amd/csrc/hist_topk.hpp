@@ -228,6 +228,57 @@ struct HistTopK {
     __syncthreads();
   }
 
+  // ---- free-running appends -----------------------------------------------------------------
+  // The waves of a workgroup append on their own, a row of candidates at a time, without a
+  // barrier: free_append reserves the slots of the wave with one atomic and fails -- writing
+  // nothing -- when the buffer cannot take them. The failing wave then asks for a free_sync
+  // (caller's flag + barrier: every wave must join), which compacts (or, with ties, sorts
+  // and truncates), moves the threshold and zeroes the free tail; a failed reservation leaves
+  // its slots below CAP empty (0), which every consumer skips. C_FILL may run past CAP.
+  __device__ __forceinline__ bool free_append(bool p, float score, uint32_t slot, bool counted = false) {
+    const unsigned long long m = __ballot(p);
+    const int c = __popcll(m);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&ctl[C_FILL], c);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base + c > CAP) return false;
+    if (p) {
+      const int b = score_bucket(score);
+      keys[base + __popcll(m & ((1ull << lane) - 1ull))] = ((u64)f2ord(score) << 32) | (u64)slot;
+      if (!sort_mode && !counted) atomicAdd(&hist[b], 1);
+    }
+    return true;
+  }
+  // all threads, after a barrier that every wave reached
+  __device__ __forceinline__ void free_sync() {
+    const int cf = ctl[C_FILL];
+    __syncthreads();
+    fill = cf < CAP ? cf : CAP;
+    if (tid == 0) ctl[C_FILL] = fill;
+    __syncthreads();
+    if (!sort_mode) {
+      fill = compact();
+      if (fill > CAP - ROUND_VECS) {   // ties defeat the buckets: exact flushes from now on
+        sort_mode = true;
+        tk.slot_ids = slot_ids;
+        tk.conv_from = 0;
+      }
+    }
+    if (sort_mode && fill > CAP - ROUND_VECS) fill = tk.flush(tid);
+    for (int i = fill + tid; i < CAP; i += NT) keys[i] = 0ull;
+    __syncthreads();
+    refresh_threshold();
+  }
+  // before finish(): the fill level as the appends left it (no reservation is pending)
+  __device__ __forceinline__ void free_done() {
+    __syncthreads();
+    const int cf = ctl[C_FILL];
+    fill = cf < CAP ? cf : CAP;
+    __syncthreads();
+    if (tid == 0) ctl[C_FILL] = fill;
+    __syncthreads();
+  }
+
   // drop every buffered key whose bucket is below bstar; returns the new fill
   __device__ __forceinline__ int compact() {
     update_bstar();

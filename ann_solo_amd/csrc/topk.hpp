@@ -243,7 +243,7 @@ struct StreamTopK {
 #pragma unroll
         for (int u = 0; u < PERC; ++u) {
           const int i = conv_from + tid + u * NT;
-          idv[u] = i < f ? slot_ids[(uint32_t)kk[u]] : -1;
+          idv[u] = (i < f && kk[u] != 0ull) ? slot_ids[(uint32_t)kk[u]] : -1;   // 0: an empty slot
         }
 #pragma unroll
         for (int u = 0; u < PERC; ++u) {
@@ -255,7 +255,7 @@ struct StreamTopK {
       } else {
         for (int i = conv_from + tid; i < f; i += NT) {
           const u64 key = buf[i];
-          const int32_t id = slot_ids[(uint32_t)key];
+          const int32_t id = key != 0ull ? slot_ids[(uint32_t)key] : -1;
           buf[i] = id >= 0 ? ((key & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - (uint32_t)id)) : 0ull;
         }
       }

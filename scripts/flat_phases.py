@@ -27,8 +27,8 @@ ev1.record()
 torch.cuda.synchronize()
 print('search call: %.2f ms' % ev0.elapsed_time(ev1))
 ph = torch.as_tensor(D)[:, :64].double().reshape(-1, 8, 8) / 100.0      # us, [query, wave, phase]
-names = ['prologue', 'chunk table+sort+end barrier', 'zero+table fetch', 'dimension batches',
-         'count pass', 'reserve (barrier)', 'offers', 'finish']
+names = ['prologue', 'chunk table + end barrier', 'zero + table fetch', 'rows',
+         'cold start + offers (incl. syncs asked for)', 'syncs joined between blocks', 'end-of-chunk wait', 'finish']
 m = ph.mean((0, 1))
 for n, v in zip(names, m):
     print(f'{n:32s} {v:8.1f} us per wave per query')
