@@ -143,6 +143,48 @@ def test_knn_id_sets_equal_the_oracle_at_bench_size(world, O):
     assert np.array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
 
 
+def test_ivfflat_knn_equal_the_oracle_at_bench_size(world, O):
+    """IVF-Flat over the same 2.1 M library at the bench's geometry (nlist 4096, nprobe 112 /
+    128, k 1024): the postings scan -- rows of long dimensions (a fragment bin that half of the
+    library shares has ~260 postings per block), histogram cold start, free-running appends --
+    returns the ids AND score bits of the oracle's exact scan of the probed lists."""
+    import torch
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    sl, q, _ = world
+    lib = sl.partitions[2].spectra
+    cfg = Config(num_list=4096, num_probe=128, num_candidates=1024, index='ivfflat',
+                 kmeans_niter=5, batch_size=16384, seed=1234)
+    fl = SpectralLibrary(lib, config=cfg, device=lib.mz.device)
+    try:
+        idx = fl._get_ann_index(2)
+        off, ids, vecs = idx.lists()
+        info = idx.info()
+        ivf = O.HostIVF.__new__(O.HostIVF)
+        ivf.centroids, ivf.nlist, ivf.d = idx.centroids(), info.nlist, info.d
+        ivf.list_offsets, ivf.ids, ivf.payload, ivf.codebooks, ivf.kind = off, ids, vecs, None, 0
+        rows = np.arange(0, q.n, 32)                                  # 64 sampled queries
+        vec = fl._encode(q)[rows].contiguous()
+        for nprobe in (128, 112):
+            idx.nprobe = nprobe
+            D, I = idx.search(vec, 1024)
+            Do, Io = ivf.search(vec.cpu().numpy(), 1024, nprobe)
+            assert np.array_equal(torch.as_tensor(I).cpu().numpy(), Io)
+            assert np.array_equal(torch.as_tensor(D).cpu().numpy().view(np.uint32), Do.view(np.uint32))
+        # a whole batch: ordered rows == the unordered set mode, second call == first
+        full = fl._encode(q)
+        D1, I1 = idx.search(full, 1024)
+        D2, I2 = idx.search(full, 1024)
+        assert torch.equal(I1, I2) and torch.equal(D1, D2)
+        idx.set_unordered(True)
+        try:
+            _, Iu = idx.search(full, 1024)
+        finally:
+            idx.set_unordered(False)
+        assert torch.equal(I1.sort(1)[0], Iu.sort(1)[0])
+    finally:
+        fl.shutdown()
+
+
 def test_cascade_std_then_open_on_the_remainder(world, O):
     """configs[4] at full size on one GPU (spectral_library.py:237-259): the standard search
     identifies what a 20 ppm window can, the gate keeps confident SSMs, the open search runs on
