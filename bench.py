@@ -57,6 +57,9 @@ def main():
     ap.add_argument('--refine-k', type=int, default=0,
                     help="IVF-PQ: exact re-rank of the k' best ADC candidates (asl_index_set_refine); "
                          '0 = off (the default workload)')
+    ap.add_argument('--no-fixed-recall', action='store_true',
+                    help='skip the IVF-Flat measurement at the fixed-recall operating point '
+                         '(default run, N = 1, IVF-PQ: same library, same coarse quantiser)')
     ap.add_argument('--no-pipeline', action='store_true',
                     help='run the stages of consecutive batches strictly one after the other '
                          '(default: two-stream software pipeline, asl_set_pipeline)')
@@ -145,6 +148,7 @@ def main():
 
     # ---- recall@k vs exact inner product (outside the timed region; unsharded index)
     recall = None
+    recall_ctx = None
     if rank == 0 and args.recall_queries > 0:
         nr = min(args.recall_queries, q.n)
         qs = q.select(torch.arange(nr, device=dev))
@@ -188,6 +192,7 @@ def main():
                            'fixed_recall_criterion': 'recall@k >= 0.95 x IVF-Flat(nlist, nprobe) '
                                                      '(SURVEY.md 8d)',
                            'meets_criterion': bool(rf > 0 and rec / rf >= 0.95)})
+        recall_ctx = (qs, Ie, nr) if args.index == 'ivfpq' else None
         torch.cuda.empty_cache()
 
     def barrier():
@@ -273,6 +278,59 @@ def main():
         stages[name] = {'ms_total': ms.value, 'launches': n.value}
     scanned = L.asl_profile_scanned_vectors()
 
+    # ---- the same metric at FIXED RECALL: IVF-Flat over the same library and the
+    # same coarse quantiser, at the smallest nprobe (steps of 8) whose recall@k is still >= 0.95 x
+    # IVF-Flat(nlist, nprobe) -- the whole hot path timed like `value`, after it, in the same run
+    fixed_recall = None
+    if (world == 1 and rank == 0 and args.index == 'ivfpq' and recall_ctx is not None
+            and not args.no_fixed_recall and not args.refine_k):
+        from dataclasses import replace
+        qs, Ie, nr = recall_ctx
+        sl_f = SpectralLibrary(lib, config=replace(cfg, index='ivfflat', refine_k=None), device=dev)
+        idx_f = sl_f._get_ann_index(charge)
+        same_q = bool(np.array_equal(idx_f.centroids(), idx.centroids()))
+        vq = sl_f._encode(qs)
+
+        def recall_at(nprobe):
+            idx_f.nprobe = nprobe
+            _, If = idx_f.search(vq, args.k)
+            return sum(int(torch.isin(If[i][If[i] >= 0], Ie[i]).sum()) for i in range(nr)) / float(nr * args.k)
+        ref_rec = recall_at(args.nprobe)
+        best, best_rec = args.nprobe, ref_rec
+        for nprobe in range(args.nprobe - 8, args.nprobe // 2, -8):
+            r_ = recall_at(nprobe)
+            if r_ < 0.95 * ref_rec:
+                break
+            best, best_rec = nprobe, r_
+        sl_f._num_probe = best
+
+        def flat_step():
+            return sl_f._search_batch(q, charge, 'open', device_out=True)
+        sl_f.set_pipeline(pipelined)
+        for _ in range(args.warmup):
+            flat_step()
+        sl_f.synchronize()
+        L.asl_profile_enable(1)
+        L.asl_profile_reset()
+        el_f, _ = timed(flat_step, args.steps)
+        sl_f.synchronize()
+        L.asl_profile_enable(0)
+        sl_f.set_pipeline(False)
+        ms_f, n_f = C.c_double(), C.c_int64()
+        L.asl_profile_get(b'scan', C.byref(ms_f), C.byref(n_f))
+        fixed_recall = {'index': 'ivfflat', 'nlist': args.nlist, 'nprobe': best,
+                        'same_coarse_quantiser_as_the_ivfpq_index': same_q,
+                        'recall_at_k_vs_exact_ip': best_rec,
+                        'criterion': f'>= 0.95 x {ref_rec:.4f} (IVF-Flat, nprobe {args.nprobe})',
+                        'value': round(args.batch * args.steps / el_f, 2), 'unit': 'query spectra/s',
+                        'ms_per_step': round(el_f / args.steps * 1e3, 3), 'steps': args.steps,
+                        'scan_ms_per_step': round(ms_f.value / max(args.steps, 1), 3),
+                        'pipelined': pipelined}
+        sl_f.shutdown()
+        del sl_f, idx_f
+        torch.cuda.empty_cache()
+
+
     if rank == 0:
         total_queries = world * args.batch * args.steps
         scan = stages['scan']
@@ -343,6 +401,7 @@ def main():
                          'note': 'stage times overlap across consecutive steps when true: their '
                                  'sum exceeds ms_per_step'},
             'recall': recall,
+            'fixed_recall': fixed_recall,
             'shard_check': shard_check,
             'alt_layouts': alt,
             'stages_ms_per_step': {k: round(v['ms_total'] / args.steps, 3) for k, v in stages.items()},
