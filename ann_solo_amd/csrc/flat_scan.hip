@@ -445,10 +445,6 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
           }
         }
       }
-      // Offers. Few accumulators pass the running threshold, so the waves first count their
-      // passing candidates and reserve room for all of them with ONE barrier (bulk_reserve),
-      // then append without synchronising; lockstep rounds of 64 per wave only while the
-      // threshold is still low (first blocks of a query) or ties force exact flushes.
       FI_T(3)
       // the first blocks of a query: every accumulator of eight blocks would pass (4 k candidates
       // against a buffer of 2 k) -- the threshold is fixed from a histogram of all of them first
