@@ -171,40 +171,6 @@ struct HistTopK {
     return sort_mode ? (f2ord(score) >= thr_hi) : (score >= thr_f);
   }
 
-  // Bulk rounds: a wave that holds MANY scored candidates (e.g. a block of accumulators in
-  // LDS) first counts the ones that pass (`passes`, wave-local, no barrier), then all waves
-  // call bulk_reserve with their counts: 1 = room for all of them -- every wave may now
-  // offer() exactly the candidates it counted, with no further synchronisation; 0 = the
-  // buffer was compacted instead and the threshold moved: count again and call again;
-  // -1 = use lockstep rounds (offer / end_round) for these candidates. One barrier per call
-  // instead of one per 64 candidates per wave.
-  __device__ __forceinline__ int bulk_reserve(int cnt, bool may_compact) {
-    if (sort_mode) return -1;
-    if (lane == 0) ctl[C_WCNT + parity * NW + wave] = cnt;
-    __syncthreads();
-    int total = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) total += ctl[C_WCNT + parity * NW + w];
-    parity ^= 1;
-    if (fill + total <= CAP) {
-      fill += total;
-      ++round_no;
-      return 1;
-    }
-    if (!may_compact) return -1;   // (the buffer was compacted by the previous call: a lockstep round fits)
-    // same steps as end_round: compact; if ties defeat the buckets, exact flushes from now on
-    // (the lockstep rounds the caller falls back to need ROUND_VECS free slots)
-    fill = compact();
-    if (fill > CAP - ROUND_VECS) {
-      sort_mode = true;
-      tk.slot_ids = slot_ids;
-      tk.conv_from = 0;
-      fill = tk.flush(tid);
-    }
-    refresh_threshold();
-    return sort_mode ? -1 : 0;
-  }
-
   __device__ __forceinline__ void update_bstar() {
     constexpr int BPT = HT_NB / NT;  // buckets per thread (2 or 1), highest buckets in thread 0
     int h[BPT], s = 0;
