@@ -148,7 +148,8 @@ struct HistTopK {
   // above it, with offer(..., counted = true) -- instead of appending everything 64 per wave at
   // a time and compacting on the way. Candidates below the bucket leave the histogram again, so
   // it counts exactly what is stored. If what is left does not fit the buffer (a crowded
-  // threshold bucket), cold_undo() restores the empty state and the caller streams as usual.
+  // threshold bucket), the free-running appends below run into a free_sync, whose compaction
+  // cannot free a slot, and the top-k falls back to exact sort-and-truncate flushes.
   __device__ __forceinline__ void cold_count(bool valid, float score) {
     if (valid) atomicAdd(&hist[score_bucket(score)], 1);
   }
@@ -158,12 +159,6 @@ struct HistTopK {
     refresh_threshold();
     for (int i = tid; i < bstar; i += NT) hist[i] = 0;
     __syncthreads();
-  }
-  __device__ __forceinline__ void cold_undo() {
-    for (int i = tid; i < HT_NB; i += NT) hist[i] = 0;
-    if (tid == 0) ctl[C_BSTAR] = 0;
-    __syncthreads();
-    refresh_threshold();
   }
 
   // the test offer() applies, against the current snapshot (scores are never NaN)
