@@ -57,7 +57,10 @@ int flat_sparse_scan(const float *xq, int nq, int d, const int32_t *coarse_I, in
                      int nnz_stride, const int32_t *ids_tiled, int k, float *D, int64_t *I64,
                      int32_t *I32);
 // dimension-major IVF-Flat (flat_scan.hip): blocks of FI_BLK vectors with per-dimension postings
-constexpr int FI_BLK = 768;
+#ifndef FI_BLK_
+#define FI_BLK_ 832     // measured (scan ms at nprobe 128): 512 7.69 | 640 7.14 | 768 6.81 | 832 6.71 | 864 6.70 (the LDS limit of three workgroups per CU) | 1024: two workgroups per CU
+#endif
+constexpr int FI_BLK = FI_BLK_;
 bool flat_inv_supported(int d, int k, int nprobe);
 int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *list_offsets, const int32_t *blk_offsets,

@@ -327,7 +327,7 @@ def test_ivfflat_postings_scan_many_small_lists():
                                              (800, 70, 4, 4), (400, 30, 5, 2)])
 def test_ivfflat_postings_scan_shapes(d, nnz, nlist, hot):
     """Postings scan outside the bench's shape: queries with more than 64 non-zero
-    dimensions, lists longer than one 768-vector block, dimensions with more postings than
+    dimensions, lists longer than one block (832 vectors), dimensions with more postings than
     lanes, d not a multiple of 4, an empty list; ``hot`` dimensions shared by more than half of
     the vectors and by every query (segments of hundreds of postings: more than 64 rows in a
     chunk of the row pipeline). Must equal the dense GEMM formulation bit for bit (scores) and
@@ -355,7 +355,7 @@ def test_ivfflat_postings_scan_shapes(d, nnz, nlist, hot):
     idx.set_trained(cen.numpy())
     idx.add(xb.numpy())
     off = idx.lists()[0]
-    assert (np.diff(off) == 0).any() and (np.diff(off) > 768).any()
+    assert (np.diff(off) == 0).any() and (np.diff(off) > 832).any()
     # k > 1280: the postings kernel with the 4096-key buffer
     for k, nprobe in ((1024, nlist), (100, 2), (1500, nlist), (2000, nlist)):
         idx.nprobe = nprobe
