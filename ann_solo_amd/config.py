@@ -1,0 +1,131 @@
+"""The options that reach the hot path.
+
+``Config`` carries the reference's flags under the reference's names and defaults
+(/root/reference/src/ann_solo/config.py:62-216) plus the ADDITIVE flags of this implementation
+(``index``, ``pq_m``, ``pq_bits``, ``refine_k``, ``kmeans_niter``, ``ann_seed``, ``num_gpus``).
+``Config.from_reference(obj)`` snapshots any configuration object -- in particular the
+reference's own ``ann_solo.config.config`` singleton, whose ``__getattr__`` answers unknown
+options with ``KeyError`` (config.py:285-291), not ``AttributeError`` -- so the engine can be
+constructed exactly as ``ann_solo.py:78-79`` does. ``add_arguments(parser)`` is the additive
+patch for the reference's ``Config.__init__``."""
+from dataclasses import dataclass, fields
+from typing import Optional
+
+_MISSING = object()
+
+
+@dataclass
+class Config:
+    # --- the reference's flags (config.py:62-216), same names, same defaults
+    resolution: Optional[int] = None
+    min_mz: int = 11
+    max_mz: int = 2010
+    remove_precursor: bool = False
+    remove_precursor_tolerance: float = 0
+    min_intensity: float = 0.01
+    min_peaks: int = 10
+    min_mz_range: float = 250
+    max_peaks_used: int = 50
+    max_peaks_used_library: int = 50
+    scaling: Optional[str] = 'rank'
+    fdr: float = 0.01
+    fdr_min_group_size: int = 100
+    spectral_library_filename: str = ''
+    query_filename: str = ''
+    out_filename: str = ''
+    bin_size: float = 0.04
+    hash_len: int = 800
+    num_candidates: int = 1024
+    batch_size: int = 16384
+    num_list: int = 256
+    num_probe: int = 128
+    mode: str = 'ann'                       # 'ann' | 'bf'
+    precursor_tolerance_mass: float = 20.0
+    precursor_tolerance_mode: str = 'ppm'   # 'Da' | 'ppm'
+    precursor_tolerance_mass_open: Optional[float] = 300.0
+    precursor_tolerance_mode_open: Optional[str] = 'Da'
+    fragment_mz_tolerance: float = 0.02
+    allow_peak_shifts: bool = True
+    no_gpu: bool = False
+    # SSM scoring (config.py:158-164): carried for the caller's scorer. The engine itself has no
+    # FDR model (out of scope): ``score_ssms=`` is injected; without one every SSM is
+    # accepted with its cosine as the score and q = 0.
+    model: Optional[str] = None
+    # --- additive flags of this implementation
+    index: str = 'ivfflat'                  # 'ivfflat' (the reference's index type) | 'ivfpq'
+    pq_m: int = 32
+    pq_bits: int = 8
+    refine_k: Optional[int] = None          # IVF-PQ: exact re-rank of the refine_k best ADC candidates
+    kmeans_niter: int = 25                  # FAISS' ClusteringParameters.niter default
+    seed: int = 1234                        # flag --ann_seed; FAISS' ClusteringParameters.seed default
+    num_gpus: int = 0                       # > 1: list-shard the ANN indexes over that many ranks
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    @property
+    def ann_seed(self) -> int:              # the flag's name on the command line
+        return self.seed
+
+    @classmethod
+    def from_reference(cls, obj, **overrides) -> 'Config':
+        """Snapshot of ``obj`` (a ``Config``, the reference's ``config`` singleton, an
+        ``argparse.Namespace``, a mapping ...): every field it answers is taken, every field it
+        does not know (``KeyError`` / ``AttributeError`` / ``RuntimeError`` of an unparsed
+        reference config is NOT swallowed) keeps the default above."""
+        if isinstance(obj, cls) and not overrides:
+            return obj
+        kw = {}
+        for f in fields(cls):
+            v = _lookup(obj, 'ann_seed' if f.name == 'seed' else f.name)
+            if v is _MISSING and f.name == 'seed':
+                v = _lookup(obj, 'seed')
+            if v is not _MISSING:
+                kw[f.name] = v
+        kw.update(overrides)
+        if kw.get('index') is None:
+            kw.pop('index', None)
+        return cls(**kw)
+
+
+def _lookup(obj, name):
+    if obj is None:
+        return _MISSING
+    if isinstance(obj, dict):
+        return obj.get(name, _MISSING)
+    try:
+        return getattr(obj, name)
+    except (AttributeError, KeyError):
+        return _MISSING
+
+
+def add_arguments(parser) -> None:
+    """The additive command-line flags, for the reference's parser: one call at the end of
+    ``ann_solo.config.Config.__init__`` (config.py:275, before ``self._namespace = None``):
+
+        from ann_solo_amd.config import add_arguments; add_arguments(self._parser)
+
+    No existing flag changes name, default or meaning."""
+    d = Config()
+    parser.add_argument('--index', default=d.index, type=str, choices=['ivfflat', 'ivfpq'],
+                        help='ANN index type: inverted file with exact inner products (the '
+                             "reference's index) or with product-quantised codes "
+                             '(default: %(default)s)')
+    parser.add_argument('--pq_m', default=d.pq_m, type=int,
+                        help='IVF-PQ: number of sub-quantisers; must divide hash_len '
+                             '(default: %(default)s)')
+    parser.add_argument('--pq_bits', default=d.pq_bits, type=int,
+                        help='IVF-PQ: bits per sub-quantiser code (default: %(default)s)')
+    parser.add_argument('--refine_k', default=d.refine_k, type=int,
+                        help='IVF-PQ: re-rank this many ADC candidates with exact inner products '
+                             '(default: no re-ranking)')
+    parser.add_argument('--kmeans_niter', default=d.kmeans_niter, type=int,
+                        help='k-means iterations when training the ANN index '
+                             '(default: %(default)s)')
+    parser.add_argument('--ann_seed', default=d.seed, type=int,
+                        help='random seed of the ANN index trainer (default: %(default)s)')
+    parser.add_argument('--num_gpus', default=d.num_gpus, type=int,
+                        help='shard the ANN index by inverted list over this many GPUs; the job '
+                             'runs one process per GPU (torchrun --nproc-per-node N) and N must '
+                             'equal this value; 0 or 1: every process searches the whole index '
+                             '(default: %(default)s)')

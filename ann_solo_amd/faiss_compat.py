@@ -9,6 +9,7 @@ plus ``IndexIVFPQ`` (the north star's addition). ``import ann_solo_amd.faiss_com
 faiss`` is the whole change at those call sites. Indexes always live on the GPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -260,7 +261,16 @@ class IndexIVFPQ(Index):
 
 
 def write_index(index: Index, path: str):
-    _lib.check(_lib.lib().asl_index_save(index._h, str(path).encode()))
+    # private name + rename: concurrent ranks write the same cache file, readers never see a
+    # truncated one
+    path = str(path)
+    tmp = f'{path}.tmp{os.getpid()}'
+    try:
+        _lib.check(_lib.lib().asl_index_save(index._h, tmp.encode()))
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
 
 
 def read_index(path: str) -> Index:
@@ -350,6 +360,8 @@ def read_index_faiss(path: str) -> 'IndexIVFFlat':
             raise ValueError(f'{path}: not a FAISS IndexIVFFlat file')
         d, ntotal, _, _, trained, metric = take('iqqqBi')
         nlist, nprobe = take('QQ')
+        if ntotal < 0 or ntotal * max(d, 0) * 4 > len(buf) or nlist * max(d, 0) * 4 > len(buf):
+            raise ValueError(f'{path}: header promises more data than the file holds')
         q4 = cc()
         if q4 not in (b'IxFI', b'IxF2', b'IxFl') or metric != METRIC_INNER_PRODUCT:
             raise ValueError(f'{path}: only inner-product IVF-Flat over a flat quantiser is supported')
@@ -370,10 +382,18 @@ def read_index_faiss(path: str) -> 'IndexIVFFlat':
         lt = cc()
         sizes = np.zeros(nlist, np.int64)
         if lt == b'full':
-            sizes[:] = arr('<u8', take('Q'))
+            full = arr('<u8', take('Q'))
+            if len(full) != nlist or (len(full) and full.max() > ntotal):
+                raise ValueError(f'{path}: list size table out of range')
+            sizes[:] = full.astype(np.int64)
         elif lt == b'sprs':
-            pr = arr('<u8', take('Q')).reshape(-1, 2)
-            sizes[pr[:, 0].astype(np.int64)] = pr[:, 1]
+            npr = take('Q')
+            if npr % 2:
+                raise ValueError(f'{path}: odd sparse list table')
+            pr = arr('<u8', npr).reshape(-1, 2)
+            if len(pr) and (pr[:, 0].max() >= nlist or pr[:, 1].max() > ntotal):
+                raise ValueError(f'{path}: sparse list table out of range')
+            sizes[pr[:, 0].astype(np.int64)] = pr[:, 1].astype(np.int64)
         else:
             raise ValueError(f'{path}: unknown list layout {lt!r}')
         if int(sizes.sum()) != ntotal:
@@ -387,13 +407,16 @@ def read_index_faiss(path: str) -> 'IndexIVFFlat':
                 continue
             codes = arr('<f4', n * d).reshape(n, d)
             ids = arr('<i8', n)
-            if ids.min() < 0 or ids.max() >= ntotal or seen[ids].any():
+            if (ids.min() < 0 or ids.max() >= ntotal or seen[ids].any() or
+                    len(np.unique(ids)) != n):
                 raise ValueError(f'{path}: ids are not a permutation of 0..ntotal-1')
             seen[ids] = True
             x[ids] = codes
             lists[ids] = l
     except struct.error as e:
         raise ValueError(f'{path}: truncated ({e})') from None
+    except (IndexError, OverflowError, MemoryError) as e:      # a damaged header: sizes, counts
+        raise ValueError(f'{path}: corrupt ({type(e).__name__}: {e})') from None
     idx = IndexIVFFlat(IndexFlatIP(d), d, int(nlist), METRIC_INNER_PRODUCT)
     idx.set_trained(cen)
     if ntotal:

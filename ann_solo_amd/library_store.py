@@ -48,6 +48,8 @@ _PROCESS_KEYS = ['resolution', 'min_mz', 'max_mz', 'remove_precursor',
 def store_hash(config, hyperparameter_hash: str, annotation_alignment: str) -> str:
     """Key of a packed store: the reference's hyper-parameter hash (what its ``.spcfg`` is keyed
     by) + every option that changes the processed library peaks + the store layout version."""
+    from .config import Config
+    config = Config.from_reference(config)
     opts = {k: getattr(config, k, None) for k in _PROCESS_KEYS}
     b = json.dumps({'hyper': hyperparameter_hash, 'process': opts,
                     'annotation': annotation_alignment, 'layout': 2}, sort_keys=True)

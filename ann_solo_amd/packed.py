@@ -9,6 +9,7 @@ Peaks of one spectrum are ascending in m/z and already processed
 (``process_spectrum``, spectrum.py:57-119).
 """
 import json
+import os
 import struct
 from dataclasses import dataclass
 from typing import Optional
@@ -125,13 +126,21 @@ class PackedSpectra:
         if extra is not None:
             meta['extra'] = extra
         meta = json.dumps(meta).encode('utf-8')
-        with open(path, 'wb') as f:
-            f.write(STORE_MAGIC)
-            f.write(struct.pack('<QQI', self.n, int(mz.shape[0]), len(meta)))
-            f.write(meta)
-            for a, dt in ((o, '<i8'), (mz, '<f4'), (it, '<f4'), (chg, 'u1'), (pmz, '<f8'),
-                          (pz, 'u1')):
-                f.write(np.ascontiguousarray(a).astype(dt, copy=False).tobytes())
+        # written under a private name and renamed: the ranks of a sharded job build the same
+        # store at the same time, and a reader must never see a half-written file
+        tmp = f'{path}.tmp{os.getpid()}'
+        try:
+            with open(tmp, 'wb') as f:
+                f.write(STORE_MAGIC)
+                f.write(struct.pack('<QQI', self.n, int(mz.shape[0]), len(meta)))
+                f.write(meta)
+                for a, dt in ((o, '<i8'), (mz, '<f4'), (it, '<f4'), (chg, 'u1'), (pmz, '<f8'),
+                              (pz, 'u1')):
+                    f.write(np.ascontiguousarray(a).astype(dt, copy=False).tobytes())
+            os.replace(tmp, path)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
 
     @staticmethod
     def load(path: str, hyperparameter_hash: Optional[str] = None,

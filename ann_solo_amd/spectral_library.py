@@ -30,57 +30,9 @@ import torch
 
 from . import _lib
 from . import faiss_compat as faiss
+from .config import Config
 from .packed import PackedSpectra
 from .spectrum import get_dim, spectra_to_vectors, HASH_SEED
-
-
-@dataclass
-class Config:
-    """The reference's flags that reach the hot path, same names and defaults
-    (/root/reference/src/ann_solo/config.py:71-216). ``index``/``pq_m``/``pq_bits`` are
-    the additive flags of this implementation."""
-    resolution: Optional[int] = None
-    min_mz: int = 11
-    max_mz: int = 2010
-    remove_precursor: bool = False
-    remove_precursor_tolerance: float = 0
-    min_intensity: float = 0.01
-    min_peaks: int = 10
-    min_mz_range: float = 250
-    max_peaks_used: int = 50
-    max_peaks_used_library: int = 50
-    scaling: Optional[str] = 'rank'
-    fdr: float = 0.01
-    fdr_min_group_size: int = 100
-    spectral_library_filename: str = ''
-    query_filename: str = ''
-    bin_size: float = 0.04
-    hash_len: int = 800
-    num_candidates: int = 1024
-    batch_size: int = 16384
-    num_list: int = 256
-    num_probe: int = 128
-    mode: str = 'ann'                       # 'ann' | 'bf'
-    precursor_tolerance_mass: float = 20.0
-    precursor_tolerance_mode: str = 'ppm'   # 'Da' | 'ppm'
-    precursor_tolerance_mass_open: Optional[float] = 300.0
-    precursor_tolerance_mode_open: Optional[str] = 'Da'
-    fragment_mz_tolerance: float = 0.02
-    allow_peak_shifts: bool = True
-    no_gpu: bool = False
-    index: str = 'ivfflat'                  # 'ivfflat' | 'ivfpq'
-    pq_m: int = 32
-    pq_bits: int = 8
-    kmeans_niter: int = 25
-    seed: int = 1234
-    refine_k: Optional[int] = None          # IVF-PQ: exact re-rank of the refine_k best ADC candidates
-    # SSM scoring (config.py:158-164). 'none': target-decoy q-values on the cosine (fdr.py).
-    # 'rf' / 'svm' (mokapot models) are not built: pass a ``score_ssms`` callable for those.
-    # None (default here): without a callable every SSM is accepted with q = 0.
-    model: Optional[str] = None
-
-    def __getitem__(self, k):
-        return getattr(self, k)
 
 
 @dataclass
@@ -123,6 +75,16 @@ def _reference_reader_factory(filename: str, config_hash: str):
     return ref_reader.SpectralLibraryReader(filename, config_hash)
 
 
+def _reference_config():
+    """Default options: the reference's parsed ``config`` singleton (``ann_solo.py:76``) when the
+    ``ann_solo`` package is installed and ``config.parse()`` has run, else the defaults."""
+    try:
+        from ann_solo.config import config as ref_config      # noqa: the reference package
+    except Exception:
+        return None
+    return ref_config if getattr(ref_config, '_namespace', None) is not None else None
+
+
 def _reference_query_reader(filename: str):
     try:
         from ann_solo import reader as ref_reader
@@ -161,7 +123,8 @@ class SpectralLibrary:
         ``import_faiss_cache``: with the reference's own index type (``index='ivfflat'``) an
         existing ``<library>_<hash7>_<charge>.idxann`` written by the reference's FAISS is loaded
         (its centroids and list assignments kept) instead of training a new index."""
-        self.config = config or Config()
+        self.config = Config.from_reference(config if config is not None
+                                            else _reference_config())
         self.device = torch.device(device)
         cfg = self.config
         k_max = _lib.TK_MAX_K
@@ -239,6 +202,15 @@ class SpectralLibrary:
                     create.append(z)
             if create:
                 self._create_ann_indexes(create)
+        if cfg.num_gpus and cfg.num_gpus > 1:      # additive flag --num_gpus (config.py)
+            import torch.distributed as dist
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            if world != cfg.num_gpus:
+                raise RuntimeError(
+                    f'num_gpus={cfg.num_gpus} needs a torch.distributed job of that many ranks '
+                    f'(one process per GPU, e.g. torchrun --nproc-per-node {cfg.num_gpus}); '
+                    f'this process sees {world}')
+            self.enable_sharding()
 
     def _init_from_packed(self, library: PackedSpectra, identifiers, valid) -> None:
         n = library.n
@@ -574,7 +546,7 @@ class SpectralLibrary:
         identifiers are unique).
 
         ``query_meta[charge][i]`` / ``library_meta[charge][row]``: mappings with the reference's
-        attribute names (see ``writer.ssms_from_batch``). ``score_ssms`` stands for
+        attribute names (see ``spectrum.ssms_from_batch``). ``score_ssms`` stands for
         ``utils.score_ssms`` (:319-326, mokapot -- out of scope): called as ``score_ssms(ssms,
         mode)`` with a list of SSM records it assigns ``search_engine_score`` / ``q`` and
         returns the SSMs to keep; a callable with the attribute ``columnar = True`` receives the
@@ -587,6 +559,7 @@ class SpectralLibrary:
         ``writer.write_mztab``; its columns (``charge, qrow, lib_row, score, q``) are there for
         consumers that do not want 10^5 Python objects."""
         cfg = self.config
+        score_ssms = score_ssms or getattr(self, '_score_ssms', None)
         do_cascade_open = (cfg.precursor_tolerance_mass_open is not None and
                            cfg.precursor_tolerance_mode_open is not None)
         uid = _query_uids(query_meta, list(query_spectra))
@@ -667,14 +640,12 @@ class SpectralLibrary:
             torch.cuda.synchronize() if self.device.type == 'cuda' else None
             sec, a, b = acc.get(mode, (0.0, 0, 0))
             acc[mode] = (sec + time.perf_counter() - t_level, a + n_in, b + len(table))
-        if score_ssms is None and self.config.model is not None:
-            if self.config.model != 'none':
-                raise NotImplementedError(
-                    f"model={self.config.model!r}: the mokapot rf / svm models are outside this "
-                    "library; pass score_ssms= (utils.score_ssms) or use model='none'")
-            from .fdr import CosineTDC
-            score_ssms = CosineTDC(self.config.fdr_min_group_size)
         if score_ssms is None:    # no scorer: cosine (spectrum_similarity.py:81-106), accepted
+            if self.config.model is not None and not getattr(self, '_warned_model', False):
+                self._warned_model = True
+                logging.warning('model=%r but no score_ssms callable was given: the FDR models '
+                                '(utils.score_ssms / mokapot) stay with the caller; every SSM is '
+                                'accepted with its cosine as the score', self.config.model)
             table.q[:] = 0.0
             return table
         if getattr(score_ssms, 'columnar', False):
@@ -711,7 +682,7 @@ class SSMTable:
     """Spectrum-spectrum matches of a cascade level / the identifications of a search, columnar:
     ``charge``, ``qrow`` (row inside ``query_spectra[charge]``), ``lib_row`` (row inside the
     charge partition), ``score`` (search_engine_score), ``q``. Behaves as a sequence of the
-    reference's SSM records (``writer.SpectrumSpectrumMatch``: the attributes writer.py:129-148
+    reference's SSM records (``spectrum.SpectrumSpectrumMatch``: the attributes writer.py:129-148
     reads), built on access from the query / library metadata and the peak matches the device
     emitted (kept per batch, fetched from the device when first needed)."""
 
@@ -830,7 +801,7 @@ class SSMTable:
         return b[1][p, :b[0][p]].astype(np.int64)
 
     def __getitem__(self, i):
-        from .writer import SpectrumSpectrumMatch
+        from .spectrum import SpectrumSpectrumMatch
         if isinstance(i, slice):
             return [self[j] for j in range(*i.indices(len(self)))]
         if i < 0:

@@ -5,6 +5,8 @@ Same names, argument meaning and error behaviour; the arithmetic runs on the GPU
 """
 import ctypes as C
 import functools
+from dataclasses import dataclass
+from typing import Any, List, Optional
 
 import numpy as np
 
@@ -87,7 +89,9 @@ def process_spectra(raw, is_library: bool, config=None, device='cuda'):
     import ctypes as C
     import torch
     from .packed import PackedSpectra
-    g = lambda k, dflt: getattr(config, k, dflt) if config is not None else dflt
+    from .config import Config
+    config = Config.from_reference(config)
+    g = lambda k, dflt: getattr(config, k, dflt)
     scaling = g('scaling', 'rank')
     scaling = {'rank': 1, 'sqrt': 2, 'root': 2, None: 0}[scaling]
     max_peaks = g('max_peaks_used_library', 50) if is_library else g('max_peaks_used', 50)
@@ -117,3 +121,42 @@ def process_spectra(raw, is_library: bool, config=None, device='cuda'):
                         r.precursor_mz.clone(), r.precursor_charge.clone(),
                         identifiers=raw.identifiers)
     return out, o_val.bool()
+
+
+@dataclass
+class SpectrumSpectrumMatch:
+    """The fields of the reference's SSM the writer consumes (spectrum.py:217-271,
+    writer.py:129-148), flattened."""
+    sequence: str
+    query_identifier: str
+    query_index: int
+    library_identifier: Any
+    retention_time: Any
+    charge: int
+    exp_mass_to_charge: float
+    calc_mass_to_charge: float
+    is_decoy: bool
+    search_engine_score: float = float('nan')
+    q: float = float('nan')
+    peak_matches: Optional[np.ndarray] = None
+
+
+def ssms_from_batch(result, query_meta, library_meta, scores=None, q_values=None
+                    ) -> List[SpectrumSpectrumMatch]:
+    """SSMs of one ``BatchResult``. ``query_meta[i]`` / ``library_meta[row]`` are mappings with
+    the reference's attribute names (identifier, index, retention_time, precursor_charge,
+    precursor_mz / identifier, peptide, precursor_mz, is_decoy). Queries without a
+    candidate are skipped (spectral_library.py:359)."""
+    out = []
+    for i in range(len(result.best_row)):
+        r = int(result.best_row[i])
+        if r < 0:
+            continue
+        qm, lm = query_meta[i], library_meta[r]
+        out.append(SpectrumSpectrumMatch(
+            lm['peptide'], qm['identifier'], qm['index'], lm['identifier'],
+            qm.get('retention_time'), qm['precursor_charge'], qm['precursor_mz'],
+            lm['precursor_mz'], lm.get('is_decoy', False),
+            float('nan') if scores is None else scores[i],
+            float('nan') if q_values is None else q_values[i], result.peak_matches(i)))
+    return out

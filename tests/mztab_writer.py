@@ -1,19 +1,15 @@
-"""mzTab output, byte-compatible with the reference writer
-(/root/reference/src/ann_solo/writer.py:40-150), for SSMs produced by the device path.
-
-Host-side text formatting only; kept next to the hot path because the north star requires
-that "mzTab output stays identical" (SURVEY.md 8f row 4). Note the reference's header has 23
-columns and its rows 22 (``opt_ms_run[1]_num_candidates`` has no value, writer.py:125 vs
-:129-148) -- reproduced as is.
+"""mzTab byte-compatibility CHECKER (test infrastructure, not product): a restatement of the
+reference writer's output format (/root/reference/src/ann_solo/writer.py:40-150) used to prove
+that the SSM records of the device path carry everything the reference's own writer prints
+(SURVEY.md 8f row 4). An integration keeps the reference's ``writer.write_mztab``
+(INTEGRATION.md 4a). Note the reference's header has 23 columns and its rows 22
+(``opt_ms_run[1]_num_candidates`` has no value, writer.py:125 vs :129-148) -- reproduced as is.
 """
 import logging
 import os
 import pathlib
 import re
-from dataclasses import dataclass
-from typing import Any, List, Optional
-
-import numpy as np
+from typing import List
 
 REFERENCE_VERSION = '0.3.3'          # /root/reference/src/ann_solo/__init__.py:1
 
@@ -25,45 +21,6 @@ def natural_sort_key(s: str):
     return [int(text) if text.isdigit() else text.lower() for text in re.split(_NSRE, s)]
 
 
-@dataclass
-class SpectrumSpectrumMatch:
-    """The fields of the reference's SSM the writer consumes (spectrum.py:217-271,
-    writer.py:129-148), flattened."""
-    sequence: str
-    query_identifier: str
-    query_index: int
-    library_identifier: Any
-    retention_time: Any
-    charge: int
-    exp_mass_to_charge: float
-    calc_mass_to_charge: float
-    is_decoy: bool
-    search_engine_score: float = float('nan')
-    q: float = float('nan')
-    peak_matches: Optional[np.ndarray] = None
-
-
-def ssms_from_batch(result, query_meta, library_meta, scores=None, q_values=None
-                    ) -> List[SpectrumSpectrumMatch]:
-    """SSMs of one ``BatchResult``. ``query_meta[i]`` / ``library_meta[row]`` are mappings with
-    the reference's attribute names (identifier, index, retention_time, precursor_charge,
-    precursor_mz / identifier, peptide, precursor_mz, is_decoy). Queries without a
-    candidate are skipped (spectral_library.py:359)."""
-    out = []
-    for i in range(len(result.best_row)):
-        r = int(result.best_row[i])
-        if r < 0:
-            continue
-        qm, lm = query_meta[i], library_meta[r]
-        out.append(SpectrumSpectrumMatch(
-            lm['peptide'], qm['identifier'], qm['index'], lm['identifier'],
-            qm.get('retention_time'), qm['precursor_charge'], qm['precursor_mz'],
-            lm['precursor_mz'], lm.get('is_decoy', False),
-            float('nan') if scores is None else scores[i],
-            float('nan') if q_values is None else q_values[i], result.peak_matches(i)))
-    return out
-
-
 CONFIG_KEYS = [          # writer.py:93-100
     'resolution', 'min_mz', 'max_mz', 'remove_precursor', 'remove_precursor_tolerance',
     'min_intensity', 'min_peaks', 'min_mz_range', 'max_peaks_used', 'max_peaks_used_library',
@@ -73,7 +30,7 @@ CONFIG_KEYS = [          # writer.py:93-100
 CONFIG_KEYS_ANN = ['bin_size', 'hash_len', 'num_candidates', 'num_list', 'num_probe']
 
 
-def write_mztab(identifications: List[SpectrumSpectrumMatch], filename: str, config,
+def write_mztab(identifications: List, filename: str, config,
                 database_version: str = 'null', version: str = REFERENCE_VERSION) -> str:
     """writer.py:40-150. ``config`` answers ``config[key]`` for the reference's option names
     and has ``query_filename`` / ``spectral_library_filename``; ``database_version`` is

@@ -1,4 +1,5 @@
-"""The cascade's FDR gate without a learned model (ann_solo_amd/fdr.py) against the reference:
+"""The cascade's FDR gate without a learned model (tests/fdr_gate.py: test infrastructure,
+the stand-in for ``utils.score_ssms(model=None)`` the cascade tests inject) against the reference:
 group labels against ``utils._get_ssm_groups`` run on seeded mass differences, q-values against
 the constants of the reference's own test (tests/golden/make_golden.py gen_fdr)."""
 import json
@@ -7,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from ann_solo_amd import fdr
+import fdr_gate as fdr
 from ann_solo_amd.spectral_library import SSMTable
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -42,7 +42,8 @@ def test_round_trip_keeps_centroids_lists_and_results(tmp_path):
     assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
 
 
-def _hand_made(path, d, cen, lists, sparse=False, metric=0, quant=b'IxFI', ids_bad=False):
+def _hand_made(path, d, cen, lists, sparse=False, metric=0, quant=b'IxFI', ids_bad=False,
+               list_oob=False, size_huge=False, dup_ids=False):
     """A file assembled field by field from the layout, independently of write_index_faiss:
     ``lists``: {list: (ids, vectors)}; FAISS keeps whatever assignment it was given."""
     nlist = len(cen)
@@ -56,6 +57,10 @@ def _hand_made(path, d, cen, lists, sparse=False, metric=0, quant=b'IxFI', ids_b
     sizes = [len(lists[l][0]) if l in lists else 0 for l in range(nlist)]
     if sparse:
         pairs = [(l, s) for l, s in enumerate(sizes) if s]
+        if list_oob:
+            pairs[-1] = (nlist + 3, pairs[-1][1])
+        if size_huge:
+            pairs[0] = (pairs[0][0], (1 << 63) + 5)
         out += b'sprs' + struct.pack('<Q', 2 * len(pairs)) + b''.join(struct.pack('<QQ', *p) for p in pairs)
     else:
         out += b'full' + struct.pack('<Q', nlist) + b''.join(struct.pack('<Q', s) for s in sizes)
@@ -65,6 +70,9 @@ def _hand_made(path, d, cen, lists, sparse=False, metric=0, quant=b'IxFI', ids_b
             ids = np.asarray(ids, '<i8')
             if ids_bad:
                 ids = ids + 1
+            if dup_ids and len(ids) > 1:
+                ids = ids.copy()
+                ids[1] = ids[0]
             out += np.asarray(vec, '<f4').tobytes() + ids.tobytes()
     open(path, 'wb').write(out)
 

@@ -39,7 +39,7 @@ def setup():
 
 def test_filename_constructor_search_and_caches(setup, tmp_path, monkeypatch):
     from ann_solo_amd.spectral_library import Config, SpectralLibrary, INDEX_EXT
-    from ann_solo_amd.writer import write_mztab
+    from mztab_writer import write_mztab
     lib, aux, q, truth = setup
     lib_objs = _objects(lib)
     rng = np.random.default_rng(1)

@@ -140,7 +140,7 @@ def test_search_driver_end_to_end_to_mztab(tmp_path, monkeypatch):
     import torch
     from ann_solo_amd import synthetic
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
-    from ann_solo_amd.writer import write_mztab
+    from mztab_writer import write_mztab
     lib, aux = synthetic.make_library(4000, seed=71, device='cpu', charges=(2,), charge_p=(1.0,))
     q, truth = synthetic.make_queries(lib, aux, 300, seed=72, charge=2, open_range=300.0)
     cfg = Config(num_list=32, num_probe=32, num_candidates=1024, index='ivfpq', kmeans_niter=5,
@@ -188,17 +188,18 @@ def test_search_driver_end_to_end_to_mztab(tmp_path, monkeypatch):
 
 
 def test_cascade_with_the_cosine_tdc_gate():
-    """``model='none'`` (reference ``--model none``): both cascade levels gated by target-decoy
-    q-values on the cosine (ann_solo_amd/fdr.py); the open level competes per mass-difference
-    group. Checked against the gate applied by hand to the same levels' SSMs."""
+    """An injected columnar scorer (tests/fdr_gate.py: the reference's ``--model none`` gate,
+    target-decoy q-values on the cosine, per mass-difference group at the open level) drives both
+    cascade levels. Checked against the gate applied by hand to the same levels' SSMs."""
     import torch
-    from ann_solo_amd import fdr, synthetic
+    import fdr_gate as fdr
+    from ann_solo_amd import synthetic
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     lib, aux = synthetic.make_library(6000, seed=81, device='cpu', charges=(2,), charge_p=(1.0,))
     q, truth = synthetic.make_queries(lib, aux, 900, seed=82, charge=2, open_range=300.0)
     cfg = Config(num_list=32, num_probe=32, num_candidates=1024, index='ivfpq', kmeans_niter=5,
                  batch_size=256, model='none', fdr=0.05, fdr_min_group_size=10)
-    sl = SpectralLibrary(lib, config=cfg)
+    sl = SpectralLibrary(lib, config=cfg, score_ssms=fdr.CosineTDC(cfg.fdr_min_group_size))
     rng = np.random.default_rng(7)
     decoy = rng.random(lib.n) < 0.5                    # half the library flagged as decoys,
     decoy[truth['source_row'].numpy()] = False         # none of them a query's true source
@@ -233,7 +234,4 @@ def test_cascade_with_the_cosine_tdc_gate():
     assert np.isnan(ids.score[decoy[ids.lib_row]]).all() and not np.isnan(ids.score[~decoy[ids.lib_row]]).any()
     rec = ids[0]
     assert rec.q == ids.q[0] and rec.is_decoy == bool(decoy[ids.lib_row[0]])
-    with pytest.raises(NotImplementedError):
-        sl.config.model = 'rf'
-        sl.search({2: q}, qmeta, lmeta)
     sl.shutdown()
