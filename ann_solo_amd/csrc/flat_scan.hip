@@ -1,17 +1,12 @@
-// flat_scan.hip -- exact IVF-Flat list scan over SPARSE inverted lists (replaces the scan
-// inside FAISS IndexIVFFlat.search, /root/reference/src/ann_solo/spectral_library.py:443-444).
-// Two generations: 64-vector sparse tiles (first half of this file; scan variant 2) and
-// per-dimension postings (second half; the default).
+// flat_scan.hip -- exact IVF-Flat list scan over per-dimension POSTINGS inside every inverted
+// list (replaces the scan inside FAISS IndexIVFFlat.search,
+// /root/reference/src/ann_solo/spectral_library.py:443-444).
 //
-// A hashed spectrum vector has at most ~50 non-zeros out of 800 (one per peak), so the
-// lists store (index u16, value f32) pairs instead of 3 200-byte dense rows: 64-vector
-// tiles, [t][64] planes of the t-th non-zero of every vector (ascending index), i.e. a
-// wave reads 128 B of indices + 256 B of values per step, fully coalesced. The score is
-// acc = fmaf(q[idx_t], val_t, acc) over t -- the ascending-index fp32 chain restricted to
-// the stored non-zeros, which is bit-identical to the dense chain (a zero factor leaves
-// the accumulator unchanged), to the fp32-MFMA GEMM and to the oracle. 300 B/vector
-// instead of 3 200 (fp32) / 1 600 (FAISS-GPU fp16): ~10x less HBM traffic, exact results.
-// Top-k: hist_topk.hpp (no sorting while streaming).
+// A hashed spectrum vector has at most ~50 non-zeros out of 800 (one per peak). The score of a
+// stored vector is acc = fmaf(q[dim], val, acc) over its non-zeros in ascending dimension --
+// the ascending-index fp32 chain restricted to the stored non-zeros, which is bit-identical to
+// the dense chain (a zero factor leaves the accumulator unchanged), to the fp32-MFMA GEMM and
+// to the oracle. Top-k: hist_topk.hpp (no sorting while streaming).
 #include <cstdlib>
 
 #include "common.hpp"
@@ -21,110 +16,8 @@
 
 namespace asl {
 
-constexpr int FS_NT = 256, FS_CHUNK = 128, FS_CAP = 2048, FS_ROUND_VECS = 256;
-
-__global__ __launch_bounds__(FS_NT) void flat_sparse_scan_kernel(
-    const float *__restrict__ xq, int d, const int32_t *__restrict__ coarse_I, int nprobe,
-    const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ tile_offsets,
-    const uint16_t *__restrict__ idx_tiled, const float *__restrict__ val_tiled,
-    const int32_t *__restrict__ tile_nnz, int nnz_stride, const int32_t *__restrict__ ids_tiled,
-    int k, float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32) {
-  using TopK = HistTopK<FS_CAP, FS_ROUND_VECS>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *s_q = reinterpret_cast<float *>(smem + TopK::lds_bytes());
-  TileEnt *table = reinterpret_cast<TileEnt *>(s_q + ((d + 3) & ~3));
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
-  for (int i = tid; i < d; i += FS_NT) s_q[i] = xq[(size_t)q * d + i];
-
-  int my_len = 0, my_tile0 = 0, my_nt = 0;
-  if (tid < nprobe) {
-    const int l = coarse_I[(size_t)q * nprobe + tid];
-    if (l >= 0) {
-      my_len = list_offsets[l + 1] - list_offsets[l];
-      my_tile0 = tile_offsets[l];
-      my_nt = (my_len + 63) >> 6;
-    }
-  }
-  int total;
-  const int my_pre = block_excl_scan256(my_nt, reinterpret_cast<int *>(table), tid, total);
-  __syncthreads();
-  TopK top;
-  top.init(smem, k, ids_tiled, tid);
-
-  for (int c0 = 0; c0 < total; c0 += FS_CHUNK) {
-    {
-      const int lo = max(my_pre, c0), hi = min(my_pre + my_nt, c0 + FS_CHUNK);
-      for (int t = lo; t < hi; ++t) {
-        const int local = t - my_pre;
-        TileEnt e;
-        e.tile = (uint32_t)(my_tile0 + local);
-        e.coarse = 0.0f;
-        e.nvalid = min(64, my_len - local * 64);
-        e.pad = 0;
-        table[t - c0] = e;
-      }
-    }
-    __syncthreads();
-    const int nent = min(FS_CHUNK, total - c0);
-    for (int r0 = 0; r0 < nent; r0 += 4) {
-      top.begin_round();
-      int appended = 0;
-      const int i = r0 + wave;
-      if (i < nent) {  // wave-uniform
-        const TileEnt e = table[i];
-        const int nt = tile_nnz[e.tile];
-        const uint16_t *ip = idx_tiled + (size_t)e.tile * nnz_stride * 64 + lane;
-        const float *vp = val_tiled + (size_t)e.tile * nnz_stride * 64 + lane;
-        float acc = 0.0f;
-        int t = 0;
-        for (; t + 4 <= nt; t += 4) {   // 4 independent (index, value) loads in flight
-          const uint32_t i0 = ip[(t + 0) * 64], i1 = ip[(t + 1) * 64], i2 = ip[(t + 2) * 64],
-                         i3 = ip[(t + 3) * 64];
-          const float v0 = vp[(t + 0) * 64], v1 = vp[(t + 1) * 64], v2 = vp[(t + 2) * 64],
-                      v3 = vp[(t + 3) * 64];
-          acc = __builtin_fmaf(s_q[i0], v0, acc);
-          acc = __builtin_fmaf(s_q[i1], v1, acc);
-          acc = __builtin_fmaf(s_q[i2], v2, acc);
-          acc = __builtin_fmaf(s_q[i3], v3, acc);
-        }
-        for (; t < nt; ++t) acc = __builtin_fmaf(s_q[ip[t * 64]], vp[t * 64], acc);
-        const bool take = top.offer(lane < e.nvalid, acc, e.tile * 64u + (uint32_t)lane);
-        appended = __popcll(__ballot(take));
-      }
-      top.end_round(appended);
-    }
-    __syncthreads();
-  }
-  top.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
-             I32 ? I32 + (size_t)q * k : nullptr);
-}
-
-int flat_sparse_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
-                     const int32_t *list_offsets, const int32_t *tile_offsets,
-                     const uint16_t *idx_tiled, const float *val_tiled, const int32_t *tile_nnz,
-                     int nnz_stride, const int32_t *ids_tiled, int k, float *D, int64_t *I64,
-                     int32_t *I32) {
-  if (nq <= 0) return ASL_OK;
-  const size_t lds = HistTopK<FS_CAP, FS_ROUND_VECS>::lds_bytes() + (size_t)((d + 3) & ~3) * 4 +
-                     (size_t)FS_CHUNK * sizeof(TileEnt);
-  if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "flat scan: d=%d does not fit LDS", d);
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)flat_sparse_scan_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(flat_sparse_scan_kernel, dim3(nq), dim3(FS_NT), lds, stream(), xq, d,
-                     coarse_I, nprobe, list_offsets, tile_offsets, idx_tiled, val_tiled, tile_nnz,
-                     nnz_stride, ids_tiled, k, D, I64, I32);
-  ASL_CHECK_LAUNCH();
-  return ASL_OK;
-}
-
-bool flat_sparse_supported(int d, int k, int nprobe, int nnz_stride) {
-  return d <= 65535 && nprobe <= FS_NT && k >= 1 && k + FS_ROUND_VECS + 256 <= FS_CAP &&
-         nnz_stride > 0 && nnz_stride <= 255;
-}
-
-// ---- building the sparse tiles from dense rows
-// pass 1: non-zeros per vector (one wave per vector)
+// non-zeros per vector (one wave per vector) and their maximum: decides at build time whether
+// the postings layout pays
 __global__ void count_nnz_kernel(const float *__restrict__ vecs, int d, int64_t n,
                                  int32_t *__restrict__ nnz, int32_t *__restrict__ nnz_max) {
   const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -139,42 +32,6 @@ __global__ void count_nnz_kernel(const float *__restrict__ vecs, int d, int64_t 
   }
 }
 
-// pass 2: list-ordered position i (add-order row order[i]) -> its tile slot dst_slot[i]
-__global__ void sparsify_tiles_kernel(const float *__restrict__ vecs, int d,
-                                      const int32_t *__restrict__ order,
-                                      const int32_t *__restrict__ dst_slot, int64_t n,
-                                      const int32_t *__restrict__ ids, int nnz_stride,
-                                      uint16_t *__restrict__ idx_tiled,
-                                      float *__restrict__ val_tiled,
-                                      int32_t *__restrict__ tile_nnz,
-                                      int32_t *__restrict__ ids_tiled) {
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (i >= n) return;
-  const float *row = vecs + (size_t)order[i] * d;
-  const int slot = dst_slot[i];
-  const int64_t tile = slot >> 6;
-  const int v = slot & 63;
-  uint16_t *ip = idx_tiled + (size_t)tile * nnz_stride * 64 + v;
-  float *vp = val_tiled + (size_t)tile * nnz_stride * 64 + v;
-  int base = 0;
-  for (int j0 = 0; j0 < d; j0 += 64) {
-    const int j = j0 + lane;
-    const float x = j < d ? row[j] : 0.0f;
-    const unsigned long long m = __ballot(x != 0.0f);
-    if (x != 0.0f) {
-      const int t = base + __popcll(m & ((1ull << lane) - 1ull));
-      ip[(size_t)t * 64] = (uint16_t)j;
-      vp[(size_t)t * 64] = x;
-    }
-    base += __popcll(m);
-  }
-  if (lane == 0) {
-    atomicMax(&tile_nnz[tile], base);
-    ids_tiled[tile * 64 + v] = ids[i];
-  }
-}
-
 int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_max_dev) {
   HIP_TRY(hipMemsetAsync(nnz_max_dev, 0, sizeof(int32_t), stream()));
   if (n <= 0) return ASL_OK;
@@ -184,26 +41,11 @@ int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_ma
   return ASL_OK;
 }
 
-int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t *dst_slot,
-                   const int32_t *ids, int64_t n, int64_t ntiles, int nnz_stride,
-                   uint16_t *idx_tiled, float *val_tiled, int32_t *tile_nnz,
-                   int32_t *ids_tiled) {
-  HIP_TRY(hipMemsetAsync(idx_tiled, 0, (size_t)ntiles * nnz_stride * 64 * 2, stream()));
-  HIP_TRY(hipMemsetAsync(val_tiled, 0, (size_t)ntiles * nnz_stride * 64 * 4, stream()));
-  HIP_TRY(hipMemsetAsync(tile_nnz, 0, (size_t)ntiles * 4, stream()));
-  HIP_TRY(hipMemsetAsync(ids_tiled, 0xff, (size_t)ntiles * 64 * 4, stream()));
-  if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(sparsify_tiles_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(),
-                     vecs, d, order, dst_slot, n, ids, nnz_stride, idx_tiled, val_tiled, tile_nnz,
-                     ids_tiled);
-  ASL_CHECK_LAUNCH();
-  return ASL_OK;
-}
-
 // ---------------------------------------------------------------------------------------
-// Dimension-major ("postings") IVF-Flat. The tiles above stream EVERY stored non-zero of the
-// probed lists (~27 per vector) although a query has <= ~50 non-zero components of 800: only
-// stored entries in those dimensions can contribute. So every inverted list is cut into blocks
+// Dimension-major ("postings") IVF-Flat. Streaming EVERY stored non-zero of the probed lists
+// (~27 per vector; the sparse-tile scan of round 1) reads 16x more than needed: a query has
+// <= ~50 non-zero components of 800 and only stored entries in those dimensions can
+// contribute. So every inverted list is cut into blocks
 // of FI_BLK vectors and each block keeps, per dimension, the postings (local vector index
 // u16, value f32) of the vectors that are non-zero there -- an inverted file inside the
 // inverted file. Storage: one segment per (block, dimension), its c values followed by its c

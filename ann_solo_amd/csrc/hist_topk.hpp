@@ -373,17 +373,15 @@ struct HistTopK {
     }
   }
 
-  __device__ __forceinline__ void finish(float *D, int64_t *I64, int32_t *I32,
-                                         long long *ts = nullptr) {
+  __device__ __forceinline__ void finish(float *D, int64_t *I64, int32_t *I32) {
     __syncthreads();
     if (!sort_mode) {
       fill = compact();          // typically leaves k .. k + one bucket's population
       tk.slot_ids = slot_ids;    // every surviving key still carries its storage slot
       tk.conv_from = 0;
     }
-    if (ts) ts[0] = wall_clock64();   // measurement: after the compaction
     tk.emit_keys = out_keys;
-    tk.finish(out_keys ? nullptr : D, I64, out_keys ? nullptr : I32, tid, ts ? ts + 1 : nullptr);
+    tk.finish(out_keys ? nullptr : D, I64, out_keys ? nullptr : I32, tid);
   }
 };
 

@@ -82,19 +82,13 @@ struct asl_index {
   DevBuf<uint8_t> codes_tiled;
   DevBuf<int32_t> ids_tiled, tile_offsets;
   bool has_tiles = false;
-  // sparse 64-vector tiles for flat_sparse_scan (IVF-Flat)
-  DevBuf<uint16_t> idx_tiled;
-  DevBuf<float> val_tiled;
-  DevBuf<int32_t> tile_nnz;
-  int nnz_stride = 0;
-  bool has_sparse = false;
   // dimension-major postings for flat_inv_scan (IVF-Flat): blocks of FI_BLK vectors
   DevBuf<int32_t> blk_offsets;   // [nlist + 1] first block of each list
   DevBuf<uint32_t> blk_base;     // [nblocks] start of the block's postings, 64-byte units
   DevBuf<uint32_t> inv_tab;      // [nblocks * d] (start from the block's base in 64-byte units) << 16 | postings
   DevBuf<char> inv_data;         // segments: c values (f32) then c local vector indices (u16), placed by 128-byte line
   bool has_inv = false;
-  int scan_variant = 0;  // 0 = auto (v2 when supported), 1 = force v1
+  int scan_variant = 0;  // 0 = the layout-specific scan when the shape allows; 1 = the generic kernels
   int unordered = 0;  // 1: search rows = exact top-k as a set, unspecified order (no final sort); 2: rows of packed keys
   bool lists_dirty = true;
   // exact re-rank of the IVF-PQ short-list (refine.hip): sparse copies of the added vectors,
@@ -307,7 +301,6 @@ static int build_lists(asl_index *ix) {
     ASL_TRY(sync_stream());
     ix->has_tiles = true;
   }
-  ix->has_sparse = false;
   ix->has_inv = false;
   if (ix->kind == ASL_INDEX_IVFFLAT && n > 0 && ix->d <= 65535) {
     DevBuf<int32_t> nnz, nnz_max;
@@ -317,27 +310,6 @@ static int build_lists(asl_index *ix) {
     int32_t h_max = 0;
     ASL_TRY(nnz_max.download(&h_max, 1));
     ASL_TRY(sync_stream());
-    if (h_max > 0 && h_max <= 255 && (size_t)h_max * 6 < (size_t)ix->d * 2) {  // sparse enough to pay
-      std::vector<int32_t> tile_off((size_t)ix->nlist + 1, 0), dst_slot((size_t)n);
-      for (int l = 0; l < ix->nlist; l++)
-        tile_off[(size_t)l + 1] = tile_off[(size_t)l] + (off[(size_t)l + 1] - off[(size_t)l] + 63) / 64;
-      for (int l = 0; l < ix->nlist; l++)
-        for (int32_t i = off[(size_t)l]; i < off[(size_t)l + 1]; i++)
-          dst_slot[(size_t)i] = tile_off[(size_t)l] * 64 + (i - off[(size_t)l]);
-      const int64_t ntiles = std::max<int64_t>(tile_off[(size_t)ix->nlist], 1);
-      DevBuf<int32_t> slot_dev;
-      ASL_TRY(slot_dev.upload(dst_slot.data(), (size_t)n));
-      ASL_TRY(ix->tile_offsets.upload(tile_off.data(), tile_off.size()));
-      ix->nnz_stride = h_max;
-      ASL_TRY(ix->idx_tiled.reserve((size_t)ntiles * h_max * 64));
-      ASL_TRY(ix->val_tiled.reserve((size_t)ntiles * h_max * 64));
-      ASL_TRY(ix->tile_nnz.reserve((size_t)ntiles));
-      ASL_TRY(ix->ids_tiled.reserve((size_t)ntiles * 64));
-      ASL_TRY(sparsify_tiles(ix->vecs.p, ix->d, order.p, slot_dev.p, ix->ids.p, n, ntiles, h_max,
-                             ix->idx_tiled.p, ix->val_tiled.p, ix->tile_nnz.p, ix->ids_tiled.p));
-      ASL_TRY(sync_stream());
-      ix->has_sparse = true;
-    }
     // dimension-major postings (the default IVF-Flat scan)
     if (h_max > 0 && (size_t)h_max * 8 < (size_t)ix->d) {
       std::vector<int32_t> blk_off((size_t)ix->nlist + 1, 0), pos_blk((size_t)n);
@@ -444,21 +416,14 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
         HIP_TRY(hipMemcpyAsync(ix->coarse_I.p, pre_I, (size_t)nq * nprobe * 4, hipMemcpyDeviceToDevice, stream()));
       }
       ASL_TRY(build_lists(ix));
-      // variant 0: dimension-major postings; 2: sparse tiles; 1: dense GEMM + masked top-k
-      const bool use_inv = ix->has_inv && (ix->scan_variant & 0xff) == 0 &&
-                           flat_inv_supported(d, k, nprobe);
-      if (use_inv || (ix->has_sparse && (ix->scan_variant & 0xff) != 1 &&
-                      flat_sparse_supported(d, k, nprobe, ix->nnz_stride))) {
-        if (use_inv) {
+      // variant 0: dimension-major postings; 1 (or an unsupported shape): dense GEMM + masked top-k
+      const bool use_inv = ix->has_inv && ix->scan_variant == 0 && flat_inv_supported(d, k, nprobe);
+      if (use_inv) {
+        {
           ProfScope ps("scan");
           ASL_TRY(flat_inv_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
                                 ix->blk_offsets.p, ix->blk_base.p, ix->inv_tab.p, ix->inv_data.p,
                                 ix->ids.p, k, D, I64, I32, set_mode || ix->unordered == 1));
-        } else {
-          ProfScope ps("scan");
-          ASL_TRY(flat_sparse_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
-                                   ix->tile_offsets.p, ix->idx_tiled.p, ix->val_tiled.p,
-                                   ix->tile_nnz.p, ix->nnz_stride, ix->ids_tiled.p, k, D, I64, I32));
         }
         if (prof_enabled()) {
           // vectors scored by this launch, summed on the device (nothing waits inside a step)
@@ -527,11 +492,11 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   }
   {
     ProfScope ps("scan");
-    const int sv = ix->scan_variant & 0xff;
-    if (ix->unordered == 2 &&
-        !(ix->has_tiles && sv != 1 && sv != 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe) && I64))
+    const bool tiled = ix->has_tiles && ix->scan_variant == 0 &&
+                       pq_scan_tiled_supported(ix->pq_m, ix->ksub, k, nprobe);
+    if (ix->unordered == 2 && !(tiled && I64))
       return fail(ASL_ERR_STATE, "packed-key rows need the tiled IVF-PQ scan (m = 32, 8 bits) and an int64 output");
-    if (ix->has_tiles && sv != 1 && sv != 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe)) {
+    if (tiled) {
       if (!ix->cbt_ready) {
         const size_t ncb = (size_t)ix->pq_m * ix->ksub * ix->dsub;
         std::vector<float> h((size_t)ncb), ht((size_t)ncb);
@@ -547,12 +512,8 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       }
       ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks_t.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
-                         ix->ids_tiled.p, k, D, I64, I32, sv, ix->unordered ? ix->unordered : (set_mode ? 1 : 0),
-                         ix->scan_variant >> 8));
-    } else if (ix->has_tiles && sv == 2 && pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe))
-      ASL_TRY(pq_scan_v2(xq, nq, d, ix->codebooks.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
-                         nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
-                         ix->ids_tiled.p, k, D, I64, I32, ix->scan_variant >> 8));
+                         ix->ids_tiled.p, k, D, I64, I32, ix->unordered ? ix->unordered : (set_mode ? 1 : 0)));
+    }
     else
       ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, ix->coarse_D.p,
                       ix->coarse_I.p, nprobe, ix->list_offsets.p, ix->ids.p, ix->codes.p, k, D,
@@ -641,14 +602,8 @@ int asl_index_set_unordered(asl_index_t *ix, int32_t unordered) {
 
 int asl_index_set_scan_variant(asl_index_t *ix, int32_t variant) {
   clear_error();
-  if (!ix || variant < 0) return fail(ASL_ERR_INVALID, "set_scan_variant");
-#ifndef ASL_ENABLE_DBG
-  // bits 8+ are measurement knobs of the scan kernels (results invalid when set): accepted
-  // only by the instrumented build of scripts/ab_*.sh (EXTRA=-DASL_ENABLE_DBG)
-  if (variant > 4)
-    return fail(ASL_ERR_INVALID, "set_scan_variant: %d is not a kernel id (0..4); measurement "
-                "bits need a library built with -DASL_ENABLE_DBG", variant);
-#endif
+  if (!ix || variant < 0 || variant > 1)
+    return fail(ASL_ERR_INVALID, "set_scan_variant: 0 (layout-specific scan) or 1 (generic kernels)");
   ix->scan_variant = variant;
   return ASL_OK;
 }
@@ -658,10 +613,9 @@ int asl_index_set_scan_variant(asl_index_t *ix, int32_t variant) {
 // choose the exchange format up front (ann_solo_amd/distributed.py).
 int asl_index_supports_keys(const asl_index_t *ix, int32_t k, int32_t nprobe) {
   if (!ix || ix->kind != ASL_INDEX_IVFPQ) return 0;
-  const int sv = ix->scan_variant & 0xff;
   nprobe = std::max(1, std::min(nprobe, ix->nlist));
-  return ix->pq_m == 32 && ix->ksub == 256 && sv != 1 && sv != 2 &&
-         pq_scan_v2_supported(ix->pq_m, ix->ksub, k, nprobe) && k + 768 <= TK_MAX_K;
+  return ix->scan_variant == 0 && pq_scan_tiled_supported(ix->pq_m, ix->ksub, k, nprobe) &&
+         k + 768 <= TK_MAX_K;
 }
 
 int asl_index_set_niter(asl_index_t *ix, int32_t niter) {

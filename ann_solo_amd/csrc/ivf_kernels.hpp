@@ -37,25 +37,15 @@ int pq_scan(const float *xq, int nq, int d, const float *codebooks, int m, int k
             const float *coarse_D, const int32_t *coarse_I, int nprobe,
             const int32_t *list_offsets, const int32_t *ids, const uint8_t *codes, int k,
             float *D, int64_t *I64, int32_t *I32);
-bool pq_scan_v2_supported(int m, int ksub, int k, int nprobe);
-int pq_scan_v2(const float *xq, int nq, int d, const float *codebooks, int dsub,
-               const float *coarse_D, const int32_t *coarse_I, int nprobe,
-               const int32_t *list_offsets, const int32_t *tile_offsets,
-               const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
-               int64_t *I64, int32_t *I32, int dbg = 0);
+// tiled IVF-PQ scan (pq_scan_v3.hip): m = 32 sub-quantisers of 8 bits
+bool pq_scan_tiled_supported(int m, int ksub, int k, int nprobe);
 int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                const float *coarse_D, const int32_t *coarse_I, int nprobe,
                const int32_t *list_offsets, const int32_t *tile_offsets,
                const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
-               int64_t *I64, int32_t *I32, int variant, int set_mode, int dbg);
+               int64_t *I64, int32_t *I32, int set_mode);
 int tile_codes(const uint8_t *codes, const int32_t *ids, const int32_t *dst_slot, int64_t n,
                int64_t ntiles, uint8_t *codes_tiled, int32_t *ids_tiled);
-bool flat_sparse_supported(int d, int k, int nprobe, int nnz_stride);
-int flat_sparse_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
-                     const int32_t *list_offsets, const int32_t *tile_offsets,
-                     const uint16_t *idx_tiled, const float *val_tiled, const int32_t *tile_nnz,
-                     int nnz_stride, const int32_t *ids_tiled, int k, float *D, int64_t *I64,
-                     int32_t *I32);
 // dimension-major IVF-Flat (flat_scan.hip): blocks of FI_BLK vectors with per-dimension postings
 #ifndef FI_BLK_
 #define FI_BLK_ 832     // measured (scan ms at nprobe 128): 512 7.69 | 640 7.14 | 768 6.81 | 832 6.71 | 864 6.70 (the LDS limit of three workgroups per CU) | 1024: two workgroups per CU
@@ -80,9 +70,6 @@ int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_
              const uint16_t *pos_loc, int64_t n, const uint32_t *blk_base,
              const uint32_t *seg_tab, uint32_t *cursor, char *seg_bytes);
 int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_max_dev);
-int sparsify_tiles(const float *vecs, int d, const int32_t *order, const int32_t *dst_slot,
-                   const int32_t *ids, int64_t n, int64_t ntiles, int nnz_stride,
-                   uint16_t *idx_tiled, float *val_tiled, int32_t *tile_nnz, int32_t *ids_tiled);
 int scanned_count(const int32_t *coarse_I, int64_t n, const int32_t *list_offsets,
                   unsigned long long *out_dev);
 

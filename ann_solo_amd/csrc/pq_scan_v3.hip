@@ -1,8 +1,23 @@
-// pq_scan_v3.hip -- tiled IVF-PQ scan (layout and ADC of pq_scan_v2.hip) with a
-// histogram-thresholded top-k instead of sort-based flushes.
+// pq_scan_v3.hip -- IVF-PQ asymmetric-distance scan, m = 32 sub-quantisers of 8 bits, laid out
+// for gfx950's LDS: the dominant kernel of the hot path (replaces the list scan inside FAISS'
+// IndexIVF*.search, call site /root/reference/src/ann_solo/spectral_library.py:443-444).
 //
-// v2 spent ~40 % of its cycles sorting its 4096-key LDS buffer two or three times per
-// query. Only the k-th best SCORE is needed while scanning, so v3 keeps
+// Layout (helpers in pq_tile.hpp). "One lane per vector" makes 32 random LUT reads per vector
+// hit random LDS banks (~3.5-way conflicts on ds_read_b32); here lanes are SUB-QUANTISERS:
+//   * LUT image in LDS: lut[c*32 + m] (row stride 128 B) -> bank == m. A 16-lane row reads 16
+//     different m for one code position, the neighbouring row the other 16: every ds_read_b32
+//     is bank-conflict-free BY CONSTRUCTION, whatever the codes are.
+//   * codes are stored in 64-vector tiles (2 KiB): chunk[rho][m][16 B], the 16 bytes being
+//     sub-quantiser m's codes of the row's 16 vectors, permuted b -> b ^ (m & 15). Lane
+//     (rho, j) loads the chunks of m = j and m = j + 16 (two coalesced 16-B loads).
+//   * register r of lane j then holds p_j(vector r ^ j); four DPP butterflies (row_mirror,
+//     row_half_mirror, quad [3,2,1,0], quad [1,0,3,2]) reduce the 16x16 block with 15
+//     v_add_dpp and NO selects, leaving vector j's sum in lane j -- the canonical mirror tree
+//     of DESIGN.md, bit-identical to the oracle.
+//   * ids are fetched only for the survivors of the top-k.
+//
+// Top-k without sorting while streaming (hist_topk.hpp). Only the k-th best SCORE is needed
+// while scanning, so the kernel keeps
 //   * hist[512]: counts of the appended candidates per score bucket (monotone linear
 //     bucketing of the fp32 score over [-0.25, 1), i.e. 0.0024 per bucket),
 //   * bstar: the highest bucket with at least k appended candidates at or above it.
@@ -12,9 +27,10 @@
 // best are sorted exactly once, at the end, after the storage slots of the survivors
 // have been turned into ids -- (score desc, id asc), identical to the oracle.
 // If compaction cannot free the buffer (thousands of bit-identical scores) the kernel
-// switches, for that query, to v2's exact sort-and-truncate flushes.
+// switches, for that query, to exact sort-and-truncate flushes.
 //
-// Smaller LDS footprint (key buffer 2048 or 4096) => up to 3 workgroups per CU.
+// LDS: LUT 32 KB + key buffer (2048 or 4096 keys) + histogram + tile table => three (two)
+// workgroups of 8 waves per CU.
 #include "common.hpp"
 #include "hist_topk.hpp"
 #include "ivf_kernels.hpp"
@@ -37,14 +53,14 @@ struct TileEnt8 {
 // waves that share one LUT and one key buffer: 24 waves per CU at 80 VGPRs instead of 12 at
 // 157 -- measured 8.28 -> 7.46 ms at the bench config (with ONE round of prefetch: at this
 // occupancy the second prefetch stage only costs registers).
-template <int CAP, int T, int NW, int DEPTH = 2>
+template <int CAP, int T, int NW, int DEPTH>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <= 2048 ? 3 : 1))) void pq_scan_v3_kernel(
     const float *__restrict__ xq, int d, const float *__restrict__ codebooks, int dsub,
     const float *__restrict__ coarse_D, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ tile_offsets,
     const uint8_t *__restrict__ codes_tiled, const int32_t *__restrict__ ids_tiled, int k,
-    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode,
-    int dbg) {
+    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode) {
+  static_assert(DEPTH == 1, "one round of prefetch: at 24 waves per CU a second stage only costs registers");
   constexpr int NT = 64 * NW, ROUND_TILES = NW * T, ROUND_VECS = ROUND_TILES * 64;
   using TopK = HistTopK<CAP, ROUND_VECS, NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -53,7 +69,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
   float *s_q = reinterpret_cast<float *>(smem);  // aliases the key buffer during the LUT build
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
-  const long long t_start = (dbg & 32) ? wall_clock64() : 0;
   // ---- my probe (thread p < nprobe): its dependent gathers are issued before the table build
   // and complete under it
   int my_len = 0, my_tile0 = 0, my_nt = 0;
@@ -76,11 +91,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
   const int my_pre = block_excl_scan<NW>(my_nt, scan_part, tid, total);
   __syncthreads();
 
-  const long long t_lut = (dbg & 32) ? wall_clock64() : 0;
   TopK top;   // init zeroes the keys (which aliased s_q)
   top.init(smem, k, ids_tiled, tid);
   top.out_keys = set_mode == 2 && I64 != nullptr;
-  const long long t_init = (dbg & 32) ? wall_clock64() : 0;
 
   const char *lut_bytes = reinterpret_cast<const char *>(s_lut);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -103,10 +116,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
     __syncthreads();
     const int nent = min(V3_CHUNK, total - c0);
     const int nrounds = (nent + ROUND_TILES - 1) / ROUND_TILES;
-    // Register pipeline, two rounds deep: with one query per workgroup and 12 waves per CU
-    // a single round of prefetch keeps too few bytes in flight to cover the HBM latency.
-    uint4 A0[T], B0[T], A1[T], B1[T], A2[T], B2[T];
-    TileEnt e0[T], e1[T], e2[T];
+    // Register pipeline, one round deep (the codes of round rr + 1 are in flight while round rr
+    // is scored).
+    uint4 A0[T], B0[T], A1[T], B1[T];
+    TileEnt e0[T], e1[T];
     auto fetch = [&](int rr, uint4 *a, uint4 *b, TileEnt *e) {
 #pragma unroll
       for (int u = 0; u < T; ++u) {
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
       for (int u = 0; u < T; ++u) {
         if (e[u].nvalid > 0) {  // wave-uniform
           const float score = e[u].coarse + tile_adc(lut_bytes, a[u], b[u], offA, offB);
-          const bool take = top.offer(lane < e[u].nvalid && !(dbg & 1), score,
+          const bool take = top.offer(lane < e[u].nvalid, score,
                                       e[u].tile * 64u + (uint32_t)lane);
           appended += __popcll(__ballot(take));
         }
@@ -138,61 +151,30 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
       top.end_round(appended);
     };
     fetch(0, A0, B0, e0);
-    if constexpr (DEPTH == 1) {
-      for (int rr = 0; rr < nrounds; rr += 2) {
-        if (rr + 1 < nrounds) fetch(rr + 1, A1, B1, e1);
-        process(A0, B0, e0);
-        if (rr + 1 < nrounds) {
-          if (rr + 2 < nrounds) fetch(rr + 2, A0, B0, e0);
-          process(A1, B1, e1);
-        }
-      }
-    } else {
-    if (nrounds > 1) fetch(1, A1, B1, e1);
-    for (int rr = 0; rr < nrounds; rr += 3) {
-      if (rr + 2 < nrounds) fetch(rr + 2, A2, B2, e2);
+    for (int rr = 0; rr < nrounds; rr += 2) {
+      if (rr + 1 < nrounds) fetch(rr + 1, A1, B1, e1);
       process(A0, B0, e0);
       if (rr + 1 < nrounds) {
-        if (rr + 3 < nrounds) fetch(rr + 3, A0, B0, e0);
+        if (rr + 2 < nrounds) fetch(rr + 2, A0, B0, e0);
         process(A1, B1, e1);
       }
-      if (rr + 2 < nrounds) {
-        if (rr + 4 < nrounds) fetch(rr + 4, A1, B1, e1);
-        process(A2, B2, e2);
-      }
-    }
     }
     __syncthreads();
   }
-  const long long t_loop = (dbg & 32) ? wall_clock64() : 0;
-  long long ts_fin[2] = {0, 0};
   if (set_mode && CAP * 8 <= PQT_KSUB * PQT_M * 4)   // unordered exact top-k; the LUT is dead: scratch
     top.finish_set(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
                    I32 ? I32 + (size_t)q * k : nullptr, reinterpret_cast<u64 *>(s_lut));
   else
     top.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
-               I32 ? I32 + (size_t)q * k : nullptr, (dbg & 32) ? ts_fin : nullptr);
-  if ((dbg & 32) && D && k >= 8) {   // measurement: phase durations (100 MHz ticks) replace the scores
-    __syncthreads();
-    if (tid == 0) {
-      float *o = D + (size_t)q * k;
-      o[0] = (float)(t_lut - t_start);
-      o[1] = (float)(t_init - t_lut);
-      o[2] = (float)(t_loop - t_init);
-      o[3] = (float)(wall_clock64() - t_loop);
-      o[4] = (float)total;
-      o[5] = (float)(ts_fin[0] - t_loop);      // compaction
-      o[6] = (float)(ts_fin[1] - ts_fin[0]);   // id resolution + sort
-    }
-  }
+               I32 ? I32 + (size_t)q * k : nullptr);
 }
 
-template <int CAP, int T, int NW = 4, int DEPTH = 2>
+template <int CAP, int T, int NW, int DEPTH>
 static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                      const float *coarse_D, const int32_t *coarse_I, int nprobe,
                      const int32_t *list_offsets, const int32_t *tile_offsets,
                      const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
-                     int64_t *I64, int32_t *I32, int set_mode, int dbg) {
+                     int64_t *I64, int32_t *I32, int set_mode) {
   if ((size_t)d * 4 > (size_t)CAP * 8 || dsub > 64 ||
       (size_t)d * 2 + 8 > (size_t)V3_CHUNK * sizeof(TileEnt8) || d != PQT_M * dsub)
     return fail(ASL_ERR_CAPACITY, "pq scan: d=%d too large for the LDS staging", d);
@@ -204,34 +186,54 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((pq_scan_v3_kernel<CAP, T, NW, DEPTH>), dim3(nq), dim3(64 * NW), lds, stream(), xq, d,
                      codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets,
-                     codes_tiled, ids_tiled, k, D, I64, I32, set_mode, dbg);
+                     codes_tiled, ids_tiled, k, D, I64, I32, set_mode);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
 
-// variant: 0 = choose by k; 3 = 4-wave workgroups, CAP 2048 / 2 tiles per wave;
-// 4 = CAP 4096 / 4 tiles per wave; 8 = 8-wave workgroups with two rounds of prefetch
+bool pq_scan_tiled_supported(int m, int ksub, int k, int nprobe) {
+  return m == PQT_M && ksub == PQT_KSUB && nprobe <= 256 && k >= 1 && k <= TK_MAX_K;
+}
+
+// k <= 1280: 2048-key buffer, three workgroups per CU; larger k: 4096 keys, two per CU
 int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                const float *coarse_D, const int32_t *coarse_I, int nprobe,
                const int32_t *list_offsets, const int32_t *tile_offsets,
                const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
-               int64_t *I64, int32_t *I32, int variant, int set_mode, int dbg) {
+               int64_t *I64, int32_t *I32, int set_mode) {
   if (nq <= 0) return ASL_OK;
 #define V3_ARGS xq, nq, d, codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets, \
-                codes_tiled, ids_tiled, k, D, I64, I32, set_mode, dbg
-  // default for k <= 1280: 8 waves per workgroup, one tile per wave and round, one round of
-  // prefetch (24 waves per CU); variants 3 / 5 / 8: the 4-wave kernels and the deeper prefetch
-  if (k + 256 + 512 <= 2048) {
-    if (variant == 3) return launch_v3<2048, 2>(V3_ARGS);
-    if (variant == 5 && k + 256 + 768 <= 2048) return launch_v3<2048, 3>(V3_ARGS);
-    if (variant == 8) return launch_v3<2048, 1, 8>(V3_ARGS);
-    if (variant != 4) return launch_v3<2048, 1, 8, 1>(V3_ARGS);
-  }
-  // larger k: 4096-key buffer, still 8 waves per workgroup (two workgroups per CU)
-  if (variant != 4 && k + 256 + 512 <= 4096) return launch_v3<4096, 1, 8, 1>(V3_ARGS);
-  if (k + 256 + 1024 <= 4096) return launch_v3<4096, 4>(V3_ARGS);
-  return launch_v3<8192, 4>(V3_ARGS);
+                codes_tiled, ids_tiled, k, D, I64, I32, set_mode
+  if (k + 256 + 512 <= 2048) return launch_v3<2048, 1, 8, 1>(V3_ARGS);
+  return launch_v3<4096, 1, 8, 1>(V3_ARGS);
 #undef V3_ARGS
+}
+
+// list-ordered codes [n,32] -> 64-vector tiles (see file header); dst_slot[i] = tile*64 + v
+__global__ void tile_codes_kernel(const uint8_t *__restrict__ codes, const int32_t *__restrict__ ids,
+                                  const int32_t *__restrict__ dst_slot, int64_t n,
+                                  uint8_t *__restrict__ codes_tiled,
+                                  int32_t *__restrict__ ids_tiled) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * PQT_M) return;
+  const int64_t i = t >> 5;
+  const int m = (int)(t & 31);
+  const int32_t slot = dst_slot[i];
+  const int64_t tile = slot >> 6;
+  const int v = slot & 63, rho = v >> 4, b = (v & 15) ^ (m & 15);
+  codes_tiled[tile * 2048 + rho * 512 + m * 16 + b] = codes[t];
+  if (m == 0) ids_tiled[tile * 64 + v] = ids[i];
+}
+
+int tile_codes(const uint8_t *codes, const int32_t *ids, const int32_t *dst_slot, int64_t n,
+               int64_t ntiles, uint8_t *codes_tiled, int32_t *ids_tiled) {
+  HIP_TRY(hipMemsetAsync(codes_tiled, 0, (size_t)ntiles * 2048, stream()));
+  HIP_TRY(hipMemsetAsync(ids_tiled, 0xff, (size_t)ntiles * 64 * 4, stream()));
+  if (n <= 0) return ASL_OK;
+  hipLaunchKernelGGL(tile_codes_kernel, dim3((unsigned)cdiv(n * PQT_M, 256)), dim3(256), 0,
+                     stream(), codes, ids, dst_slot, n, codes_tiled, ids_tiled);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
 }
 
 }  // namespace asl

@@ -277,11 +277,9 @@ struct StreamTopK {
   }
 
   // Final sort + write-out: D/I rows of length k (missing: -FLT_MAX / -1).
-  __device__ __forceinline__ void finish(float *D, int64_t *I, int32_t *I32, int tid,
-                                         long long *ts = nullptr) {
+  __device__ __forceinline__ void finish(float *D, int64_t *I, int32_t *I32, int tid) {
     __syncthreads();
     flush(tid);
-    if (ts) ts[0] = wall_clock64();   // measurement: after id resolution + sort
     const int f = ctl[0];
     for (int i = tid; i < k; i += NT) {
       const u64 key = buf[i];

@@ -575,6 +575,52 @@ def pmc_traffic(args, world):
         return None, f'{PMC_TRAFFIC_FILE} unreadable: {e}'
 
 
+def faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_queries):
+    """when ``import faiss`` succeeds on this box, time the reference's own
+    retrieval library on the host cores -- ``IndexIVFFlat`` / ``IndexIVFPQ`` (inner product) over
+    the same hashed vectors, with THIS index's coarse centroids as the quantiser (so nothing but
+    the PQ codebooks is trained), same nlist / nprobe / k, ``omp_set_num_threads(cores)``.
+    Retrieval only (FAISS has no rescoring). Returns a dict, or the string 'unavailable'."""
+    try:
+        import faiss as F
+    except Exception:
+        return 'unavailable'
+    import numpy as np
+    import torch
+    try:
+        info = idx.info()
+        d, nlist = info.d, info.nlist
+        F.omp_set_num_threads(int(cores))
+        quantizer = F.IndexFlatIP(d)
+        quantizer.add(np.ascontiguousarray(idx.centroids(), np.float32))
+        if info.kind == 2:
+            fx = F.IndexIVFPQ(quantizer, d, nlist, info.pq_m, 8, F.METRIC_INNER_PRODUCT)
+        else:
+            fx = F.IndexIVFFlat(quantizer, d, nlist, F.METRIC_INNER_PRODUCT)
+        t0 = time.perf_counter()
+        n = part.spectra.n
+        step = 262144
+        if not fx.is_trained:          # PQ codebooks: FAISS' own trainer on <= 256 points per code
+            rows = torch.randperm(n)[:min(n, 65536)].sort().values
+            fx.train(sl._encode(part.spectra.select(rows)).cpu().numpy())
+        for a in range(0, n, step):    # encode on the GPU in slices, add on the host
+            rows = torch.arange(a, min(n, a + step))
+            fx.add(sl._encode(part.spectra.select(rows)).cpu().numpy())
+        t_build = time.perf_counter() - t0
+        fx.nprobe = int(args.nprobe)
+        nq = int(min(q.n, max(64, n_queries)))
+        xq = sl._encode(q.select(torch.arange(nq, device=q.device))).cpu().numpy()
+        fx.search(xq[:min(nq, 64)], args.k)                      # warm-up
+        t0 = time.perf_counter()
+        _, I = fx.search(xq, args.k)
+        dt = time.perf_counter() - t0
+        return {'value': round(nq / dt, 2), 'unit': 'query spectra/s (retrieval only)',
+                'index': 'IndexIVFPQ' if info.kind == 2 else 'IndexIVFFlat', 'threads': int(cores),
+                'queries': nq, 'build_s': round(t_build, 1), 'version': getattr(F, '__version__', '?')}
+    except Exception as e:             # a FAISS build without these classes, out of memory, ...
+        return f'importable, leg failed: {type(e).__name__}: {e}'
+
+
 def cpu_baseline(args, sl, part, idx, q, res, charge, cfg):
     """The oracle (plain-C port of the reference path, oracle/) on the host cores of this
     box, on a bounded sample of the SAME batch against the SAME index; doubles as a
@@ -623,11 +669,7 @@ def cpu_baseline(args, sl, part, idx, q, res, charge, cfg):
               'knn_ids_compared': int(knn_gpu.size),
               'best_row_equal': bool(np.array_equal(best_row, r_all['best_row'])),
               'best_score_max_abs_diff': float(np.abs(best_score - r_all['best_score']).max())}
-    try:                       # time FAISS' own CPU index when it is installed
-        import faiss as _faiss   # noqa: F401
-        faiss_note = 'importable (not timed: wire IndexIVFPQ here)'
-    except Exception:
-        faiss_note = 'unavailable'
+    faiss_note = faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_all)
     log(f'[bench] cpu baseline: {n_all} queries on {cores} threads in {t_all:.2f}s, '
         f'single core {per_q * 1e3:.2f} ms/query (setup {time.time() - t0:.1f}s)')
     return {'value': round(n_all / t_all, 2), 'unit': 'query spectra/s', 'cores': cores,
