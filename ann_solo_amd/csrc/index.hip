@@ -759,6 +759,25 @@ int asl_index_set_refine(asl_index_t *ix, int32_t kprime) {
   return ASL_OK;
 }
 
+int asl_index_get_refine(const asl_index_t *ix) { return ix ? ix->refine_k : 0; }
+
+namespace asl {
+// sharded.hip: k' when the exact re-rank is usable, else 0; and the re-rank of merged device rows
+int index_refine_k(const asl_index *ix) {
+  return (ix->refine_rows && !ix->refine_bad && ix->r_n == ix->ntotal) ? ix->refine_k : 0;
+}
+int index_swap_unordered(asl_index *ix, int mode, int *prev) {
+  if (prev) *prev = ix->unordered;
+  ix->unordered = mode;
+  return ASL_OK;
+}
+int index_refine_device(asl_index *ix, int nq, const float *xq, int kp, const int64_t *I_in, int k,
+                        float *D, int64_t *I) {
+  return refine_topk(xq, nq, ix->d, nullptr, I_in, kp, ix->r_dim.p, ix->r_val.p, ix->r_cnt.p, ix->r_n, k, D, I,
+                     nullptr);
+}
+}  // namespace asl
+
 int asl_index_refine(asl_index_t *ix, int32_t nq, const float *xq, int32_t kp, const int64_t *I_in,
                      int32_t k, float *D, int64_t *I) {
   clear_error();

@@ -402,7 +402,9 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
     // the synchronous path below, after the batches in flight have drained
     Pipeline &pp = pipeline();
     auto dev_or_null = [](const void *p) { return !p || is_device_ptr(p); };
-    if (pp.on && P->use_ann && queries->n_peaks > 0 && peaks_on_device(queries) &&
+    // (an exhaustive ASL_INDEX_FLAT index has no coarse stage to overlap: synchronous path)
+    if (pp.on && P->use_ann && index_nprobe(idx, P->nprobe) > 0 && queries->n_peaks > 0 &&
+        peaks_on_device(queries) &&
         is_device_ptr(best_row) && is_device_ptr(best_score) && dev_or_null(n_cand) &&
         dev_or_null(pm_count) && dev_or_null(pm_pairs) && dev_or_null(knn_I)) {
       pp.in_call = true;                    // do not drain: this call joins the pipeline

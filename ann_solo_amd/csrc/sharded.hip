@@ -26,6 +26,10 @@ int index_prepare(asl_index *ix);
 int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, float *out_D,
                         int32_t *out_I);
 int index_shard_world(const asl_index *ix, int *rank);
+int index_refine_k(const asl_index *ix);
+int index_swap_unordered(asl_index *ix, int mode, int *prev);
+int index_refine_device(asl_index *ix, int nq, const float *xq, int kp, const int64_t *I_in, int k,
+                        float *D, int64_t *I);
 
 // the few RCCL declarations used (rccl.h: stable since NCCL 2.7)
 typedef void *nccl_comm_t;
@@ -83,6 +87,9 @@ using namespace asl;
 //   all-gathered -> scan of the local inverted lists for all world x nq queries (exact top-k
 //   sets) -> all-to-all of the per-shard rows (grouped send/recv: direct peer copies over xGMI)
 //   -> k-way merge under (score desc, id asc).
+// With the exact re-rank on (asl_index_set_refine, k' > k) every shard returns its k' best ADC
+// hits, the merge yields the k' best of the whole index -- the unsharded short-list -- and the
+// owner of the query re-ranks that against the exact rows (replicated on every rank).
 // D / I [nq, k]: identical to what the unsharded index returns for these queries.
 extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_t nq,
                                         const float *xq, int32_t k, int32_t nprobe, float *D,
@@ -103,6 +110,10 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
   const int np = index_nprobe(ix, nprobe);
   if (np <= 0) return fail(ASL_ERR_INVALID, "search_sharded: an IVF index is required");
   ASL_TRY(index_prepare(ix));
+  const int k_out = k;
+  const int kref = index_refine_k(ix);
+  const bool refine = kref > k;
+  if (refine) k = std::min(kref, (int)TK_MAX_K);     // per-shard rows and the merge carry k' hits
   const size_t all = (size_t)world * nq;
   static DevBuf<float> &x_all = *new DevBuf<float>(), &cD = *new DevBuf<float>(),
                        &cD_all = *new DevBuf<float>(), &Dp = *new DevBuf<float>(),
@@ -127,7 +138,12 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
   RCCL_TRY(R.AllGather(cD.p, cD_all.p, (size_t)nq * np, NCCL_FLOAT32, comm, st));
   RCCL_TRY(R.AllGather(cI.p, cI_all.p, (size_t)nq * np, NCCL_INT32, comm, st));
   // 2. the local lists, for all queries (rank-major rows), as exact top-k sets
-  ASL_TRY(index_search_device(ix, (int)all, x_all.p, k, np, Dp.p, Ip.p, nullptr, cD_all.p, cI_all.p, true));
+  //    (unordered mode: un-refined ADC rows, see annsolo_mi.h at asl_index_set_refine)
+  int prev_unordered = 0;
+  ASL_TRY(index_swap_unordered(ix, 1, &prev_unordered));
+  const int rc_scan = index_search_device(ix, (int)all, x_all.p, k, np, Dp.p, Ip.p, nullptr, cD_all.p, cI_all.p, true);
+  ASL_TRY(index_swap_unordered(ix, prev_unordered, nullptr));
+  ASL_TRY(rc_scan);
   // 3. rank r receives the `world` partial rows of its own queries
   RCCL_TRY(R.GroupStart());
   for (int r = 0; r < world; ++r) {
@@ -137,12 +153,21 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
     RCCL_TRY(R.Recv(Ir.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_INT64, r, comm, st));
   }
   RCCL_TRY(R.GroupEnd());
-  // 4. merge
+  // 4. merge (and the exact re-rank of the merged short-list)
+  static DevBuf<int64_t> &Im = *new DevBuf<int64_t>();
   float *Dout = D;
-  if (!Dout) {
+  if (!Dout || refine) {
     ASL_TRY(Dtmp.reserve((size_t)nq * k));
     Dout = Dtmp.p;
   }
-  ASL_TRY(topk_merge(Dr.p, Ir.p, world, nq, k, Dout, I));
-  return ASL_OK;
+  if (!refine) return topk_merge(Dr.p, Ir.p, world, nq, k, Dout, I);
+  ASL_TRY(Im.reserve((size_t)nq * k));
+  ASL_TRY(topk_merge(Dr.p, Ir.p, world, nq, k, Dout, Im.p));
+  static DevBuf<float> &Dfin = *new DevBuf<float>();
+  float *Df = D;
+  if (!Df) {
+    ASL_TRY(Dfin.reserve((size_t)nq * k_out));
+    Df = Dfin.p;
+  }
+  return index_refine_device(ix, nq, xq, k, Im.p, k_out, Df, I);
 }

@@ -103,6 +103,12 @@ class HipShardBackend:
                       if charge in spectral_library._ann_filenames else None)
         self.device = spectral_library.device
         self.k = spectral_library._num_candidates
+        # exact re-rank of the IVF-PQ short-list (Config.refine_k): every shard returns its k'
+        # best ADC hits UN-refined, the merge yields the k' best of the whole index -- the
+        # short-list one GPU would re-rank -- and the query's owner re-ranks it against the exact
+        # rows every rank keeps: 1 and N GPUs hand the same k candidates to the rescoring
+        rk = self.index.refine_k if self.index is not None else 0
+        self.k_scan = rk if rk > self.k else self.k
 
     def encode(self, queries: PackedSpectra) -> torch.Tensor:
         return self.sl._encode(queries.to(self.device))
@@ -122,7 +128,7 @@ class HipShardBackend:
         # per-shard rows go straight into the merge, which orders them: skip the shard's sort
         self.index.set_unordered(True)
         try:
-            return self.index.search_preassigned(vectors, self.k, coarse_D, coarse_I)
+            return self.index.search_preassigned(vectors, self.k_scan, coarse_D, coarse_I)
         finally:
             self.index.set_unordered(False)
 
@@ -132,15 +138,21 @@ class HipShardBackend:
         """Packed-key rows exist only in the tiled IVF-PQ scan (index.hip: m = 32, 8-bit codes,
         automatic scan variant, nprobe within the tiled kernel's limit, k + 768 <= 2048); every
         other configuration exchanges (D, I) rows."""
-        return bool(_lib.lib().asl_index_supports_keys(self.index._h, int(self.k),
+        return bool(_lib.lib().asl_index_supports_keys(self.index._h, int(self.k_scan),
                                                        int(self.sl._num_probe)))
 
     def shard_search_keys(self, vectors, coarse_D, coarse_I):
-        return self.index.search_preassigned_keys(vectors, self.k, coarse_D, coarse_I)
+        return self.index.search_preassigned_keys(vectors, self.k_scan, coarse_D, coarse_I)
 
     def merge_keys(self, Ks: torch.Tensor):
         from . import faiss_compat
         return faiss_compat.topk_merge_keys(Ks, unordered=True)   # rescoring consumes a set
+
+    def refine(self, vectors: torch.Tensor, knn: torch.Tensor):
+        """Merged k' short-list of the own queries -> the k best by exact inner product."""
+        if self.k_scan == self.k:
+            return knn
+        return self.index.refine(vectors, knn, self.k)[1]
 
     def merge(self, Ds: torch.Tensor, Is: torch.Tensor):
         from . import faiss_compat
@@ -248,19 +260,37 @@ def _all_gather_rows(x: torch.Tensor, world: int, group=None, async_op: bool = F
 PEAK_ROW_ALIGN = 16      # fixed row width of the peak exchange = max peaks rounded up to this
 
 
-def _peak_row_width(queries: PackedSpectra) -> int:
-    """Width every rank derives WITHOUT communication: processed queries hold at most
-    ``max_peaks_used`` (default 50) peaks (spectrum.py:97-99), so 64 covers the reference's
-    configuration; wider spectra widen the row in steps of PEAK_ROW_ALIGN. Ranks must agree --
-    they do whenever their slices come from the same preprocessing."""
-    m = max(queries.max_peaks(), 50)
+def _peak_row_width(queries: PackedSpectra, world: int, group=None,
+                    agreed: Optional[int] = None) -> int:
+    """Row width of the peak exchange: the widest spectrum of ANY rank's slice (at least 50:
+    the reference's ``max_peaks_used``, spectrum.py:97-99), rounded up to PEAK_ROW_ALIGN. Every
+    rank must arrive at the same number or ``all_gather_into_tensor`` runs with mismatched
+    shapes, so it comes either from ``agreed`` -- a bound the caller guarantees to be identical
+    on every rank (the full batch's widest spectrum in ``sharded_cascade_batch``,
+    ``config.max_peaks_used`` for processed queries; a wider local spectrum is an error) -- or
+    from an all-reduce(MAX) of the local widths."""
+    local = int(queries.max_peaks())
+    if agreed is not None:
+        if local > agreed:
+            raise ValueError(f'peak exchange: a local spectrum has {local} peaks, more than the '
+                             f'agreed width {agreed}')
+        m = int(agreed)
+    elif world > 1:
+        t = torch.tensor([local], dtype=torch.int64)
+        if dist.get_backend(group) == 'nccl':
+            t = t.to(queries.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        m = int(t[0])
+    else:
+        m = local
+    m = max(m, 50)
     return -(-m // PEAK_ROW_ALIGN) * PEAK_ROW_ALIGN
 
 
-def _all_gather_peaks(queries: PackedSpectra, world: int, group=None):
+def _all_gather_peaks(queries: PackedSpectra, world: int, group=None, agreed: Optional[int] = None):
     """All-gather of the local queries' peaks as fixed-width rows [n, 2 W + 1] of 4-byte words
     (W m/z values, W intensities, the peak count). Returns (gathered [world * n, 2 W + 1], work)."""
-    W = _peak_row_width(queries)
+    W = _peak_row_width(queries, world, group, agreed)
     dev = queries.device
     n = queries.n
     off = queries.offsets.to(torch.int64)
@@ -319,9 +349,13 @@ def _concat_results(parts):
 
 def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, device_out=False,
                          chunks: Optional[int] = None, _force_exchange: bool = False,
-                         pm_stride: Optional[int] = None, check_sizes: bool = False):
+                         pm_stride: Optional[int] = None, check_sizes: bool = False,
+                         peak_width: Optional[int] = None):
     """One batch: ``queries_local`` is this rank's equally sized slice of the global
     batch. Returns the BatchResult of the local slice (library rows are global).
+    ``peak_width``: a bound on the peaks per query that is IDENTICAL on every rank (e.g.
+    ``config.max_peaks_used`` for processed queries); without it the ranks agree on the row
+    width of the peak exchange by an all-reduce.
 
     The shard scan runs in ``chunks`` pieces (the same sub-slice of every rank's queries per
     piece) so that the all-to-all of one piece travels over xGMI while the next piece is
@@ -350,7 +384,7 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     # peaks (8 B each) but 800 floats once hashed, so the PEAKS travel (fixed-width rows,
     # ~0.5 KB per query instead of 3.2 KB) while the coarse quantiser runs on the own slice, and
     # every rank hashes the foreign queries itself (encode: ~6 us per 1000 queries)
-    packed, w_vec = _all_gather_peaks(queries_local, world, group)
+    packed, w_vec = _all_gather_peaks(queries_local, world, group, peak_width)
     co = backend.coarse(vec) if getattr(backend, 'supports_preassigned', False) else None
     if co is not None:
         cD, cI = _all_gather_rows(co[0], world, group), _all_gather_rows(co[1], world, group)
@@ -376,6 +410,8 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
             knn = backend.merge_keys(payload[0].contiguous())[1]
         else:
             knn = backend.merge(payload[0].contiguous(), payload[1].contiguous())[1]
+        if hasattr(backend, 'refine'):       # exact re-rank of the merged short-list (k' -> k)
+            knn = backend.refine(vec[lo:hi], knn)
         sub = queries_local if (lo, hi) == (0, n_local) else queries_local.select(
             torch.arange(lo, hi, device=queries_local.device))
         results.append(backend.rescore_knn(sub, knn, device_out, **kw))
@@ -445,7 +481,9 @@ def sharded_cascade_batch(backend, queries: PackedSpectra, mode: str, use_ann: b
     q_loc = queries.select(rows.to(queries.device))
     stride = queries.max_peaks()
     if use_ann:
-        res = sharded_search_batch(backend, q_loc, group=group, device_out=True, pm_stride=stride)
+        # (every rank holds the whole batch: its widest spectrum is the same number everywhere)
+        res = sharded_search_batch(backend, q_loc, group=group, device_out=True, pm_stride=stride,
+                                   peak_width=stride)
     else:
         res = backend.window_search(q_loc, mode, pm_stride=stride)
     out = {}

@@ -187,6 +187,11 @@ class Index:
         return the k best (FAISS ``IndexRefineFlat``); call before ``add``. 0 switches it off."""
         _lib.check(_lib.lib().asl_index_set_refine(self._h, int(kprime)))
 
+    @property
+    def refine_k(self) -> int:
+        """k' of the exact re-rank (0: off) -- also for an index read from a file."""
+        return int(_lib.lib().asl_index_get_refine(self._h))
+
     def refine(self, x, I_in, k):
         """Exact re-rank of a short-list obtained elsewhere: (D [nq,k], I [nq,k])."""
         x = _as_f32(x, self.d)

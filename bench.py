@@ -243,7 +243,9 @@ def main():
             shard_backend = HipShardBackend(sl, charge, 'open')
 
             def step():
-                return sharded_search_batch(shard_backend, q, group=group, device_out=True)
+                # synthetic queries are processed spectra: at most max_peaks_used peaks on every rank
+                return sharded_search_batch(shard_backend, q, group=group, device_out=True,
+                                            peak_width=cfg.max_peaks_used)
         else:
             step = unsharded_step
         got = step()

@@ -110,8 +110,15 @@ int asl_index_set_niter(asl_index_t *idx, int32_t niter);
  * and asl_index_search / asl_search_batch with k < kprime let the ADC scan return kprime
  * candidates, rescore them with the exact inner product and return the k best, (score desc, id
  * asc) -- for the vectors it reaches, IVF-Flat's scores. kprime = 0 switches the re-rank off (the
- * rows stay). asl_index_refine re-ranks a short-list obtained elsewhere (e.g. merged shard rows). */
+ * rows stay). asl_index_refine re-ranks a short-list obtained elsewhere (e.g. merged shard rows).
+ * In the unordered modes (asl_index_set_unordered: per-shard rows of a sharded search) the scan
+ * returns its ADC candidates UN-refined: a sharded driver asks every shard for kprime hits, merges
+ * them by ADC score into the kprime best of the whole index -- the unsharded short-list -- and
+ * re-ranks that with asl_index_refine (every rank keeps the exact rows of ALL vectors), so 1 and
+ * N GPUs return the same rows. asl_index_search_sharded does exactly this. */
 int asl_index_set_refine(asl_index_t *idx, int32_t kprime);
+/* kprime of the index (0: re-rank off) -- what a sharded driver needs to size the per-shard rows. */
+int asl_index_get_refine(const asl_index_t *idx);
 int asl_index_refine(asl_index_t *idx, int32_t nq, const float *xq, int32_t kprime,
                      const int64_t *I_in /* [nq,kprime], -1 = empty */, int32_t k, float *D, int64_t *I);
 

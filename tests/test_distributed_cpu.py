@@ -19,6 +19,27 @@ def _free_port():
     return p
 
 
+def _widen(q, extra):
+    """Queries with ``extra[i]`` additional weak peaks each (so that spectra exceed the 50 peaks
+    of the reference's default ``max_peaks_used``; exactly ``50 + extra[i]`` for the widest)."""
+    from ann_solo_amd.packed import PackedSpectra
+    o, mz, it, chg, pmz, pz = q.numpy()
+    rng = np.random.default_rng(5)
+    offs, mzs, its, chgs = [0], [], [], []
+    for i in range(q.n):
+        sl = slice(o[i], o[i + 1])
+        n_add = 50 + extra[i] - (o[i + 1] - o[i])
+        add = np.sort(rng.uniform(150, 1400, n_add)).astype(np.float32)
+        m = np.concatenate([mz[sl], add])
+        order = np.argsort(m, kind='stable')
+        mzs.append(m[order])
+        its.append(np.concatenate([it[sl], np.full(n_add, 0.01, np.float32)])[order])
+        chgs.append(np.concatenate([chg[sl], np.zeros(n_add, np.uint8)])[order])
+        offs.append(offs[-1] + len(m))
+    return PackedSpectra.from_numpy(np.asarray(offs), np.concatenate(mzs), np.concatenate(its),
+                                    np.concatenate(chgs), pmz, pz)
+
+
 def _worker(rank, world, port, kind, out_dir):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,13 +61,31 @@ def _worker(rank, world, port, kind, out_dir):
     if kind == 'pq':
         cb = O.pq_train(xb, cen, 8, 16, 4, 1241)
         payload = O.pq_encode(xb, cen, a, cb)
-    else:
+    else:      # 'flat', 'flat_wide'
         cb, payload = None, xb
     pmz32 = lib_np[4].astype(np.float32)
     be = OracleShardBackend(lib_np, pmz32, cen, a, payload, cb, rank, world, 2, 64, 4, 300, 'Da',
                             0.02, True, lpt_owner)
     nloc = q_all.n // world
+    if kind == 'flat_wide':
+        # slices whose widest spectra differ (rank 0: <= 70 peaks -> 80-wide rows,
+        # rank 1: <= 90 -> 96) must still agree on ONE row width for the peak all-gather
+        q_all = _widen(q_all, [20] * nloc + [40] * (q_all.n - nloc))
     q = q_all.select(torch.arange(rank * nloc, (rank + 1) * nloc))
+    if kind == 'flat_wide':
+        from ann_solo_amd.distributed import _all_gather_peaks, _unpack_peaks
+        assert q.max_peaks() == (70 if rank == 0 else 90)
+        rows, w = _all_gather_peaks(q, world)
+        assert rows.shape == (q_all.n, 2 * 96 + 1)
+        back = _unpack_peaks(rows, q)
+        assert torch.equal(back.mz, q_all.mz) and torch.equal(back.offsets, q_all.offsets.to(torch.int32))
+        rows2, _ = _all_gather_peaks(q, world, agreed=100)     # a caller-guaranteed common bound
+        assert rows2.shape == (q_all.n, 2 * 112 + 1)
+        try:
+            _all_gather_peaks(q, world, agreed=64)
+            raise AssertionError('a spectrum wider than the agreed row must be refused')
+        except ValueError:
+            pass
     res = sharded_search_batch(be, q)
     # unsharded reference for my slice
     D, I = be.full.search(be.encode(q).numpy(), 64, 4)
@@ -61,7 +100,7 @@ def _worker(rank, world, port, kind, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind', ['pq', 'flat'])
+@pytest.mark.parametrize('kind', ['pq', 'flat', 'flat_wide'])
 def test_two_rank_sharded_search_equals_unsharded(tmp_path, kind):
     world = 2
     port = _free_port()

@@ -116,3 +116,59 @@ def test_standalone_entry_round_trip_and_errors(O, world, tmp_path):
         dense.search(xd[:8], 50)
     dense.set_refine(0)
     assert dense.search(xd[:8], 50)[1].shape == (8, 50)
+
+
+def test_sharded_refine_equals_unsharded(O, world, tmp_path):
+    """with the exact re-rank on, N shards must hand the rescoring the same k
+    candidates as one GPU. Per shard the ADC scan returns k' UN-refined hits (unordered modes),
+    the merge yields the k' best of the whole index, the re-rank runs on that -- checked for a
+    3-way split on one GPU (rows and packed keys) and through the torch.distributed driver
+    (collectives at world 1), against the unsharded index and the oracle."""
+    import os
+    import torch.distributed as dist
+    from ann_solo_amd import faiss_compat as faiss
+    from ann_solo_amd.distributed import HipShardBackend, sharded_search_batch
+    sl, q, xb, xq, ivf = world
+    k, kp = 256, 1024
+    idx = sl._get_ann_index(2)
+    idx.nprobe = 32
+    assert idx.refine_k == kp
+    D, I = idx.search(xq, k)
+    _, I_short = ivf.search(xq, kp, 32)
+    Do, Io = O.refine(xb, xq, I_short, k)
+    assert np.array_equal(I, Io)
+    path = str(tmp_path / 'refined.idxmi')
+    faiss.write_index(idx, path)
+    cD, cI = idx.coarse(xq, 32)
+    rows, keys = [], []
+    for r in range(3):
+        sh = faiss.read_index(path)
+        assert sh.refine_k == kp
+        sh.shard(r, 3)
+        sh.set_unordered(1)
+        rows.append(sh.search_preassigned(xq, kp, cD, cI))
+        sh.set_unordered(0)
+        keys.append(sh.search_preassigned_keys(xq, kp, cD, cI))
+        last = sh
+    Dm, Im = faiss.topk_merge(np.stack([p[0] for p in rows]), np.stack([p[1] for p in rows]))
+    assert np.array_equal(np.sort(Im, 1), np.sort(I_short, 1))          # the unsharded short-list
+    D3, I3 = last.refine(xq, Im, k)                                       # any rank can re-rank
+    assert np.array_equal(I3, I) and np.array_equal(D3.view(np.uint32), D.view(np.uint32))
+    _, Ik = faiss.topk_merge_keys(np.stack(keys), unordered=True)
+    D4, I4 = last.refine(xq, Ik, k)
+    assert np.array_equal(I4, I)
+    # the driver: same winners as the unsharded engine
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29653')
+        dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        ref = sl._search_batch(q, 2, 'open', want_knn=True)
+        be = HipShardBackend(sl, 2, 'open')
+        assert be.k_scan == kp and be.k == k
+        got = sharded_search_batch(be, q.to('cuda'), device_out=True, _force_exchange=True)
+        assert np.array_equal(np.sort(got.knn.cpu().numpy(), 1), np.sort(ref.knn, 1))
+        assert np.array_equal(got.best_row.cpu().numpy(), ref.best_row)
+        assert np.array_equal(got.best_score.cpu().numpy(), ref.best_score)
+    finally:
+        dist.destroy_process_group()
