@@ -761,6 +761,8 @@ int asl_index_set_refine(asl_index_t *ix, int32_t kprime) {
 
 int asl_index_get_refine(const asl_index_t *ix) { return ix ? ix->refine_k : 0; }
 
+}  // extern "C"
+
 namespace asl {
 // sharded.hip: k' when the exact re-rank is usable, else 0; and the re-rank of merged device rows
 int index_refine_k(const asl_index *ix) {
@@ -777,6 +779,8 @@ int index_refine_device(asl_index *ix, int nq, const float *xq, int kp, const in
                      nullptr);
 }
 }  // namespace asl
+
+extern "C" {
 
 int asl_index_refine(asl_index_t *ix, int32_t nq, const float *xq, int32_t kp, const int64_t *I_in,
                      int32_t k, float *D, int64_t *I) {
