@@ -75,8 +75,13 @@ EXPORTS = [
 
 
 def build(force: bool = False) -> str:
-    """Compile libannsolo_mi.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    """Compile libannsolo_mi.so for gfx950 with hipcc (cross-compiles without a GPU).
+    ``force`` (or ASL_FORCE_REBUILD=1) recompiles every translation unit; otherwise only what is
+    older than its sources. Every run appends one line to ``csrc/build/build.log`` naming the
+    objects that were recompiled."""
+    import time
     src = os.path.join(_HERE, 'csrc')
+    force = force or os.environ.get('ASL_FORCE_REBUILD', '') not in ('', '0')
     stale = force or not os.path.exists(LIB_PATH)
     if not stale:
         t = os.path.getmtime(LIB_PATH)
@@ -84,10 +89,28 @@ def build(force: bool = False) -> str:
                 if f.endswith(('.hip', '.hpp'))]
         deps.append(os.path.join(_HERE, '..', 'include', 'annsolo_mi.h'))
         stale = any(os.path.getmtime(p) > t for p in deps)
+    rebuilt = []
     if stale:
         if not os.path.exists('/opt/rocm/bin/hipcc'):
             raise AnnSoloMiError('hipcc not found and libannsolo_mi.so is stale/missing')
-        subprocess.check_call(['make', '-C', src, '-j8'])
+        obj_dir = os.path.join(src, 'build')
+        before = {f: os.path.getmtime(os.path.join(obj_dir, f))
+                  for f in (os.listdir(obj_dir) if os.path.isdir(obj_dir) else []) if f.endswith('.o')}
+        cmd = ['make', '-C', src, '-j8'] + (['-B'] if force else [])
+        subprocess.check_call(cmd)
+        for f in sorted(os.listdir(obj_dir)):
+            if f.endswith('.o') and os.path.getmtime(os.path.join(obj_dir, f)) > before.get(f, 0.0):
+                rebuilt.append(f)
+    try:
+        os.makedirs(os.path.join(src, 'build'), exist_ok=True)
+        with open(os.path.join(src, 'build', 'build.log'), 'a') as f:
+            f.write('%s force=%d recompiled=%d [%s] -> %s\n' % (
+                time.strftime('%Y-%m-%dT%H:%M:%S'), int(force), len(rebuilt), ' '.join(rebuilt),
+                os.path.basename(LIB_PATH)))
+    except OSError:
+        pass
+    print('[build] libannsolo_mi.so: %d translation units recompiled for gfx950%s'
+          % (len(rebuilt), (' (' + ' '.join(rebuilt) + ')') if rebuilt else ' (up to date)'))
     return LIB_PATH
 
 
