@@ -69,7 +69,7 @@ EXPORTS = [
     'asl_index_pq_lut', 'asl_rescore_batch', 'asl_library_create', 'asl_library_free',
     'asl_library_size', 'asl_search_batch', 'asl_window_candidates', 'asl_profile_enable',
     'asl_profile_reset', 'asl_profile_get', 'asl_profile_scanned_vectors',
-    'asl_rescore_knn', 'asl_lpt_owner', 'asl_index_supports_keys', 'asl_index_search_sharded', 'asl_index_set_refine', 'asl_index_get_refine', 'asl_index_refine', 'asl_index_set_scan_variant', 'asl_index_search_preassigned', 'asl_process_batch',
+    'asl_rescore_knn', 'asl_lpt_owner', 'asl_index_supports_keys', 'asl_index_search_sharded', 'asl_index_postings_work', 'asl_index_set_refine', 'asl_index_get_refine', 'asl_index_refine', 'asl_index_set_scan_variant', 'asl_index_search_preassigned', 'asl_process_batch',
     'asl_ssm_features_batch', 'asl_ssm_cosine_batch', 'asl_index_set_unordered', 'asl_topk_merge_keys',
 ]
 
@@ -163,6 +163,7 @@ def lib():
         L.asl_index_load.restype = C.c_void_p
         L.asl_index_set_niter.argtypes = [C.c_void_p, C.c_int32]
         L.asl_index_set_scan_variant.argtypes = [C.c_void_p, C.c_int32]
+        L.asl_index_postings_work.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, c_i64p, c_i64p]
         L.asl_index_get_refine.argtypes = [C.c_void_p]
         L.asl_index_get_refine.restype = C.c_int32
         L.asl_index_set_unordered.argtypes = [C.c_void_p, C.c_int32]

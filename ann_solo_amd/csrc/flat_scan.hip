@@ -73,6 +73,12 @@ constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = 128, FI_U = FI_U_;
 #ifndef FI_PHASES
 #define FI_PHASES 0
 #endif
+#ifndef FI_SPLIT
+#define FI_SPLIT 1      // measurement switches (same-box A/B builds); 1 / 1 is the product
+#endif
+#ifndef FI_ORDER
+#define FI_ORDER 1
+#endif
 #if FI_PHASES
 #define FI_T(i)                                   \
   {                                               \
@@ -155,6 +161,16 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   TopK top;
   top.init(smem, k, ids, tid);
   float *acc = s_acc + wave * FI_BLK;
+  // Posting p of a row goes to lane (p >> 1) + 32 (p & 1): the LDS services ds_read_b32 /
+  // ds_write_b32 in two lane groups {0-31} and {32-63} and only lanes of one group conflict, so
+  // a typical row (~28 postings) is spread over both groups instead of filling the first one;
+  // the index builder (inv_order_kernel) orders every row so that the even and the odd postings
+  // each fall into distinct LDS banks wherever the block's local indices allow it.
+#if FI_SPLIT
+  const uint32_t plane = (uint32_t)(((lane & 31) << 1) | (lane >> 5));
+#else
+  const uint32_t plane = (uint32_t)lane;
+#endif
 
   int chunks_done = 0;
   auto sync = [&]() {             // raise the flag, meet the other waves, compact
@@ -263,12 +279,12 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
     const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)rlo, (r));                      \
     cn[u] = (uint32_t)__builtin_amdgcn_readlane((int)rc, (r));                                    \
     qj[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rq), (r))); \
-    const uint32_t l_ = min((uint32_t)lane, cn[u] - 1u);                                          \
+    const uint32_t l_ = min(plane, cn[u] - 1u);                                                   \
     val[u] = *reinterpret_cast<const float *>(bptr + (vo_ + 4u * l_));                            \
     loc[u] = *reinterpret_cast<const uint16_t *>(bptr + (lo_ + 2u * l_));                         \
   }
 #define FI_APPLY(u) \
-  if ((uint32_t)lane < cn[u]) acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);
+  if (plane < cn[u]) acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);
             const int n = (int)min(64u, R - r0);
             const int n_up = (n + FI_U - 1) & ~(FI_U - 1);
 #pragma unroll
@@ -395,6 +411,66 @@ int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int n
                                seg_tab, seg_bytes, ids, k, D, I64, I32, set_mode);
 }
 
+// ---- algorithmic work of a postings scan (bench.py: the roofline of this kernel). Per (query,
+// probed block, non-zero query dimension) the scan needs the 4-byte table word and the
+// dimension's postings (6 bytes each): out[0] += 4 + 6 c. out[1] counts what that costs in
+// 128-byte lines: the lines every non-empty segment spans plus the distinct lines of the
+// block's table row that hold a wanted word. One workgroup per query, outside any timed region.
+__global__ __launch_bounds__(256) void flat_inv_work_kernel(
+    const float *__restrict__ xq, int d, const int32_t *__restrict__ coarse_I, int nprobe,
+    const int32_t *__restrict__ blk_offsets, const uint32_t *__restrict__ seg_tab,
+    unsigned long long *__restrict__ out) {
+  extern __shared__ int s_work[];          // [d] non-zero dimensions, then 1 counter
+  int *s_dim = s_work, *s_n = s_work + d;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) *s_n = 0;
+  __syncthreads();
+  for (int j = tid; j < d; j += 256)
+    if (xq[(size_t)q * d + j] != 0.0f) s_dim[atomicAdd(s_n, 1)] = j;
+  __syncthreads();
+  const int K = *s_n;
+  unsigned long long bytes = 0, lines = 0;
+  for (int p = 0; p < nprobe; ++p) {
+    const int l = coarse_I[(size_t)q * nprobe + p];
+    if (l < 0) continue;
+    for (int b = blk_offsets[l]; b < blk_offsets[l + 1]; ++b) {
+      const uint32_t *row = seg_tab + (size_t)b * d;
+      for (int t = tid; t < K; t += 256) {
+        const uint32_t w = row[s_dim[t]];
+        const uint32_t c = w & 0xffffu, st = (w >> 16) * 64u;
+        bytes += 4ull + 6ull * c;
+        if (c) lines += ((st + 6u * c - 1u) >> 7) - (st >> 7) + 1u;
+      }
+      // distinct table lines: one wave walks the query's dimensions in line order
+      if (tid < 64) {
+        for (int ln0 = 0; ln0 * 32 < d; ln0 += 64) {      // 32 words per 128-byte line
+          const int ln = ln0 + lane;
+          bool hit = false;
+          for (int t = 0; t < K; ++t) hit |= (s_dim[t] >> 5) == ln;
+          lines += __popcll(__ballot(hit)) * (lane == 0);
+        }
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    bytes += __shfl_xor(bytes, off);
+    lines += __shfl_xor(lines, off);
+  }
+  if (lane == 0) {
+    atomicAdd(&out[0], bytes);
+    atomicAdd(&out[1], lines);
+  }
+}
+
+int flat_inv_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
+                  const int32_t *blk_offsets, const uint32_t *seg_tab, unsigned long long *out_dev) {
+  if (nq <= 0) return ASL_OK;
+  hipLaunchKernelGGL(flat_inv_work_kernel, dim3(nq), dim3(256), (size_t)(d + 1) * 4, stream(), xq, d,
+                     coarse_I, nprobe, blk_offsets, seg_tab, out_dev);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
 // Placement of a block's segments (counts cnt[0..d) -> table words tab[0..d)); returns the
 // block's size in 64-byte units, or 0 with *ok = false when a start does not fit 16 bits.
 uint32_t inv_place_block(const uint32_t *cnt, int d, uint32_t *tab, bool *ok) {
@@ -457,6 +533,90 @@ __global__ void inv_fill_kernel(const float *__restrict__ vecs, int d,
       *reinterpret_cast<uint16_t *>(bptr + st + 4 * (size_t)c + 2 * (size_t)p) = loc;
     }
   }
+}
+
+// ---- canonical, bank-aware order inside every segment. inv_fill_kernel leaves the postings of
+// a segment in the order its atomics happened to run; a vector occurs at most once per
+// dimension, so ANY order gives the same accumulators. This pass (one wave per segment) makes
+// the layout deterministic -- postings sorted by local index -- and then, row of 64 by row,
+// deals them to the even (lane group {0-31}) and odd (lane group {32-63}) slots so that the LDS
+// banks (local index mod 32) inside each group are distinct whenever the row allows it: first
+// fit into the group where the bank is still free and a slot is left, else wherever a slot is
+// left (three or more postings of one bank in a row cannot all be separated).
+constexpr int IO_WAVES = 4;
+__global__ __launch_bounds__(64 * IO_WAVES) void inv_order_kernel(
+    int64_t nseg, int d, const uint32_t *__restrict__ blk_base,
+    const uint32_t *__restrict__ seg_tab, char *__restrict__ seg_bytes) {
+  __shared__ float s_val[IO_WAVES][2][FI_BLK];
+  __shared__ uint16_t s_loc[IO_WAVES][2][FI_BLK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t seg = (int64_t)blockIdx.x * IO_WAVES + wave;
+  if (seg >= nseg) return;
+  const uint32_t w = seg_tab[seg];
+  const int c = (int)(w & 0xffffu);
+  if (c <= 1 || c > FI_BLK) return;
+  char *ptr = seg_bytes + (size_t)blk_base[seg / d] * 64 + (size_t)(w >> 16) * 64;
+  float *gv = reinterpret_cast<float *>(ptr);
+  uint16_t *gl = reinterpret_cast<uint16_t *>(ptr + 4 * (size_t)c);
+  float *v0 = s_val[wave][0], *v1 = s_val[wave][1];
+  uint16_t *l0 = s_loc[wave][0], *l1 = s_loc[wave][1];
+  for (int i = lane; i < c; i += 64) {
+    v0[i] = gv[i];
+    l0[i] = gl[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  // rank sort by local index (unique inside a segment)
+  for (int i = lane; i < c; i += 64) {
+    const uint16_t me = l0[i];
+    int r = 0;
+    for (int t = 0; t < c; ++t) r += l0[t] < me;
+    v1[r] = v0[i];
+    l1[r] = me;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // greedy deal, serial per row (c is ~30; a shared fragment bin has a few hundred)
+  if (lane == 0) {
+    for (int r0 = 0; r0 < c; r0 += 64) {
+      const int n = min(64, c - r0);
+      const int cap0 = (n + 1) >> 1, cap1 = n >> 1;
+      uint32_t used0 = 0, used1 = 0;
+      int n0 = 0, n1 = 0;
+      for (int t = 0; t < n; ++t) {
+        const uint32_t bit = 1u << (l1[r0 + t] & 31);
+        int g;
+        if (!(used0 & bit) && n0 < cap0) g = 0;
+        else if (!(used1 & bit) && n1 < cap1) g = 1;
+        else g = (n0 < cap0 && (n1 >= cap1 || n0 - cap0 <= n1 - cap1)) ? 0 : 1;
+        int dst;
+        if (g == 0) {
+          used0 |= bit;
+          dst = r0 + 2 * n0++;
+        } else {
+          used1 |= bit;
+          dst = r0 + 2 * n1++ + 1;
+        }
+        v0[dst] = v1[r0 + t];
+        l0[dst] = l1[r0 + t];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < c; i += 64) {
+    gv[i] = v0[i];
+    gl[i] = l0[i];
+  }
+}
+
+int inv_order(int64_t nblocks, int d, const uint32_t *blk_base, const uint32_t *seg_tab,
+              char *seg_bytes) {
+#if FI_ORDER
+  const int64_t nseg = nblocks * d;
+  if (nseg <= 0) return ASL_OK;
+  hipLaunchKernelGGL(inv_order_kernel, dim3((unsigned)cdiv(nseg, IO_WAVES)), dim3(64 * IO_WAVES), 0,
+                     stream(), nseg, d, blk_base, seg_tab, seg_bytes);
+  ASL_CHECK_LAUNCH();
+#endif
+  return ASL_OK;
 }
 
 int inv_count(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk, int64_t n,

@@ -356,6 +356,7 @@ static int build_lists(asl_index *ix) {
         HIP_TRY(hipMemsetAsync(cnt_dev.p, 0, ncell * 4, stream()));
         ASL_TRY(inv_fill(ix->vecs.p, ix->d, order.p, pos_blk_dev.p, pos_loc_dev.p, n,
                          ix->blk_base.p, ix->inv_tab.p, cnt_dev.p, ix->inv_data.p));
+        ASL_TRY(inv_order((int64_t)nblk, ix->d, ix->blk_base.p, ix->inv_tab.p, ix->inv_data.p));
         ASL_TRY(sync_stream());
         ix->has_inv = true;
       }
@@ -1025,6 +1026,34 @@ int asl_index_coarse(asl_index_t *ix, int32_t nq, const float *xq, int32_t nprob
   if (coarse_I)
     HIP_TRY(hipMemcpyAsync(coarse_I, ix->coarse_I.p, (size_t)nq * nprobe * 4, hipMemcpyDefault, stream()));
   return sync_stream();
+}
+
+int asl_index_postings_work(asl_index_t *ix, int32_t nq, const float *xq, int32_t nprobe,
+                            int64_t *bytes, int64_t *lines) {
+  clear_error();
+  if (!ix || ix->kind != ASL_INDEX_IVFFLAT || !ix->trained)
+    return fail(ASL_ERR_STATE, "postings_work: trained IVF-Flat index required");
+  if (bytes) *bytes = 0;
+  if (lines) *lines = 0;
+  if (nq <= 0) return ASL_OK;
+  ASL_TRY(ensure_device());
+  nprobe = std::max(1, std::min(nprobe, ix->nlist));
+  if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "postings_work: nprobe=%d > %d", nprobe, TK_MAX_K);
+  ASL_TRY(build_lists(ix));
+  if (!ix->has_inv) return fail(ASL_ERR_STATE, "postings_work: the index holds no postings (dense vectors)");
+  In<float> dq;
+  ASL_TRY(dq.init(xq, (size_t)nq * ix->d));
+  ASL_TRY(coarse_search(ix, dq.d, nq, nprobe));
+  DevBuf<unsigned long long> acc;
+  ASL_TRY(acc.reserve(2));
+  HIP_TRY(hipMemsetAsync(acc.p, 0, 16, stream()));
+  ASL_TRY(flat_inv_work(dq.d, nq, ix->d, ix->coarse_I.p, nprobe, ix->blk_offsets.p, ix->inv_tab.p, acc.p));
+  unsigned long long h[2] = {0, 0};
+  ASL_TRY(acc.download(h, 2));
+  ASL_TRY(sync_stream());
+  if (bytes) *bytes = (int64_t)h[0];
+  if (lines) *lines = (int64_t)h[1];
+  return ASL_OK;
 }
 
 int asl_index_pq_lut(asl_index_t *ix, int32_t nq, const float *xq, float *lut) {

@@ -56,6 +56,8 @@ int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int n
                   const int32_t *list_offsets, const int32_t *blk_offsets,
                   const uint32_t *blk_base, const uint32_t *seg_tab, const char *seg_bytes,
                   const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode);
+int flat_inv_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
+                  const int32_t *blk_offsets, const uint32_t *seg_tab, unsigned long long *out_dev);
 uint32_t inv_place_block(const uint32_t *cnt, int d, uint32_t *tab, bool *ok);
 // exact re-rank of a short-list against sparse stored rows (refine.hip)
 int refine_stride();
@@ -69,6 +71,8 @@ int inv_count(const float *vecs, int d, const int32_t *order, const int32_t *pos
 int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk,
              const uint16_t *pos_loc, int64_t n, const uint32_t *blk_base,
              const uint32_t *seg_tab, uint32_t *cursor, char *seg_bytes);
+int inv_order(int64_t nblocks, int d, const uint32_t *blk_base, const uint32_t *seg_tab,
+              char *seg_bytes);
 int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_max_dev);
 int scanned_count(const int32_t *coarse_I, int64_t n, const int32_t *list_offsets,
                   unsigned long long *out_dev);

@@ -182,6 +182,15 @@ class Index:
         _lib.check(_lib.lib().asl_index_pq_lut(self._h, x.shape[0], _lib.ptr(x), _lib.ptr(lut)))
         return lut
 
+    def postings_work(self, x, nprobe=None):
+        """(algorithmic bytes, 128-byte lines) the IVF-Flat postings scan needs for these queries
+        (``asl_index_postings_work``: measurement, for the kernel's roofline)."""
+        x = _as_f32(x, self.d)
+        b, l = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().asl_index_postings_work(self._h, x.shape[0], _lib.ptr(x),
+                                                      int(nprobe or self.nprobe), C.byref(b), C.byref(l)))
+        return b.value, l.value
+
     def set_refine(self, kprime: int):
         """IVF-PQ: re-rank the ``kprime`` best ADC candidates with the exact inner product and
         return the k best (FAISS ``IndexRefineFlat``); call before ``add``. 0 switches it off."""

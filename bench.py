@@ -320,6 +320,8 @@ def main():
         sl_f.set_pipeline(False)
         ms_f, n_f = C.c_double(), C.c_int64()
         L.asl_profile_get(b'scan', C.byref(ms_f), C.byref(n_f))
+        res_f = flat_step()
+        sl_f.synchronize()
         fixed_recall = {'index': 'ivfflat', 'nlist': args.nlist, 'nprobe': best,
                         'same_coarse_quantiser_as_the_ivfpq_index': same_q,
                         'recall_at_k_vs_exact_ip': best_rec,
@@ -327,7 +329,16 @@ def main():
                         'value': round(args.batch * args.steps / el_f, 2), 'unit': 'query spectra/s',
                         'ms_per_step': round(el_f / args.steps * 1e3, 3), 'steps': args.steps,
                         'scan_ms_per_step': round(ms_f.value / max(args.steps, 1), 3),
-                        'pipelined': pipelined}
+                        'pipelined': pipelined,
+                        'roofline': postings_roofline(sl_f, idx_f, q, best, ms_f.value / max(n_f.value, 1))}
+        if args.cpu_seconds > 0:
+            # the SAME index (this leg's 25-iteration quantiser, nprobe = best) against the oracle:
+            # neighbour id sets, winners and scores of a sample of the batch
+            from argparse import Namespace
+            a_f = Namespace(**{**vars(args), 'nprobe': best, 'cpu_seconds': min(args.cpu_seconds, 8.0)})
+            cb = cpu_baseline(a_f, sl_f, sl_f.partitions[charge], idx_f, q, res_f, charge, cfg, faiss_leg=False)
+            fixed_recall['parity_vs_gpu'] = cb['parity_vs_gpu']
+            fixed_recall['cpu_baseline'] = {k_: cb[k_] for k_ in ('value', 'unit', 'cores', 'kind', 'sample')}
         sl_f.shutdown()
         del sl_f, idx_f
         torch.cuda.empty_cache()
@@ -339,23 +350,21 @@ def main():
         roofline = None
         if scan['launches'] > 0 and scan['ms_total'] > 0:
             avg_ms = scan['ms_total'] / scan['launches']
-            # IVF-Flat (not the default workload): SURVEY.md 8(d) prices a scanned vector at its
-            # dense fp32 row; the postings scan reads only the dimensions the query has, so its
-            # "algorithmic" rate exceeds the HBM peak -- that ratio is the saving, not a bandwidth
-            per_vec = BYTES_PER_SCANNED_VECTOR if args.index == 'ivfpq' else 4 * cfg.hash_len
-            bytes_per_launch = scanned / scan['launches'] * per_vec
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic(args, world)
-            roofline = {'bound': 'hbm', 'kernel': 'pq_scan_v3_kernel' if args.index == 'ivfpq'
-                        else 'flat_inv_scan_kernel (dense-row bytes per SURVEY 8d; reads ~1/40 of them)',
-                        'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': round(achieved / HBM_PEAK_GBS, 5),
-                        'bytes_per_vector': per_vec,
-                        'traffic': traffic, 'traffic_source': traffic_src,
-                        'avg_launch_ms': round(avg_ms, 4),
-                        'algorithmic_bytes_per_launch': int(bytes_per_launch),
-                        'vectors_scanned_per_query': round(scanned / args.steps /
-                                                           (degree * args.batch), 1)}
+            if args.index == 'ivfpq':
+                per_vec = BYTES_PER_SCANNED_VECTOR
+                bytes_per_launch = scanned / scan['launches'] * per_vec
+                achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+                roofline = {'bound': 'hbm', 'kernel': 'pq_scan_v3_kernel',
+                            'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': round(achieved / HBM_PEAK_GBS, 5),
+                            'bytes_per_vector': per_vec,
+                            'traffic': traffic, 'traffic_source': traffic_src,
+                            'avg_launch_ms': round(avg_ms, 4),
+                            'algorithmic_bytes_per_launch': int(bytes_per_launch)}
+            else:
+                roofline = postings_roofline(sl, idx, q, args.nprobe, avg_ms)
+            roofline['vectors_scanned_per_query'] = round(scanned / args.steps / (degree * args.batch), 1)
             if args.index == 'ivfpq':
                 # the ids are read for survivors only: SURVEY.md 8(d)'s "ids implicit" variant
                 codes = achieved * BYTES_PER_CODE / BYTES_PER_SCANNED_VECTOR
@@ -577,6 +586,24 @@ def pmc_traffic(args, world):
         return None, f'{PMC_TRAFFIC_FILE} unreadable: {e}'
 
 
+def postings_roofline(sl, idx, q, nprobe, avg_ms):
+    """Roofline of ``flat_inv_scan_kernel`` for this batch: algorithmic bytes = sum over (query,
+    probed block, non-zero query dimension) of the 4-byte table word + 6 bytes per posting
+    (u16 local index + f32 value), counted on the device by ``asl_index_postings_work`` outside
+    the timed region; ``lines`` = the 128-byte lines those bytes occupy (what a cold scan has to
+    move). HBM-bound: every (query, block) pair touches its own lines."""
+    b, l = idx.postings_work(sl._encode(q), nprobe)
+    achieved = b / (avg_ms * 1e-3) / 1e9
+    by_line = l * 128 / (avg_ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernel': 'flat_inv_scan_kernel', 'achieved': round(achieved, 2),
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
+            'bytes': '4-B table word + 6 B per posting, per (probed block, non-zero query dimension)',
+            'algorithmic_bytes_per_launch': int(b), 'avg_launch_ms': round(avg_ms, 4),
+            'lines_128B_per_launch': int(l), 'achieved_by_lines': round(by_line, 2),
+            'frac_by_lines': round(by_line / HBM_PEAK_GBS, 5), 'traffic': None,
+            'traffic_source': 'see profiles/ (rocprofv3 --pmc FETCH_SIZE pass of the IVF-Flat bench)'}
+
+
 def faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_queries):
     """when ``import faiss`` succeeds on this box, time the reference's own
     retrieval library on the host cores -- ``IndexIVFFlat`` / ``IndexIVFPQ`` (inner product) over
@@ -623,7 +650,7 @@ def faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_queries):
         return f'importable, leg failed: {type(e).__name__}: {e}'
 
 
-def cpu_baseline(args, sl, part, idx, q, res, charge, cfg):
+def cpu_baseline(args, sl, part, idx, q, res, charge, cfg, faiss_leg=True):
     """The oracle (plain-C port of the reference path, oracle/) on the host cores of this
     box, on a bounded sample of the SAME batch against the SAME index; doubles as a
     full-size parity check of the GPU results."""
@@ -671,7 +698,7 @@ def cpu_baseline(args, sl, part, idx, q, res, charge, cfg):
               'knn_ids_compared': int(knn_gpu.size),
               'best_row_equal': bool(np.array_equal(best_row, r_all['best_row'])),
               'best_score_max_abs_diff': float(np.abs(best_score - r_all['best_score']).max())}
-    faiss_note = faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_all)
+    faiss_note = faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_all) if faiss_leg else None
     log(f'[bench] cpu baseline: {n_all} queries on {cores} threads in {t_all:.2f}s, '
         f'single core {per_q * 1e3:.2f} ms/query (setup {time.time() - t0:.1f}s)')
     return {'value': round(n_all / t_all, 2), 'unit': 'query spectra/s', 'cores': cores,

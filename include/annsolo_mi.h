@@ -202,6 +202,13 @@ int asl_index_search_preassigned(asl_index_t *idx, int32_t nq, const float *xq, 
 int asl_topk_merge(int32_t S, int32_t nq, int32_t k, const float *Ds, const int64_t *Is,
                    float *D, int64_t *I);
 
+/* Algorithmic work of the IVF-Flat postings scan for these queries at this nprobe (measurement;
+ * no reference counterpart): *bytes = sum over (query, probed block, non-zero query dimension)
+ * of the 4-byte table word + 6 bytes per posting; *lines = the 128-byte lines those bytes lie
+ * in (segments are placed by line). What bench.py prices the scan kernel's roofline with. */
+int asl_index_postings_work(asl_index_t *idx, int32_t nq, const float *xq, int32_t nprobe,
+                            int64_t *bytes, int64_t *lines);
+
 /* Exposed stages of the IVF search (parity tests; each mirrors one oracle function). */
 int asl_index_coarse(asl_index_t *idx, int32_t nq, const float *xq, int32_t nprobe,
                      float *coarse_D /* [nq,nprobe] */, int32_t *coarse_I /* [nq,nprobe] */);

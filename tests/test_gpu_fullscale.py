@@ -149,21 +149,26 @@ def test_ivfflat_knn_equal_the_oracle_at_bench_size(world, O):
     library shares has ~260 postings per block), histogram cold start, free-running appends --
     returns the ids AND score bits of the oracle's exact scan of the probed lists."""
     import torch
-    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    from ann_solo_amd import faiss_compat as faiss
     sl, q, _ = world
-    lib = sl.partitions[2].spectra
-    cfg = Config(num_list=4096, num_probe=128, num_candidates=1024, index='ivfflat',
-                 kmeans_niter=5, batch_size=16384, seed=1234)
-    fl = SpectralLibrary(lib, config=cfg, device=lib.mz.device)
+    # the index the bench's fixed-recall leg times: IVF-Flat over the 25-iteration coarse
+    # quantiser of the IVF-PQ index (same seed, same library -> bench.py's sl_f trains these very
+    # centroids; here they are taken over with set_trained, as bench.py's recall block does)
+    pq = sl._get_ann_index(2)
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 4096)
+    idx.set_trained(pq.centroids())
+    xb = sl._encode(sl.partitions[2].spectra)
+    idx.add(xb)
+    del xb
     try:
-        idx = fl._get_ann_index(2)
         off, ids, vecs = idx.lists()
         info = idx.info()
+        assert info.ntotal == N_LIB and np.array_equal(idx.centroids(), pq.centroids())
         ivf = O.HostIVF.__new__(O.HostIVF)
         ivf.centroids, ivf.nlist, ivf.d = idx.centroids(), info.nlist, info.d
         ivf.list_offsets, ivf.ids, ivf.payload, ivf.codebooks, ivf.kind = off, ids, vecs, None, 0
         rows = np.arange(0, q.n, 32)                                  # 64 sampled queries
-        vec = fl._encode(q)[rows].contiguous()
+        vec = sl._encode(q)[rows].contiguous()
         for nprobe in (128, 112):
             idx.nprobe = nprobe
             D, I = idx.search(vec, 1024)
@@ -171,7 +176,7 @@ def test_ivfflat_knn_equal_the_oracle_at_bench_size(world, O):
             assert np.array_equal(torch.as_tensor(I).cpu().numpy(), Io)
             assert np.array_equal(torch.as_tensor(D).cpu().numpy().view(np.uint32), Do.view(np.uint32))
         # a whole batch: ordered rows == the unordered set mode, second call == first
-        full = fl._encode(q)
+        full = sl._encode(q)
         D1, I1 = idx.search(full, 1024)
         D2, I2 = idx.search(full, 1024)
         assert torch.equal(I1, I2) and torch.equal(D1, D2)
@@ -181,8 +186,12 @@ def test_ivfflat_knn_equal_the_oracle_at_bench_size(world, O):
         finally:
             idx.set_unordered(False)
         assert torch.equal(I1.sort(1)[0], Iu.sort(1)[0])
+        # the roofline counter of the postings scan: bytes = 4 per (block, dimension) + 6 per
+        # posting, lines >= bytes / 128
+        b, l = idx.postings_work(vec, 112)
+        assert b > 0 and l * 128 >= b and l * 128 < 4 * b
     finally:
-        fl.shutdown()
+        del idx
 
 
 def test_cascade_std_then_open_on_the_remainder(world, O):

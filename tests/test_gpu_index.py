@@ -296,6 +296,30 @@ def test_ivfflat_search_identical_to_oracle(O, vecs, trained):
     assert np.array_equal(I, O.flat_search(xb, xq, 50)[1])
 
 
+def test_postings_work_counter(vecs, trained):
+    """asl_index_postings_work (the roofline bytes of the postings scan) against numpy: per
+    (query, probed block of 832 vectors, non-zero query dimension) 4 bytes + 6 per posting."""
+    from ann_solo_amd import faiss_compat as faiss
+    xb, xq = vecs
+    cen, _ = trained
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    idx.set_trained(cen)
+    idx.add(xb)
+    off, ids, v = idx.lists()
+    nq, nprobe = 24, 5
+    _, cI = idx.coarse(xq[:nq], nprobe)
+    want = 0
+    for i in range(nq):
+        dims = np.nonzero(xq[i])[0]
+        for l in cI[i]:
+            for b0 in range(off[l], off[l + 1], 832):
+                blk = v[b0:min(b0 + 832, off[l + 1])][:, dims]
+                want += 4 * len(dims) + 6 * int(np.count_nonzero(blk))
+    got, lines = idx.postings_work(xq[:nq], nprobe)
+    assert got == want
+    assert lines * 128 >= got - 4 * 0 and lines > 0
+
+
 def test_ivfflat_postings_scan_many_small_lists():
     """The postings scan where the candidate set only just exceeds the key buffer and the
     threshold bucket is crowded (small scores, k = 1024): bulk offers have to fall back to
