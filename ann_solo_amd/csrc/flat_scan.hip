@@ -73,12 +73,7 @@ constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = 128, FI_U = FI_U_;
 #ifndef FI_PHASES
 #define FI_PHASES 0
 #endif
-#ifndef FI_SPLIT
-#define FI_SPLIT 1      // measurement switches (same-box A/B builds); 1 / 1 is the product
-#endif
-#ifndef FI_ORDER
-#define FI_ORDER 1
-#endif
+
 #if FI_PHASES
 #define FI_T(i)                                   \
   {                                               \
@@ -161,17 +156,6 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   TopK top;
   top.init(smem, k, ids, tid);
   float *acc = s_acc + wave * FI_BLK;
-  // Posting p of a row goes to lane (p >> 1) + 32 (p & 1): the LDS services ds_read_b32 /
-  // ds_write_b32 in two lane groups {0-31} and {32-63} and only lanes of one group conflict, so
-  // a typical row (~28 postings) is spread over both groups instead of filling the first one;
-  // the index builder (inv_order_kernel) orders every row so that the even and the odd postings
-  // each fall into distinct LDS banks wherever the block's local indices allow it.
-#if FI_SPLIT
-  const uint32_t plane = (uint32_t)(((lane & 31) << 1) | (lane >> 5));
-#else
-  const uint32_t plane = (uint32_t)lane;
-#endif
-
   int chunks_done = 0;
   auto sync = [&]() {             // raise the flag, meet the other waves, compact
     if (lane == 0) *s_flag = 1;
@@ -279,12 +263,12 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
     const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)rlo, (r));                      \
     cn[u] = (uint32_t)__builtin_amdgcn_readlane((int)rc, (r));                                    \
     qj[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rq), (r))); \
-    const uint32_t l_ = min(plane, cn[u] - 1u);                                                   \
+    const uint32_t l_ = min((uint32_t)lane, cn[u] - 1u);                                          \
     val[u] = *reinterpret_cast<const float *>(bptr + (vo_ + 4u * l_));                            \
     loc[u] = *reinterpret_cast<const uint16_t *>(bptr + (lo_ + 2u * l_));                         \
   }
 #define FI_APPLY(u) \
-  if (plane < cn[u]) acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);
+  if ((uint32_t)lane < cn[u]) acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);
             const int n = (int)min(64u, R - r0);
             const int n_up = (n + FI_U - 1) & ~(FI_U - 1);
 #pragma unroll
@@ -535,14 +519,15 @@ __global__ void inv_fill_kernel(const float *__restrict__ vecs, int d,
   }
 }
 
-// ---- canonical, bank-aware order inside every segment. inv_fill_kernel leaves the postings of
-// a segment in the order its atomics happened to run; a vector occurs at most once per
-// dimension, so ANY order gives the same accumulators. This pass (one wave per segment) makes
-// the layout deterministic -- postings sorted by local index -- and then, row of 64 by row,
-// deals them to the even (lane group {0-31}) and odd (lane group {32-63}) slots so that the LDS
-// banks (local index mod 32) inside each group are distinct whenever the row allows it: first
-// fit into the group where the bank is still free and a slot is left, else wherever a slot is
-// left (three or more postings of one bank in a row cannot all be separated).
+// ---- canonical order inside every segment. inv_fill_kernel leaves the postings of a segment
+// in the order its atomics happened to run; a vector occurs at most once per dimension, so ANY
+// order gives the same accumulators. This pass (one wave per segment) makes the layout
+// deterministic -- postings sorted by local index -- and, for segments longer than a row, deals
+// each row of 64 to its first and second half (the LDS services lanes {0-31} and {32-63} of a
+// ds instruction separately) so that the banks (local index mod 32) inside a half are distinct
+// where the row allows it. Measured (profiles/r03_flat_scan_notes.txt): bank conflicts are NOT
+// what this kernel waits for -- a layout without any conflict runs at the same speed -- the
+// sorted order is worth 1 %; it is kept for the reproducible file image.
 constexpr int IO_WAVES = 4;
 __global__ __launch_bounds__(64 * IO_WAVES) void inv_order_kernel(
     int64_t nseg, int d, const uint32_t *__restrict__ blk_base,
@@ -578,7 +563,7 @@ __global__ __launch_bounds__(64 * IO_WAVES) void inv_order_kernel(
   if (lane == 0) {
     for (int r0 = 0; r0 < c; r0 += 64) {
       const int n = min(64, c - r0);
-      const int cap0 = (n + 1) >> 1, cap1 = n >> 1;
+      const int cap0 = min(n, 32), cap1 = n - cap0;      // lanes 0-31 | lanes 32-63 of the row
       uint32_t used0 = 0, used1 = 0;
       int n0 = 0, n1 = 0;
       for (int t = 0; t < n; ++t) {
@@ -590,10 +575,10 @@ __global__ __launch_bounds__(64 * IO_WAVES) void inv_order_kernel(
         int dst;
         if (g == 0) {
           used0 |= bit;
-          dst = r0 + 2 * n0++;
+          dst = r0 + n0++;
         } else {
           used1 |= bit;
-          dst = r0 + 2 * n1++ + 1;
+          dst = r0 + cap0 + n1++;
         }
         v0[dst] = v1[r0 + t];
         l0[dst] = l1[r0 + t];
@@ -609,13 +594,11 @@ __global__ __launch_bounds__(64 * IO_WAVES) void inv_order_kernel(
 
 int inv_order(int64_t nblocks, int d, const uint32_t *blk_base, const uint32_t *seg_tab,
               char *seg_bytes) {
-#if FI_ORDER
   const int64_t nseg = nblocks * d;
   if (nseg <= 0) return ASL_OK;
   hipLaunchKernelGGL(inv_order_kernel, dim3((unsigned)cdiv(nseg, IO_WAVES)), dim3(64 * IO_WAVES), 0,
                      stream(), nseg, d, blk_base, seg_tab, seg_bytes);
   ASL_CHECK_LAUNCH();
-#endif
   return ASL_OK;
 }
 
