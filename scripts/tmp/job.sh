@@ -1,3 +1,11 @@
 cd $GRAFT_REPO_ROOT
-NPROBE=112 REPS=2 bash scripts/ab_flat.sh scripts/tmp/flatA.so scripts/tmp/flatD.so scripts/tmp/flatF.so > gpurun_out/r3_flat_ab3.txt 2>&1
-cat gpurun_out/r3_flat_ab3.txt
+python bench.py > gpurun_out/r3_bench_a.json 2> gpurun_out/r3_bench_a.err
+tail -c 3000 gpurun_out/r3_bench_a.err | tail -5
+python -c "
+import json
+d=json.load(open('gpurun_out/r3_bench_a.json'))
+print(d['value'], d['ms_per_step'], d['stages_ms_per_step'])
+print(json.dumps(d['roofline']))
+print(json.dumps(d['fixed_recall'], indent=0))
+print(json.dumps(d['cpu_baseline']))
+"
