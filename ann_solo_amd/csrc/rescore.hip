@@ -340,15 +340,15 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_kernel(
   long long c0, c1;
   cv.range(q, c0, c1);
   if (c0 >= c1) return;
-  // second-launch mode: only the pairs the fast kernel marked RS_DEFER (-2)
-  if (q_defer && !q_defer[q]) return;
+  // deferred mode: only the pairs the fast kernels marked RS_DEFER_BS (-3)
+  if (q_defer && !(q_defer[q] & 2)) return;
   int qn;
   load_query(threadIdx.x, blockDim.x, Qs, q, Q, qn, status);
   __syncthreads();
   const double q_pmz = Qs.precursor_mz[q];
   const long long step = (long long)RS_WAVES * gridDim.y;
   for (long long c = c0 + (long long)blockIdx.y * RS_WAVES + wave; c < c1; c += step) {
-    if (q_defer && pair_score[c] != -2.0) continue;
+    if (q_defer && pair_score[c] != -3.0) continue;
     const long long row = cv.cand(c, q_pmz, L.n);
     double s = -1.0;
     if (row >= 0)
@@ -386,7 +386,14 @@ constexpr int RS_BM_BITS = 1 << 14;   // bin filter: <= 300 bits set of 16 384
 constexpr int RS_SUPER = 1024;        // candidate slots compacted at a time
 constexpr int RS_PF = 2;              // candidates staged per burst
 constexpr int RS_HC = 64;             // matches per candidate resolved in this kernel
-constexpr double RS_DEFER = -2.0;     // pair_score marker: left to the binary-search kernel
+constexpr double RS_DEFER = -2.0;     // pair_score marker: left to the pair kernel (second launch)
+constexpr double RS_DEFER_BS = -3.0;  // pair_score marker: left to the binary-search kernel (third launch)
+enum { RS_QD_PAIR = 1, RS_QD_BS = 2 };   // q_defer bits: the query has slots marked RS_DEFER / RS_DEFER_BS;
+                                         // bits 2.. count the RS_DEFER slots (work split of the second launch)
+#ifndef RS_DEF_Y_
+#define RS_DEF_Y_ 8
+#endif
+constexpr int RS_DEF_Y = RS_DEF_Y_;      // blocks per query the second launch may use
 
 struct QueryLds2 {   // hash path: at most RS_HQ_MAX query peaks
   float mz[128];
@@ -620,11 +627,25 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
 // rows, 2: int64 rows), packed row records for the precursor filter, annotated library peaks --
 // are compiled with those facts folded in (each open "is this pointer null" question is a
 // wave-uniform predicate held in scalar registers across the hot loops); 0 = any shape.
-template <bool KNOBS, int FORM>
+// DEF: second-launch mode behind rescore_flat_kernel -- only the slots that kernel marked
+// RS_DEFER, only for queries whose q_defer has RS_QD_PAIR; what this kernel cannot resolve
+// either goes on to the binary-search kernel (RS_DEFER_BS / RS_QD_BS).
+template <bool KNOBS, int FORM, bool DEF = false>
 __global__ __launch_bounds__(64 * RS_WAVES, RS_OCC) void rescore_score_v2_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
     double *__restrict__ pair_score, int *__restrict__ q_defer, int *status, int dbg_arg) {
   const int dbg = KNOBS ? dbg_arg : 0;
+  // DEF: a query's deferred slots are few (a handful) or nearly all of its candidates (two
+  // query peaks closer than the tolerance make every candidate with a peak there a conflict):
+  // as many of the launch's blocks per query take part as there is work for, the others leave
+  int ny = (int)gridDim.y;
+  if (DEF) {
+    const int qd = q_defer[blockIdx.x];
+    if (!(qd & RS_QD_PAIR)) return;
+    const int want = ((qd >> 2) + 2 * RS_WAVES - 1) / (2 * RS_WAVES);     // one pair step per wave
+    ny = want < ny ? want : ny;
+    if ((int)blockIdx.y >= ny) return;
+  }
   if (FORM != 0) {
     cv.offsets = nullptr;
     cv.flt.lib_pmz = nullptr;
@@ -656,9 +677,9 @@ __global__ __launch_bounds__(64 * RS_WAVES, RS_OCC) void rescore_score_v2_kernel
   if (!(tol > 0.0) || qn > RS_HQ_MAX || margin > 0.45) {   // uniform: whole query deferred
     for (long long c = c0 + (long long)blockIdx.y * blockDim.x + tid; c < c1;
          c += (long long)blockDim.x * gridDim.y) {
-      pair_score[c] = cv.cand(c, q_pmz, L.n) >= 0 ? RS_DEFER : -1.0;
+      pair_score[c] = cv.cand(c, q_pmz, L.n) >= 0 ? RS_DEFER_BS : -1.0;
     }
-    if (tid == 0) q_defer[q] = 1;
+    if (tid == 0) atomicOr(&q_defer[q], RS_QD_BS);
     return;
   }
   for (int i = tid; i < qn; i += blockDim.x) {   // qn <= RS_HQ_MAX here
@@ -690,7 +711,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, RS_OCC) void rescore_score_v2_kernel
   }
   __syncthreads();
   PairLds &Wv = W[wave];
-  const int parts = RS_WAVES * gridDim.y, part = blockIdx.y * RS_WAVES + wave;
+  const int parts = RS_WAVES, part = wave;
 
   for (long long sb = c0; sb < c1; sb += RS_SUPER) {
     // ---- compact the valid slots of this super-chunk (order is irrelevant: scores are
@@ -702,8 +723,15 @@ __global__ __launch_bounds__(64 * RS_WAVES, RS_OCC) void rescore_score_v2_kernel
       const int i = i0 + tid;
       bool ok = false;
       if (i < sn) {
-        ok = cv.cand(sb + i, q_pmz, L.n) >= 0;
-        if (!ok && blockIdx.y == 0) pair_score[sb + i] = -1.0;
+        if (DEF) {
+          ok = pair_score[sb + i] == RS_DEFER;     // a valid candidate: the first launch checked
+        } else {
+          ok = cv.cand(sb + i, q_pmz, L.n) >= 0;
+          if (!ok && blockIdx.y == 0) pair_score[sb + i] = -1.0;
+        }
+        // several blocks per query: each takes the slots of every ny-th group of 32 (the order
+        // inside s_list depends on the waves' timing, so blocks must not split it by position)
+        ok = ok && (ny == 1 || ((i >> 5) % ny) == (int)blockIdx.y);
       }
       const unsigned long long bal = __ballot(ok);
       int wbase = 0;
@@ -779,19 +807,327 @@ __global__ __launch_bounds__(64 * RS_WAVES, RS_OCC) void rescore_score_v2_kernel
                       rl_d(m_pmz, vA ? lA : 0), rl_d(m_pmz, vB ? lB : 0), q_pmz, tol, inv_w,
                       allow_shift, status, sA, sB, dbg);
           }
-          if (defA) sA = RS_DEFER;
-          if (defB) sB = RS_DEFER;
+          if (defA || sA == RS_DEFER) sA = RS_DEFER_BS;
+          if (defB || sB == RS_DEFER) sB = RS_DEFER_BS;
           if (vA && lane == lA) my_score = sA;
           if (vB && lane == lB) my_score = sB;
         }
         wave_sync();
       }
       if (okr) pair_score[sb + slot] = my_score;
-      if (__ballot(okr && my_score == RS_DEFER) && lane == 0) s_defer = 1;
+      if (__ballot(okr && my_score == RS_DEFER_BS) && lane == 0) s_defer = 1;
     }
     __syncthreads();   // s_list is rebuilt for the next super-chunk
   }
-  if (tid == 0 && s_defer) q_defer[q] = 1;
+  if (tid == 0 && s_defer) atomicOr(&q_defer[q], RS_QD_BS);
+}
+
+// ---------------------------------------------------------------------------------
+// Pass 1, FLAT formulation (the first launch of the search path). The pair kernel above spends
+// two thirds of its instructions outside the probing loop: per pair of candidates it stages
+// peaks through LDS, sets up shifts and tables with every lane, and resolves two match lists
+// with DPP trees. Here a wave takes RF_NC candidates at a time and
+//   * SETS THEM UP ONE LANE PER CANDIDATE (row record, shift count, mass-difference table,
+//     zeroed accumulators, a prefix sum of the peak counts),
+//   * walks their peaks as ONE STREAM, one candidate peak per lane whatever candidate it
+//     belongs to (an owner table maps stream positions to candidates; peaks are loaded straight
+//     from HBM a step ahead, no LDS staging), probing the query's bin bitmap / hash per shift
+//     exactly like the pair kernel,
+//   * and ACCUMULATES a match where it is found: atomicOr into the candidate's masks of matched
+//     query / candidate peaks (a bit that was already set = a doubly matched peak), atomic
+//     min / max of the product's exponent, and an fp64 atomic add of the product.
+// If no peak was matched twice the reference's greedy pass accepts every match, and if the
+// products span <= 23 binades the fp64 sum of <= 64 fp32 products is exact in ANY order
+// (24 + 23 + 6 = 53 bits): the accumulated sum IS the reference's sorted sum, bit for bit.
+// Anything else -- a doubly matched peak, a wider span, more shifts than the table holds -- is
+// marked RS_DEFER for the pair kernel (second launch, ~2 % of the candidates); what that
+// kernel does not take either (> 64 peaks, > 64 matches, query > 100 peaks, tol <= 0) goes to
+// the binary-search kernel as RS_DEFER_BS.
+constexpr int RF_NC = 32;        // candidates per wave chunk (set-up lanes)
+constexpr int RF_PMAX = 1024;    // candidate peaks per wave chunk (owner table)
+constexpr int RF_SMAX = 5;       // shifts the mass-difference table holds (precursor charge <= 4)
+
+struct FlatLds {   // per wave
+  double sum[RF_NC];
+  double pmd[RF_NC];
+  float mdf[RF_NC][RF_SMAX - 1];   // (float)(pmd / s), s = 1..4: the probe bins
+  uint32_t qmask[RF_NC][4];        // matched query peaks (<= 128 on this path)
+  uint32_t cmask[RF_NC][2];        // matched candidate peaks (<= 64)
+  uint32_t emax[RF_NC];            // largest exponent byte of a product | bit 31: doubly matched peak
+  uint32_t emin[RF_NC];
+  int base[RF_NC];                 // first peak in the library arrays
+  uint32_t rec[RF_NC];             // peaks | shifts << 8 | precursor charge << 16
+  uint16_t pref[RF_NC];            // first stream position
+  uint8_t owner[RF_PMAX];
+};
+
+#ifndef RF_OCC
+#define RF_OCC RS_OCC
+#endif
+template <int FORM>
+__global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
+    DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
+    double *__restrict__ pair_score, int *__restrict__ q_defer, int *status) {
+  if (FORM != 0) {
+    cv.offsets = nullptr;
+    cv.flt.lib_pmz = nullptr;
+    cv.flt.valid = nullptr;
+    __builtin_assume(cv.flt.meta != nullptr);
+    __builtin_assume(L.charge != nullptr);
+    if (FORM == 1) {
+      cv.rows64 = nullptr;
+    } else {
+      __builtin_assume(cv.rows64 != nullptr);
+    }
+  }
+  __shared__ QueryLds2 Q;
+  __shared__ HashLds H;
+  __shared__ FlatLds W[RS_WAVES];
+  __shared__ uint16_t s_list[RS_SUPER];
+  __shared__ int s_nv, s_defer, s_ndef;
+  const int q = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  long long c0, c1;
+  cv.range(q, c0, c1);
+  if (c0 >= c1) return;
+  const int qo = Qs.offsets[q];
+  const int qn = Qs.offsets[q + 1] - qo;
+  const double q_pmz = Qs.precursor_mz[q];
+  // (same bin filter as the pair kernel: see there)
+  const double margin = 1e-3 + (tol > 0.0 ? (0.5 / tol) * (3.75e-4 + 2600.0 * 1.2e-7) : 1.0);
+  if (!(tol > 0.0) || qn > RS_HQ_MAX || margin > 0.45) {   // uniform: whole query deferred
+    for (long long c = c0 + (long long)blockIdx.y * blockDim.x + tid; c < c1;
+         c += (long long)blockDim.x * gridDim.y) {
+      pair_score[c] = cv.cand(c, q_pmz, L.n) >= 0 ? RS_DEFER_BS : -1.0;
+    }
+    if (tid == 0) atomicOr(&q_defer[q], RS_QD_BS);
+    return;
+  }
+  for (int i = tid; i < qn; i += blockDim.x) {
+    Q.mz[i] = Qs.mz[qo + i];
+    Q.inten[i] = Qs.intensity[qo + i];
+  }
+  for (int i = tid; i < RS_HT; i += blockDim.x) H.bin[i] = RS_EMPTY;
+  for (int i = tid; i < RS_BM_BITS / 32; i += blockDim.x) H.bm[i] = 0u;
+  if (tid == 0) s_defer = s_ndef = 0;
+  __syncthreads();
+  const double inv_w = 1.0 / (2.0 * tol);
+  if (tid < qn) {
+    const double qm = (double)Q.mz[tid];
+    const int blo = (int)floor((qm - tol) * inv_w - margin);
+    const int bhi = (int)floor((qm + tol) * inv_w + margin);
+    for (int b = blo; b <= bhi; ++b) {
+      const uint32_t bit = hbit(b);
+      atomicOr(&H.bm[bit >> 5], 1u << (bit & 31));
+      uint32_t h = hbin(b);
+      for (;;) {
+        const int old = atomicCAS(&H.bin[h], RS_EMPTY, b);
+        if (old == RS_EMPTY) {
+          H.peak[h] = (uint8_t)tid;
+          break;
+        }
+        h = (h + 1) & (RS_HT - 1);
+      }
+    }
+  }
+  __syncthreads();
+  FlatLds &Wv = W[wave];
+  const float inv_w_f = (float)inv_w;
+  const int parts = RS_WAVES, part = wave, ny = (int)gridDim.y;
+  const int t = lane & 31, hi = lane >> 5;
+
+  for (long long sb = c0; sb < c1; sb += RS_SUPER) {
+    // ---- compact the valid slots of this super-chunk
+    const int sn = (int)((c1 - sb) < RS_SUPER ? (c1 - sb) : RS_SUPER);
+    if (tid == 0) s_nv = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < sn; i0 += blockDim.x) {
+      const int i = i0 + tid;
+      bool ok = false;
+      if (i < sn) {
+        ok = cv.cand(sb + i, q_pmz, L.n) >= 0;
+        if (!ok && blockIdx.y == 0) pair_score[sb + i] = -1.0;
+        ok = ok && (ny == 1 || ((i >> 5) % ny) == (int)blockIdx.y);   // (see the pair kernel)
+      }
+      const unsigned long long bal = __ballot(ok);
+      int wbase = 0;
+      if (lane == 0 && bal) wbase = atomicAdd(&s_nv, __popcll(bal));
+      wbase = rl_i(wbase, 0);
+      if (ok) s_list[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int nv = s_nv;
+    const int per = (nv + parts - 1) / parts;
+    const int wb = part * per;
+    const int we = wb + per < nv ? wb + per : nv;
+
+    for (int base = wb; base < we;) {
+      // ---- set-up: lanes t and t + 32 both hold candidate t (they share the owner fill)
+      const bool okr = base + t < we;
+      const int slot = okr ? (int)s_list[base + t] : 0;
+      int m_co = 0, m_cn = 0, m_chg = 0;
+      double m_pmz = 0.0;
+      if (okr) {
+        const long long row = cv.row(sb + slot);
+        if (cv.flt.meta) {     // one 32-byte sector per candidate
+          const uint4 a = *reinterpret_cast<const uint4 *>(&cv.flt.meta[row]);
+          m_co = (int)a.x;
+          m_cn = (int)a.y;
+          m_chg = (int)a.z;
+          m_pmz = cv.flt.meta[row].pmz64;
+        } else {
+          m_co = L.offsets[row];
+          m_cn = L.offsets[row + 1] - m_co;
+          m_chg = L.precursor_charge[row];
+          m_pmz = L.precursor_mz[row];
+        }
+      }
+      const double pmd = (q_pmz - m_pmz) * (double)(unsigned)m_chg;            // cpp:18
+      const int S = (allow_shift && fabs(pmd) >= tol) ? m_chg + 1 : 1;          // cpp:20
+      const bool def_bs = okr && (m_cn > 64 || m_chg >= 31);
+      const bool def_pair = okr && !def_bs && S > RF_SMAX;
+      const int cn_eff = (okr && !def_bs && !def_pair && qn > 0) ? m_cn : 0;
+      int incl = cn_eff;
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        const int v = __shfl_up(incl, o, 32);
+        if (t >= o) incl += v;
+      }
+      // the chunk ends where the owner table is full (the prefix sums ascend)
+      const uint32_t fit = (uint32_t)__ballot(okr && incl <= RF_PMAX);
+      const int ntake = __popc(fit);          // >= 1: a candidate has <= 64 peaks here
+      const bool take = t < ntake;
+      const int excl = incl - cn_eff;
+      const int P = rl_i(incl, ntake - 1);
+      int cmaxw = take ? cn_eff : 0, Smaxw = (take && cn_eff > 0) ? S : 0;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        cmaxw = max(cmaxw, __shfl_xor(cmaxw, o, 32));
+        Smaxw = max(Smaxw, __shfl_xor(Smaxw, o, 32));
+      }
+      cmaxw = rl_i(cmaxw, 0);
+      Smaxw = rl_i(Smaxw, 0);
+      if (take && hi == 0) {
+        Wv.base[t] = m_co;
+        Wv.rec[t] = (uint32_t)cn_eff | ((uint32_t)S << 8) | ((uint32_t)m_chg << 16);
+        Wv.pref[t] = (uint16_t)excl;
+        Wv.pmd[t] = pmd;
+        Wv.sum[t] = 0.0;
+        Wv.qmask[t][0] = Wv.qmask[t][1] = Wv.qmask[t][2] = Wv.qmask[t][3] = 0u;
+        Wv.cmask[t][0] = Wv.cmask[t][1] = 0u;
+        Wv.emax[t] = 0u;
+        Wv.emin[t] = 255u;
+        // mass_diff[s] = pmd / s (cpp:26-31); x / 1, x / 2, x / 4 are exact scalings
+        Wv.mdf[t][0] = (float)pmd;
+        Wv.mdf[t][1] = (float)(pmd * 0.5);
+        Wv.mdf[t][3] = (float)(pmd * 0.25);
+      }
+      if (Smaxw > 3) {          // wave-uniform: the fp64 division only where a charge-3 candidate is
+        if (take && hi == 0) Wv.mdf[t][2] = (float)(pmd / 3.0);
+      }
+      for (int j0 = 0; j0 < cmaxw; j0 += 2) {
+        const int j = j0 + hi;
+        if (take && j < cn_eff) Wv.owner[excl + j] = (uint8_t)t;
+      }
+      wave_sync();
+
+      // ---- the chunk's peaks as one stream, loads one step ahead
+      float n_cm = 0.0f, n_ci = 0.0f;
+      int n_cc = 0, n_tt = 0, n_j = 0, n_co = 0;
+      uint32_t n_rec = 0;
+      auto fetch = [&](int p0) {
+        const int p = p0 + lane;
+        const bool act = p < P;
+        n_tt = act ? (int)Wv.owner[p] : 0;
+        n_rec = act ? Wv.rec[n_tt] : 0u;
+        n_j = p - (int)Wv.pref[n_tt];
+        n_co = Wv.base[n_tt];
+        n_cm = act ? L.mz[n_co + n_j] : 0.0f;
+        n_ci = act ? L.intensity[n_co + n_j] : 0.0f;
+        n_cc = (act && L.charge) ? (int)L.charge[n_co + n_j] : 0;
+      };
+      if (P > 0) fetch(0);
+      for (int p0 = 0; p0 < P; p0 += 64) {
+        const float cm = n_cm, ci = n_ci;
+        const int cc = n_cc, tt = n_tt, j = n_j, co = n_co;
+        const int cn = (int)(n_rec & 0xffu), Sc = (int)((n_rec >> 8) & 0xffu);
+        const bool act = p0 + lane < P;
+        if (p0 + 64 < P) fetch(p0 + 64);
+        // shifts this peak takes part in (cpp:58-75): every s < S for an unannotated peak, else
+        // s = 0 and s = its fragment charge
+        const uint32_t smask = !act ? 0u : cc == 0 ? (1u << Sc) - 1u : (1u | (cc < Sc ? 1u << cc : 0u));
+        for (int s = 0; s < Smaxw; ++s) {        // wave-uniform
+          const bool can = (smask >> s) & 1u;
+          const float mdv = s ? Wv.mdf[tt][s - 1] : 0.0f;
+          const int b = (int)floorf((cm + mdv) * inv_w_f);
+          const bool maybe = can && bm_test(H, b);
+          if (!__ballot(maybe)) continue;         // wave-uniform
+          if (maybe) {
+            const double pm = Wv.pmd[tt];
+            const double md = s == 0 ? 0.0 : s == 1 ? pm : s == 2 ? pm * 0.5 : s == 4 ? pm * 0.25 : pm / (double)s;
+            const double mult = (s == 0 || cc == s) ? 1.0 : 2.0 / 3.0;
+            uint32_t h = hbin(b);
+            for (;;) {
+              const int eb = H.bin[h];
+              if (eb == RS_EMPTY) break;
+              if (eb == b) {
+                const int i = H.peak[h];
+                const double x = (double)cm + md;
+                const double qm = (double)Q.mz[i];
+                const double lim = qm - tol;
+                if (fabs(qm - x) <= tol && (!(lim > x) || j == cn - 1)) {
+                  // the reference walks from its cursor: every peak between the cursor and j
+                  // must pass the window test too (differs only on fp boundaries)
+                  bool run = true;
+                  for (int jj = j; jj > 0; --jj) {
+                    const double xp = (double)L.mz[co + jj - 1] + md;
+                    if (lim > xp) break;
+                    if (!(fabs(qm - xp) <= tol)) {
+                      run = false;
+                      break;
+                    }
+                  }
+                  if (run) {
+                    const float prod = (float)(mult * (double)Q.inten[i] * (double)ci);   // cpp:81
+                    const uint32_t e = max((__float_as_uint(prod) >> 23) & 0xffu, 1u);
+                    const uint32_t qb = 1u << (i & 31), cb = 1u << (j & 31);
+                    const uint32_t oq = atomicOr(&Wv.qmask[tt][i >> 5], qb);
+                    const uint32_t oc = atomicOr(&Wv.cmask[tt][j >> 5], cb);
+                    atomicMax(&Wv.emax[tt], ((oq & qb) || (oc & cb)) ? (0x80000000u | e) : e);
+                    atomicMin(&Wv.emin[tt], e);
+                    atomicAdd(&Wv.sum[tt], (double)prod);
+                  }
+                }
+              }
+              h = (h + 1) & (RS_HT - 1);
+            }
+          }
+        }
+      }
+      wave_sync();
+      // ---- scores of the chunk
+      if (take && hi == 0) {
+        const uint32_t em = Wv.emax[t], en = Wv.emin[t];
+        double sc = Wv.sum[t];
+        if ((em >> 31) || ((em & 0xffu) > en + 23u)) sc = RS_DEFER;     // sort + greedy pass needed
+        if (def_pair) sc = RS_DEFER;
+        if (def_bs) sc = RS_DEFER_BS;
+        pair_score[sb + slot] = sc;
+        if (sc == RS_DEFER) {
+          atomicOr(&s_defer, RS_QD_PAIR);
+          atomicAdd(&s_ndef, 1);
+        }
+        if (sc == RS_DEFER_BS) atomicOr(&s_defer, RS_QD_BS);
+      }
+      base += ntake;
+      wave_sync();     // the chunk's tables are rebuilt
+    }
+    __syncthreads();   // s_list is rebuilt for the next super-chunk
+  }
+  if (tid == 0 && s_defer) {      // (several blocks per query when gridDim.y > 1: or + add)
+    atomicOr(&q_defer[q], s_defer);
+    if (s_ndef) atomicAdd(&q_defer[q], s_ndef << 2);
+  }
 }
 
 // tie_by_row = 0: first position wins ties (get_best_match on a caller-ordered list);
@@ -907,6 +1243,20 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
       ASL_TRY(q_defer.reserve((size_t)nq));
       HIP_TRY(hipMemsetAsync(q_defer.p, 0, sizeof(int) * (size_t)nq, stream()));
       const bool shaped = !cand_offsets && filter.meta && L.charge && (rows64 || rows32);
+#ifndef RS_NO_FLAT
+      // 1. flat kernel; 2. pair kernel on what it marked RS_DEFER; 3. binary-search kernel on
+      // RS_DEFER_BS (blocks of 2 / 3 return at once for queries without such slots)
+      auto flat = !shaped ? rescore_flat_kernel<0> : rows64 ? rescore_flat_kernel<2> : rescore_flat_kernel<1>;
+      hipLaunchKernelGGL(flat, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, tol,
+                         allow_shift, pair_score, q_defer.p, status);
+      ASL_CHECK_LAUNCH();
+      auto kern = !shaped ? rescore_score_v2_kernel<false, 0, true>
+                  : rows64 ? rescore_score_v2_kernel<false, 2, true>
+                           : rescore_score_v2_kernel<false, 1, true>;
+      hipLaunchKernelGGL(kern, dim3(nq, std::max(ysplit, RS_DEF_Y)), dim3(64 * RS_WAVES), 0, stream(), Q,
+                         L, cv, tol, allow_shift, pair_score, q_defer.p, status, rs_dbg);
+      ASL_CHECK_LAUNCH();
+#else     // same-box A/B builds: the pair kernel on everything (rounds 1-2)
       auto kern = rs_dbg ? rescore_score_v2_kernel<true, 0>
                   : !shaped ? rescore_score_v2_kernel<false, 0>
                   : rows64  ? rescore_score_v2_kernel<false, 2>
@@ -914,6 +1264,7 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
       hipLaunchKernelGGL(kern, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, tol,
                          allow_shift, pair_score, q_defer.p, status, rs_dbg);
       ASL_CHECK_LAUNCH();
+#endif
       hipLaunchKernelGGL(rescore_score_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
                          stream(), Q, L, cv, tol, allow_shift, pair_score,
                          (const int *)q_defer.p, status);
