@@ -1,6 +1,7 @@
 """GPU parity: HIP encoder and rescoring kernels (through the C ABI) vs the oracle
 and vs the committed golden vectors of the reference."""
 import numpy as np
+import torch
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -93,6 +94,39 @@ def test_rescoring_vs_oracle(O, data):
     off = np.array(off, np.int32)
     for tol, shift in ((0.02, True), (0.02, False), (0.05, True)):
         res = spectrum_match.rescore_batch(q, lib, cand, off, tol, shift)
+        _check_rescoring(O, Q, L, cand, off, tol, shift, res)
+
+
+def test_rescoring_few_queries_long_lists(O, data):
+    """Few queries with very long candidate lists: the kernels run several blocks per query
+    (each block takes every n-th group of 32 slots; results must not depend on how the blocks
+    order their compacted lists) -- and a query whose two strongest peaks are closer than the
+    tolerance, which makes nearly every candidate a doubly-matched one (pair kernel, up to 8
+    blocks per query in the second launch)."""
+    from ann_solo_amd import spectrum_match, synthetic
+    from ann_solo_amd.packed import PackedSpectra
+    lib, aux = synthetic.make_library(9000, seed=23, device='cpu')
+    q, truth = synthetic.make_queries(lib, aux, 8, seed=24)
+    rng = np.random.default_rng(3)
+    nq = 3
+    o, mz, it, chg, pmz, pz = q.select(torch.arange(nq)).numpy()
+    mz, it = mz.copy(), it.copy()
+    # query 0: plant a twin 0.01 Da above its most intense peak
+    a, b = o[0], o[1]
+    top = a + int(np.argmax(it[a:b]))
+    other = a + int(np.argmin(it[a:b]))
+    mz[other] = mz[top] + np.float32(0.01)
+    it[other] = it[top] * np.float32(0.9)
+    order = np.argsort(mz[a:b], kind='stable')
+    mz[a:b], it[a:b], chg[a:b] = mz[a:b][order], it[a:b][order], chg[a:b][order]
+    qq = PackedSpectra.from_numpy(o, mz, it, chg, pmz, pz)
+    L, Q = O.Spectra(*lib.numpy()), O.Spectra(*qq.numpy())
+    cands = [np.sort(rng.choice(lib.n, size=8500, replace=False)).astype(np.int64)    # > 4096: ysplit
+             for _ in range(nq)]
+    off = np.concatenate([[0], np.cumsum([len(c) for c in cands])]).astype(np.int32)
+    cand = np.concatenate(cands)
+    for tol, shift in ((0.02, True), (0.02, False)):
+        res = spectrum_match.rescore_batch(qq, lib, cand, off, tol, shift)
         _check_rescoring(O, Q, L, cand, off, tol, shift, res)
 
 
