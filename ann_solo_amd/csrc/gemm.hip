@@ -53,7 +53,11 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ p, int row, in
 template <bool VEC4>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M,
-    int N, int K, int lda, int ldb, int ldc, int nbx, int nby) {
+    int N, int K, int lda, int ldb, int ldc, int nbx, int nby, const int *__restrict__ gate,
+    int gate_max) {
+  // gated launch (coarse quantiser): the sparse kernel scores the batch unless more than
+  // gate_max query rows are dense -- decided on the device, no host round trip
+  if (gate && *gate <= gate_max) return;
   __shared__ float As[2][GBK][GLD];
   __shared__ float Bs[2][GBK][GLD];
   // XCD-aware remap: consecutive workgroup ids round-robin over the 8 XCDs; give
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(
 
 // C = A . B^T, all device pointers, row-major with leading dimensions.
 int gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K, int lda,
-                int ldb, int ldc) {
+                int ldb, int ldc, const int *gate, int gate_max) {
   if (M <= 0 || N <= 0) return ASL_OK;
   if (K <= 0) return fail(ASL_ERR_INVALID, "gemm: K must be positive");
   const int nbx = (int)cdiv(N, GBN), nby = (int)cdiv(M, GBM);
@@ -150,10 +154,10 @@ int gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K, i
   dim3 grid((unsigned)(nbx * nby));
   if (vec4)
     hipLaunchKernelGGL(gemm_nt_f32_kernel<true>, grid, dim3(256), 0, stream(), A, B, C, M, N,
-                       K, lda, ldb, ldc, nbx, nby);
+                       K, lda, ldb, ldc, nbx, nby, gate, gate_max);
   else
     hipLaunchKernelGGL(gemm_nt_f32_kernel<false>, grid, dim3(256), 0, stream(), A, B, C, M, N,
-                       K, lda, ldb, ldc, nbx, nby);
+                       K, lda, ldb, ldc, nbx, nby, gate, gate_max);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }

@@ -68,6 +68,12 @@ struct asl_index {
   DevBuf<float> centroids, codebooks;
   DevBuf<float> codebooks_t;  // [m][dsub][ksub] copy for the tiled scan's LUT build
   bool cbt_ready = false;
+  // sparse coarse quantiser (coarse_sparse.hip): transposed centroids [d][nlist] + per-batch scratch
+  DevBuf<float> centroids_t;
+  bool cent_t_ready = false;
+  DevBuf<uint2> cs_ent;
+  DevBuf<int32_t> cs_cnt;
+  DevBuf<int> cs_over;
   // add-order storage
   DevBuf<float> vecs;        // FLAT, IVFFLAT
   DevBuf<int32_t> vlist;     // IVF kinds: inverted list of each stored vector
@@ -367,6 +373,15 @@ static int build_lists(asl_index *ix) {
   return ASL_OK;
 }
 
+// transposed centroid copy for the sparse coarse quantiser (rebuilt after train / set_trained)
+static int coarse_transposed(asl_index *ix) {
+  if (ix->cent_t_ready) return ASL_OK;
+  ASL_TRY(ix->centroids_t.reserve((size_t)ix->nlist * ix->d));
+  ASL_TRY(transpose_f32(ix->centroids.p, ix->nlist, ix->d, ix->centroids_t.p));
+  ix->cent_t_ready = true;
+  return ASL_OK;
+}
+
 // coarse quantiser: top-nprobe centroids by inner product -> ix->coarse_D / coarse_I
 static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe,
                          float *out_D = nullptr, int32_t *out_I = nullptr) {
@@ -379,11 +394,26 @@ static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe,
   }
   int rows = (int)std::min<int64_t>(nq, std::max<int64_t>(1, (int64_t)(SCORE_CHUNK_BYTES / ((size_t)nlist * 4))));
   ASL_TRY(ix->ws_scores.reserve((size_t)rows * nlist));
+  // Hashed spectra are sparse (<= ~50 of 800 components): the scores come from the sparse
+  // kernel, bit-identical to the GEMM. Both are enqueued; a device-side count of dense rows
+  // (more than 64 non-zeros) decides which of the two does the work (the other returns at once).
+  const bool sparse = ix->scan_variant == 0 && coarse_sparse_supported(d, nlist);
+  if (sparse) {
+    ASL_TRY(coarse_transposed(ix));
+    ASL_TRY(ix->cs_ent.reserve((size_t)rows * coarse_sparse_cap()));
+    ASL_TRY(ix->cs_cnt.reserve((size_t)rows));
+    ASL_TRY(ix->cs_over.reserve(1));
+  }
   for (int r0 = 0; r0 < nq; r0 += rows) {
     const int m = std::min(rows, nq - r0);
     {
       ProfScope ps("coarse_gemm");
-      ASL_TRY(gemm_nt_f32(xq + (size_t)r0 * d, ix->centroids.p, ix->ws_scores.p, m, nlist, d, d, d, nlist));
+      const int over_max = m / 64;
+      if (sparse)
+        ASL_TRY(coarse_sparse(xq + (size_t)r0 * d, m, d, ix->centroids_t.p, nlist, ix->cs_ent.p, ix->cs_cnt.p,
+                              ix->cs_over.p, over_max, ix->ws_scores.p, nlist));
+      ASL_TRY(gemm_nt_f32(xq + (size_t)r0 * d, ix->centroids.p, ix->ws_scores.p, m, nlist, d, d, d, nlist,
+                          sparse ? ix->cs_over.p : nullptr, over_max));
     }
     {
       ProfScope ps("coarse_select");
@@ -542,7 +572,9 @@ int index_nprobe(const asl_index *ix, int nprobe) {
 }
 int index_prepare(asl_index *ix) {   // everything that may allocate or synchronise, up front
   if (!ix->trained) return fail(ASL_ERR_STATE, "search: index is not trained");
-  return ix->kind == ASL_INDEX_FLAT ? ASL_OK : build_lists(ix);
+  if (ix->kind == ASL_INDEX_FLAT) return ASL_OK;
+  if (coarse_sparse_supported(ix->d, ix->nlist)) ASL_TRY(coarse_transposed(ix));
+  return build_lists(ix);
 }
 int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, float *out_D,
                         int32_t *out_I) {
@@ -643,6 +675,7 @@ int asl_index_train(asl_index_t *ix, int64_t n, const float *x, uint64_t seed) {
   ASL_TRY(sync_stream());
   ix->trained = true;
   ix->cbt_ready = false;
+  ix->cent_t_ready = false;
   return ASL_OK;
 }
 
@@ -661,6 +694,7 @@ int asl_index_set_trained(asl_index_t *ix, const float *centroids, const float *
   ASL_TRY(sync_stream());
   ix->trained = true;
   ix->cbt_ready = false;
+  ix->cent_t_ready = false;
   return ASL_OK;
 }
 

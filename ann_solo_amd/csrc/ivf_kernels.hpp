@@ -3,14 +3,24 @@
 #pragma once
 #include <cstdint>
 
+#include <hip/hip_runtime.h>
+
 namespace asl {
 
 constexpr int TK_NT = 256;        // threads per top-k workgroup
 constexpr int TK_MAX_K = 2048;    // largest k / nprobe the LDS top-k supports
 constexpr int PQ_MAX_DSUB = 32;   // register fast path of the PQ L2 kernels
 
+// gate != nullptr: the kernel returns at once when *gate <= gate_max (device-side choice
+// between this GEMM and the sparse coarse quantiser)
 int gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K, int lda,
-                int ldb, int ldc);
+                int ldb, int ldc, const int *gate = nullptr, int gate_max = 0);
+// coarse quantiser for sparse queries (coarse_sparse.hip)
+bool coarse_sparse_supported(int d, int nlist);
+int coarse_sparse_cap();
+int transpose_f32(const float *in, int rows, int cols, float *out);
+int coarse_sparse(const float *xq, int nq, int d, const float *Ct, int nlist, uint2 *ent,
+                  int32_t *cnt, int *n_over, int over_max, float *scores, int ld);
 int row_topk(const float *scores, int64_t ld, int rows, int n, int k, const int32_t *ids,
              int32_t id_base, const int32_t *vlist, const uint32_t *bitmap, int bitmap_words,
              float *D, int64_t *I64, int32_t *I32, int64_t out_ld);

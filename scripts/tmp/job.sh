@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_encode_rescore.py tests/test_gpu_search.py tests/test_gpu_edge_cases.py tests/test_gpu_configs.py -x -q 2>&1 | tail -3
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
 for r in 1 2; do
-for lib in scripts/tmp/base.so ann_solo_amd/libannsolo_mi.so; do
-ASL_LIB_PATH=$PWD/$lib python bench.py --no-pipeline --cpu-seconds 0 --recall-queries 0 --no-fixed-recall --steps 5 --warmup 1 2>/dev/null | grep -E "^\{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); s=d['stages_ms_per_step']; print('$lib', 'step', d['ms_per_step'], 'scan', s['scan'], 'rescore', s['rescore'])"
-done; done
+python bench.py --no-pipeline --cpu-seconds 0 --recall-queries 0 --no-fixed-recall --steps 5 --warmup 1 2>/dev/null | grep -E "^\{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); s=d['stages_ms_per_step']; print('serial step', d['ms_per_step'], s)"
+done
+python bench.py --cpu-seconds 0 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('pipelined', d['value'], d['ms_per_step'], d['stages_ms_per_step']); print('fixed_recall', d['fixed_recall']['value'], d['fixed_recall']['ms_per_step'], d['fixed_recall']['scan_ms_per_step'])"
