@@ -20,9 +20,10 @@
 //     broadcast inside the row that costs one v_mov (the dimension, for the LDS address) and
 //     nothing for the value (a DPP operand of the v_fmac). Entries beyond a query's count are
 //     (dimension 0, value +0): fmaf(+0, c, acc) leaves acc unchanged, bit for bit.
-// Per step and wave: 1 v_mov_dpp + 1 address add + 1 ds_read_b64 + 2 v_fmac_dpp for 4 queries x
-// 32 lists -- 16 x fewer multiply-adds than the GEMM, and LDS-bound (~0.1 ms for 16 384 queries x
-// 4 096 lists, against 0.86 ms for the dense MFMA GEMM at 125 TFLOP/s).
+// Per step and wave: 1 v_add_u32_dpp (address) + 1 ds_read_b64 + 2 v_fmac_f32_dpp for 4 queries
+// x 32 lists, eight reads in flight -- 16 x fewer multiply-adds than the GEMM. The kernel is
+// LDS-bound (13.4 GB of tile reads per 16 384 queries x 4 096 lists = 85 us at 256 B/clk/CU):
+// 0.23 ms measured against 0.86 ms for the dense MFMA GEMM at 125 TFLOP/s.
 // Queries with more than 64 non-zeros (none among processed spectra: max_peaks_used = 50) are
 // walked entry by entry from the dense row instead.
 #include "common.hpp"
@@ -36,6 +37,7 @@ constexpr int CS_CAP = 64;         // entries a query keeps in registers
 
 // ---- the non-zero components of every query row, ascending: ent[q][CS_CAP] = (dim, value bits),
 // cnt[q] = their number (or -1 - count when there are more than CS_CAP). One wave per row.
+// The dimension is stored as the byte offset of its tile row (dim * 128).
 __global__ __launch_bounds__(256) void list_nonzeros_kernel(const float *__restrict__ xq, int nq, int d,
                                                             uint2 *__restrict__ ent,
                                                             int32_t *__restrict__ cnt,
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void list_nonzeros_kernel(const float *__restr
     const unsigned long long m = __ballot(x != 0.0f);
     if (x != 0.0f) {
       const int t = base + __popcll(m & ((1ull << lane) - 1ull));
-      if (t < CS_CAP) out[t] = make_uint2((uint32_t)j, __float_as_uint(x));
+      if (t < CS_CAP) out[t] = make_uint2((uint32_t)j * (CS_TL * 4), __float_as_uint(x));   // byte offset of the tile row
     }
     base += __popcll(m);
   }
@@ -62,25 +64,37 @@ __global__ __launch_bounds__(256) void list_nonzeros_kernel(const float *__restr
   }
 }
 
-template <int CTRL>
-__device__ __forceinline__ uint32_t cs_row_share(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
-}
+typedef float cs_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) cs_f2 cs_lds_f2;
 
-// one step: entry K (0..15) of the register set (ed, ev) against the tile
-#define CS_STEP(K, ED, EV)                                                                     \
-  {                                                                                            \
-    const uint32_t dm = cs_row_share<0x150 + (K)>(ED);                                         \
-    const float vv = __uint_as_float(cs_row_share<0x150 + (K)>(EV));                           \
-    const float2 c = *reinterpret_cast<const float2 *>(tile_lane + (size_t)dm * (CS_TL * 4));  \
-    acc0 = __builtin_fmaf(vv, c.x, acc0);                                                      \
-    acc1 = __builtin_fmaf(vv, c.y, acc1);                                                      \
+// one step: entry K (0..15) of the register set (ED = dimension * 128, the byte offset of the
+// tile row; EV = value bits). Three VALU instructions: the address add and the two multiply-adds
+// take the row's lane K as a DPP operand (row_newbcast = row_share), no separate broadcast moves.
+#define CS_ADDR(K, ED, I)                                                            \
+  asm("v_add_u32_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf"     \
+      : "=v"(ad[I])                                                                  \
+      : "v"(ED), "v"(lane_off));
+#define CS_FMA(K, EV, I)                                                             \
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf"    \
+      : "+v"(acc0)                                                                   \
+      : "v"(EV), "v"(cv[I].x));                                                      \
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf"    \
+      : "+v"(acc1)                                                                   \
+      : "v"(EV), "v"(cv[I].y));
+// eight steps: all addresses, all LDS reads (in flight together), then the multiply-adds in
+// entry order (the canonical chain)
+#define CS_BLOCK8(K0, K1, K2, K3, K4, K5, K6, K7, ED, EV)                                       \
+  {                                                                                             \
+    uint32_t ad[8];                                                                             \
+    cs_f2 cv[8];                                                                                \
+    CS_ADDR(K0, ED, 0) CS_ADDR(K1, ED, 1) CS_ADDR(K2, ED, 2) CS_ADDR(K3, ED, 3)                 \
+    CS_ADDR(K4, ED, 4) CS_ADDR(K5, ED, 5) CS_ADDR(K6, ED, 6) CS_ADDR(K7, ED, 7)                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) cv[i_] = *(const cs_lds_f2 *)(uintptr_t)ad[i_]; \
+    CS_FMA(K0, EV, 0) CS_FMA(K1, EV, 1) CS_FMA(K2, EV, 2) CS_FMA(K3, EV, 3)                     \
+    CS_FMA(K4, EV, 4) CS_FMA(K5, EV, 5) CS_FMA(K6, EV, 6) CS_FMA(K7, EV, 7)                     \
   }
-#define CS_BLOCK16(ED, EV)                                                                    \
-  CS_STEP(0, ED, EV) CS_STEP(1, ED, EV) CS_STEP(2, ED, EV) CS_STEP(3, ED, EV) CS_STEP(4, ED, EV)   \
-  CS_STEP(5, ED, EV) CS_STEP(6, ED, EV) CS_STEP(7, ED, EV) CS_STEP(8, ED, EV) CS_STEP(9, ED, EV)   \
-  CS_STEP(10, ED, EV) CS_STEP(11, ED, EV) CS_STEP(12, ED, EV) CS_STEP(13, ED, EV)                  \
-  CS_STEP(14, ED, EV) CS_STEP(15, ED, EV)
+#define CS_BLOCK8A(ED, EV) CS_BLOCK8(0, 1, 2, 3, 4, 5, 6, 7, ED, EV)
+#define CS_BLOCK8B(ED, EV) CS_BLOCK8(8, 9, 10, 11, 12, 13, 14, 15, ED, EV)
 
 // grid (tiles, query parts); scores[q][l] row-major with leading dimension ld
 __global__ __launch_bounds__(64 * CS_NW) void coarse_sparse_kernel(
@@ -93,39 +107,69 @@ __global__ __launch_bounds__(64 * CS_NW) void coarse_sparse_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l0 = blockIdx.x * CS_TL;
   // ---- the tile: row `dim` = Ct[dim][l0 .. l0 + 32) (zero beyond nlist)
-  for (int i = tid; i < d * CS_TL; i += 64 * CS_NW) {
-    const int dim = i >> 5, l = i & 31;
-    tile[i] = l0 + l < nlist ? Ct[(size_t)dim * nlist + l0 + l] : 0.0f;
+  if (l0 + CS_TL <= nlist && (nlist & 3) == 0) {     // 16-byte loads: 8 lanes per dimension
+    for (int i = tid; i < d * (CS_TL / 4); i += 64 * CS_NW) {
+      const int dim = i >> 3, l4 = (i & 7) * 4;
+      reinterpret_cast<float4 *>(tile)[i] =
+          *reinterpret_cast<const float4 *>(Ct + (size_t)dim * nlist + l0 + l4);
+    }
+  } else {
+    for (int i = tid; i < d * CS_TL; i += 64 * CS_NW) {
+      const int dim = i >> 5, l = i & 31;
+      tile[i] = l0 + l < nlist ? Ct[(size_t)dim * nlist + l0 + l] : 0.0f;
+    }
   }
   __syncthreads();
   const int row = lane >> 4, j = lane & 15;
   const char *tile_lane = reinterpret_cast<const char *>(tile) + j * 8;
+  // (LDS byte address of the lane's two lists in row 0 of the tile)
+  const uint32_t lane_off =
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)cs_smem + (uint32_t)(j * 8);
   const int groups = (nq + 3) >> 2;
   const int gper = (groups + gridDim.y - 1) / gridDim.y;
   const int g_lo = blockIdx.y * gper, g_hi = min(groups, g_lo + gper);
-  for (int g = g_lo + wave; g < g_hi; g += CS_NW) {
+  // a group's entries are requested one group ahead: the 64 steps of a group take ~0.3 us, an
+  // entry load from L2 / HBM 1 - 2 us
+  uint32_t n_ed[4] = {0u, 0u, 0u, 0u}, n_ev[4] = {0u, 0u, 0u, 0u};
+  int n_c = 0;
+  auto fetch = [&](int g) {
     const int q = g * 4 + row;
-    const bool live = q < nq;
-    const int c = live ? cnt[q] : 0;
-    uint32_t ed[4] = {0u, 0u, 0u, 0u}, ev[4] = {0u, 0u, 0u, 0u};
-    if (live) {
+    if (g < g_hi && q < nq) {
+      n_c = cnt[q];
       const uint2 *e = ent + (size_t)q * CS_CAP + j;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint2 x = e[16 * u];
-        ed[u] = x.x;
-        ev[u] = x.y;
+        n_ed[u] = x.x;
+        n_ev[u] = x.y;
       }
+    } else {
+      n_c = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) n_ed[u] = n_ev[u] = 0u;
     }
+  };
+  fetch(g_lo + wave);
+  for (int g = g_lo + wave; g < g_hi; g += CS_NW) {
+    const int q = g * 4 + row;
+    const bool live = q < nq;
+    const int c = n_c;
+    const uint32_t ed[4] = {n_ed[0], n_ed[1], n_ed[2], n_ed[3]};
+    const uint32_t ev[4] = {n_ev[0], n_ev[1], n_ev[2], n_ev[3]};
+    fetch(g + CS_NW);
     float acc0 = 0.0f, acc1 = 0.0f;
     int cm = c < 0 ? 0 : c;                    // entries to walk (wave maximum)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cm = max(cm, __shfl_xor(cm, o, 64));
     cm = __builtin_amdgcn_readfirstlane(cm);
-    if (cm > 0) { CS_BLOCK16(ed[0], ev[0]) }
-    if (cm > 16) { CS_BLOCK16(ed[1], ev[1]) }
-    if (cm > 32) { CS_BLOCK16(ed[2], ev[2]) }
-    if (cm > 48) { CS_BLOCK16(ed[3], ev[3]) }
+    if (cm > 0) { CS_BLOCK8A(ed[0], ev[0]) }
+    if (cm > 8) { CS_BLOCK8B(ed[0], ev[0]) }
+    if (cm > 16) { CS_BLOCK8A(ed[1], ev[1]) }
+    if (cm > 24) { CS_BLOCK8B(ed[1], ev[1]) }
+    if (cm > 32) { CS_BLOCK8A(ed[2], ev[2]) }
+    if (cm > 40) { CS_BLOCK8B(ed[2], ev[2]) }
+    if (cm > 48) { CS_BLOCK8A(ed[3], ev[3]) }
+    if (cm > 56) { CS_BLOCK8B(ed[3], ev[3]) }
     if (__ballot(c < 0)) {          // wave-uniform: a row with more than CS_CAP non-zeros -> its dense row
       if (c < 0) {
         acc0 = acc1 = 0.0f;

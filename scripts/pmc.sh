@@ -7,7 +7,7 @@ tag=$1; shift
 mkdir -p gpurun_out/$tag
 run() {  # name, counters...
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "pq_scan|flat_inv|rescore_|gemm_nt|row_topk|row_select" \
+  rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "pq_scan|flat_inv|rescore_|gemm_nt|row_topk|row_select|coarse_sparse" \
      --output-format csv -d /tmp/pmc_$name -o x -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --recall-queries 0 "${BENCH_ARGS[@]}" > /tmp/pmc_$name.log 2>&1
   python3 - "$name" <<'PY' >> gpurun_out/$TAG/summary.txt
 import csv, sys, collections, glob
