@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_index.py -x -q 2>&1 | tail -2
-for c in 256 512 1024 2048; do
-ASL_CS_COVER=$c python bench.py --no-pipeline --cpu-seconds 0 --recall-queries 0 --no-fixed-recall --steps 5 --warmup 1 2>/dev/null | grep -E "^\{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); s=d['stages_ms_per_step']; print('cover', $c, 'step', d['ms_per_step'], 'coarse', s['coarse_gemm'])"
-done
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python bench.py --cpu-seconds 0 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('pipelined', d['value'], d['ms_per_step'], d['stages_ms_per_step']); print('fixed_recall', d['fixed_recall']['value'], d['fixed_recall']['ms_per_step'], d['fixed_recall']['scan_ms_per_step'])"
+python bench.py --cpu-seconds 0 --no-pipeline --no-fixed-recall --recall-queries 0 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('serial', d['value'], d['ms_per_step'], d['stages_ms_per_step'])"

@@ -296,6 +296,43 @@ def test_ivfflat_search_identical_to_oracle(O, vecs, trained):
     assert np.array_equal(I, O.flat_search(xb, xq, 50)[1])
 
 
+@pytest.mark.parametrize('d,nlist', [(800, 256), (96, 40), (800, 33)])
+def test_sparse_coarse_quantiser_equals_the_gemm(d, nlist):
+    """The coarse scores of sparse queries come from coarse_sparse.hip (32-list centroid tiles in
+    LDS, entries broadcast by DPP); a batch with many dense rows is left to the MFMA GEMM by a
+    device-side gate, and the odd dense row is walked inside the sparse kernel. All three must
+    give the GEMM's bits (scan variant 1 forces the GEMM): same probe lists, same scores."""
+    from ann_solo_amd import faiss_compat as faiss
+    rng = np.random.default_rng(d + nlist)
+
+    def rows(n, nnz_lo, nnz_hi):
+        x = np.zeros((n, d), np.float32)
+        for i in range(n):
+            k = int(rng.integers(nnz_lo, nnz_hi + 1))
+            c = rng.choice(d, size=min(k, d), replace=False)
+            x[i, c] = (rng.random(len(c)) + 0.05).astype(np.float32)
+        return x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-20)
+    cen = rows(nlist, 8, min(d, 200))
+    cen[1] *= -1.0                                   # signs must not matter
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(d), d, nlist)
+    idx.set_trained(cen)
+    nprobe = min(nlist, 16)
+    batches = {
+        'sparse': rows(301, 0, 50),                   # incl. all-zero rows
+        'one dense row in 100': np.concatenate([rows(150, 1, 60), rows(1, min(d, 90), min(d, 90)),
+                                                rows(149, 1, 64)]),
+        'dense': rows(70, min(d, 70), min(d, 90)),    # every row above 64: the gate picks the GEMM
+    }
+    for name, xq in batches.items():
+        idx.set_scan_variant(0)
+        D0, I0 = idx.coarse(xq, nprobe)
+        idx.set_scan_variant(1)
+        D1, I1 = idx.coarse(xq, nprobe)
+        idx.set_scan_variant(0)
+        assert np.array_equal(I0, I1), name
+        assert np.array_equal(D0.view(np.uint32), D1.view(np.uint32)), name
+
+
 def test_postings_work_counter(vecs, trained):
     """asl_index_postings_work (the roofline bytes of the postings scan) against numpy: per
     (query, probed block of 832 vectors, non-zero query dimension) 4 bytes + 6 per posting."""
