@@ -330,7 +330,7 @@ def main():
                         'ms_per_step': round(el_f / args.steps * 1e3, 3), 'steps': args.steps,
                         'scan_ms_per_step': round(ms_f.value / max(args.steps, 1), 3),
                         'pipelined': pipelined,
-                        'roofline': postings_roofline(sl_f, idx_f, q, best, ms_f.value / max(n_f.value, 1))}
+                        'roofline': postings_roofline(sl_f, idx_f, q, best, ms_f.value / max(n_f.value, 1), args)}
         if args.cpu_seconds > 0:
             # the SAME index (this leg's 25-iteration quantiser, nprobe = best) against the oracle:
             # neighbour id sets, winners and scores of a sample of the batch
@@ -363,7 +363,7 @@ def main():
                             'avg_launch_ms': round(avg_ms, 4),
                             'algorithmic_bytes_per_launch': int(bytes_per_launch)}
             else:
-                roofline = postings_roofline(sl, idx, q, args.nprobe, avg_ms)
+                roofline = postings_roofline(sl, idx, q, args.nprobe, avg_ms, args if world == 1 else None)
             roofline['vectors_scanned_per_query'] = round(scanned / args.steps / (degree * args.batch), 1)
             if args.index == 'ivfpq':
                 # the ids are read for survivors only: SURVEY.md 8(d)'s "ids implicit" variant
@@ -559,7 +559,8 @@ def _lib_handle():
     return _lib.lib()
 
 
-PMC_TRAFFIC_FILE = 'profiles/r02_pmc_traffic.json'
+PMC_TRAFFIC_FILE = 'profiles/r03_pmc_traffic.json'
+PMC_TRAFFIC_FILE_FLAT = 'profiles/r03_ivfflat_np112_pmc_traffic.json'     # IVF-Flat, nprobe 112
 
 
 def pmc_traffic(args, world):
@@ -586,13 +587,32 @@ def pmc_traffic(args, world):
         return None, f'{PMC_TRAFFIC_FILE} unreadable: {e}'
 
 
-def postings_roofline(sl, idx, q, nprobe, avg_ms):
+def flat_pmc_traffic(args, nprobe):
+    """Fabric bytes per launch of the postings scan from the committed PMC pass (same rule as
+    ``pmc_traffic``: only for the workload the pass was taken on)."""
+    ok = (args.library_size == 2_100_000 and args.nlist == 4096 and nprobe == 112 and
+          args.k == 1024 and args.batch == 16384 and args.niter == 25)
+    path = os.path.join(ROOT, PMC_TRAFFIC_FILE_FLAT)
+    if not ok or not os.path.exists(path):
+        return None, 'no committed PMC pass for this workload'
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return int(d['scan_hbm_bytes_per_launch']), (
+            f"{PMC_TRAFFIC_FILE_FLAT} (committed rocprofv3 --pmc FETCH_SIZE pass, x2: one 128-byte "
+            f"request per line tallied at 64 B, which agrees with the line count; not measured in this run)")
+    except Exception as e:
+        return None, f'{PMC_TRAFFIC_FILE_FLAT} unreadable: {e}'
+
+
+def postings_roofline(sl, idx, q, nprobe, avg_ms, args=None):
     """Roofline of ``flat_inv_scan_kernel`` for this batch: algorithmic bytes = sum over (query,
     probed block, non-zero query dimension) of the 4-byte table word + 6 bytes per posting
     (u16 local index + f32 value), counted on the device by ``asl_index_postings_work`` outside
     the timed region; ``lines`` = the 128-byte lines those bytes occupy (what a cold scan has to
     move). HBM-bound: every (query, block) pair touches its own lines."""
     b, l = idx.postings_work(sl._encode(q), nprobe)
+    traffic, src = flat_pmc_traffic(args, nprobe) if args is not None else (None, None)
     achieved = b / (avg_ms * 1e-3) / 1e9
     by_line = l * 128 / (avg_ms * 1e-3) / 1e9
     return {'bound': 'hbm', 'kernel': 'flat_inv_scan_kernel', 'achieved': round(achieved, 2),
@@ -600,8 +620,10 @@ def postings_roofline(sl, idx, q, nprobe, avg_ms):
             'bytes': '4-B table word + 6 B per posting, per (probed block, non-zero query dimension)',
             'algorithmic_bytes_per_launch': int(b), 'avg_launch_ms': round(avg_ms, 4),
             'lines_128B_per_launch': int(l), 'achieved_by_lines': round(by_line, 2),
-            'frac_by_lines': round(by_line / HBM_PEAK_GBS, 5), 'traffic': None,
-            'traffic_source': 'see profiles/ (rocprofv3 --pmc FETCH_SIZE pass of the IVF-Flat bench)'}
+            'frac_by_lines': round(by_line / HBM_PEAK_GBS, 5), 'traffic': traffic,
+            'traffic_source': src,
+            'frac_measured_traffic': (round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                      if traffic else None)}
 
 
 def faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_queries):
