@@ -412,6 +412,14 @@ def main():
                          'note': 'stage times overlap across consecutive steps when true: their '
                                  'sum exceeds ms_per_step'},
             'recall': recall,
+            # which number answers "query spectra/sec at fixed recall@k" (north star / SURVEY 8d)
+            'metric_note': (None if args.index != 'ivfpq' or recall is None else
+                            'value is configs[2] as BASELINE.json names it (IVF-PQ m=32): its recall@k is '
+                            f"{recall.get('ratio_to_ivfflat', 0) or 0:.2f} of IVF-Flat(nlist, nprobe), "
+                            + ('which meets' if recall.get('meets_criterion') else 'which does NOT meet')
+                            + ' the fixed-recall criterion (>= 0.95); the throughput AT FIXED RECALL is '
+                            'fixed_recall.value (IVF-Flat over the same quantiser, measured in this run '
+                            'with its own roofline and oracle parity)'),
             'fixed_recall': fixed_recall,
             'shard_check': shard_check,
             'alt_layouts': alt,
