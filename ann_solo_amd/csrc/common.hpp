@@ -180,6 +180,10 @@ struct DevPeaks {
   const uint8_t *charge = nullptr;  // may be nullptr
   const double *precursor_mz = nullptr;
   const int32_t *precursor_charge = nullptr;
+  // library only (asl_library): every spectrum's peaks as ONE record, [mz f32 x n][intensity f32
+  // x n][charge u8 x n] at a 16-byte aligned offset (RowMeta::rec4) -- 3 cache lines per
+  // candidate instead of 5 from the three arrays above
+  const uint8_t *records = nullptr;
 };
 
 struct PeaksStage {  // stages an asl_peaks_t whose arrays may be on the host

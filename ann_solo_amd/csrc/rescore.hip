@@ -646,6 +646,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, RS_OCC) void rescore_score_v2_kernel
     ny = want < ny ? want : ny;
     if ((int)blockIdx.y >= ny) return;
   }
+  cv.flt.wcol = nullptr;      // this kernel wants filter column and metadata from ONE gather
   if (FORM != 0) {
     cv.offsets = nullptr;
     cv.flt.lib_pmz = nullptr;
@@ -873,7 +874,9 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
     cv.flt.lib_pmz = nullptr;
     cv.flt.valid = nullptr;
     __builtin_assume(cv.flt.meta != nullptr);
+    __builtin_assume(cv.flt.wcol != nullptr);
     __builtin_assume(L.charge != nullptr);
+    __builtin_assume(L.records != nullptr);
     if (FORM == 1) {
       cv.rows64 = nullptr;
     } else {
@@ -975,6 +978,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
           m_cn = (int)a.y;
           m_chg = (int)a.z;
           m_pmz = cv.flt.meta[row].pmz64;
+          if (L.records) m_co = (int)cv.flt.meta[row].rec4;     // base of the peak record, 4-byte units
         } else {
           m_co = L.offsets[row];
           m_cn = L.offsets[row + 1] - m_co;
@@ -1042,9 +1046,17 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
         n_rec = act ? Wv.rec[n_tt] : 0u;
         n_j = p - (int)Wv.pref[n_tt];
         n_co = Wv.base[n_tt];
-        n_cm = act ? L.mz[n_co + n_j] : 0.0f;
-        n_ci = act ? L.intensity[n_co + n_j] : 0.0f;
-        n_cc = (act && L.charge) ? (int)L.charge[n_co + n_j] : 0;
+        if (L.records && cv.flt.meta) {      // [mz x cn][intensity x cn][charge x cn], one record
+          const float *rf = reinterpret_cast<const float *>(L.records) + (uint32_t)n_co;
+          const int cnr = (int)(n_rec & 0xffu);
+          n_cm = act ? rf[n_j] : 0.0f;
+          n_ci = act ? rf[cnr + n_j] : 0.0f;
+          n_cc = act ? (int)reinterpret_cast<const uint8_t *>(rf)[8 * cnr + n_j] : 0;
+        } else {
+          n_cm = act ? L.mz[n_co + n_j] : 0.0f;
+          n_ci = act ? L.intensity[n_co + n_j] : 0.0f;
+          n_cc = (act && L.charge) ? (int)L.charge[n_co + n_j] : 0;
+        }
       };
       if (P > 0) fetch(0);
       for (int p0 = 0; p0 < P; p0 += 64) {
@@ -1080,7 +1092,10 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
                   // must pass the window test too (differs only on fp boundaries)
                   bool run = true;
                   for (int jj = j; jj > 0; --jj) {
-                    const double xp = (double)L.mz[co + jj - 1] + md;
+                    const float *pm_ = (L.records && cv.flt.meta)
+                                           ? reinterpret_cast<const float *>(L.records) + (uint32_t)co
+                                           : L.mz + co;
+                    const double xp = (double)pm_[jj - 1] + md;
                     if (lim > xp) break;
                     if (!(fabs(qm - xp) <= tol)) {
                       run = false;

@@ -17,7 +17,8 @@ struct __attribute__((aligned(32))) RowMeta {
   int32_t charge;   // precursor charge
   float pmz32;      // spec_info's float32 precursor m/z column; NaN for invalid spectra
   double pmz64;     // precursor m/z
-  double pad;
+  uint32_t rec4;    // the spectrum's packed peak record (DevPeaks::records), in 4-byte units
+  uint32_t pad;
 };
 
 struct PrecFilter {
@@ -27,6 +28,9 @@ struct PrecFilter {
   int mode = ASL_TOL_DA;
   int charge = 0;
   const RowMeta *meta = nullptr;    // packed rows (asl_library): replaces lib_pmz / valid
+  // the window column alone, NaN for invalid spectra (4 bytes per row: the flat kernel filters
+  // 16.7 M slots per batch on it and touches the 32-byte records of the survivors only)
+  const float *wcol = nullptr;
 };
 
 // spectral_library.py:421-427 (numexpr evaluates in float64)
@@ -38,6 +42,7 @@ __device__ __forceinline__ bool precursor_ok(double q, float lib, int charge, do
 }
 
 __device__ __forceinline__ bool filter_pass(const PrecFilter &f, double q_pmz, long long row) {
+  if (f.wcol) return precursor_ok(q_pmz, f.wcol[row], f.charge, f.tol, f.mode);
   if (f.meta) return precursor_ok(q_pmz, f.meta[row].pmz32, f.charge, f.tol, f.mode);
   if (!f.lib_pmz) return true;
   if (f.valid && !f.valid[row]) return false;

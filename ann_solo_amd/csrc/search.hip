@@ -79,6 +79,8 @@ struct asl_library {
   DevBuf<uint8_t> charge, valid;
   DevBuf<double> pmz;
   DevBuf<RowMeta> meta;   // packed per-row record for the rescoring kernel
+  DevBuf<float> wcol;     // window column alone, NaN for invalid spectra
+  DevBuf<uint8_t> records;   // packed peak records (DevPeaks::records)
   bool has_valid = false;
   DevPeaks dev;
   // precursor-sorted view (window search)
@@ -94,6 +96,33 @@ struct asl_library {
   DevBuf<long long> best_slot;
   DevBuf<int> status;
 };
+
+// one wave per spectrum: its peaks from the three arrays into one record
+__global__ void pack_records_kernel(const int32_t *__restrict__ offsets, const float *__restrict__ mz,
+                                    const float *__restrict__ inten, const uint8_t *__restrict__ chg,
+                                    const RowMeta *__restrict__ meta, int64_t n,
+                                    uint8_t *__restrict__ rec) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= n) return;
+  const int co = offsets[r], cn = offsets[r + 1] - co;
+  uint8_t *b = rec + (size_t)meta[r].rec4 * 4;
+  float *f = reinterpret_cast<float *>(b);
+  for (int j = lane; j < cn; j += 64) {
+    f[j] = mz[co + j];
+    f[cn + j] = inten[co + j];
+    b[8 * (size_t)cn + j] = chg[co + j];
+  }
+}
+
+static int pack_peak_records(const int32_t *offsets, const float *mz, const float *inten,
+                             const uint8_t *chg, const RowMeta *meta, int64_t n, uint8_t *rec) {
+  if (n <= 0) return ASL_OK;
+  hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), offsets,
+                     mz, inten, chg, meta, n, rec);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
 
 extern "C" {
 
@@ -150,15 +179,30 @@ asl_library_t *asl_library_create(const asl_peaks_t *p, const float *lib_pmz_f32
          sync_stream() == ASL_OK;
     if (ok && valid) ok = hipMemcpy(h_valid.data(), valid, n, hipMemcpyDefault) == hipSuccess;
     std::vector<RowMeta> hm(n);
+    std::vector<float> h_wcol(n);
+    uint64_t rec_bytes = 0;
     for (size_t i = 0; ok && i < n; i++) {
       hm[i].off = h_off[i];
       hm[i].cn = h_off[i + 1] - h_off[i];
       hm[i].charge = h_chg[i];
       hm[i].pmz32 = h_valid[i] ? h_pmz32[i] : __builtin_nanf("");
       hm[i].pmz64 = h_pmz[i];
-      hm[i].pad = 0.0;
+      hm[i].rec4 = (uint32_t)(rec_bytes >> 2);
+      hm[i].pad = 0u;
+      h_wcol[i] = hm[i].pmz32;
+      rec_bytes += ((uint64_t)hm[i].cn * 9 + 15) & ~15ull;
+    }
+    if (rec_bytes >= (1ull << 34)) {     // rec4 is 32 bits of 4-byte units
+      ok = false;
+      fail(ASL_ERR_CAPACITY, "library_create: more than 16 GiB of peak records in one partition");
     }
     up(L->meta, hm.data(), n);
+    up(L->wcol, h_wcol.data(), n);
+    if (ok && np) {
+      ok = L->records.reserve((size_t)rec_bytes + 16) == ASL_OK &&
+           pack_peak_records(L->offsets.p, L->mz.p, L->intensity.p, L->charge.p, L->meta.p, (int64_t)n,
+                             L->records.p) == ASL_OK;
+    }
   }
   if (ok && n) {
     std::vector<int32_t> order(n);
@@ -184,6 +228,7 @@ asl_library_t *asl_library_create(const asl_peaks_t *p, const float *lib_pmz_f32
   L->dev.charge = L->charge.p;
   L->dev.precursor_mz = L->pmz.p;
   L->dev.precursor_charge = L->pcharge.p;
+  L->dev.records = L->records.p;
   return L;
 }
 
@@ -283,6 +328,7 @@ int asl_rescore_knn(asl_library_t *L, const asl_peaks_t *queries, const asl_sear
   flt.lib_pmz = L->pmz32.p;
   flt.valid = L->has_valid ? L->valid.p : nullptr;
   flt.meta = L->meta.p;
+  flt.wcol = L->wcol.p;
   flt.tol = P->precursor_tol;
   flt.mode = P->precursor_mode;
   flt.charge = P->charge;
@@ -372,6 +418,7 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
     flt.lib_pmz = L->pmz32.p;
     flt.valid = L->has_valid ? L->valid.p : nullptr;
     flt.meta = L->meta.p;
+  flt.wcol = L->wcol.p;
     flt.tol = P->precursor_tol;
     flt.mode = P->precursor_mode;
     flt.charge = P->charge;
@@ -446,6 +493,7 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
     flt.lib_pmz = L->pmz32.p;
     flt.valid = L->has_valid ? L->valid.p : nullptr;
     flt.meta = L->meta.p;
+  flt.wcol = L->wcol.p;
     flt.tol = P->precursor_tol;
     flt.mode = P->precursor_mode;
     flt.charge = P->charge;
