@@ -1257,7 +1257,8 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
       static DevBuf<int> &q_defer = *new DevBuf<int>();   // process lifetime (one device per process)
       ASL_TRY(q_defer.reserve((size_t)nq));
       HIP_TRY(hipMemsetAsync(q_defer.p, 0, sizeof(int) * (size_t)nq, stream()));
-      const bool shaped = !cand_offsets && filter.meta && L.charge && (rows64 || rows32);
+      const bool shaped = !cand_offsets && filter.meta && filter.wcol && L.charge && L.records &&
+                          (rows64 || rows32);
 #ifndef RS_NO_FLAT
       // 1. flat kernel; 2. pair kernel on what it marked RS_DEFER; 3. binary-search kernel on
       // RS_DEFER_BS (blocks of 2 / 3 return at once for queries without such slots)
