@@ -39,12 +39,12 @@ constexpr int CS_CAP = 64;         // entries a query keeps in registers
 // cnt[q] = their number (or -1 - count when there are more than CS_CAP). One wave per row.
 // The dimension is stored as the byte offset of its tile row (dim * 128).
 __global__ __launch_bounds__(256) void list_nonzeros_kernel(const float *__restrict__ xq, int nq, int d,
-                                                            uint2 *__restrict__ ent,
+                                                            int64_t ldq, uint2 *__restrict__ ent,
                                                             int32_t *__restrict__ cnt,
                                                             int *__restrict__ n_over) {
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (q >= nq) return;
-  const float *row = xq + (size_t)q * d;
+  const float *row = xq + (size_t)q * ldq;
   uint2 *out = ent + (size_t)q * CS_CAP;
   int base = 0;
   for (int j0 = 0; j0 < d; j0 += 64) {
@@ -98,7 +98,7 @@ typedef __attribute__((address_space(3))) cs_f2 cs_lds_f2;
 
 // grid (tiles, query parts); scores[q][l] row-major with leading dimension ld
 __global__ __launch_bounds__(64 * CS_NW) void coarse_sparse_kernel(
-    const float *__restrict__ xq, int nq, int d, const uint2 *__restrict__ ent,
+    const float *__restrict__ xq, int nq, int d, int64_t ldq, const uint2 *__restrict__ ent,
     const int32_t *__restrict__ cnt, const float *__restrict__ Ct, int nlist,
     float *__restrict__ scores, int ld, const int *__restrict__ n_over, int over_max) {
   if (*n_over > over_max) return;       // a dense batch: gemm_nt_f32 (gated the other way) scores it
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * CS_NW) void coarse_sparse_kernel(
     if (__ballot(c < 0)) {          // wave-uniform: a row with more than CS_CAP non-zeros -> its dense row
       if (c < 0) {
         acc0 = acc1 = 0.0f;
-        const float *xr = xq + (size_t)q * d;
+        const float *xr = xq + (size_t)q * ldq;
         for (int k = 0; k < d; ++k) {
           const float vv = xr[k];
           if (vv != 0.0f) {
@@ -228,11 +228,12 @@ int transpose_f32(const float *in, int rows, int cols, float *out) {
 // the kernel leaves the batch alone (the caller's gated dense GEMM then runs instead): the
 // decision is taken on the device, nothing waits.
 int coarse_sparse(const float *xq, int nq, int d, const float *Ct, int nlist, uint2 *ent,
-                  int32_t *cnt, int *n_over, int over_max, float *scores, int ld) {
+                  int32_t *cnt, int *n_over, int over_max, float *scores, int ld, int64_t ldq) {
+  if (ldq <= 0) ldq = d;
   if (nq <= 0) return ASL_OK;
   HIP_TRY(hipMemsetAsync(n_over, 0, sizeof(int), stream()));
   hipLaunchKernelGGL(list_nonzeros_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, stream(), xq,
-                     nq, d, ent, cnt, n_over);
+                     nq, d, ldq, ent, cnt, n_over);
   ASL_CHECK_LAUNCH();
   const int tiles = (int)cdiv(nlist, CS_TL);
   // one workgroup per CU (the tile fills LDS): cover the chip about twice over
@@ -241,7 +242,7 @@ int coarse_sparse(const float *xq, int nq, int d, const float *Ct, int nlist, ui
   HIP_TRY(hipFuncSetAttribute((const void *)coarse_sparse_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(coarse_sparse_kernel, dim3(tiles, parts), dim3(64 * CS_NW), lds, stream(), xq, nq, d,
-                     ent, cnt, Ct, nlist, scores, ld, n_over, over_max);
+                     ldq, ent, cnt, Ct, nlist, scores, ld, n_over, over_max);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }

@@ -71,6 +71,7 @@ struct asl_index {
   // sparse coarse quantiser (coarse_sparse.hip): transposed centroids [d][nlist] + per-batch scratch
   DevBuf<float> centroids_t;
   bool cent_t_ready = false;
+  DevBuf<float> kmeans_ct;       // transposed centroids of the running k-means iteration
   DevBuf<uint2> cs_ent;
   DevBuf<int32_t> cs_cnt;
   DevBuf<int> cs_over;
@@ -123,9 +124,25 @@ static int assign_ip(asl_index *ix, const float *x, int64_t ld, int64_t n, const
   int64_t rows = (int64_t)std::max<size_t>(1, SCORE_CHUNK_BYTES / ((size_t)k * 4));
   rows = std::min<int64_t>(rows, n);
   ASL_TRY(ix->ws_scores.reserve((size_t)rows * k));
+  // hashed spectra are sparse: the scores come from the sparse kernel (same bits as the GEMM,
+  // 1/16 of its multiply-adds); a chunk with many dense rows is left to the GEMM by the
+  // device-side gate (coarse_sparse.hip). The centroids change every iteration: transposed here.
+  const bool sparse = ix->scan_variant == 0 && coarse_sparse_supported(d, k);
+  if (sparse) {
+    ASL_TRY(ix->kmeans_ct.reserve((size_t)k * d));
+    ASL_TRY(transpose_f32(cent, k, d, ix->kmeans_ct.p));
+    ASL_TRY(ix->cs_ent.reserve((size_t)rows * coarse_sparse_cap()));
+    ASL_TRY(ix->cs_cnt.reserve((size_t)rows));
+    ASL_TRY(ix->cs_over.reserve(1));
+  }
   for (int64_t r0 = 0; r0 < n; r0 += rows) {
     const int m = (int)std::min<int64_t>(rows, n - r0);
-    ASL_TRY(gemm_nt_f32(x + (size_t)r0 * ld, cent, ix->ws_scores.p, m, k, d, (int)ld, d, k));
+    const int over_max = m / 64;
+    if (sparse)
+      ASL_TRY(coarse_sparse(x + (size_t)r0 * ld, m, d, ix->kmeans_ct.p, k, ix->cs_ent.p, ix->cs_cnt.p,
+                            ix->cs_over.p, over_max, ix->ws_scores.p, k, ld));
+    ASL_TRY(gemm_nt_f32(x + (size_t)r0 * ld, cent, ix->ws_scores.p, m, k, d, (int)ld, d, k,
+                        sparse ? ix->cs_over.p : nullptr, over_max));
     ASL_TRY(row_argmax(ix->ws_scores.p, k, m, k, assign_dev + r0));
   }
   return ASL_OK;

@@ -20,7 +20,7 @@ bool coarse_sparse_supported(int d, int nlist);
 int coarse_sparse_cap();
 int transpose_f32(const float *in, int rows, int cols, float *out);
 int coarse_sparse(const float *xq, int nq, int d, const float *Ct, int nlist, uint2 *ent,
-                  int32_t *cnt, int *n_over, int over_max, float *scores, int ld);
+                  int32_t *cnt, int *n_over, int over_max, float *scores, int ld, int64_t ldq = 0);
 int row_topk(const float *scores, int64_t ld, int rows, int n, int k, const int32_t *ids,
              int32_t id_base, const int32_t *vlist, const uint32_t *bitmap, int bitmap_words,
              float *D, int64_t *I64, int32_t *I32, int64_t out_ld);

@@ -1,6 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-for r in 1 2; do
-for lib in scripts/tmp/base.so ann_solo_amd/libannsolo_mi.so; do
-ASL_LIB_PATH=$PWD/$lib python bench.py --no-pipeline --cpu-seconds 0 --recall-queries 0 --no-fixed-recall --steps 5 --warmup 1 2>/dev/null | grep -E "^\{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); s=d['stages_ms_per_step']; print('$lib', 'step', d['ms_per_step'], 'scan', s['scan'], 'rescore', s['rescore'])"
-done; done
+python -m pytest tests/test_gpu_index.py tests/test_gpu_search.py tests/test_gpu_faiss_file.py -x -q 2>&1 | tail -3
+python bench.py --cpu-seconds 0 --recall-queries 0 --no-fixed-recall --steps 5 2>&1 | grep -E "built in|^\{" | cut -c1-200
+python bench.py --index ivfflat --nprobe 112 --cpu-seconds 0 --recall-queries 0 --steps 5 2>&1 | grep -E "built in" | cut -c1-200
