@@ -76,19 +76,10 @@ int pipeline_init() {
   // ready one batch ahead: B's workgroups are dispatched first, A's fill what is left
   int least = 0, greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-#ifdef ASL_ENABLE_DBG   // A/B knobs of profiles/r02_pipeline_ab.txt: instrumented builds only
-  const bool flat = getenv("ASL_PIPE_FLAT_PRIORITY") != nullptr;
-#else
-  const bool flat = false;
-#endif
-  HIP_TRY(hipStreamCreateWithPriority(&p.A, hipStreamNonBlocking, flat ? greatest : least));
+  // (front stages at the lowest, scan + rescoring at the highest priority: measured in
+  // profiles/r02_pipeline_ab.txt)
+  HIP_TRY(hipStreamCreateWithPriority(&p.A, hipStreamNonBlocking, least));
   HIP_TRY(hipStreamCreateWithPriority(&p.B, hipStreamNonBlocking, greatest));
-#ifdef ASL_ENABLE_DBG
-  if (getenv("ASL_PIPE_SINGLE")) {   // measurement: asynchronous calls, but everything in order on B
-    (void)hipStreamDestroy(p.A);
-    p.A = p.B;
-  }
-#endif
   HIP_TRY(hipStreamCreateWithPriority(&p.C, hipStreamNonBlocking, greatest));
   HIP_TRY(hipEventCreateWithFlags(&p.ev_in, hipEventDisableTiming));
   for (int i = 0; i < 2; i++) {

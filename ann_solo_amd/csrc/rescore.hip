@@ -2,17 +2,19 @@
 // Replaces get_best_match (/root/reference/src/ann_solo/spectrum_match.pyx:28-108)
 // and SpectrumMatcher::dot (/root/reference/src/ann_solo/SpectrumMatch.cpp:8-133).
 //
-// Pass 1 (rescore_score_v2_kernel): one workgroup per query. The query's peaks are hashed
-// once into LDS (m/z bins of width 2*tol + a bitmap of occupied bins); the candidate list is
-// filtered (precursor window, rescore.hpp) and compacted in LDS; every wave scores two
-// candidates at a time, one per half-wave, lanes = candidate peaks probing the hash for every
-// shift; matches go to per-half LDS lists keyed (product desc, generation order asc) and are
-// resolved by a conflict-free fast path (exact fp64 tree sum) or a bitonic sort + scalar
-// greedy loop. Built for 7 waves per SIMD. Cases outside its LDS budget are marked and
-// scored by the binary-search formulation:
-// Pass 1b (rescore_score_kernel): one wave per (query, candidate) pair, lanes = query
+// Pass 1a (rescore_flat_kernel): one workgroup per query. The query's peaks are hashed once
+// into LDS (m/z bins of width 2*tol + a bitmap of occupied bins); the candidate list is
+// filtered (precursor window, rescore.hpp) and compacted in LDS; a wave sets 32 candidates up
+// one lane each and walks their peaks as ONE stream, a peak per lane, probing the hash for
+// every shift; a match is accumulated where it is found (LDS atomics: masks of matched peaks,
+// exponent range, exact fp64 sum). Candidates with a doubly matched peak are marked for
+// Pass 1b (rescore_score_v2_kernel, the pair kernel): two candidates per wave, one per
+// half-wave, matches into per-half LDS lists keyed (product desc, generation order asc),
+// resolved by a conflict-free fast path or a bitonic sort + scalar greedy loop. What neither
+// takes (> 64 peaks or matches, > 100 query peaks, tol <= 0) goes to
+// Pass 1c (rescore_score_kernel): one wave per (query, candidate) pair, lanes = query
 // peaks, cursor by binary search (same cursor value as the reference's running cursor
-// because both peak lists ascend). Also the whole pass 1 under ASL_RESCORE_V1.
+// because both peak lists ascend).
 // Pass 2 (rescore_argmax_kernel): per query first-strict-maximum (cpp:118-129).
 // Pass 3 (rescore_matches_kernel): the winning pair is re-run once per query to
 // emit its peak_matches in greedy order.
@@ -510,7 +512,7 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
                                           PairLds &Wv, int slotA, int slotB, int cnA, int cnB,
                                           int chgA, int chgB, double pmzA, double pmzB,
                                           double q_pmz, double tol, double inv_w, int allow_shift,
-                                          int *status, double &scoreA, double &scoreB, int dbg) {
+                                          int *status, double &scoreA, double &scoreB) {
   const int half = lane >> 5, hl = lane & 31;
   if (lane == 0) {
     Wv.pad[0] = 0;
@@ -545,7 +547,7 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
   unsigned long long *keys = Wv.keys + half * RS_HC;
   uint32_t *pay = Wv.pay + half * RS_HC;
   wave_sync();
-  for (int jb = 0; jb < ((dbg & 32) ? 0 : cmax); jb += 32) {   // wave-uniform
+  for (int jb = 0; jb < cmax; jb += 32) {   // wave-uniform
     const int j = jb + hl;
     const bool act = j < cn;
     const float cm = act ? s_mz[j] : 0.0f, ci = act ? s_in[j] : 0.0f;
@@ -559,7 +561,7 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
       // fp32 rounding); bitmap reject first, the exact fp64 window test on the rare hits
       const bool can = (smask >> s) & 1u;
       const int b = (int)floorf((cm + (float)md) * inv_w_f);
-      const bool maybe = can && bm_test(H, b) && !(dbg & 64);
+      const bool maybe = can && bm_test(H, b);
       if (!__ballot(maybe)) continue;         // wave-uniform
       if (maybe) {
         const double mult = (s == 0 || cc == s) ? 1.0 : 2.0 / 3.0;
@@ -602,14 +604,14 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
     }
   }
   wave_sync();
-  const int MA = (dbg & 16) ? 0 : __builtin_amdgcn_readfirstlane(Wv.pad[0]);
-  const int MB = (dbg & 16) ? 0 : __builtin_amdgcn_readfirstlane(Wv.pad[1]);
+  const int MA = __builtin_amdgcn_readfirstlane(Wv.pad[0]);
+  const int MB = __builtin_amdgcn_readfirstlane(Wv.pad[1]);
   if (MA == 0 && MB == 0) {   // wave-uniform: nothing matched
     scoreA = scoreB = 0.0;
     return;
   }
   int ok = 0;
-  if (MA <= 32 && MB <= 32 && !(dbg & 128)) ok = resolve_two_fast(lane, Wv, MA, MB, scoreA, scoreB);
+  if (MA <= 32 && MB <= 32) ok = resolve_two_fast(lane, Wv, MA, MB, scoreA, scoreB);
   if (!(ok & 1))
     scoreA = MA > RS_HC ? RS_DEFER
              : MA     ? resolve_half_slow(lane, Wv, status, 0, MA)
@@ -620,9 +622,6 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
                       : 0.0;
 }
 
-// KNOBS: the ablation switches of scripts/pmc_rescore.sh (ASL_RESCORE_DBG) exist only in the
-// instrumented instantiation; the product kernel is compiled with dbg == 0 folded away (the
-// switches cost scalar registers in a kernel that already spills them).
 // FORM: the two shapes the search path calls with -- fixed-stride neighbour lists (1: int32
 // rows, 2: int64 rows), packed row records for the precursor filter, annotated library peaks --
 // are compiled with those facts folded in (each open "is this pointer null" question is a
@@ -630,11 +629,10 @@ __device__ __forceinline__ void score_two(int lane, const QueryLds2 &Q, const Ha
 // DEF: second-launch mode behind rescore_flat_kernel -- only the slots that kernel marked
 // RS_DEFER, only for queries whose q_defer has RS_QD_PAIR; what this kernel cannot resolve
 // either goes on to the binary-search kernel (RS_DEFER_BS / RS_QD_BS).
-template <bool KNOBS, int FORM, bool DEF = false>
+template <int FORM, bool DEF = false>
 __global__ __launch_bounds__(64 * RS_WAVES, RS_OCC) void rescore_score_v2_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
-    double *__restrict__ pair_score, int *__restrict__ q_defer, int *status, int dbg_arg) {
-  const int dbg = KNOBS ? dbg_arg : 0;
+    double *__restrict__ pair_score, int *__restrict__ q_defer, int *status) {
   // DEF: a query's deferred slots are few (a handful) or nearly all of its candidates (two
   // query peaks closer than the tolerance make every candidate with a peak there a conflict):
   // as many of the launch's blocks per query take part as there is work for, the others leave
@@ -800,13 +798,10 @@ __global__ __launch_bounds__(64 * RS_WAVES, RS_OCC) void rescore_score_v2_kernel
           const bool runA = vA && !defA && cnA > 0 && qn > 0;
           const bool runB = vB && !defB && cnB > 0 && qn > 0;
           double sA = 0.0, sB = 0.0;
-          if (dbg & 1) {   // measurement knob: no probing / resolving
-            sA = (double)cnA;
-            sB = (double)cnB;
-          } else if (runA || runB) {
+          if (runA || runB) {
             score_two(lane, Q, H, Wv, u, u + 1, runA ? cnA : 0, runB ? cnB : 0, chA, chB,
                       rl_d(m_pmz, vA ? lA : 0), rl_d(m_pmz, vB ? lB : 0), q_pmz, tol, inv_w,
-                      allow_shift, status, sA, sB, dbg);
+                      allow_shift, status, sA, sB);
           }
           if (defA || sA == RS_DEFER) sA = RS_DEFER_BS;
           if (defB || sB == RS_DEFER) sB = RS_DEFER_BS;
@@ -1244,14 +1239,7 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
     int64_t avg = total_slots / (nq > 0 ? nq : 1);
     int ysplit = 1;
     if (nq < 2048 && avg > 4096) ysplit = (int)std::min<int64_t>(64, cdiv(avg, 4096));
-#ifdef ASL_ENABLE_DBG   // A/B and ablation knobs: instrumented builds only (scripts/ab_*.sh, pmc_rescore.sh)
-    static const bool force_v1 = getenv("ASL_RESCORE_V1") != nullptr;
-    static const int rs_dbg = getenv("ASL_RESCORE_DBG") ? atoi(getenv("ASL_RESCORE_DBG")) : 0;
-#else
-    constexpr bool force_v1 = false;
-    constexpr int rs_dbg = 0;
-#endif
-    if (!force_v1) {
+    {
       // hash kernel, then the binary-search kernel on whatever it deferred (its blocks
       // return at once for queries with nothing deferred)
       static DevBuf<int> &q_defer = *new DevBuf<int>();   // process lifetime (one device per process)
@@ -1259,35 +1247,21 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
       HIP_TRY(hipMemsetAsync(q_defer.p, 0, sizeof(int) * (size_t)nq, stream()));
       const bool shaped = !cand_offsets && filter.meta && filter.wcol && L.charge && L.records &&
                           (rows64 || rows32);
-#ifndef RS_NO_FLAT
       // 1. flat kernel; 2. pair kernel on what it marked RS_DEFER; 3. binary-search kernel on
       // RS_DEFER_BS (blocks of 2 / 3 return at once for queries without such slots)
       auto flat = !shaped ? rescore_flat_kernel<0> : rows64 ? rescore_flat_kernel<2> : rescore_flat_kernel<1>;
       hipLaunchKernelGGL(flat, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, tol,
                          allow_shift, pair_score, q_defer.p, status);
       ASL_CHECK_LAUNCH();
-      auto kern = !shaped ? rescore_score_v2_kernel<false, 0, true>
-                  : rows64 ? rescore_score_v2_kernel<false, 2, true>
-                           : rescore_score_v2_kernel<false, 1, true>;
+      auto kern = !shaped ? rescore_score_v2_kernel<0, true>
+                  : rows64 ? rescore_score_v2_kernel<2, true>
+                           : rescore_score_v2_kernel<1, true>;
       hipLaunchKernelGGL(kern, dim3(nq, std::max(ysplit, RS_DEF_Y)), dim3(64 * RS_WAVES), 0, stream(), Q,
-                         L, cv, tol, allow_shift, pair_score, q_defer.p, status, rs_dbg);
+                         L, cv, tol, allow_shift, pair_score, q_defer.p, status);
       ASL_CHECK_LAUNCH();
-#else     // same-box A/B builds: the pair kernel on everything (rounds 1-2)
-      auto kern = rs_dbg ? rescore_score_v2_kernel<true, 0>
-                  : !shaped ? rescore_score_v2_kernel<false, 0>
-                  : rows64  ? rescore_score_v2_kernel<false, 2>
-                            : rescore_score_v2_kernel<false, 1>;
-      hipLaunchKernelGGL(kern, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, tol,
-                         allow_shift, pair_score, q_defer.p, status, rs_dbg);
-      ASL_CHECK_LAUNCH();
-#endif
       hipLaunchKernelGGL(rescore_score_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
                          stream(), Q, L, cv, tol, allow_shift, pair_score,
                          (const int *)q_defer.p, status);
-    } else {
-      hipLaunchKernelGGL(rescore_score_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
-                         stream(), Q, L, cv, tol, allow_shift, pair_score, (const int *)nullptr,
-                         status);
     }
     ASL_CHECK_LAUNCH();
     hipLaunchKernelGGL(rescore_argmax_kernel, dim3(nq), dim3(64), 0, stream(), cv, nq,
