@@ -234,6 +234,23 @@ def test_engine_from_reference_config_cpu(O, tmp_path, monkeypatch):
     assert 'software[1]-setting[19]\tmode = bf' in head and 'num_list' not in head   # writer.py:101-105
 
 
+def test_num_gpus_flag_needs_a_matching_job(O, monkeypatch):
+    """``--num_gpus N`` shards at construction over the N ranks of the torch.distributed job the
+    process belongs to; a single process asking for 2 GPUs is told how to launch."""
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.spectral_library import SpectralLibrary
+
+    class Engine(_OracleEngineMixin, SpectralLibrary):
+        pass
+    lib, _ = synthetic.make_library(50, seed=3, device='cpu', charges=(2,), charge_p=(1.0,))
+    config = RefConfig(additive=True)
+    config.parse(f'l.splib q.mgf out {REQUIRED} --mode bf --num_gpus 2')
+    with pytest.raises(RuntimeError, match='torchrun --nproc-per-node 2'):
+        Engine(lib, config=config, device='cpu')
+    config.parse(f'l.splib q.mgf out {REQUIRED} --mode bf --num_gpus 1')
+    Engine(lib, config=config, device='cpu')          # 0 / 1: no sharding asked for
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('flags', ['', '--index ivfpq --pq_m 32 --kmeans_niter 4'])
 def test_engine_from_reference_config_gpu(tmp_path, flags):
