@@ -197,6 +197,14 @@ __global__ __launch_bounds__(64 * CS_NW) void coarse_sparse_kernel(
   }
 }
 
+int list_nonzeros(const float *xq, int nq, int d, int64_t ldq, uint2 *ent, int32_t *cnt, int *n_over) {
+  if (nq <= 0) return ASL_OK;
+  hipLaunchKernelGGL(list_nonzeros_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, stream(), xq,
+                     nq, d, ldq > 0 ? ldq : (int64_t)d, ent, cnt, n_over);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
 bool coarse_sparse_supported(int d, int nlist) {
   return d >= 1 && (size_t)d * CS_TL * 4 <= 150 * 1024 && nlist >= 1;
 }

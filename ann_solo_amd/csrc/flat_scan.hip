@@ -100,7 +100,8 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ blk_offsets,
     const uint32_t *__restrict__ blk_base, const uint32_t *__restrict__ seg_tab,
     const char *__restrict__ seg_bytes, const int32_t *__restrict__ ids, int k,
-    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode) {
+    float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode,
+    const uint2 *__restrict__ ent, const int32_t *__restrict__ ent_cnt) {
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *s_acc = reinterpret_cast<float *>(smem + TopK::lds_bytes());      // [FI_NW][FI_BLK]
@@ -117,9 +118,13 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long t_prev = wall_clock64();
 #endif
-  // the query's non-zero components, ascending (staged through the accumulator area)
+  // the query's non-zero components, ascending: from the ready entry list (list_nonzeros: 512
+  // bytes) or listed here from the dense row (staged through the accumulator area)
   float *s_q = s_acc;
-  for (int i = tid; i < d; i += FI_NT) s_q[i] = xq[(size_t)q * d + i];
+  const int ecnt = ent ? ent_cnt[q] : -1;          // block-uniform; < 0: more than 64 non-zeros
+  const bool fast = ecnt >= 0;
+  if (!fast)
+    for (int i = tid; i < d; i += FI_NT) s_q[i] = xq[(size_t)q * d + i];
   int my_len = 0, my_pos = 0, my_b0 = 0, my_nb = 0;
   if (tid < nprobe) {
     const int l = coarse_I[(size_t)q * nprobe + tid];
@@ -132,7 +137,18 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   }
   int total;
   const int my_pre = block_excl_scan<FI_NW>(my_nb, s_misc, tid, total);   // barrier inside: s_q complete
-  if (wave == 0) {
+  if (wave == 0 && fast) {
+    if (lane < ecnt) {
+      const uint2 e = ent[(size_t)q * 64 + lane];
+      s_nzd[lane] = (uint16_t)(e.x >> 7);
+      s_nzv[lane] = __uint_as_float(e.y);
+    }
+    if (lane == 0) {
+      s_misc[8] = ecnt;
+      s_misc[9] = 0;      // sync flag
+      s_misc[10] = 0;     // finished waves
+    }
+  } else if (wave == 0) {
     int base = 0;
     for (int j0 = 0; j0 < d; j0 += 64) {
       const int j = j0 + lane;
@@ -368,7 +384,8 @@ static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse
                            const int32_t *list_offsets, const int32_t *blk_offsets,
                            const uint32_t *blk_base, const uint32_t *seg_tab,
                            const char *seg_bytes, const int32_t *ids, int k, float *D,
-                           int64_t *I64, int32_t *I32, int set_mode) {
+                           int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent,
+                           const int32_t *ent_cnt) {
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   const size_t lds = TopK::lds_bytes() + (size_t)FI_NW * FI_BLK * 4 + (size_t)((d + 3) & ~3) * 4 +
                      (size_t)FI_CHUNK * sizeof(FiUnit) + 64 + (size_t)((d + 7) & ~7) * 2;
@@ -378,7 +395,7 @@ static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(flat_inv_scan_kernel<FI_CAP>, dim3(nq), dim3(FI_NT), lds, stream(), xq, d,
                      coarse_I, nprobe, list_offsets, blk_offsets, blk_base, seg_tab, seg_bytes, ids,
-                     k, D, I64, I32, set_mode);
+                     k, D, I64, I32, set_mode, ent, ent_cnt);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -386,13 +403,14 @@ static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse
 int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *list_offsets, const int32_t *blk_offsets,
                   const uint32_t *blk_base, const uint32_t *seg_tab, const char *seg_bytes,
-                  const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode) {
+                  const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode,
+                  const uint2 *ent, const int32_t *ent_cnt) {
   if (nq <= 0) return ASL_OK;
   if (k + FI_NT + 256 <= 2048)
     return launch_flat_inv<2048>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base,
-                                 seg_tab, seg_bytes, ids, k, D, I64, I32, set_mode);
+                                 seg_tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt);
   return launch_flat_inv<4096>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base,
-                               seg_tab, seg_bytes, ids, k, D, I64, I32, set_mode);
+                               seg_tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt);
 }
 
 // ---- algorithmic work of a postings scan (bench.py: the roofline of this kernel). Per (query,

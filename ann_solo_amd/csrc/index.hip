@@ -72,6 +72,9 @@ struct asl_index {
   DevBuf<float> centroids_t;
   bool cent_t_ready = false;
   DevBuf<float> kmeans_ct;       // transposed centroids of the running k-means iteration
+  DevBuf<uint2> scan_ent;        // the scan's own entry lists (the coarse stage of the NEXT batch
+  DevBuf<int32_t> scan_cnt;      // overwrites cs_ent on the other stream of the pipeline)
+  DevBuf<int> scan_over;
   DevBuf<uint2> cs_ent;
   DevBuf<int32_t> cs_cnt;
   DevBuf<int> cs_over;
@@ -469,9 +472,14 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       if (use_inv) {
         {
           ProfScope ps("scan");
+          ASL_TRY(ix->scan_ent.reserve((size_t)nq * 64));
+          ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
+          ASL_TRY(ix->scan_over.reserve(1));
+          ASL_TRY(list_nonzeros(xq, nq, d, d, ix->scan_ent.p, ix->scan_cnt.p, ix->scan_over.p));
           ASL_TRY(flat_inv_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
                                 ix->blk_offsets.p, ix->blk_base.p, ix->inv_tab.p, ix->inv_data.p,
-                                ix->ids.p, k, D, I64, I32, set_mode || ix->unordered == 1));
+                                ix->ids.p, k, D, I64, I32, set_mode || ix->unordered == 1,
+                                ix->scan_ent.p, ix->scan_cnt.p));
         }
         if (prof_enabled()) {
           // vectors scored by this launch, summed on the device (nothing waits inside a step)
@@ -558,9 +566,17 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
         ASL_TRY(sync_stream());
         ix->cbt_ready = true;
       }
+      // the queries' non-zero components as ready lists: the table build of every workgroup
+      // starts from 512 bytes instead of listing a 3.2 KB row (17 us per 16 384 queries here,
+      // ~4 us saved per (query, shard) workgroup)
+      ASL_TRY(ix->scan_ent.reserve((size_t)nq * 64));
+      ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
+      ASL_TRY(ix->scan_over.reserve(1));
+      ASL_TRY(list_nonzeros(xq, nq, d, d, ix->scan_ent.p, ix->scan_cnt.p, ix->scan_over.p));
       ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks_t.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
-                         ix->ids_tiled.p, k, D, I64, I32, ix->unordered ? ix->unordered : (set_mode ? 1 : 0)));
+                         ix->ids_tiled.p, k, D, I64, I32, ix->unordered ? ix->unordered : (set_mode ? 1 : 0),
+                         ix->scan_ent.p, ix->scan_cnt.p));
     }
     else
       ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, ix->coarse_D.p,

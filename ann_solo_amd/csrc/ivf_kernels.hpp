@@ -18,6 +18,9 @@ int gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K, i
 // coarse quantiser for sparse queries (coarse_sparse.hip)
 bool coarse_sparse_supported(int d, int nlist);
 int coarse_sparse_cap();
+// ent[q][64] = (dimension * 128, value bits) of the non-zero components of row q, ascending;
+// cnt[q] = their number or -1 - count beyond 64; *n_over += rows beyond 64
+int list_nonzeros(const float *xq, int nq, int d, int64_t ldq, uint2 *ent, int32_t *cnt, int *n_over);
 int transpose_f32(const float *in, int rows, int cols, float *out);
 int coarse_sparse(const float *xq, int nq, int d, const float *Ct, int nlist, uint2 *ent,
                   int32_t *cnt, int *n_over, int over_max, float *scores, int ld, int64_t ldq = 0);
@@ -53,7 +56,8 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                const float *coarse_D, const int32_t *coarse_I, int nprobe,
                const int32_t *list_offsets, const int32_t *tile_offsets,
                const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
-               int64_t *I64, int32_t *I32, int set_mode);
+               int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent = nullptr,
+               const int32_t *ent_cnt = nullptr);   // ent / ent_cnt: list_nonzeros (64 entries per query)
 int tile_codes(const uint8_t *codes, const int32_t *ids, const int32_t *dst_slot, int64_t n,
                int64_t ntiles, uint8_t *codes_tiled, int32_t *ids_tiled);
 // dimension-major IVF-Flat (flat_scan.hip): blocks of FI_BLK vectors with per-dimension postings
@@ -65,7 +69,8 @@ bool flat_inv_supported(int d, int k, int nprobe);
 int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *list_offsets, const int32_t *blk_offsets,
                   const uint32_t *blk_base, const uint32_t *seg_tab, const char *seg_bytes,
-                  const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode);
+                  const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode,
+                  const uint2 *ent = nullptr, const int32_t *ent_cnt = nullptr);
 int flat_inv_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *blk_offsets, const uint32_t *seg_tab, unsigned long long *out_dev);
 uint32_t inv_place_block(const uint32_t *cnt, int d, uint32_t *tab, bool *ok);

@@ -86,20 +86,47 @@ __device__ __forceinline__ float tile_adc(const char *lut_bytes, const uint4 A, 
 // per-query fixed cost of a sharded search). The non-zeros of all sub-vectors are listed
 // once (wave 0) and walked flat, U codebook loads in flight per thread: the build is
 // latency-bound otherwise. s_q: staging of the query; s_nz: 8 + 2*d bytes of scratch.
+//
+// ENTRY LISTS (ent_row != nullptr, 0 <= ent_cnt <= 64): the query's non-zero components come
+// ready-made, ascending, as (dimension * 128, value bits) -- list_nonzeros_kernel of
+// coarse_sparse.hip. Wave 0 then needs one coalesced 512-byte load instead of the 3.2 KB row,
+// its staging barrier and the serial listing: ~4 of the ~12 us a table costs, which is paid once
+// per (query, shard) in a sharded search.
 template <int NT = 256>
 __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, int d,
                                               const float *__restrict__ cbT, int dsub,
-                                              float *s_q, float *s_lut, uint8_t *s_nz, int tid) {
+                                              float *s_q, float *s_lut, uint8_t *s_nz, int tid,
+                                              const uint2 *__restrict__ ent_row = nullptr,
+                                              int ent_cnt = -1) {
   // s_nz: [0..4) K (int), [4..8) K16 = entries of the sub-quantisers 0..15, then K
-  // sub-quantiser indices at +8 and K offsets t at +8+d
-  for (int i = tid; i < d; i += NT) s_q[i] = xq_row[i];
-  __syncthreads();
-  uint8_t *nz_m = s_nz + 8, *nz_t = s_nz + 8 + d;
+  // sub-quantiser indices at +8 and K offsets t at +8+d (entry lists: t at +72, values at +136)
+  const bool fast = ent_row != nullptr && ent_cnt >= 0;      // block-uniform
+  uint8_t *nz_m = s_nz + 8, *nz_t = s_nz + 8 + (fast ? 64 : d);
+  float *nz_v = reinterpret_cast<float *>(s_nz + 136);
+  if (!fast) {
+    for (int i = tid; i < d; i += NT) s_q[i] = xq_row[i];
+    __syncthreads();
+  }
   if (tid >= 64) {  // the other waves zero the table meanwhile (sub-quantisers without non-zeros)
     float4 *z = reinterpret_cast<float4 *>(s_lut);
     for (int i = tid - 64; i < PQT_KSUB * PQT_M / 4; i += NT - 64) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  if (tid < 64) {   // wave 0: lane m lists the non-zero components of sub-vector m, in order
+  if (fast) {
+    if (tid < 64) {   // wave 0: one entry per lane (ascending dimension = ascending (m, t))
+      const bool live = tid < ent_cnt;
+      const uint2 e = live ? ent_row[tid] : make_uint2(0u, 0u);
+      const int dim = (int)(e.x >> 7);
+      const int m = dim / dsub;
+      nz_m[tid] = (uint8_t)m;
+      nz_t[tid] = (uint8_t)(dim - m * dsub);
+      nz_v[tid] = __uint_as_float(e.y);
+      const unsigned long long lo = __ballot(live && m < 16);
+      if (tid == 0) {
+        reinterpret_cast<int *>(s_nz)[0] = ent_cnt;
+        reinterpret_cast<int *>(s_nz)[1] = __popcll(lo);
+      }
+    }
+  } else if (tid < 64) {   // wave 0: lane m lists the non-zero components of sub-vector m, in order
     const int m = tid;
     // per lane a bit mask of its non-zero components, read 8 at a time (independent LDS reads
     // in flight; one read at a time made this serial listing half of the table build)
@@ -153,7 +180,7 @@ __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, 
       const int k = k0 + u < K ? k0 + u : K - 1;
       mm[u] = nz_m[k];
       const int e = mm[u] * dsub + nz_t[k];
-      qv[u] = s_q[e];
+      qv[u] = fast ? nz_v[k] : s_q[e];
       cbv[u] = cbT[(size_t)e * PQT_KSUB + c];
     }
 #pragma unroll

@@ -1,3 +1,8 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python scripts/fuzz_paths.py 1400 77 > gpurun_out/r03_fuzz_paths_long.log 2>&1; tail -2 gpurun_out/r03_fuzz_paths_long.log
-timeout 500 python scripts/fuzz_shards.py 400 5 > gpurun_out/r03_fuzz_shards2.log 2>&1; tail -1 gpurun_out/r03_fuzz_shards2.log
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for r in 1 2; do
+for lib in scripts/tmp/base.so ann_solo_amd/libannsolo_mi.so; do
+ASL_LIB_PATH=$PWD/$lib python bench.py --no-pipeline --cpu-seconds 0 --recall-queries 0 --no-fixed-recall --steps 5 --warmup 1 2>/dev/null | grep -E "^\{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); s=d['stages_ms_per_step']; print('$lib pq', 'step', d['ms_per_step'], 'scan', s['scan'])"
+ASL_LIB_PATH=$PWD/$lib python bench.py --index ivfflat --nprobe 112 --no-pipeline --cpu-seconds 0 --recall-queries 0 --steps 5 --warmup 1 2>/dev/null | grep -E "^\{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); s=d['stages_ms_per_step']; print('$lib flat', 'step', d['ms_per_step'], 'scan', s['scan'])"
+done; done
+bash scripts/ab_rank.sh scripts/tmp/base.so ann_solo_amd/libannsolo_mi.so 8 1
