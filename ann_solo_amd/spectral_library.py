@@ -127,6 +127,12 @@ class SpectralLibrary:
                                             else _reference_config())
         self.device = torch.device(device)
         cfg = self.config
+        if cfg.no_gpu:
+            # the reference's --no_gpu keeps FAISS on the CPU (spectral_library.py:73-75); this
+            # engine IS the GPU path and has no CPU fallback: say so instead of ignoring the flag
+            raise _lib.AnnSoloMiError(
+                'no_gpu=True: ann_solo_amd is the MI355X path and has no CPU fallback; run the '
+                "reference's own SpectralLibrary for a CPU search")
         k_max = _lib.TK_MAX_K
         if cfg.num_probe > k_max:
             # the reference clamps both to 1024 on the GPU (FAISS-GPU's limit, :76-87); this

@@ -249,6 +249,11 @@ def test_num_gpus_flag_needs_a_matching_job(O, monkeypatch):
         Engine(lib, config=config, device='cpu')
     config.parse(f'l.splib q.mgf out {REQUIRED} --mode bf --num_gpus 1')
     Engine(lib, config=config, device='cpu')          # 0 / 1: no sharding asked for
+    # the reference's --no_gpu cannot be honoured (no CPU fallback): refused, not ignored
+    from ann_solo_amd._lib import AnnSoloMiError
+    config.parse(f'l.splib q.mgf out {REQUIRED} --mode bf --no_gpu')
+    with pytest.raises(AnnSoloMiError, match='no CPU fallback'):
+        Engine(lib, config=config, device='cpu')
 
 
 @pytest.mark.gpu
