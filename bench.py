@@ -52,7 +52,7 @@ def main():
     ap.add_argument('--niter', type=int, default=25)
     ap.add_argument('--open-da', type=float, default=500.0)
     ap.add_argument('--scan-variant', type=int, default=0,
-                    help='A/B of scan kernels (asl_index_set_scan_variant); 0 = default')
+                    help='0 = the layout-specific kernels (default), 1 = the generic ones (asl_index_set_scan_variant)')
     ap.add_argument('--recall-queries', type=int, default=2048)
     ap.add_argument('--refine-k', type=int, default=0,
                     help="IVF-PQ: exact re-rank of the k' best ADC candidates (asl_index_set_refine); "
