@@ -242,10 +242,16 @@ def main():
             idx.shard(shard_rank, degree)
             shard_backend = HipShardBackend(sl, charge, 'open')
 
+            # the row width of the peak all-gather must be the same number on every rank: agreed
+            # once, outside the timed loop (every step then runs without that all-reduce)
+            wmax = torch.tensor([max(int(q.max_peaks()), int(cfg.max_peaks_used))], dtype=torch.int64,
+                                device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(wmax, op=dist.ReduceOp.MAX, group=group)
+            peak_width = int(wmax.item())
+
             def step():
-                # synthetic queries are processed spectra: at most max_peaks_used peaks on every rank
                 return sharded_search_batch(shard_backend, q, group=group, device_out=True,
-                                            peak_width=cfg.max_peaks_used)
+                                            peak_width=peak_width)
         else:
             step = unsharded_step
         got = step()
