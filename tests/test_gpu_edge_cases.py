@@ -64,6 +64,23 @@ def test_deferred_rescoring_cases_match_oracle(O, tol, shift):
         assert n_match > 64          # the long-match-list path was exercised
 
 
+@pytest.mark.parametrize('z', [3, 4, 5, 7, 31])
+def test_high_precursor_charges_match_oracle(O, z):
+    """Shifted matching with many shifts (S = charge + 1): the flat kernel's mass-difference
+    table holds five (charge <= 4; 3 and 5-shift tables use the exact fp64 division), charge 5+
+    goes to the pair kernel, charge >= 31 to the binary-search kernel -- all equal the oracle."""
+    rng = np.random.default_rng(40 + z)
+    lib = _spectra(rng, 150, [12, 27, 40, 64], z=z)
+    q = _spectra(rng, 60, [20, 50, 80], z=z)
+    cands, off = [], [0]
+    for qi in range(q.n):
+        c = np.sort(rng.choice(lib.n, int(rng.integers(1, 80)), replace=False)).astype(np.int64)
+        cands.append(c)
+        off.append(off[-1] + len(c))
+    for tol in (0.02, 0.3):
+        _check(O, q, lib, np.concatenate(cands), np.array(off, np.int32), tol, True)
+
+
 def test_more_than_256_peaks_is_a_capacity_error():
     from ann_solo_amd import _lib, spectrum_match
     rng = np.random.default_rng(6)
