@@ -101,7 +101,7 @@ def _lookup(obj, name):
 
 def add_arguments(parser) -> None:
     """The additive command-line flags, for the reference's parser: one call at the end of
-    ``ann_solo.config.Config.__init__`` (config.py:275, before ``self._namespace = None``):
+    ``ann_solo.config.Config.__init__`` (config.py:268, before ``self._namespace = None`` at :270):
 
         from ann_solo_amd.config import add_arguments; add_arguments(self._parser)
 

@@ -1,5 +1,5 @@
 """A stand-in with the BEHAVIOUR of the reference's configuration singleton
-(/root/reference/src/ann_solo/config.py:17-295) for tests: an argparse parser holding the
+(/root/reference/src/ann_solo/config.py:17-294) for tests: an argparse parser holding the
 reference's option names, types and defaults (as data below), ``parse(args)`` filling
 ``_namespace``, ``__getattr__`` answering from it -- ``RuntimeError`` before ``parse``,
 ``KeyError`` for an option the parser does not define (config.py:285-291) -- and
@@ -7,7 +7,7 @@ reference's option names, types and defaults (as data below), ``parse(args)`` fi
 ``Config.__init__``: one call of ``ann_solo_amd.config.add_arguments``."""
 import argparse
 
-# (flag, default, type / 'flag', required) -- config.py:52-273, the options of the search path
+# (flag, default, type / 'flag', required) -- config.py:52-267, the options of the search path
 _OPTIONS = [
     ('--resolution', None, int), ('--min_mz', 11, int), ('--max_mz', 2010, int),
     ('--remove_precursor', False, 'flag'), ('--remove_precursor_tolerance', 0, float),
