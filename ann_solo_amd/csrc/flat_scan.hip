@@ -245,7 +245,11 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
           const uint32_t pre = incl - rows_j;      // first row of my dimension
           const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
           for (uint32_t r0 = 0; r0 < R; r0 += 64) {
-            const uint32_t x = r0 + lane;          // my row
+            // my row; a lane past the last row takes the last row again with a zero query value
+            // (fmaf(0, val, acc) == acc: the accumulators are never -0), so every row the
+            // pipeline sees is a real one
+            const bool live = r0 + lane < R;
+            const uint32_t x = min(r0 + (uint32_t)lane, R - 1u);
             int lo = 0, hi = 63;                   // the last dimension with pre <= x
 #pragma unroll
             for (int it = 0; it < 6; ++it) {
@@ -256,35 +260,41 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
             const uint32_t pj = (uint32_t)__builtin_amdgcn_ds_bpermute(lo << 2, (int)pre);
             const uint32_t stj = (uint32_t)__builtin_amdgcn_ds_bpermute(lo << 2, (int)e.x);
             const uint32_t cnj = (uint32_t)__builtin_amdgcn_ds_bpermute(lo << 2, (int)e.y);
-            const float rq = __builtin_bit_cast(
+            const float rq0 = __builtin_bit_cast(
                 float, __builtin_amdgcn_ds_bpermute(lo << 2, __builtin_bit_cast(int, qv)));
+            const float rq = live ? rq0 : 0.0f;
             const uint32_t t = x - pj;             // row inside the dimension
-            const bool live = x < R;
-            const uint32_t rc = live ? min(64u, cnj - 64u * t) : 0u;    // postings in my row
-            const uint32_t rvo = live ? stj + 256u * t : 0u;             // its values ...
-            const uint32_t rlo = live ? stj + 4u * cnj + 128u * t : 0u;  // ... and local indices
+            const uint32_t rc1 = min(64u, cnj - 64u * t) - 1u;    // last lane of my row with a posting of its own
+            const uint32_t rvo = stj + 256u * t;                  // its values ...
+            const uint32_t rlo = stj + 4u * cnj + 128u * t;       // ... and local indices
             // Software pipeline over the rows, FI_U deep: row r + FI_U is requested as soon as
             // row r has been applied, so FI_U - 1 rows are always in flight (loads return in
             // order: the wait before applying r is "all but the 2 (FI_U - 1) youngest"). Loads
-            // are unconditional -- a lane without a posting repeats the row's last one (same
-            // line, no traffic; rows past the end read the block's first line) -- so no branch
-            // hides them from the wait counters, and the loop runs to a multiple of FI_U
-            // without a tail case. Rows of one dimension touch different vectors; rows of
-            // different dimensions are applied in dimension order: the canonical chain.
-            uint32_t cn[FI_U], loc[FI_U];
+            // AND updates are unconditional: a lane without a posting of its own repeats the
+            // row's last one -- same line, no traffic; it computes the same sum from the same
+            // accumulator and stores the same bits -- so the row loop has neither an execution
+            // mask nor a branch (4 of its ~20 instructions), nothing hides a load from the wait
+            // counters, and the loop runs to a multiple of FI_U without a tail case. Rows of
+            // one dimension touch different vectors; rows of different dimensions are applied in
+            // dimension order: the canonical chain.
+            uint32_t loc[FI_U];
             float qj[FI_U], val[FI_U];
 #define FI_FETCH(u, r)                                                                            \
   {                                                                                               \
     const uint32_t vo_ = (uint32_t)__builtin_amdgcn_readlane((int)rvo, (r));                      \
     const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)rlo, (r));                      \
-    cn[u] = (uint32_t)__builtin_amdgcn_readlane((int)rc, (r));                                    \
+    const uint32_t c1_ = (uint32_t)__builtin_amdgcn_readlane((int)rc1, (r));                      \
     qj[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rq), (r))); \
-    const uint32_t l_ = min((uint32_t)lane, cn[u] - 1u);                                          \
+    const uint32_t l_ = min((uint32_t)lane, c1_);                                                 \
     val[u] = *reinterpret_cast<const float *>(bptr + (vo_ + 4u * l_));                            \
     loc[u] = *reinterpret_cast<const uint16_t *>(bptr + (lo_ + 2u * l_));                         \
+    __builtin_amdgcn_sched_barrier(0);   /* the request stays here: FI_U - 1 rows in flight */     \
   }
-#define FI_APPLY(u) \
-  if ((uint32_t)lane < cn[u]) acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);
+#define FI_APPLY(u)                                              \
+  {                                                              \
+    acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);    \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  }
             const int n = (int)min(64u, R - r0);
             const int n_up = (n + FI_U - 1) & ~(FI_U - 1);
 #pragma unroll
