@@ -70,6 +70,7 @@ int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_ma
 #define FI_U_ 8
 #endif
 constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = 128, FI_U = FI_U_;
+constexpr int FI_ROWS = (FI_BLK + 63) / 64;      // rows of accumulators in a block
 #ifndef FI_PHASES
 #define FI_PHASES 0
 #endif
@@ -329,14 +330,51 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
       // raises the sync flag and waits; every wave looks at the flag between blocks (and in
       // the wait at the end of the chunk) and joins; then the row is tried again against the
       // new threshold.
-      for (int r = 0; r * 64 < nb; ++r) {
+      // A block past the first few of a query holds a handful of candidates: the wave reads
+      // all its accumulators at once (13 rows, one LDS latency instead of 13), counts what
+      // passes and, if that fits one row of slots, reserves it with ONE atomic instead of one
+      // per row.
+      bool offered = false;
+      if (!cold && !top.sort_mode) {
+        float sc[FI_ROWS];
+#pragma unroll
+        for (int r = 0; r < FI_ROWS; ++r) {
+          const int v = r * 64 + lane;
+          sc[r] = v < nb ? acc[v] : 0.0f;
+        }
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < FI_ROWS; ++r)
+          c += __popcll(__ballot(r * 64 + lane < nb && top.passes(sc[r])));
+        if (c == 0) {
+          offered = true;
+        } else if (c <= 64) {
+          int base = top.free_reserve(c);
+          if (base >= 0) {
+#pragma unroll
+            for (int r = 0; r < FI_ROWS; ++r) {
+              const int v = r * 64 + lane;
+              const bool p = v < nb && top.passes(sc[r]);
+              const unsigned long long m = __ballot(p);
+              if (m) {                                                     // wave-uniform
+                top.free_write(p, m, sc[r], (uint32_t)(pos0 + v), base);
+                base += __popcll(m);
+              }
+            }
+            offered = true;
+          }
+        }
+      }
+      for (int r = 0; !offered && r * 64 < nb; ++r) {
         const int v = r * 64 + lane;
         const float score = v < nb ? acc[v] : 0.0f;
         for (;;) {
           const bool p = v < nb && top.passes(score);
           if (!__ballot(p)) break;                                        // wave-uniform
           if (top.free_append(p, score, (uint32_t)(pos0 + v), cold)) break;
+          FI_T(4)
           sync();
+          FI_T(5)
         }
       }
       FI_T(4)

@@ -210,6 +210,23 @@ struct HistTopK {
     }
     return true;
   }
+  // The same in two steps, for a wave that offers several rows at once: one reservation of c
+  // slots (c <= 64, wave-uniform; -1: the buffer cannot take them -- nothing was written, go
+  // through free_append and the sync it asks for), then the rows' candidates one after the
+  // other into base, base + popcount(row 0), ...
+  __device__ __forceinline__ int free_reserve(int c) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&ctl[C_FILL], c);
+    base = __builtin_amdgcn_readfirstlane(base);
+    return base + c > CAP ? -1 : base;
+  }
+  __device__ __forceinline__ void free_write(bool p, unsigned long long m, float score, uint32_t slot,
+                                             int base) {
+    if (p) {
+      keys[base + __popcll(m & ((1ull << lane) - 1ull))] = ((u64)f2ord(score) << 32) | (u64)slot;
+      if (!sort_mode) atomicAdd(&hist[score_bucket(score)], 1);
+    }
+  }
   // all threads, after a barrier that every wave reached
   __device__ __forceinline__ void free_sync() {
     const int cf = ctl[C_FILL];
