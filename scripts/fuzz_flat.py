@@ -20,12 +20,15 @@ for t in range(trials):
     k = int(rng.integers(1, 2049))
     nq = int(rng.integers(1, 700))
     dup = rng.random() < 0.3          # many identical vectors: ties everywhere
+    signed = rng.random() < 0.3       # negative components too (exact cancellations, zero scores)
 
     def rows(m):
         x = np.zeros((m, d), np.float32)
         for i in range(m):
             c = rng.choice(d, size=min(nnz, d), replace=False)
             x[i, c] = rng.random(len(c)).astype(np.float32) + 0.05
+            if signed:
+                x[i, c] *= rng.choice(np.float32([-1.0, 1.0]), size=len(c))
         x /= np.linalg.norm(x, axis=1, keepdims=True)
         return x
     xb = rows(n if not dup else max(50, n // 40))
