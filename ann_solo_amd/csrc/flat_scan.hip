@@ -69,7 +69,12 @@ int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_ma
 #ifndef FI_U_
 #define FI_U_ 8
 #endif
-constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = 128, FI_U = FI_U_;
+#ifndef FI_CHUNK_
+#define FI_CHUNK_ 256
+#endif
+// FI_CHUNK: blocks of a query listed at a time (a query of the bench probes ~150: one chunk, so the
+// waves of a workgroup wait for each other once per query)
+constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = FI_CHUNK_, FI_U = FI_U_;
 constexpr int FI_ROWS = (FI_BLK + 63) / 64;      // rows of accumulators in a block
 #ifndef FI_PHASES
 #define FI_PHASES 0
@@ -90,9 +95,7 @@ static_assert(64 % FI_U == 0, "a batch of dimensions must not straddle the 64 la
 struct FiUnit {
   uint32_t blk;   // block index into the per-dimension table
   int32_t pos0;   // list-order position of the block's first vector
-  int32_t nb;     // vectors in the block
-  uint32_t base;  // the block's postings start here, in 64-byte units
-};
+};                // (+ the block's vector count in a 16-bit array: 10 bytes per block of a chunk)
 
 // FI_CAP: key buffer of the top-k (2048: k <= 1280, three workgroups per CU; 4096: k <= 3328, two)
 template <int FI_CAP>
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   float *s_nzv = s_acc + FI_NW * FI_BLK;                                   // [d]
   FiUnit *table = reinterpret_cast<FiUnit *>(s_nzv + ((d + 3) & ~3));      // [FI_CHUNK]
   int *s_misc = reinterpret_cast<int *>(table + FI_CHUNK);                 // [16]
-  uint16_t *s_nzd = reinterpret_cast<uint16_t *>(s_misc + 16);             // [d]
+  uint16_t *s_nzd = reinterpret_cast<uint16_t *>(s_misc + 16);             // [d rounded up to 8]
+  uint16_t *s_nbv = s_nzd + ((d + 7) & ~7);                                // [FI_CHUNK] vectors per block
   volatile int *s_flag = s_misc + 9;      // a wave asks for a sync of the top-k
   int *s_done = s_misc + 10;              // waves that finished their blocks, summed over the chunks
   int *s_next = s_misc + 11;              // next block of the chunk to hand out
@@ -190,9 +194,8 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
         FiUnit u;
         u.blk = (uint32_t)(my_b0 + j);
         u.pos0 = my_pos + j * FI_BLK;
-        u.nb = min(FI_BLK, my_len - j * FI_BLK);
-        u.base = blk_base[my_b0 + j];
         table[t - c0] = u;
+        s_nbv[t - c0] = (uint16_t)min(FI_BLK, my_len - j * FI_BLK);
       }
     }
     __syncthreads();
@@ -208,11 +211,10 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
       int nb = 0, pos0 = 0;
       if (i < nent) {          // wave-uniform
         const FiUnit u = table[i];
-        nb = __builtin_amdgcn_readfirstlane(u.nb);
+        nb = __builtin_amdgcn_readfirstlane((int)s_nbv[i]);
         pos0 = __builtin_amdgcn_readfirstlane(u.pos0);
         const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.blk);
-        const char *bptr =
-            seg_bytes + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)u.base) * 64;
+        const char *bptr = seg_bytes + (size_t)blk_base[blk] * 64;     // (a scalar load: blk is wave-uniform)
         for (int o = lane; o < nb; o += 64) acc[o] = 0.0f;
         const uint32_t *erow = seg_tab + (size_t)blk * d;
         for (int kk0 = 0; kk0 < K; kk0 += 64) {
@@ -436,7 +438,7 @@ static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse
                            const int32_t *ent_cnt) {
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   const size_t lds = TopK::lds_bytes() + (size_t)FI_NW * FI_BLK * 4 + (size_t)((d + 3) & ~3) * 4 +
-                     (size_t)FI_CHUNK * sizeof(FiUnit) + 64 + (size_t)((d + 7) & ~7) * 2;
+                     (size_t)FI_CHUNK * (sizeof(FiUnit) + 2) + 64 + (size_t)((d + 7) & ~7) * 2;
   if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "flat scan: d=%d does not fit LDS", d);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)flat_inv_scan_kernel<FI_CAP>,
