@@ -842,6 +842,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, RS_OCC) void rescore_score_v2_kernel
 constexpr int RF_NC = 32;        // candidates per wave chunk (set-up lanes)
 constexpr int RF_PMAX = 1024;    // candidate peaks per wave chunk (owner table)
 constexpr int RF_SMAX = 5;       // shifts the mass-difference table holds (precursor charge <= 4)
+constexpr int RF_MQ = 128;       // (peak, shift) items queued per wave before a drain
 
 struct FlatLds {   // per wave
   double sum[RF_NC];
@@ -855,6 +856,7 @@ struct FlatLds {   // per wave
   uint32_t rec[RF_NC];             // peaks | shifts << 8 | precursor charge << 16
   uint16_t pref[RF_NC];            // first stream position
   uint8_t owner[RF_PMAX];
+  uint16_t mq[RF_MQ];              // queued (peak | shift << 10) items whose bin is marked
 };
 
 #ifndef RF_OCC
@@ -1030,46 +1032,57 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
       }
       wave_sync();
 
-      // ---- the chunk's peaks as one stream, loads one step ahead
-      float n_cm = 0.0f, n_ci = 0.0f;
-      int n_cc = 0, n_tt = 0, n_j = 0, n_co = 0;
+      // ---- the chunk's peaks as one stream, loads one step ahead. The stream needs a peak's m/z
+      // and fragment charge only; intensities are read by the drain, for the peaks that hit
+      float n_cm = 0.0f;
+      int n_cc = 0, n_tt = 0;
       uint32_t n_rec = 0;
       auto fetch = [&](int p0) {
         const int p = p0 + lane;
         const bool act = p < P;
         n_tt = act ? (int)Wv.owner[p] : 0;
         n_rec = act ? Wv.rec[n_tt] : 0u;
-        n_j = p - (int)Wv.pref[n_tt];
-        n_co = Wv.base[n_tt];
+        const int n_j = p - (int)Wv.pref[n_tt];
+        const int n_co = Wv.base[n_tt];
         if (L.records && cv.flt.meta) {      // [mz x cn][intensity x cn][charge x cn], one record
           const float *rf = reinterpret_cast<const float *>(L.records) + (uint32_t)n_co;
           const int cnr = (int)(n_rec & 0xffu);
           n_cm = act ? rf[n_j] : 0.0f;
-          n_ci = act ? rf[cnr + n_j] : 0.0f;
           n_cc = act ? (int)reinterpret_cast<const uint8_t *>(rf)[8 * cnr + n_j] : 0;
         } else {
           n_cm = act ? L.mz[n_co + n_j] : 0.0f;
-          n_ci = act ? L.intensity[n_co + n_j] : 0.0f;
           n_cc = (act && L.charge) ? (int)L.charge[n_co + n_j] : 0;
         }
       };
-      if (P > 0) fetch(0);
-      for (int p0 = 0; p0 < P; p0 += 64) {
-        const float cm = n_cm, ci = n_ci;
-        const int cc = n_cc, tt = n_tt, j = n_j, co = n_co;
-        const int cn = (int)(n_rec & 0xffu), Sc = (int)((n_rec >> 8) & 0xffu);
-        const bool act = p0 + lane < P;
-        if (p0 + 64 < P) fetch(p0 + 64);
-        // shifts this peak takes part in (cpp:58-75): every s < S for an unannotated peak, else
-        // s = 0 and s = its fragment charge
-        const uint32_t smask = !act ? 0u : cc == 0 ? (1u << Sc) - 1u : (1u | (cc < Sc ? 1u << cc : 0u));
-        for (int s = 0; s < Smaxw; ++s) {        // wave-uniform
-          const bool can = (smask >> s) & 1u;
-          const float mdv = s ? Wv.mdf[tt][s - 1] : 0.0f;
-          const int b = (int)floorf((cm + mdv) * inv_w_f);
-          const bool maybe = can && bm_test(H, b);
-          if (!__ballot(maybe)) continue;         // wave-uniform
-          if (maybe) {
+      // ---- queued (peak, shift) items, a row at a time: everything about the item is looked up
+      // again (the peak's values come from the lines the stream has just read)
+      int mq_n = 0;
+      auto drain = [&]() {
+        wave_sync();
+        for (int e0 = 0; e0 < mq_n; e0 += 64) {
+          const bool on = e0 + lane < mq_n;
+          const uint32_t ent = on ? (uint32_t)Wv.mq[e0 + lane] : 0u;
+          const int s = (int)(ent >> 10), p = (int)(ent & 1023u);
+          const int tt = (int)Wv.owner[p];
+          const int j = p - (int)Wv.pref[tt], co = Wv.base[tt];
+          const int cn = (int)(Wv.rec[tt] & 0xffu);
+          float cm = 0.0f, ci = 0.0f;
+          int cc = 0;
+          if (on) {
+            if (L.records && cv.flt.meta) {
+              const float *rf = reinterpret_cast<const float *>(L.records) + (uint32_t)co;
+              cm = rf[j];
+              ci = rf[cn + j];
+              cc = (int)reinterpret_cast<const uint8_t *>(rf)[8 * cn + j];
+            } else {
+              cm = L.mz[co + j];
+              ci = L.intensity[co + j];
+              cc = L.charge ? (int)L.charge[co + j] : 0;
+            }
+          }
+          if (on) {
+            const float mdv = s ? Wv.mdf[tt][s - 1] : 0.0f;
+            const int b = (int)floorf((cm + mdv) * inv_w_f);
             const double pm = Wv.pmd[tt];
             const double md = s == 0 ? 0.0 : s == 1 ? pm : s == 2 ? pm * 0.5 : s == 4 ? pm * 0.25 : pm / (double)s;
             const double mult = (s == 0 || cc == s) ? 1.0 : 2.0 / 3.0;
@@ -1113,7 +1126,36 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
             }
           }
         }
+        mq_n = 0;
+        wave_sync();
+      };
+      if (P > 0) fetch(0);
+      for (int p0 = 0; p0 < P; p0 += 64) {
+        const float cm = n_cm;
+        const int cc = n_cc, tt = n_tt;
+        const int Sc = (int)((n_rec >> 8) & 0xffu);
+        const bool act = p0 + lane < P;
+        if (p0 + 64 < P) fetch(p0 + 64);
+        // shifts this peak takes part in (cpp:58-75): every s < S for an unannotated peak, else
+        // s = 0 and s = its fragment charge. A (peak, shift) whose bin is marked goes to the
+        // wave's queue; the probing proper runs over full rows of queued items (drain) instead
+        // of inside this loop with the one or two lanes that hit.
+        const uint32_t smask = !act ? 0u : cc == 0 ? (1u << Sc) - 1u : (1u | (cc < Sc ? 1u << cc : 0u));
+        for (int s = 0; s < Smaxw; ++s) {        // wave-uniform
+          const bool can = (smask >> s) & 1u;
+          const float mdv = s ? Wv.mdf[tt][s - 1] : 0.0f;
+          const int b = (int)floorf((cm + mdv) * inv_w_f);
+          const bool maybe = can && bm_test(H, b);
+          const unsigned long long mm = __ballot(maybe);
+          if (!mm) continue;                      // wave-uniform
+          const int c = __popcll(mm);
+          if (mq_n + c > RF_MQ) drain();
+          if (maybe)
+            Wv.mq[mq_n + __popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)((p0 + lane) | (s << 10));
+          mq_n += c;
+        }
       }
+      drain();
       wave_sync();
       // ---- scores of the chunk
       if (take && hi == 0) {
