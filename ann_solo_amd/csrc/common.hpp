@@ -180,11 +180,15 @@ struct DevPeaks {
   const uint8_t *charge = nullptr;  // may be nullptr
   const double *precursor_mz = nullptr;
   const int32_t *precursor_charge = nullptr;
-  // library only (asl_library): every spectrum's peaks as ONE record, [mz f32 x n][intensity f32
-  // x n][charge u8 x n] at a 16-byte aligned offset (RowMeta::rec4) -- 3 cache lines per
-  // candidate instead of 5 from the three arrays above
+  // library only (asl_library): every spectrum's peaks as ONE record, [mz f32 x n][charge u8 x n]
+  // [intensity f32 x n, at float index rec_int0(n)] at a 16-byte aligned offset (RowMeta::rec4).
+  // The rescoring stream reads m/z and charges -- the first 5 n bytes, one or two cache lines --
+  // and the intensities only of the peaks that match
   const uint8_t *records = nullptr;
 };
+// float index of the first intensity in a record of n peaks; the record's size in bytes
+__host__ __device__ inline int rec_int0(int n) { return n + ((n + 3) >> 2); }
+__host__ __device__ inline uint64_t rec_bytes(uint64_t n) { return 4ull * (uint64_t)rec_int0((int)n) + 4ull * n; }
 
 struct PeaksStage {  // stages an asl_peaks_t whose arrays may be on the host
   In<int32_t> offsets, pcharge;

@@ -421,7 +421,9 @@ struct PairLds {   // per wave
   int pad[3];
 };
 
-__device__ __forceinline__ uint32_t hbit(int b) { return ((uint32_t)b * 2654435761u) >> 18; }
+// bit of a bin in the query's bin filter: the bin's low bits (bins 16 384 apart = 650 Da at the
+// default tolerance share a bit; as dense as a multiplicative hash, without the quarter-rate multiply)
+__device__ __forceinline__ uint32_t hbit(int b) { return (uint32_t)b & (uint32_t)(RS_BM_BITS - 1); }
 __device__ __forceinline__ bool bm_test(const HashLds &H, int b) {
   const uint32_t bit = hbit(b);
   return (H.bm[bit >> 5] >> (bit & 31)) & 1u;
@@ -1044,11 +1046,11 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
         n_rec = act ? Wv.rec[n_tt] : 0u;
         const int n_j = p - (int)Wv.pref[n_tt];
         const int n_co = Wv.base[n_tt];
-        if (L.records && cv.flt.meta) {      // [mz x cn][intensity x cn][charge x cn], one record
+        if (L.records && cv.flt.meta) {      // [mz x cn][charge x cn][intensity x cn], one record
           const float *rf = reinterpret_cast<const float *>(L.records) + (uint32_t)n_co;
           const int cnr = (int)(n_rec & 0xffu);
           n_cm = act ? rf[n_j] : 0.0f;
-          n_cc = act ? (int)reinterpret_cast<const uint8_t *>(rf)[8 * cnr + n_j] : 0;
+          n_cc = act ? (int)reinterpret_cast<const uint8_t *>(rf)[4 * cnr + n_j] : 0;
         } else {
           n_cm = act ? L.mz[n_co + n_j] : 0.0f;
           n_cc = (act && L.charge) ? (int)L.charge[n_co + n_j] : 0;
@@ -1072,8 +1074,8 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
             if (L.records && cv.flt.meta) {
               const float *rf = reinterpret_cast<const float *>(L.records) + (uint32_t)co;
               cm = rf[j];
-              ci = rf[cn + j];
-              cc = (int)reinterpret_cast<const uint8_t *>(rf)[8 * cn + j];
+              ci = rf[rec_int0(cn) + j];
+              cc = (int)reinterpret_cast<const uint8_t *>(rf)[4 * cn + j];
             } else {
               cm = L.mz[co + j];
               ci = L.intensity[co + j];
@@ -1141,19 +1143,20 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
         // wave's queue; the probing proper runs over full rows of queued items (drain) instead
         // of inside this loop with the one or two lanes that hit.
         const uint32_t smask = !act ? 0u : cc == 0 ? (1u << Sc) - 1u : (1u | (cc < Sc ? 1u << cc : 0u));
-        for (int s = 0; s < Smaxw; ++s) {        // wave-uniform
+        auto probe = [&](int s, float mdv) {
           const bool can = (smask >> s) & 1u;
-          const float mdv = s ? Wv.mdf[tt][s - 1] : 0.0f;
           const int b = (int)floorf((cm + mdv) * inv_w_f);
           const bool maybe = can && bm_test(H, b);
           const unsigned long long mm = __ballot(maybe);
-          if (!mm) continue;                      // wave-uniform
+          if (!mm) return;                        // wave-uniform
           const int c = __popcll(mm);
           if (mq_n + c > RF_MQ) drain();
           if (maybe)
             Wv.mq[mq_n + __popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)((p0 + lane) | (s << 10));
           mq_n += c;
-        }
+        };
+        probe(0, 0.0f);
+        for (int s = 1; s < Smaxw; ++s) probe(s, Wv.mdf[tt][s - 1]);        // wave-uniform bound
       }
       drain();
       wave_sync();

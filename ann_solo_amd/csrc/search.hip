@@ -110,8 +110,8 @@ __global__ void pack_records_kernel(const int32_t *__restrict__ offsets, const f
   float *f = reinterpret_cast<float *>(b);
   for (int j = lane; j < cn; j += 64) {
     f[j] = mz[co + j];
-    f[cn + j] = inten[co + j];
-    b[8 * (size_t)cn + j] = chg[co + j];
+    b[4 * (size_t)cn + j] = chg[co + j];
+    f[rec_int0(cn) + j] = inten[co + j];
   }
 }
 
@@ -190,7 +190,7 @@ asl_library_t *asl_library_create(const asl_peaks_t *p, const float *lib_pmz_f32
       hm[i].rec4 = (uint32_t)(rec_bytes >> 2);
       hm[i].pad = 0u;
       h_wcol[i] = hm[i].pmz32;
-      rec_bytes += ((uint64_t)hm[i].cn * 9 + 15) & ~15ull;
+      rec_bytes += (asl::rec_bytes((uint64_t)hm[i].cn) + 15) & ~15ull;
     }
     if (rec_bytes >= (1ull << 34)) {     // rec4 is 32 bits of 4-byte units
       ok = false;
