@@ -5,9 +5,11 @@
 // Pass 1a (rescore_flat_kernel): one workgroup per query. The query's peaks are hashed once
 // into LDS (m/z bins of width 2*tol + a bitmap of occupied bins); the candidate list is
 // filtered (precursor window, rescore.hpp) and compacted in LDS; a wave sets 32 candidates up
-// one lane each and walks their peaks as ONE stream, a peak per lane, probing the hash for
-// every shift; a match is accumulated where it is found (LDS atomics: masks of matched peaks,
-// exponent range, exact fp64 sum). Candidates with a doubly matched peak are marked for
+// one lane each and walks their peaks (m/z and fragment charge) as ONE stream, a peak per lane,
+// testing the bitmap for every shift; the (peak, shift) items whose bin is marked are queued
+// and probed -- hash walk, exact window / cursor predicate -- a full row of lanes at a time;
+// a match is accumulated where it is found (LDS atomics: masks of matched peaks, exponent
+// range, exact fp64 sum). Candidates with a doubly matched peak are marked for
 // Pass 1b (rescore_score_v2_kernel, the pair kernel): two candidates per wave, one per
 // half-wave, matches into per-half LDS lists keyed (product desc, generation order asc),
 // resolved by a conflict-free fast path or a bitonic sort + scalar greedy loop. What neither
