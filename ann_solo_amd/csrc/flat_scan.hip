@@ -57,15 +57,16 @@ int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_ma
 // ~25 % padding. A wave takes one (query, block): it zeroes the block's accumulators in LDS
 // and walks the query's non-zero dimensions in ASCENDING order, acc[loc] = fmaf(q_d, val,
 // acc[loc]) over that dimension's postings (a vector occurs at most once per dimension, so
-// the lanes of one step never collide, and steps of one wave reach LDS in program order).
+// the lanes of one step never collide -- lanes past a row's count repeat its last posting and
+// store the same bits, see the row loop -- and steps of one wave reach LDS in program order).
 // Per vector this is the ascending-dimension fp32 chain restricted to the dimensions where
 // both factors are non-zero -- bit-identical to the dense chain, the MFMA GEMM and the oracle
 // (a zero factor leaves the accumulator unchanged) -- at 1/16 of the tile kernel's traffic
 // (50 of 800 dimensions) and 1/4 of its lane-steps. Then the wave offers its accumulators to
 // the workgroup's histogram top-k, vectors with score 0 included (they are candidates of the
 // dense scan too). The eight waves of a workgroup run their blocks independently (blocks are
-// handed out by an LDS counter, appends are one atomic per row of candidates) and meet only
-// when the key buffer is full: see "Offers" below.
+// handed out by an LDS counter, a block's candidates are appended with one atomic, or one per
+// row when they are many) and meet only when the key buffer is full: see "Offers" below.
 #ifndef FI_U_
 #define FI_U_ 8
 #endif

@@ -864,7 +864,7 @@ struct FlatLds {   // per wave
 };
 
 #ifndef RF_OCC
-#define RF_OCC 6      // waves per SIMD: 80 VGPRs, no spills (7 / 8: 72 / 64 VGPRs with spills: +2 % / +12 %, profiles/r03_rescore_ab.txt)
+#define RF_OCC 6      // waves per SIMD: 80 VGPRs (7 / 8: 72 / 64 VGPRs and more spills: +2 % / +12 %, profiles/r03_rescore_ab.txt)
 #endif
 template <int FORM>
 __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(

@@ -130,6 +130,39 @@ def test_rescoring_few_queries_long_lists(O, data):
         _check_rescoring(O, Q, L, cand, off, tol, shift, res)
 
 
+def test_rescoring_many_hits_per_chunk(O):
+    """A library of copies and near-copies of one spectrum, queried with it: every chunk of 32
+    candidates holds > 1 000 (peak, shift) items whose bin is marked, so the per-wave queue of the
+    flat kernel (128 items) drains many times inside the peak stream; copies with a peak moved by
+    half a tolerance give doubly matched peaks (second launch) beside the plain ones."""
+    from ann_solo_amd import spectrum_match, synthetic
+    from ann_solo_amd.packed import PackedSpectra
+    lib, aux = synthetic.make_library(400, seed=31, device='cpu')
+    o, mz, it, chg, pmz, pz = lib.numpy()
+    a, b = int(o[7]), int(o[8])
+    n = b - a
+    rng = np.random.default_rng(5)
+    copies = 300
+    O2 = np.arange(copies + 1, dtype=np.int32) * n
+    MZ, IT, CH = np.tile(mz[a:b], copies), np.tile(it[a:b], copies), np.tile(chg[a:b], copies)
+    for c in range(0, copies, 3):           # every third copy: one peak moved next to its neighbour
+        j = int(rng.integers(1, n))
+        MZ[c * n + j] = MZ[c * n + j - 1] + np.float32(0.008)
+        seg = slice(c * n, (c + 1) * n)
+        order = np.argsort(MZ[seg], kind='stable')
+        MZ[seg], IT[seg], CH[seg] = MZ[seg][order], IT[seg][order], CH[seg][order]
+    PM = np.full(copies, pmz[7]) + rng.normal(0, 30.0, copies)      # open-search mass differences: shifts on
+    PZ = np.full(copies, pz[7], np.int32)
+    L2 = PackedSpectra.from_numpy(O2, MZ, IT, CH, PM, PZ)
+    q = lib.select(torch.tensor([7, 7, 8]))
+    L, Q = O.Spectra(*L2.numpy()), O.Spectra(*q.numpy())
+    cand = np.concatenate([np.arange(copies), np.arange(copies)[::-1], np.arange(0, copies, 2)]).astype(np.int64)
+    off = np.array([0, copies, 2 * copies, 2 * copies + len(range(0, copies, 2))], np.int32)
+    for tol, shift in ((0.02, True), (0.02, False), (0.05, True)):
+        res = spectrum_match.rescore_batch(q, L2, cand, off, tol, shift)
+        _check_rescoring(O, Q, L, cand, off, tol, shift, res)
+
+
 def test_rescoring_vs_reference_golden(O, golden):
     """Every case of tests/golden/rescoring_golden.npz (outputs of the reference's own
     SpectrumMatch.cpp): best index, score within 1e-12, peak matches as a set."""
