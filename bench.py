@@ -285,6 +285,20 @@ def main():
         L.asl_profile_get(name.encode(), C.byref(ms), C.byref(n))
         stages[name] = {'ms_total': ms.value, 'launches': n.value}
     scanned = L.asl_profile_scanned_vectors()
+    # the dominant kernel on its own (outside the timed region): in the pipelined step it shares
+    # the chip with the rescoring of the previous batch, which `roofline` (timed region) includes
+    scan_alone_ms = None
+    if pipelined and world == 1:
+        L.asl_profile_reset()
+        L.asl_profile_enable(1)
+        for _ in range(3):
+            step()
+        sl.synchronize()
+        L.asl_profile_enable(0)
+        ms_a, n_a = C.c_double(), C.c_int64()
+        L.asl_profile_get(b'scan', C.byref(ms_a), C.byref(n_a))
+        if n_a.value > 0:
+            scan_alone_ms = ms_a.value / n_a.value
 
     # ---- the same metric at FIXED RECALL: IVF-Flat over the same library and the
     # same coarse quantiser, at the smallest nprobe (steps of 8) whose recall@k is still >= 0.95 x
@@ -328,6 +342,18 @@ def main():
         L.asl_profile_get(b'scan', C.byref(ms_f), C.byref(n_f))
         res_f = flat_step()
         sl_f.synchronize()
+        alone_f = None
+        if pipelined:           # the scan kernel on its own, as for the headline kernel below
+            L.asl_profile_reset()
+            L.asl_profile_enable(1)
+            for _ in range(3):
+                flat_step()
+            sl_f.synchronize()
+            L.asl_profile_enable(0)
+            ms_a, n_a = C.c_double(), C.c_int64()
+            L.asl_profile_get(b'scan', C.byref(ms_a), C.byref(n_a))
+            if n_a.value > 0:
+                alone_f = ms_a.value / n_a.value
         fixed_recall = {'index': 'ivfflat', 'nlist': args.nlist, 'nprobe': best,
                         'same_coarse_quantiser_as_the_ivfpq_index': same_q,
                         'recall_at_k_vs_exact_ip': best_rec,
@@ -337,6 +363,13 @@ def main():
                         'scan_ms_per_step': round(ms_f.value / max(args.steps, 1), 3),
                         'pipelined': pipelined,
                         'roofline': postings_roofline(sl_f, idx_f, q, best, ms_f.value / max(n_f.value, 1), args)}
+        if alone_f:
+            rf_ = fixed_recall['roofline']
+            avg_f = ms_f.value / max(n_f.value, 1)
+            rf_['kernel_alone'] = {'avg_launch_ms': round(alone_f, 4),
+                                   'frac': round(rf_['frac'] * avg_f / alone_f, 5),
+                                   'frac_by_lines': round(rf_['frac_by_lines'] * avg_f / alone_f, 5),
+                                   'note': '3 launches after the timed region, stages strictly one after the other'}
         if args.cpu_seconds > 0:
             # the SAME index (this leg's 25-iteration quantiser, nprobe = best) against the oracle:
             # neighbour id sets, winners and scores of a sample of the batch
@@ -371,6 +404,12 @@ def main():
             else:
                 roofline = postings_roofline(sl, idx, q, args.nprobe, avg_ms, args if world == 1 else None)
             roofline['vectors_scanned_per_query'] = round(scanned / args.steps / (degree * args.batch), 1)
+            if scan_alone_ms:
+                roofline['kernel_alone'] = {
+                    'avg_launch_ms': round(scan_alone_ms, 4),
+                    'frac': round(roofline['frac'] * avg_ms / scan_alone_ms, 5),
+                    'note': '3 launches after the timed region with the stages of consecutive batches '
+                            'strictly one after the other (no rescoring kernel beside the scan)'}
             if args.index == 'ivfpq':
                 # the ids are read for survivors only: SURVEY.md 8(d)'s "ids implicit" variant
                 codes = achieved * BYTES_PER_CODE / BYTES_PER_SCANNED_VECTOR
