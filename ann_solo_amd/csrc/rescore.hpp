@@ -31,6 +31,9 @@ struct PrecFilter {
   // the window column alone, NaN for invalid spectra (4 bytes per row: the flat kernel filters
   // 16.7 M slots per batch on it and touches the 32-byte records of the survivors only)
   const float *wcol = nullptr;
+  // window-only modes: the candidate rows ARE the window's hits; `meta` is passed for the packed
+  // rows (one gather per candidate, one peak record) and nothing is filtered
+  bool pass_all = false;
 };
 
 // spectral_library.py:421-427 (numexpr evaluates in float64)
@@ -42,6 +45,7 @@ __device__ __forceinline__ bool precursor_ok(double q, float lib, int charge, do
 }
 
 __device__ __forceinline__ bool filter_pass(const PrecFilter &f, double q_pmz, long long row) {
+  if (f.pass_all) return true;
   if (f.wcol) return precursor_ok(q_pmz, f.wcol[row], f.charge, f.tol, f.mode);
   if (f.meta) return precursor_ok(q_pmz, f.meta[row].pmz32, f.charge, f.tol, f.mode);
   if (!f.lib_pmz) return true;

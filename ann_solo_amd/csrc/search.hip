@@ -509,10 +509,13 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
                                        P->precursor_mode, &total));
     }
     ASL_TRY(L->pair_score.reserve((size_t)std::max<int64_t>(total, 1)));
+    PrecFilter rows_only;       // packed row records for the kernels, no second filtering
+    rows_only.meta = L->meta.p;
+    rows_only.pass_all = true;
     ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->cand.p, L->woff.p, 0, total,
                            P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
                            L->best_slot.p, nullptr, o_row.d, o_score.d, o_ncand.d, o_cnt.d,
-                           o_pairs.d, pm_stride, L->status.p));
+                           o_pairs.d, pm_stride, L->status.p, rows_only));
   }
   ASL_TRY(o_row.finish());
   ASL_TRY(o_score.finish());
