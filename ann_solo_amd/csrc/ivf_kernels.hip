@@ -136,7 +136,10 @@ __global__ __launch_bounds__(TK_NT) void row_select_kernel(
       if (c < n && bk[u] >= bstar) buf[pos++] = make_key(v[u], (uint32_t)c);
     }
     __syncthreads();
-    block_sort_desc<TK_NT, SEL_CAP / TK_NT>(buf, tid, SEL_CAP);
+    if (total <= TK_NT)      // block-uniform; the usual case (k = nprobe <= 128): half the sort
+      block_sort_desc<TK_NT, 1>(buf, tid, TK_NT);
+    else
+      block_sort_desc<TK_NT, SEL_CAP / TK_NT>(buf, tid, SEL_CAP);
     const int f = total < k ? total : k;
     for (int i = tid; i < k; i += TK_NT) {
       const u64 key = buf[i];
