@@ -1,6 +1,7 @@
 """Measurement helper: per-wave phase durations of flat_inv_scan_kernel (IVF-Flat postings scan).
 Needs a library whose flat_scan.hip was compiled with -DFI_PHASES=1 (results are replaced by the
-timers):   ASL_LIB_PATH=build_ab/lib_phases.so python scripts/flat_phases.py [nprobe]"""
+timers):   scripts/build_variant.sh scripts/tmp/phases.so "-DFI_PHASES=1" && \
+           ASL_LIB_PATH=scripts/tmp/phases.so python scripts/flat_phases.py [nprobe]"""
 import os
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
@@ -28,7 +29,7 @@ torch.cuda.synchronize()
 print('search call: %.2f ms' % ev0.elapsed_time(ev1))
 ph = torch.as_tensor(D)[:, :64].double().reshape(-1, 8, 8) / 100.0      # us, [query, wave, phase]
 names = ['prologue', 'chunk table + end barrier', 'zero + table fetch', 'rows',
-         'cold start + offers (incl. syncs asked for)', 'syncs joined between blocks', 'end-of-chunk wait', 'finish']
+         'cold start + offers', 'syncs (asked for inside the offers or joined between blocks)', 'end-of-chunk wait', 'finish']
 m = ph.mean((0, 1))
 for n, v in zip(names, m):
     print(f'{n:32s} {v:8.1f} us per wave per query')
