@@ -224,14 +224,25 @@ def ptr(a):
     if hasattr(a, 'data_ptr'):
         if not a.is_contiguous():
             raise ValueError('tensor must be contiguous')
+        if a.is_cuda:
+            _require_default_stream(a.device)
         return a.data_ptr()
     raise TypeError(type(a))
 
 
-def use_torch_stream():
-    """Issue library work on torch's current HIP stream."""
+def _require_default_stream(device):
+    """The library issues its kernels on the null stream (and, in pipeline mode, on streams of
+    its own that it orders against the null stream). That is ordered with PyTorch only while
+    PyTorch's CURRENT stream is its default stream: under ``torch.cuda.stream(s)`` with a
+    non-blocking ``s`` the tensors handed over here could still be written, or be read back
+    before the library has finished. Every device tensor crosses ``ptr()``, so the check lives
+    here and such a call fails instead of racing."""
     import torch
-    check(lib().asl_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    if torch.cuda.current_stream(device) != torch.cuda.default_stream(device):
+        raise AnnSoloMiError(
+            'libannsolo_mi issues its work on the default HIP stream: call it with '
+            "PyTorch's default stream current (not inside torch.cuda.stream(...)), or "
+            'synchronise the side stream and switch back first')
 
 
 def peaks_struct(p) -> AslPeaks:

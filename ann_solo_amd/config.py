@@ -1,8 +1,22 @@
 """The options that reach the hot path.
 
-``Config`` carries the reference's flags under the reference's names and defaults
+``Config`` carries the reference's flags under the reference's names
 (/root/reference/src/ann_solo/config.py:62-216) plus the ADDITIVE flags of this implementation
-(``index``, ``pq_m``, ``pq_bits``, ``refine_k``, ``kmeans_niter``, ``ann_seed``, ``num_gpus``).
+(``index``, ``pq_m``, ``pq_bits``, ``refine_k``, ``kmeans_niter``, ``ann_seed``, ``num_gpus``,
+``flat_storage``). Defaults are the reference's, with these DELIBERATE deviations, all of them
+options the reference's parser makes the user state (so a parsed reference configuration never
+meets them; they only matter to ``Config()`` built by hand, as the tests and ``bench.py`` do):
+``precursor_tolerance_mass`` / ``precursor_tolerance_mode`` / ``fragment_mz_tolerance`` are
+REQUIRED there (config.py:137-150) and default here to 20 ppm / 0.02 Da (the values of the
+reference's notebooks); ``precursor_tolerance_mass_open`` / ``_mode_open`` default to ``None``
+there (cascade off, config.py:151-156) and to 300 Da here; ``allow_peak_shifts`` is a
+``store_true`` flag there (default False, config.py:157) and True here. ``tests/ref_config.py``
+holds the reference's own defaults; ``Config.from_reference`` takes every value from the parsed
+reference object, so none of these defaults survives an integration.
+
+Capacity limits of the device kernels are checked at construction (``ValueError``), not deep
+inside a search: ``max_peaks_used`` / ``max_peaks_used_library`` <= 256 (the reference has no
+limit; its default is 50), ``num_candidates`` and ``num_probe`` <= 2048.
 ``Config.from_reference(obj)`` snapshots any configuration object -- in particular the
 reference's own ``ann_solo.config.config`` singleton, whose ``__getattr__`` answers unknown
 options with ``KeyError`` (config.py:285-291), not ``AttributeError`` -- so the engine can be
@@ -16,7 +30,7 @@ _MISSING = object()
 
 @dataclass
 class Config:
-    # --- the reference's flags (config.py:62-216), same names, same defaults
+    # --- the reference's flags (config.py:62-216), same names; defaults: see the module docstring
     resolution: Optional[int] = None
     min_mz: int = 11
     max_mz: int = 2010
@@ -59,6 +73,24 @@ class Config:
     kmeans_niter: int = 25                  # FAISS' ClusteringParameters.niter default
     seed: int = 1234                        # flag --ann_seed; FAISS' ClusteringParameters.seed default
     num_gpus: int = 0                       # > 1: list-shard the ANN indexes over that many ranks
+    flat_storage: str = 'fx22'              # IVF-Flat component storage: 'fx22' (22-bit fixed point
+                                            # for components in [0, 1): 4-byte postings) | 'fp32'
+
+    MAX_PEAKS = 256      # peaks per spectrum the preprocessing / rescoring kernels hold (csrc/process.hip)
+    MAX_TOPK = 2048      # largest k / nprobe of the LDS top-k (csrc/ivf_kernels.hpp: TK_MAX_K)
+
+    def __post_init__(self):
+        for name in ('max_peaks_used', 'max_peaks_used_library'):
+            v = getattr(self, name)
+            if v is not None and int(v) > self.MAX_PEAKS:
+                raise ValueError(f'{name} = {v}: the device kernels hold at most {self.MAX_PEAKS} '
+                                 'peaks per spectrum (the reference has no limit; its default is 50)')
+        for name in ('num_candidates', 'num_probe'):
+            v = getattr(self, name)
+            if v is not None and int(v) > self.MAX_TOPK:
+                raise ValueError(f'{name} = {v}: the device top-k holds at most {self.MAX_TOPK} entries')
+        if self.flat_storage not in ('fx22', 'fp32'):
+            raise ValueError(f"flat_storage = {self.flat_storage!r}: 'fx22' or 'fp32'")
 
     def __getitem__(self, k):
         return getattr(self, k)
@@ -124,6 +156,9 @@ def add_arguments(parser) -> None:
                              '(default: %(default)s)')
     parser.add_argument('--ann_seed', default=d.seed, type=int,
                         help='random seed of the ANN index trainer (default: %(default)s)')
+    parser.add_argument('--flat_storage', default=d.flat_storage, type=str, choices=['fx22', 'fp32'],
+                        help='IVF-Flat: store vector components in [0, 1) as 22-bit fixed point '
+                             '(4-byte postings, |dx| <= 1.2e-7) or as float32 (default: %(default)s)')
     parser.add_argument('--num_gpus', default=d.num_gpus, type=int,
                         help='shard the ANN index by inverted list over this many GPUs; the job '
                              'runs one process per GPU (torchrun --nproc-per-node N) and N must '

@@ -70,12 +70,20 @@ typedef __attribute__((address_space(3))) cs_f2 cs_lds_f2;
 // one step: entry K (0..15) of the register set (ED = dimension * 128, the byte offset of the
 // tile row; EV = value bits). Three VALU instructions: the address add and the two multiply-adds
 // take the row's lane K as a DPP operand (row_newbcast = row_share), no separate broadcast moves.
-#define CS_ADDR(K, ED, I)                                                            \
-  asm("v_add_u32_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf"     \
-      : "=v"(ad[I])                                                                  \
+// (The DPP source registers are compiler-allocated and the hazard recogniser does not look inside
+// inline asm: a VALU write of ED / EV -- e.g. the loop-carried copy at the back-edge -- needs two
+// wait states before a DPP read. CS_NOP2 in front of the first address add and the first
+// multiply-add of every block of eight provides them whatever the schedule; later steps of a
+// block are separated from any earlier write by those instructions.)
+#define CS_NOP2 "s_nop 1\n\t"
+#define CS_ADDR_(PRE, K, ED, I)                                                          \
+  asm(PRE "v_add_u32_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf"     \
+      : "=v"(ad[I])                                                                      \
       : "v"(ED), "v"(lane_off));
-#define CS_FMA(K, EV, I)                                                             \
-  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf"    \
+#define CS_ADDR(K, ED, I) CS_ADDR_("", K, ED, I)
+#define CS_FMA(K, EV, I) CS_FMA_("", K, EV, I)
+#define CS_FMA_(PRE, K, EV, I)                                                           \
+  asm(PRE "v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf"    \
       : "+v"(acc0)                                                                   \
       : "v"(EV), "v"(cv[I].x));                                                      \
   asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf"    \
@@ -87,10 +95,10 @@ typedef __attribute__((address_space(3))) cs_f2 cs_lds_f2;
   {                                                                                             \
     uint32_t ad[8];                                                                             \
     cs_f2 cv[8];                                                                                \
-    CS_ADDR(K0, ED, 0) CS_ADDR(K1, ED, 1) CS_ADDR(K2, ED, 2) CS_ADDR(K3, ED, 3)                 \
+    CS_ADDR_(CS_NOP2, K0, ED, 0) CS_ADDR(K1, ED, 1) CS_ADDR(K2, ED, 2) CS_ADDR(K3, ED, 3)                 \
     CS_ADDR(K4, ED, 4) CS_ADDR(K5, ED, 5) CS_ADDR(K6, ED, 6) CS_ADDR(K7, ED, 7)                 \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) cv[i_] = *(const cs_lds_f2 *)(uintptr_t)ad[i_]; \
-    CS_FMA(K0, EV, 0) CS_FMA(K1, EV, 1) CS_FMA(K2, EV, 2) CS_FMA(K3, EV, 3)                     \
+    CS_FMA_(CS_NOP2, K0, EV, 0) CS_FMA(K1, EV, 1) CS_FMA(K2, EV, 2) CS_FMA(K3, EV, 3)                     \
     CS_FMA(K4, EV, 4) CS_FMA(K5, EV, 5) CS_FMA(K6, EV, 6) CS_FMA(K7, EV, 7)                     \
   }
 #define CS_BLOCK8A(ED, EV) CS_BLOCK8(0, 1, 2, 3, 4, 5, 6, 7, ED, EV)

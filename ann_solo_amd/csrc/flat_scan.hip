@@ -67,30 +67,10 @@ int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_ma
 // dense scan too). The eight waves of a workgroup run their blocks independently (blocks are
 // handed out by an LDS counter, a block's candidates are appended with one atomic, or one per
 // row when they are many) and meet only when the key buffer is full: see "Offers" below.
-#ifndef FI_U_
-#define FI_U_ 8
-#endif
-#ifndef FI_CHUNK_
-#define FI_CHUNK_ 256
-#endif
 // FI_CHUNK: blocks of a query listed at a time (a query of the bench probes ~150: one chunk, so the
 // waves of a workgroup wait for each other once per query)
-constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = FI_CHUNK_, FI_U = FI_U_;
+constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = 256, FI_U = 8;   // FI_U: rows in flight per wave
 constexpr int FI_ROWS = (FI_BLK + 63) / 64;      // rows of accumulators in a block
-#ifndef FI_PHASES
-#define FI_PHASES 0
-#endif
-
-#if FI_PHASES
-#define FI_T(i)                                   \
-  {                                               \
-    const long long t_now = wall_clock64();       \
-    ph[i] += t_now - t_prev;                      \
-    t_prev = t_now;                               \
-  }
-#else
-#define FI_T(i)
-#endif
 static_assert(64 % FI_U == 0, "a batch of dimensions must not straddle the 64 lanes of a chunk");
 
 struct FiUnit {
@@ -120,10 +100,6 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   int *s_next = s_misc + 11;              // next block of the chunk to hand out
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
 
-#if FI_PHASES
-  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long t_prev = wall_clock64();
-#endif
   // the query's non-zero components, ascending: from the ready entry list (list_nonzeros: 512
   // bytes) or listed here from the dense row (staged through the accumulator area)
   float *s_q = s_acc;
@@ -186,7 +162,6 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
     top.free_sync();
   };
   auto sync_wanted = [&]() -> bool { return __builtin_amdgcn_readfirstlane(*s_flag) != 0; };
-  FI_T(0)
   for (int c0 = 0; c0 < total; c0 += FI_CHUNK) {
     {
       const int lo = max(my_pre, c0), hi = min(my_pre + my_nb, c0 + FI_CHUNK);
@@ -206,7 +181,6 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
     // first, they raise the threshold soonest).
     if (tid == 0) *s_next = FI_NW;
     __syncthreads();
-    FI_T(1)
     bool first = true;
     for (int i = wave;; first = false) {
       int nb = 0, pos0 = 0;
@@ -227,10 +201,6 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
             e = make_uint2((w >> 16) * 64u, w & 0xffffu);   // first byte (from the block's base), postings
             qv = s_nzv[kk];
           }
-#if FI_PHASES
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(e.x), "v"(e.y), "v"(qv));
-          FI_T(2)
-#endif
           // The unit of work is a ROW: up to 64 postings of one dimension. A dimension of a
           // 512-vector list has ~17 postings (one row), but a fragment bin that half the library
           // shares has hundreds -- a third of the work of a query that holds it -- so rows, not
@@ -317,7 +287,6 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
           }
         }
       }
-      FI_T(3)
       // the first blocks of a query: every accumulator of eight blocks would pass (4 k candidates
       // against a buffer of 2 k) -- the threshold is fixed from a histogram of all of them first
       const bool cold = c0 == 0 && first;     // the same for every wave
@@ -375,14 +344,10 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
           const bool p = v < nb && top.passes(score);
           if (!__ballot(p)) break;                                        // wave-uniform
           if (top.free_append(p, score, (uint32_t)(pos0 + v), cold)) break;
-          FI_T(4)
           sync();
-          FI_T(5)
         }
       }
-      FI_T(4)
       if (sync_wanted()) sync();
-      FI_T(5)
       if (i >= nent) break;
       if (lane == 0) i = atomicAdd(s_next, 1);
       i = __builtin_amdgcn_readfirstlane(i);
@@ -401,29 +366,15 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
         break;
       __builtin_amdgcn_s_sleep(4);
     }
-    FI_T(6)
     __syncthreads();
   }
   top.free_done();
-  FI_T(1)
-#if FI_PHASES
-  const long long t_fin = wall_clock64();
-#endif
   if (set_mode && (size_t)FI_CAP * 8 <= (size_t)FI_NW * FI_BLK * 4)   // unordered exact top-k; the accumulators are dead: scratch
     top.finish_set(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
                    I32 ? I32 + (size_t)q * k : nullptr, reinterpret_cast<u64 *>(s_acc));
   else
     top.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
                I32 ? I32 + (size_t)q * k : nullptr);
-#if FI_PHASES
-  __syncthreads();
-  if (D && k >= 16 && lane == 0) {     // phase durations (100 MHz ticks) of every wave replace the scores
-    ph[7] = wall_clock64() - t_fin;
-    float *o = D + (size_t)q * k + wave * 8;
-    if (wave * 8 + 8 <= k)
-      for (int i = 0; i < 8; ++i) o[i] = (float)ph[i];
-  }
-#endif
 }
 
 bool flat_inv_supported(int d, int k, int nprobe) {

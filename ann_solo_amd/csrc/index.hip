@@ -88,7 +88,7 @@ struct asl_index {
   DevBuf<uint8_t> codes;
   DevBuf<int32_t> ids, list_offsets;
   std::vector<int32_t> h_list_offsets;
-  // 64-vector tiles for pq_scan_v2 (m = 32)
+  // 64-vector tiles for the tiled scan, pq_scan_v3.hip (m = 32)
   DevBuf<uint8_t> codes_tiled;
   DevBuf<int32_t> ids_tiled, tile_offsets;
   bool has_tiles = false;

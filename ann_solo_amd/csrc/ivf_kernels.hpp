@@ -61,10 +61,8 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
 int tile_codes(const uint8_t *codes, const int32_t *ids, const int32_t *dst_slot, int64_t n,
                int64_t ntiles, uint8_t *codes_tiled, int32_t *ids_tiled);
 // dimension-major IVF-Flat (flat_scan.hip): blocks of FI_BLK vectors with per-dimension postings
-#ifndef FI_BLK_
-#define FI_BLK_ 832     // measured (scan ms at nprobe 128): 512 7.69 | 640 7.14 | 768 6.81 | 832 6.71 | 864 6.70 (the LDS limit of three workgroups per CU) | 1024: two workgroups per CU
-#endif
-constexpr int FI_BLK = FI_BLK_;
+// FI_BLK measured (scan ms at nprobe 128): 512 7.69 | 640 7.14 | 768 6.81 | 832 6.71 | 864 6.70 (the LDS limit of three workgroups per CU) | 1024: two workgroups per CU
+constexpr int FI_BLK = 832;
 bool flat_inv_supported(int d, int k, int nprobe);
 int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *list_offsets, const int32_t *blk_offsets,

@@ -1,5 +1,5 @@
 // pq_tile.hpp -- shared device helpers of the tiled IVF-PQ scan kernels (m = 32, 8 bits):
-// DPP butterflies and the 64-vector tile ADC (see pq_scan_v2.hip for the layout).
+// DPP butterflies and the 64-vector tile ADC (tile layout: pq_scan_v3.hip / DESIGN.md 5).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,18 +22,12 @@ __device__ __forceinline__ float dpp_mov(float x) {
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
 }
 
-#ifndef PQT_ADC_V2
-#define PQT_ADC_V2 1   // 0: the round-1 instruction selection (A/B)
-#endif
-
 __device__ __forceinline__ float lut_at(const char *lut_bytes, uint32_t word, int byte_idx,
                                         uint32_t lane_off) {
   uint32_t c = (word >> (8 * byte_idx)) & 0xffu;
-#if PQT_ADC_V2
   // keep the byte a value of its own: otherwise byte 0 is rewritten to (word << 7) & 0x7f80 and
   // costs three VALU instructions (shift, and, add) instead of two (and / bfe, lshl_add)
   asm volatile("" : "+v"(c));
-#endif
   return *reinterpret_cast<const float *>(lut_bytes + ((c << 7) + lane_off));
 }
 
@@ -45,7 +39,6 @@ __device__ __forceinline__ float tile_adc(const char *lut_bytes, const uint4 A, 
   float v[16];
   const uint32_t a[4] = {A.x, A.y, A.z, A.w};
   const uint32_t b[4] = {B.x, B.y, B.z, B.w};
-#if PQT_ADC_V2
   // the 16 first-level sums as 8 packed fp32 adds (v_pk_add_f32: two IEEE adds per instruction,
   // same bits); the DPP butterflies below have no packed form
 #pragma unroll
@@ -59,11 +52,6 @@ __device__ __forceinline__ float tile_adc(const char *lut_bytes, const uint4 A, 
     v[r] = z.x;
     v[r + 1] = z.y;
   }
-#else
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-    v[r] = lut_at(lut_bytes, a[r >> 2], r & 3, offA) + lut_at(lut_bytes, b[r >> 2], r & 3, offB);
-#endif
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = v[r] + dpp_mov<0x140>(v[r ^ 15]);   // row_mirror
 #pragma unroll
@@ -166,10 +154,7 @@ __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, 
   const int c = tid & (PQT_KSUB - 1);
   const int kbeg = (NT > PQT_KSUB && tid >= PQT_KSUB) ? K16 : 0;
   const int K = (NT > PQT_KSUB && tid < PQT_KSUB) ? K16 : Kall;   // wave-uniform
-#ifndef PQT_LUT_U
-#define PQT_LUT_U 8
-#endif
-  constexpr int U = PQT_LUT_U;   // codebook loads in flight per thread
+  constexpr int U = 8;   // codebook loads in flight per thread
   float acc = 0.0f;
   int cur = -1;
   for (int k0 = kbeg; k0 < K; k0 += U) {

@@ -394,10 +394,7 @@ constexpr double RS_DEFER = -2.0;     // pair_score marker: left to the pair ker
 constexpr double RS_DEFER_BS = -3.0;  // pair_score marker: left to the binary-search kernel (third launch)
 enum { RS_QD_PAIR = 1, RS_QD_BS = 2 };   // q_defer bits: the query has slots marked RS_DEFER / RS_DEFER_BS;
                                          // bits 2.. count the RS_DEFER slots (work split of the second launch)
-#ifndef RS_DEF_Y_
-#define RS_DEF_Y_ 8
-#endif
-constexpr int RS_DEF_Y = RS_DEF_Y_;      // blocks per query the second launch may use
+constexpr int RS_DEF_Y = 8;             // blocks per query the second launch may use
 
 struct QueryLds2 {   // hash path: at most RS_HQ_MAX query peaks
   float mz[128];
@@ -863,9 +860,7 @@ struct FlatLds {   // per wave
   uint16_t mq[RF_MQ];              // queued (peak | shift << 10) items whose bin is marked
 };
 
-#ifndef RF_OCC
-#define RF_OCC 6      // waves per SIMD: 80 VGPRs (7 / 8: 72 / 64 VGPRs and more spills: +2 % / +12 %, profiles/r03_rescore_ab.txt)
-#endif
+constexpr int RF_OCC = 6;      // waves per SIMD: 80 VGPRs (7 / 8: 72 / 64 VGPRs and more spills: +2 % / +12 %, profiles/r03_rescore_ab.txt)
 template <int FORM>
 __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,

@@ -192,7 +192,7 @@ struct StreamTopK {
   u64 *thr;   // LDS: current k-th best (0 = none yet)
   int cap, k;
   bool force_rt = false;  // measurement knob: use the run-time-sized sort
-  // Deferred id resolution (pq_scan_v2): keys appended since the last flush carry a
+  // Deferred id resolution (the tiled PQ scan): keys appended since the last flush carry a
   // storage SLOT in their low word; the flush turns them into (score, ~id) keys by
   // gathering slot_ids[slot], so the hot loop never waits on an id load.
   const int32_t *slot_ids = nullptr;

@@ -10,6 +10,7 @@ faiss`` is the whole change at those call sites. Indexes always live on the GPU.
 """
 import ctypes as C
 import os
+import tempfile
 
 import numpy as np
 
@@ -278,9 +279,12 @@ def write_index(index: Index, path: str):
     # private name + rename: concurrent ranks write the same cache file, readers never see a
     # truncated one
     path = str(path)
-    tmp = f'{path}.tmp{os.getpid()}'
+    fd, tmp = tempfile.mkstemp(dir=os.path.dirname(os.path.abspath(path)) or '.',
+                               prefix=os.path.basename(path) + '.tmp')   # unique across hosts sharing the directory
+    os.close(fd)
     try:
         _lib.check(_lib.lib().asl_index_save(index._h, tmp.encode()))
+        os.chmod(tmp, 0o644)     # mkstemp creates 0600
         os.replace(tmp, path)
     finally:
         if os.path.exists(tmp):

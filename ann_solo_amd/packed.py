@@ -10,6 +10,7 @@ Peaks of one spectrum are ascending in m/z and already processed
 """
 import json
 import os
+import tempfile
 import struct
 from dataclasses import dataclass
 from typing import Optional
@@ -128,7 +129,9 @@ class PackedSpectra:
         meta = json.dumps(meta).encode('utf-8')
         # written under a private name and renamed: the ranks of a sharded job build the same
         # store at the same time, and a reader must never see a half-written file
-        tmp = f'{path}.tmp{os.getpid()}'
+        fd, tmp = tempfile.mkstemp(dir=os.path.dirname(os.path.abspath(path)) or '.',
+                                   prefix=os.path.basename(path) + '.tmp')   # unique across hosts sharing the directory
+        os.close(fd)
         try:
             with open(tmp, 'wb') as f:
                 f.write(STORE_MAGIC)
@@ -137,6 +140,7 @@ class PackedSpectra:
                 for a, dt in ((o, '<i8'), (mz, '<f4'), (it, '<f4'), (chg, 'u1'), (pmz, '<f8'),
                               (pz, 'u1')):
                     f.write(np.ascontiguousarray(a).astype(dt, copy=False).tobytes())
+            os.chmod(tmp, 0o644)     # mkstemp creates 0600
             os.replace(tmp, path)
         finally:
             if os.path.exists(tmp):

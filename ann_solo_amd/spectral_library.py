@@ -647,11 +647,18 @@ class SpectralLibrary:
             sec, a, b = acc.get(mode, (0.0, 0, 0))
             acc[mode] = (sec + time.perf_counter() - t_level, a + n_in, b + len(table))
         if score_ssms is None:    # no scorer: cosine (spectrum_similarity.py:81-106), accepted
-            if self.config.model is not None and not getattr(self, '_warned_model', False):
+            cascade = self.config.precursor_tolerance_mass_open is not None
+            if (cascade or self.config.model is not None) and not getattr(self, '_warned_model', False):
+                # the reference gates level 1 by utils.score_ssms (model or the `--model none`
+                # FDR filter); without a scorer level 1 keeps EVERY query that had a
+                # standard-window candidate, so the open level only sees the rest
                 self._warned_model = True
-                logging.warning('model=%r but no score_ssms callable was given: the FDR models '
-                                '(utils.score_ssms / mokapot) stay with the caller; every SSM is '
-                                'accepted with its cosine as the score', self.config.model)
+                logging.warning('no score_ssms callable was given (model=%r): the FDR gate '
+                                '(utils.score_ssms / mokapot) stays with the caller; every SSM is '
+                                'accepted with its cosine as the score and q = 0%s',
+                                self.config.model,
+                                ', so the cascade hands only the queries without any '
+                                'standard-window candidate to the open search' if cascade else '')
             table.q[:] = 0.0
             return table
         if getattr(score_ssms, 'columnar', False):

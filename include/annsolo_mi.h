@@ -122,14 +122,11 @@ int asl_index_get_refine(const asl_index_t *idx);
 int asl_index_refine(asl_index_t *idx, int32_t nq, const float *xq, int32_t kprime,
                      const int64_t *I_in /* [nq,kprime], -1 = empty */, int32_t k, float *D, int64_t *I);
 
-/* PQ scan kernel selection (all return identical results; the switch exists for A/B
- * measurements): 0 = automatic (tiled sub-quantiser-per-lane kernel with histogram top-k
- * when m = 32, 8 bits, nprobe <= 256), 1 = generic lane-per-vector kernel, 2 = tiled kernel
- * with sort-based top-k, 3 / 4 = tiled + histogram top-k with a 2048- / 4096-key buffer.
- * IVF-Flat: 0 = per-dimension postings inside every list (sparse data), 2 = sparse
- * 64-vector tiles, 1 = dense GEMM + masked top-k.
- * Values above 4 are rejected: the kernels' measurement bits (8+) exist only in a library built
- * with -DASL_ENABLE_DBG (scripts/ab_*.sh). */
+/* Scan kernel selection (identical results either way; the switch exists for A/B measurements
+ * and for the parity tests): 0 = the layout-specific kernels (IVF-PQ: the tiled
+ * sub-quantiser-per-lane scan with the histogram top-k when m = 32, 8 bits, nprobe <= 256;
+ * IVF-Flat: the per-dimension postings scan), 1 = the generic kernels (IVF-PQ: lane-per-vector
+ * scan; IVF-Flat: dense GEMM + masked top-k). Any other value is ASL_ERR_INVALID. */
 int asl_index_set_scan_variant(asl_index_t *idx, int32_t variant);
 
 /* Introspection, used by the parity tests and by multi-GPU sharding. Sizes via

@@ -80,6 +80,19 @@ def test_no_cpu_fallback():
         faiss.IndexFlatIP(800)
 
 
+def test_config_refuses_what_the_kernels_cannot_hold():
+    """Capacity limits the reference does not have are a construction-time ``ValueError`` of
+    ``Config``, not an error deep inside a search."""
+    from ann_solo_amd.config import Config
+    for kw in (dict(max_peaks_used=257), dict(max_peaks_used_library=1000),
+               dict(num_candidates=4096), dict(num_probe=2049), dict(flat_storage='fp16')):
+        with pytest.raises(ValueError):
+            Config(**kw)
+    with pytest.raises(ValueError):
+        Config.from_reference(dict(max_peaks_used=500))
+    assert Config(max_peaks_used=256, num_candidates=2048).max_peaks_used == 256
+
+
 def test_hyperparameter_hash_formula():
     """spectral_library.py:118-131: sha1 of the JSON of the five index hyper-parameters."""
     from ann_solo_amd.spectral_library import Config, SpectralLibrary

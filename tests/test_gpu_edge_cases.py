@@ -91,6 +91,24 @@ def test_more_than_256_peaks_is_a_capacity_error():
                                      np.array([0, 2, 4], np.int32), 0.02, True)
 
 
+def test_calls_under_a_side_stream_are_refused():
+    """The library issues on the null stream: under a non-default current PyTorch stream its
+    inputs could still be in flight, so every device tensor handed over is refused there
+    (``_lib._require_default_stream``) -- and accepted again once the default stream is current."""
+    import torch
+    from ann_solo_amd import _lib, spectrum
+    rng = np.random.default_rng(8)
+    q = _spectra(rng, 8, [30]).to('cuda:0')
+    out = torch.zeros((8, 800), dtype=torch.float32, device='cuda:0')
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with pytest.raises(_lib.AnnSoloMiError, match='default HIP stream'):
+            spectrum.spectra_to_vectors(q.mz, q.intensity, q.offsets, 11, 2010, 0.04, 800, out=out)
+    side.synchronize()
+    v = spectrum.spectra_to_vectors(q.mz, q.intensity, q.offsets, 11, 2010, 0.04, 800, out=out)
+    assert v.shape == (8, 800) and bool(torch.isfinite(v).all()) and float(v.abs().sum()) > 0
+
+
 def test_degenerate_queries_through_the_fused_search(O):
     """Empty query spectrum (zero vector: every coarse score ties), a query whose window holds
     no library spectrum, duplicate library spectra (tie -> lowest row), k larger than the
