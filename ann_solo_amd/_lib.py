@@ -71,6 +71,8 @@ EXPORTS = [
     'asl_profile_reset', 'asl_profile_get', 'asl_profile_scanned_vectors',
     'asl_rescore_knn', 'asl_lpt_owner', 'asl_index_supports_keys', 'asl_index_search_sharded', 'asl_index_postings_work', 'asl_index_set_refine', 'asl_index_get_refine', 'asl_index_refine', 'asl_index_set_scan_variant', 'asl_index_search_preassigned', 'asl_process_batch',
     'asl_ssm_features_batch', 'asl_ssm_cosine_batch', 'asl_index_set_unordered', 'asl_topk_merge_keys',
+    'asl_index_set_flat_storage', 'asl_index_get_flat_storage', 'asl_index_flat_layout',
+    'asl_keys_split', 'asl_keys_merge_heads', 'asl_keys_extras', 'asl_keys_merge_final',
 ]
 
 
@@ -163,6 +165,15 @@ def lib():
         L.asl_index_load.restype = C.c_void_p
         L.asl_index_set_niter.argtypes = [C.c_void_p, C.c_int32]
         L.asl_index_set_scan_variant.argtypes = [C.c_void_p, C.c_int32]
+        L.asl_index_set_flat_storage.argtypes = [C.c_void_p, C.c_int32]
+        L.asl_index_flat_layout.argtypes = [C.c_void_p]
+        L.asl_index_get_flat_storage.argtypes = [C.c_void_p]
+        L.asl_keys_split.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.asl_keys_merge_heads.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 4
+        L.asl_keys_extras.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p]
+        L.asl_keys_merge_final.argtypes = [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.asl_index_postings_work.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, c_i64p, c_i64p]
         L.asl_index_get_refine.argtypes = [C.c_void_p]
         L.asl_index_get_refine.restype = C.c_int32

@@ -1,0 +1,339 @@
+// exchange.hip -- device side of the TWO-PHASE EXACT top-k exchange of the list-sharded search
+// (no reference counterpart: /root/reference/src/ann_solo/spectral_library.py:494 uses device 0
+// only; this serves SURVEY.md 8(e) / the north star's "RCCL exchange of per-shard top-k").
+//
+// Every shard holds, per query, its local top-k as a row of packed 64-bit keys (order-preserving
+// score bits << 32 | ~id: larger key = better hit, keys are unique across shards because ids
+// are). Shipping all world * k keys of a query to its owner moves 8 * world * k bytes; the owner
+// keeps k of them. Instead:
+//
+//   phase 1  every shard sends the head of its row: up to kp - 1 of its best keys (all keys at or
+//            above a score-bucket floor chosen so that at most kp - 1 qualify -- no sorting) and,
+//            in the row's last slot, T = its best UNSENT key (0: nothing was held back). kp =
+//            ceil(2 k / world): about 2 k keys per query on the wire.
+//   bound    the owner merges the heads: B = the k-th best key it has seen (0 if it has seen
+//            fewer than k). Every unsent key of shard s is <= T_s. If T_s < B nothing shard s
+//            held back can be among the k best of the union; otherwise the owner asks that
+//            shard for its keys above B.
+//   phase 2  the bounds travel back (8 bytes per (query, shard)), the shards answer with the
+//            held-back keys above the bound -- usually none -- compacted into one fixed-size
+//            buffer per destination, and the owner merges again where it asked.
+//
+// The result is the exact top-k of the union: a key that is never shipped is below a bound B
+// that k shipped keys reach. If a destination's phase-2 buffer overflows, a flag is raised and
+// the caller repeats the batch with the full exchange (ann_solo_amd/distributed.py).
+#include "common.hpp"
+#include "hist_topk.hpp"
+#include "ivf_kernels.hpp"
+
+namespace asl {
+
+constexpr u64 XK_NONE = ~0ull;      // bound meaning "send nothing"
+
+// ---- phase 1: head of a row ---------------------------------------------------------------
+// K [nrows, k] (0 = empty, any order) -> head [nrows, kp]: slots 0 .. kp-2 the kept keys (0
+// padded), slot kp-1 = T; rest [nrows, k]: the keys held back, compacted, 0 padded.
+// The kept set = all keys whose score bucket (hist_topk.hpp: 512 buckets over [-0.25, 1)) is at
+// or above the lowest bucket floor that admits at most kp - 1 keys.
+__global__ __launch_bounds__(256) void keys_split_kernel(const u64 *__restrict__ K, int k, int kp,
+                                                         u64 *__restrict__ head,
+                                                         u64 *__restrict__ rest) {
+  __shared__ int hist[HT_NB];
+  __shared__ int part[8];
+  __shared__ int s_floor, s_na, s_nr;
+  __shared__ u64 s_best_rest;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const size_t row = blockIdx.x;
+  constexpr int PER = 8;            // k <= 2048
+  u64 kk[PER];
+  int bk[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = tid + u * 256;
+    kk[u] = i < k ? K[row * k + i] : 0ull;
+    bk[u] = kk[u] ? score_bucket(key_score(kk[u])) : -1;
+  }
+  for (int i = tid; i < HT_NB; i += 256) hist[i] = 0;
+  if (tid == 0) {
+    s_floor = HT_NB;
+    s_na = s_nr = 0;
+    s_best_rest = 0ull;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+    if (bk[u] >= 0) atomicAdd(&hist[bk[u]], 1);
+  __syncthreads();
+  {  // thread t owns buckets 511 - 2t, 510 - 2t; cumulative counts from the top
+    const int h0 = hist[HT_NB - 1 - 2 * tid], h1 = hist[HT_NB - 2 - 2 * tid];
+    int tot;
+    const int above = block_excl_scan<4>(h0 + h1, part, tid, tot);
+    const int cap = kp - 1;
+    if (above + h0 + h1 <= cap) atomicMin(&s_floor, HT_NB - 2 - 2 * tid);
+    else if (above + h0 <= cap) atomicMin(&s_floor, HT_NB - 1 - 2 * tid);
+  }
+  __syncthreads();
+  const int fl = s_floor;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const bool a = bk[u] >= fl, r = bk[u] >= 0 && bk[u] < fl;
+    const unsigned long long ma = __ballot(a), mr = __ballot(r);
+    int ba = 0, br = 0;
+    if (lane == 0) {
+      if (ma) ba = atomicAdd(&s_na, __popcll(ma));
+      if (mr) br = atomicAdd(&s_nr, __popcll(mr));
+    }
+    ba = __builtin_amdgcn_readfirstlane(ba);
+    br = __builtin_amdgcn_readfirstlane(br);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (a) head[row * kp + ba + __popcll(ma & below)] = kk[u];
+    if (r) {
+      rest[row * k + br + __popcll(mr & below)] = kk[u];
+      atomicMax(&s_best_rest, kk[u]);
+    }
+  }
+  __syncthreads();
+  const int na = s_na, nr = s_nr;
+  for (int i = na + tid; i < kp - 1; i += 256) head[row * kp + i] = 0ull;
+  for (int i = nr + tid; i < k; i += 256) rest[row * k + i] = 0ull;
+  if (tid == 0) head[row * kp + kp - 1] = s_best_rest;
+}
+
+// ---- owner: merge of the heads (+ phase-2 answers) ------------------------------------------
+// heads [S, nq, kp]; extras (round 2): xbuf [S, nq + xcap] as keys_extras_kernel fills it (per
+// source nq header words count << 32 | start, then xcap payload slots).
+// Round 1 (bounds != null): out_keys [nq, k] = the best k keys seen (set, 0 padded);
+//   bounds [S, nq] = B if shard s must answer (T_s > B) else XK_NONE; need[q] = any shard asked.
+// Round 2 (I != null): I [nq, k] = ids of the exact top-k (set, -1 padded), D optional scores;
+//   queries with need[q] == 0 only convert prev_keys [nq, k].
+template <int CAP>
+__global__ __launch_bounds__(HT_NT) void keys_merge_kernel(
+    const u64 *__restrict__ heads, int S, int nq, int kp, int k, const u64 *__restrict__ xbuf,
+    long long xcap, const u64 *__restrict__ prev_keys,
+    int32_t *__restrict__ need, u64 *__restrict__ out_keys, u64 *__restrict__ bounds,
+    int64_t *__restrict__ I, float *__restrict__ D, int sorted) {
+  using TopK = HistTopK<CAP, HT_NT * 2>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ u64 s_min;
+  __shared__ int s_cnt, s_any;
+  const int tid = threadIdx.x, q = blockIdx.x;
+  const bool round2 = I != nullptr;
+  if (round2 && need && need[q] == 0 && !sorted) {   // nothing was asked for: the round-1 set stands
+    for (int i = tid; i < k; i += HT_NT) {
+      const u64 key = prev_keys[(size_t)q * k + i];
+      I[(size_t)q * k + i] = key ? (int64_t)key_id(key) : -1;
+      if (D) D[(size_t)q * k + i] = key ? key_score(key) : -3.402823466e+38f;
+    }
+    return;
+  }
+  TopK top;
+  top.init(smem, k, nullptr, tid);
+  top.out_keys = true;
+  auto stream = [&](auto &&key_at, int total) {   // total: a multiple of nothing in particular
+    for (int base = 0; base < total; base += HT_NT * 2) {
+      top.begin_round();
+      int appended = 0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int v = base + u * HT_NT + tid;
+        const u64 key = v < total ? key_at(v) : 0ull;
+        const bool take = top.offer(key != 0ull, key ? key_score(key) : 0.0f, (uint32_t)key);
+        appended += __popcll(__ballot(take));
+      }
+      top.end_round(appended);
+    }
+  };
+  // heads: 64-entry chunks of the S lists interleaved (as topk_merge_hist_kernel), slot kp-1 skipped
+  const int kin = kp - 1, kc = (kin + 63) >> 6;
+  stream([&](int v) -> u64 {
+    const int c = v >> 6, s = c % S, j = (c / S) * 64 + (v & 63);
+    return j < kin ? heads[((size_t)s * nq + q) * kp + j] : 0ull;
+  }, kc * S * 64);
+  if (round2 && xbuf) {
+    for (int s = 0; s < S; ++s) {                // block-uniform
+      const u64 *src = xbuf + (size_t)s * ((size_t)nq + (size_t)xcap);
+      const u64 h = src[q];
+      const int cnt = (int)(h >> 32);
+      const u64 *pay = src + nq + (size_t)(uint32_t)h;
+      if (cnt > 0) stream([&](int v) -> u64 { return v < cnt ? pay[v] : 0ull; }, cnt);
+    }
+  }
+  u64 *row = (round2 ? reinterpret_cast<u64 *>(I) : out_keys) + (size_t)q * k;
+  if (round2 && sorted)      // rows under (score desc, id asc), as the unsharded index returns them
+    top.finish(nullptr, reinterpret_cast<int64_t *>(row), nullptr);
+  else
+    top.finish_set(nullptr, reinterpret_cast<int64_t *>(row), nullptr,
+                   reinterpret_cast<u64 *>(smem + TopK::lds_bytes()));
+  __syncthreads();
+  if (round2) {                                  // keys -> ids in place (every thread its own slots)
+    __threadfence_block();
+    for (int i = tid; i < k; i += HT_NT) {
+      const u64 key = row[i];
+      if (D) D[(size_t)q * k + i] = key ? key_score(key) : -3.402823466e+38f;
+      I[(size_t)q * k + i] = key ? (int64_t)key_id(key) : -1;
+    }
+    return;
+  }
+  // round 1: B = the k-th best key seen (0 when fewer than k were), then the question to every shard
+  if (tid == 0) {
+    s_min = XK_NONE;
+    s_cnt = 0;
+    s_any = 0;
+  }
+  __syncthreads();
+  __threadfence_block();
+  {
+    u64 m = XK_NONE;
+    int c = 0;
+    for (int i = tid; i < k; i += HT_NT) {
+      const u64 key = row[i];
+      if (key) {
+        m = key < m ? key : m;
+        ++c;
+      }
+    }
+    atomicMin(&s_min, m);
+    atomicAdd(&s_cnt, c);
+  }
+  __syncthreads();
+  const u64 B = s_cnt >= k ? s_min : 0ull;
+  for (int s = tid; s < S; s += HT_NT) {
+    const u64 T = heads[((size_t)s * nq + q) * kp + kp - 1];
+    const bool ask = T > B;                      // T == 0: nothing held back
+    bounds[(size_t)s * nq + q] = ask ? B : XK_NONE;
+    if (ask) s_any = 1;
+  }
+  __syncthreads();
+  if (tid == 0) need[q] = s_any;
+}
+
+// ---- phase 2 on the shard: held-back keys above the owner's bound ---------------------------
+// rows are destination-major: row = dst * nq + q. xbuf [W, nq + xcap]: per destination nq
+// header words (count << 32 | start) followed by xcap payload slots; cursor [W] (zeroed by the
+// caller) hands out the payload; *overflow is raised when a destination's payload is full.
+__global__ __launch_bounds__(256) void keys_extras_kernel(const u64 *__restrict__ rest, int k,
+                                                          const u64 *__restrict__ bounds, int nq,
+                                                          long long xcap, u64 *__restrict__ xbuf,
+                                                          unsigned int *__restrict__ cursor,
+                                                          int32_t *__restrict__ overflow) {
+  __shared__ int part[8];
+  __shared__ unsigned int s_start;
+  const int tid = threadIdx.x;
+  const size_t row = blockIdx.x;
+  const int dst = (int)(row / nq), q = (int)(row % nq);
+  u64 *hdr = xbuf + (size_t)dst * (nq + xcap), *pay = hdr + nq;
+  const u64 B = bounds[row];
+  if (B == XK_NONE) {                            // block-uniform
+    if (tid == 0) hdr[q] = 0ull;
+    return;
+  }
+  constexpr int PER = 8;
+  u64 kk[PER];
+  int c = 0;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = tid + u * 256;
+    kk[u] = i < k ? rest[row * k + i] : 0ull;
+    if (kk[u] <= B) kk[u] = 0ull;
+    c += kk[u] != 0ull;
+  }
+  int tot;
+  int pos = block_excl_scan<4>(c, part, tid, tot);
+  if (tid == 0) {
+    unsigned int st = tot ? atomicAdd(&cursor[dst], (unsigned int)tot) : 0u;
+    if ((long long)st + tot > xcap) {            // no room: the caller falls back to the full exchange
+      *overflow = 1;
+      st = 0xFFFFFFFFu;
+    }
+    s_start = st;
+    hdr[q] = st == 0xFFFFFFFFu ? 0ull : (((u64)tot << 32) | st);
+  }
+  __syncthreads();
+  const unsigned int st = s_start;
+  if (st == 0xFFFFFFFFu) return;
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+    if (kk[u]) pay[st + pos++] = kk[u];
+}
+
+int keys_split(const u64 *K, int64_t nrows, int k, int kp, u64 *head, u64 *rest) {
+  if (nrows <= 0) return ASL_OK;
+  hipLaunchKernelGGL(keys_split_kernel, dim3((unsigned)nrows), dim3(256), 0, stream(), K, k, kp, head, rest);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+int keys_merge(const u64 *heads, int S, int nq, int kp, int k, const u64 *xbuf, long long xcap,
+               const u64 *prev_keys, int32_t *need, u64 *out_keys, u64 *bounds, int64_t *I, float *D,
+               int sorted) {
+  if (nq <= 0) return ASL_OK;
+  const size_t lds = HistTopK<2048, HT_NT * 2>::lds_bytes() + (size_t)2048 * 8;
+  hipLaunchKernelGGL((keys_merge_kernel<2048>), dim3(nq), dim3(HT_NT), lds, stream(), heads, S, nq, kp,
+                     k, xbuf, xcap, prev_keys, need, out_keys, bounds, I, D, sorted);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+int keys_extras(const u64 *rest, int64_t nrows, int k, const u64 *bounds, int nq, long long xcap,
+                u64 *xbuf, unsigned int *cursor, int32_t *overflow) {
+  if (nrows <= 0) return ASL_OK;
+  hipLaunchKernelGGL(keys_extras_kernel, dim3((unsigned)nrows), dim3(256), 0, stream(), rest, k, bounds,
+                     nq, xcap, xbuf, cursor, overflow);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+}  // namespace asl
+
+using namespace asl;
+
+extern "C" {
+
+// see include/annsolo_mi.h
+int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, const int64_t *K, int64_t *head, int64_t *rest) {
+  clear_error();
+  if (nrows < 0 || k < 1 || k > 2048 || kp < 2 || kp > k + 1 || !K || !head || !rest)
+    return fail(ASL_ERR_INVALID, "keys_split: need 1 <= k <= 2048, 2 <= kp <= k + 1 and non-null device arrays");
+  ASL_TRY(ensure_device());
+  return keys_split(reinterpret_cast<const u64 *>(K), nrows, k, kp, reinterpret_cast<u64 *>(head),
+                    reinterpret_cast<u64 *>(rest));
+}
+
+int asl_keys_merge_heads(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
+                         int64_t *out_keys, int64_t *bounds, int32_t *need) {
+  clear_error();
+  if (S < 1 || nq < 0 || kp < 2 || k < 1 || k + 768 > 2048 || !heads || !out_keys || !bounds || !need)
+    return fail(ASL_ERR_INVALID, "keys_merge_heads: need S >= 1, kp >= 2, 1 <= k <= 1280 and non-null device arrays");
+  ASL_TRY(ensure_device());
+  return keys_merge(reinterpret_cast<const u64 *>(heads), S, nq, kp, k, nullptr, 0, nullptr, need,
+                    reinterpret_cast<u64 *>(out_keys), reinterpret_cast<u64 *>(bounds), nullptr, nullptr, 0);
+}
+
+int asl_keys_extras(int32_t W, int32_t nq, int32_t k, const int64_t *rest, const int64_t *bounds,
+                    int64_t xcap, int64_t *xbuf, int32_t *overflow) {
+  clear_error();
+  if (W < 1 || nq < 0 || k < 1 || k > 2048 || xcap < 0 || xcap >= 0xFFFFFFFFLL || !rest || !bounds || !xbuf || !overflow)
+    return fail(ASL_ERR_INVALID, "keys_extras: bad argument");
+  ASL_TRY(ensure_device());
+  DevBuf<unsigned int> cursor;
+  ASL_TRY(cursor.reserve((size_t)W));
+  HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)W * sizeof(unsigned int), stream()));
+  ASL_TRY(keys_extras(reinterpret_cast<const u64 *>(rest), (int64_t)W * nq, k,
+                      reinterpret_cast<const u64 *>(bounds), nq, xcap, reinterpret_cast<u64 *>(xbuf), cursor.p,
+                      overflow));
+  return sync_stream();       // the cursor is a temporary of this call
+}
+
+int asl_keys_merge_final(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
+                         const int64_t *xbuf, int64_t xcap, const int64_t *prev_keys, const int32_t *need,
+                         float *D, int64_t *I) {
+  clear_error();
+  if (S < 1 || nq < 0 || kp < 2 || k < 1 || k + 768 > 2048 || !heads || !prev_keys || !I)
+    return fail(ASL_ERR_INVALID, "keys_merge_final: bad argument");
+  ASL_TRY(ensure_device());
+  return keys_merge(reinterpret_cast<const u64 *>(heads), S, nq, kp, k, reinterpret_cast<const u64 *>(xbuf),
+                    xbuf ? xcap : 0, reinterpret_cast<const u64 *>(prev_keys), const_cast<int32_t *>(need),
+                    nullptr, nullptr, I, D, 0);
+}
+
+}  // extern "C"

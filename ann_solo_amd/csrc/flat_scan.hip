@@ -18,22 +18,45 @@ namespace asl {
 
 // non-zeros per vector (one wave per vector) and their maximum: decides at build time whether
 // the postings layout pays
+// nnz_max[1] is raised when a non-zero component is NOT a fixed-point value (0 < x < 1 on the
+// grid of 2^-22): such an index keeps float postings
 __global__ void count_nnz_kernel(const float *__restrict__ vecs, int d, int64_t n,
                                  int32_t *__restrict__ nnz, int32_t *__restrict__ nnz_max) {
   const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (v >= n) return;
   int c = 0;
-  for (int j = lane; j < d; j += 64) c += vecs[v * d + j] != 0.0f;
+  bool off_grid = false;
+  for (int j = lane; j < d; j += 64) {
+    const float x = vecs[v * d + j];
+    c += x != 0.0f;
+    off_grid |= x != 0.0f && !fx22_on_grid(x);
+  }
   for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  if (__ballot(off_grid) && lane == 0) atomicMax(nnz_max + 1, 1);
   if (lane == 0) {
     nnz[v] = c;
     atomicMax(nnz_max, c);
   }
 }
 
+// add() of an IVF-Flat index in fixed-point storage mode: components in [0, 1) go to the nearest
+// multiple of 2^-22 (ties to even; the largest is 1 - 2^-22); anything else is stored as given
+// (and keeps the whole index on float postings). The oracle's orc_quantize_fx22 is the same rule.
+__global__ void quantize_fx22_kernel(float *__restrict__ x, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = fx22_round(x[i]);
+}
+
+int quantize_fx22(float *x, int64_t n) {
+  if (n <= 0) return ASL_OK;
+  hipLaunchKernelGGL(quantize_fx22_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream(), x, n);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
 int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_max_dev) {
-  HIP_TRY(hipMemsetAsync(nnz_max_dev, 0, sizeof(int32_t), stream()));
+  HIP_TRY(hipMemsetAsync(nnz_max_dev, 0, 2 * sizeof(int32_t), stream()));
   if (n <= 0) return ASL_OK;
   hipLaunchKernelGGL(count_nnz_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
                      n, nnz, nnz_max_dev);
@@ -79,14 +102,33 @@ struct FiUnit {
 };                // (+ the block's vector count in a 16-bit array: 10 bytes per block of a chunk)
 
 // FI_CAP: key buffer of the top-k (2048: k <= 1280, three workgroups per CU; 4096: k <= 3328, two)
-template <int FI_CAP>
+//
+// FX = true: the FIXED-POINT layout (round 4). Every stored component lies in (0, 1) on the grid
+// of 2^-22 (asl_index_set_flat_storage: add() rounds them there), so a posting is ONE 32-bit word
+// -- value numerator M (22 bits) << 10 | local vector index (10 bits) -- instead of a float and
+// a 16-bit index. Segments are whole 128-byte lines of 32 postings, the tail of the last line
+// repeating the last posting (a lane that applies a repeat reads the same accumulator, computes
+// the same sum and stores the same bits -- the rule the row loop already relies on), so a
+// segment needs no count, and the table shrinks from a 4-byte word to ONE BYTE per (block,
+// dimension): the segment's number of lines. Its start is the running sum of the bytes before
+// it, which the wave forms itself: lane L loads the 16 bytes of dimensions 16 L .. 16 L + 15
+// (one 16-byte load covers the whole row of a block, 7 lines for d = 800 instead of the ~18 of
+// 25 a query's dimensions hit in the 4-byte table), byte sums with v_sad_u8, a wave prefix
+// scan, and the lane that owns a query dimension pulls its 16-dimension group's prefix and words
+// (ds_bpermute) and adds the bytes in front of its own. The chain is unchanged --
+// acc = fmaf(q_d, x_d, acc) over ascending d with x_d = M 2^-22 (the 2^-22 is folded into the
+// query value: a power of two, exact) -- so ids and score bits equal the oracle's over the same
+// stored vectors. Measured on the bench library (scripts/flat_layout_model.py): 13 135 -> 8 980
+// lines per query at nprobe 112, and the row loop loses one of its two loads.
+template <int FI_CAP, bool FX>
 __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_kernel(
     const float *__restrict__ xq, int d, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ blk_offsets,
     const uint32_t *__restrict__ blk_base, const uint32_t *__restrict__ seg_tab,
     const char *__restrict__ seg_bytes, const int32_t *__restrict__ ids, int k,
     float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode,
-    const uint2 *__restrict__ ent, const int32_t *__restrict__ ent_cnt) {
+    const uint2 *__restrict__ ent, const int32_t *__restrict__ ent_cnt, int tab_stride) {
+  constexpr float FX_SCALE = FX ? 1.0f / 4194304.0f : 1.0f;      // 2^-22, folded into the query values
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *s_acc = reinterpret_cast<float *>(smem + TopK::lds_bytes());      // [FI_NW][FI_BLK]
@@ -123,7 +165,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
     if (lane < ecnt) {
       const uint2 e = ent[(size_t)q * 64 + lane];
       s_nzd[lane] = (uint16_t)(e.x >> 7);
-      s_nzv[lane] = __uint_as_float(e.y);
+      s_nzv[lane] = __uint_as_float(e.y) * FX_SCALE;
     }
     if (lane == 0) {
       s_misc[8] = ecnt;
@@ -139,7 +181,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
       if (x != 0.0f) {
         const int t = base + __popcll(m & ((1ull << lane) - 1ull));
         s_nzd[t] = (uint16_t)j;
-        s_nzv[t] = x;
+        s_nzv[t] = x * FX_SCALE;
       }
       base += __popcll(m);
     }
@@ -153,6 +195,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   const int K = s_misc[8];
   TopK top;
   top.init(smem, k, ids, tid);
+  top.out_keys = set_mode == 2 && I64 != nullptr;     // rows of packed keys (sharded exchange)
   float *acc = s_acc + wave * FI_BLK;
   int chunks_done = 0;
   auto sync = [&]() {             // raise the flag, meet the other waves, compact
@@ -189,16 +232,50 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
         nb = __builtin_amdgcn_readfirstlane((int)s_nbv[i]);
         pos0 = __builtin_amdgcn_readfirstlane(u.pos0);
         const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.blk);
-        const char *bptr = seg_bytes + (size_t)blk_base[blk] * 64;     // (a scalar load: blk is wave-uniform)
+        const char *bptr = seg_bytes + (size_t)blk_base[blk] * (FX ? 128 : 64);     // (a scalar load: blk is wave-uniform)
         for (int o = lane; o < nb; o += 64) acc[o] = 0.0f;
         const uint32_t *erow = seg_tab + (size_t)blk * d;
+        // FX: the block's byte table (lines per dimension), 16 dimensions per lane, and the
+        // lines in front of each group of 16
+        uint4 tb = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t tpre = 0;
+        if constexpr (FX) {
+          const uint8_t *trow = reinterpret_cast<const uint8_t *>(seg_tab) + (size_t)blk * tab_stride;
+          if (lane * 16 < tab_stride) tb = *reinterpret_cast<const uint4 *>(trow + lane * 16);
+          const uint32_t mine = __builtin_amdgcn_sad_u8(tb.x, 0u, 0u) + __builtin_amdgcn_sad_u8(tb.y, 0u, 0u) +
+                                __builtin_amdgcn_sad_u8(tb.z, 0u, 0u) + __builtin_amdgcn_sad_u8(tb.w, 0u, 0u);
+          uint32_t in = mine;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)in, o, 64);
+            if (lane >= o) in += t;
+          }
+          tpre = in - mine;
+        }
         for (int kk0 = 0; kk0 < K; kk0 += 64) {
           const int kk = kk0 + lane;
-          uint2 e = make_uint2(0u, 0u);
+          uint2 e = make_uint2(0u, 0u);     // first byte (from the block's base), postings (FX: padded to whole lines)
           float qv = 0.0f;
-          if (kk < K) {
+          if constexpr (FX) {
+            const int dim = kk < K ? (int)s_nzd[kk] : 0;
+            const int src = (dim >> 4) << 2, b = dim & 15, wi = b >> 2, sh = (b & 3) * 8;
+            const uint32_t gp = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)tpre);
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)tb.x);
+            const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)tb.y);
+            const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)tb.z);
+            const uint32_t w3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)tb.w);
+            const uint32_t ws = wi == 0 ? w0 : wi == 1 ? w1 : wi == 2 ? w2 : w3;
+            uint32_t before = __builtin_amdgcn_sad_u8(ws & ((1u << sh) - 1u), 0u, 0u);
+            before += wi > 0 ? __builtin_amdgcn_sad_u8(w0, 0u, 0u) : 0u;
+            before += wi > 1 ? __builtin_amdgcn_sad_u8(w1, 0u, 0u) : 0u;
+            before += wi > 2 ? __builtin_amdgcn_sad_u8(w2, 0u, 0u) : 0u;
+            if (kk < K) {
+              e = make_uint2((gp + before) * 128u, ((ws >> sh) & 0xffu) * 32u);
+              qv = s_nzv[kk];
+            }
+          } else if (kk < K) {
             const uint32_t w = erow[s_nzd[kk]];
-            e = make_uint2((w >> 16) * 64u, w & 0xffffu);   // first byte (from the block's base), postings
+            e = make_uint2((w >> 16) * 64u, w & 0xffffu);
             qv = s_nzv[kk];
           }
           // The unit of work is a ROW: up to 64 postings of one dimension. A dimension of a
@@ -239,7 +316,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
             const float rq = live ? rq0 : 0.0f;
             const uint32_t t = x - pj;             // row inside the dimension
             const uint32_t rc1 = min(64u, cnj - 64u * t) - 1u;    // last lane of my row with a posting of its own
-            const uint32_t rvo = stj + 256u * t;                  // its values ...
+            const uint32_t rvo = stj + 256u * t;                  // its values (FX: its posting words) ...
             const uint32_t rlo = stj + 4u * cnj + 128u * t;       // ... and local indices
             // Software pipeline over the rows, FI_U deep: row r + FI_U is requested as soon as
             // row r has been applied, so FI_U - 1 rows are always in flight (loads return in
@@ -251,23 +328,34 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
             // counters, and the loop runs to a multiple of FI_U without a tail case. Rows of
             // one dimension touch different vectors; rows of different dimensions are applied in
             // dimension order: the canonical chain.
+            // (FX: a row is one or two whole lines of posting words; rc1 is 31 or 63 -- a power of
+            // two minus one, so the clamp is a mask -- and the lanes past a single line repeat it)
             uint32_t loc[FI_U];
             float qj[FI_U], val[FI_U];
 #define FI_FETCH(u, r)                                                                            \
   {                                                                                               \
     const uint32_t vo_ = (uint32_t)__builtin_amdgcn_readlane((int)rvo, (r));                      \
-    const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)rlo, (r));                      \
     const uint32_t c1_ = (uint32_t)__builtin_amdgcn_readlane((int)rc1, (r));                      \
     qj[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rq), (r))); \
-    const uint32_t l_ = min((uint32_t)lane, c1_);                                                 \
-    val[u] = *reinterpret_cast<const float *>(bptr + (vo_ + 4u * l_));                            \
-    loc[u] = *reinterpret_cast<const uint16_t *>(bptr + (lo_ + 2u * l_));                         \
+    if constexpr (FX) {                                                                           \
+      loc[u] = *reinterpret_cast<const uint32_t *>(bptr + (vo_ + 4u * ((uint32_t)lane & c1_)));   \
+    } else {                                                                                      \
+      const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)rlo, (r));                    \
+      const uint32_t l_ = min((uint32_t)lane, c1_);                                               \
+      val[u] = *reinterpret_cast<const float *>(bptr + (vo_ + 4u * l_));                          \
+      loc[u] = *reinterpret_cast<const uint16_t *>(bptr + (lo_ + 2u * l_));                       \
+    }                                                                                             \
     __builtin_amdgcn_sched_barrier(0);   /* the request stays here: FI_U - 1 rows in flight */     \
   }
-#define FI_APPLY(u)                                              \
-  {                                                              \
-    acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);    \
-    __builtin_amdgcn_sched_barrier(0);                           \
+#define FI_APPLY(u)                                                     \
+  {                                                                     \
+    if constexpr (FX) {                                                 \
+      const uint32_t l_ = loc[u] & 1023u;                               \
+      acc[l_] = __builtin_fmaf(qj[u], (float)(loc[u] >> 10), acc[l_]);  \
+    } else {                                                            \
+      acc[loc[u]] = __builtin_fmaf(qj[u], val[u], acc[loc[u]]);         \
+    }                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                  \
   }
             const int n = (int)min(64u, R - r0);
             const int n_up = (n + FI_U - 1) & ~(FI_U - 1);
@@ -381,38 +469,48 @@ bool flat_inv_supported(int d, int k, int nprobe) {
   return d <= 4096 && nprobe <= FI_NT && k >= 1 && k + FI_NT + 256 <= 4096;
 }
 
-template <int FI_CAP>
+template <int FI_CAP, bool FX>
 static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                            const int32_t *list_offsets, const int32_t *blk_offsets,
                            const uint32_t *blk_base, const uint32_t *seg_tab,
                            const char *seg_bytes, const int32_t *ids, int k, float *D,
                            int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent,
-                           const int32_t *ent_cnt) {
+                           const int32_t *ent_cnt, int tab_stride) {
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   const size_t lds = TopK::lds_bytes() + (size_t)FI_NW * FI_BLK * 4 + (size_t)((d + 3) & ~3) * 4 +
                      (size_t)FI_CHUNK * (sizeof(FiUnit) + 2) + 64 + (size_t)((d + 7) & ~7) * 2;
   if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "flat scan: d=%d does not fit LDS", d);
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)flat_inv_scan_kernel<FI_CAP>,
+    HIP_TRY(hipFuncSetAttribute((const void *)flat_inv_scan_kernel<FI_CAP, FX>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(flat_inv_scan_kernel<FI_CAP>, dim3(nq), dim3(FI_NT), lds, stream(), xq, d,
+  hipLaunchKernelGGL((flat_inv_scan_kernel<FI_CAP, FX>), dim3(nq), dim3(FI_NT), lds, stream(), xq, d,
                      coarse_I, nprobe, list_offsets, blk_offsets, blk_base, seg_tab, seg_bytes, ids,
-                     k, D, I64, I32, set_mode, ent, ent_cnt);
+                     k, D, I64, I32, set_mode, ent, ent_cnt, tab_stride);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
 
-int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
+// layout: 1 = float postings behind a 4-byte table word (seg_tab u32 [nblocks, d], blk_base in
+// 64-byte units); 2 = fixed-point posting words behind a byte table (seg_tab = u8 [nblocks,
+// tab_stride], blk_base in 128-byte lines)
+int flat_inv_scan(int layout, const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *list_offsets, const int32_t *blk_offsets,
-                  const uint32_t *blk_base, const uint32_t *seg_tab, const char *seg_bytes,
+                  const uint32_t *blk_base, const void *seg_tab, int tab_stride, const char *seg_bytes,
                   const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode,
                   const uint2 *ent, const int32_t *ent_cnt) {
   if (nq <= 0) return ASL_OK;
-  if (k + FI_NT + 256 <= 2048)
-    return launch_flat_inv<2048>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base,
-                                 seg_tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt);
-  return launch_flat_inv<4096>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base,
-                               seg_tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt);
+  const uint32_t *tab = reinterpret_cast<const uint32_t *>(seg_tab);
+  const bool small = k + FI_NT + 256 <= 2048;
+#define FI_LAUNCH(CAP, FX)                                                                           \
+  return launch_flat_inv<CAP, FX>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base, \
+                                  tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt, tab_stride)
+  if (layout == 2) {
+    if (small) FI_LAUNCH(2048, true);
+    FI_LAUNCH(4096, true);
+  }
+  if (small) FI_LAUNCH(2048, false);
+  FI_LAUNCH(4096, false);
+#undef FI_LAUNCH
 }
 
 // ---- algorithmic work of a postings scan (bench.py: the roofline of this kernel). Per (query,
@@ -637,6 +735,122 @@ int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_
   if (n <= 0) return ASL_OK;
   hipLaunchKernelGGL(inv_fill_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
                      order, pos_blk, pos_loc, n, blk_base, seg_tab, cursor, seg_bytes);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// ---- the fixed-point layout (flat_inv_scan_kernel<.., true>): work accounting and builders.
+// Algorithmic bytes per (query, probed block, non-zero query dimension): the table byte + 4 bytes
+// per posting (cnt16: the real number of postings of every cell, kept for this accounting only);
+// lines: the block's table row (tab_stride / 128, read whole) + the lines of the wanted segments.
+__global__ __launch_bounds__(256) void flat_fx_work_kernel(
+    const float *__restrict__ xq, int d, const int32_t *__restrict__ coarse_I, int nprobe,
+    const int32_t *__restrict__ blk_offsets, const uint8_t *__restrict__ tab8, int tab_stride,
+    const uint16_t *__restrict__ cnt16, unsigned long long *__restrict__ out) {
+  extern __shared__ int s_work[];          // [d] non-zero dimensions, then 1 counter
+  int *s_dim = s_work, *s_n = s_work + d;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) *s_n = 0;
+  __syncthreads();
+  for (int j = tid; j < d; j += 256)
+    if (xq[(size_t)q * d + j] != 0.0f) s_dim[atomicAdd(s_n, 1)] = j;
+  __syncthreads();
+  const int K = *s_n;
+  unsigned long long bytes = 0, lines = 0;
+  for (int p = 0; p < nprobe; ++p) {
+    const int l = coarse_I[(size_t)q * nprobe + p];
+    if (l < 0) continue;
+    for (int b = blk_offsets[l]; b < blk_offsets[l + 1]; ++b) {
+      for (int t = tid; t < K; t += 256) {
+        bytes += 1ull + 4ull * cnt16[(size_t)b * d + s_dim[t]];
+        lines += tab8[(size_t)b * tab_stride + s_dim[t]];
+      }
+      if (tid == 0) lines += (unsigned long long)((d + 127) / 128);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    bytes += __shfl_xor(bytes, off);
+    lines += __shfl_xor(lines, off);
+  }
+  if (lane == 0) {
+    atomicAdd(&out[0], bytes);
+    atomicAdd(&out[1], lines);
+  }
+}
+
+int flat_fx_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
+                 const int32_t *blk_offsets, const uint8_t *tab8, int tab_stride,
+                 const uint16_t *cnt16, unsigned long long *out_dev) {
+  if (nq <= 0) return ASL_OK;
+  hipLaunchKernelGGL(flat_fx_work_kernel, dim3(nq), dim3(256), (size_t)(d + 1) * 4, stream(), xq, d,
+                     coarse_I, nprobe, blk_offsets, tab8, tab_stride, cnt16, out_dev);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+// posting words into their segments, in the order the atomics run (fx_order_kernel sorts them).
+// seg_line[cell]: first line of the cell's segment, counted from the start of the data.
+__global__ void fx_fill_kernel(const float *__restrict__ vecs, int d,
+                               const int32_t *__restrict__ order,
+                               const int32_t *__restrict__ pos_blk,
+                               const uint16_t *__restrict__ pos_loc, int64_t n,
+                               const uint32_t *__restrict__ seg_line,
+                               uint32_t *__restrict__ cursor, uint32_t *__restrict__ words) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const float *row = vecs + (size_t)order[i] * d;
+  const size_t b = (size_t)pos_blk[i] * d;
+  const uint32_t loc = pos_loc[i];
+  for (int j = lane; j < d; j += 64) {
+    const float x = row[j];
+    if (x != 0.0f) {
+      const uint32_t p = atomicAdd(&cursor[b + j], 1u);
+      words[(size_t)seg_line[b + j] * 32 + p] = ((uint32_t)(x * 4194304.0f) << 10) | loc;   // exact: x is on the grid
+    }
+  }
+}
+
+// canonical image of every segment: postings ascending in the local index (unique inside a
+// segment), the rest of the last line filled with repeats of the last posting. One wave per cell.
+__global__ __launch_bounds__(64 * IO_WAVES) void fx_order_kernel(
+    int64_t ncell, const uint32_t *__restrict__ seg_line, const uint32_t *__restrict__ count,
+    uint32_t *__restrict__ words) {
+  __shared__ uint32_t s_w[IO_WAVES][2][FI_BLK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t cell = (int64_t)blockIdx.x * IO_WAVES + wave;
+  if (cell >= ncell) return;
+  const int c = (int)count[cell];
+  if (c <= 0 || c > FI_BLK) return;
+  uint32_t *g = words + (size_t)seg_line[cell] * 32;
+  uint32_t *a = s_w[wave][0], *b = s_w[wave][1];
+  for (int i = lane; i < c; i += 64) a[i] = g[i];
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < c; i += 64) {
+    const uint32_t me = a[i] & 1023u;
+    int r = 0;
+    for (int t = 0; t < c; ++t) r += (a[t] & 1023u) < me;
+    b[r] = a[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int padded = (c + 31) & ~31;
+  for (int i = lane; i < padded; i += 64) g[i] = b[min(i, c - 1)];
+}
+
+int fx_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk,
+            const uint16_t *pos_loc, int64_t n, const uint32_t *seg_line, uint32_t *cursor,
+            uint32_t *words) {
+  if (n <= 0) return ASL_OK;
+  hipLaunchKernelGGL(fx_fill_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), vecs, d, order,
+                     pos_blk, pos_loc, n, seg_line, cursor, words);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
+}
+
+int fx_order(int64_t ncell, const uint32_t *seg_line, const uint32_t *count, uint32_t *words) {
+  if (ncell <= 0) return ASL_OK;
+  hipLaunchKernelGGL(fx_order_kernel, dim3((unsigned)cdiv(ncell, IO_WAVES)), dim3(64 * IO_WAVES), 0,
+                     stream(), ncell, seg_line, count, words);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }

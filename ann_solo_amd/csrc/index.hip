@@ -53,6 +53,7 @@ static int dev_append(DevBuf<T> &buf, size_t old_n, const T *src_dev, size_t n) 
 }
 
 constexpr size_t SCORE_CHUNK_BYTES = (size_t)1 << 30;
+constexpr int FLAT_KEYS_SLACK = 768;      // packed-key rows of the postings scan: k + 768 <= its 2048-key buffer
 
 }  // namespace asl
 
@@ -98,6 +99,13 @@ struct asl_index {
   DevBuf<uint32_t> inv_tab;      // [nblocks * d] (start from the block's base in 64-byte units) << 16 | postings
   DevBuf<char> inv_data;         // segments: c values (f32) then c local vector indices (u16), placed by 128-byte line
   bool has_inv = false;
+  // the fixed-point layout (inv_layout 2): blk_base in 128-byte lines, one byte per (block,
+  // dimension) = lines of the segment, posting words (numerator << 10 | local index) in inv_data
+  int flat_storage = 0;          // 0: add() rounds components in [0, 1) to 22 fractional bits; 1: float32 as given
+  int inv_layout = 0;            // what build_lists found the data fit for: 0 none, 1 float postings, 2 fixed-point words
+  int tab_stride = 0;            // bytes per block of inv_tab8 (d rounded up to a 128-byte line)
+  DevBuf<uint8_t> inv_tab8;
+  DevBuf<uint16_t> inv_cnt16;    // postings per (block, dimension): work accounting only (asl_index_postings_work)
   int scan_variant = 0;  // 0 = the layout-specific scan when the shape allows; 1 = the generic kernels
   int unordered = 0;  // 1: search rows = exact top-k as a set, unspecified order (no final sort); 2: rows of packed keys
   bool lists_dirty = true;
@@ -331,11 +339,14 @@ static int build_lists(asl_index *ix) {
   if (ix->kind == ASL_INDEX_IVFFLAT && n > 0 && ix->d <= 65535) {
     DevBuf<int32_t> nnz, nnz_max;
     ASL_TRY(nnz.reserve((size_t)n));
-    ASL_TRY(nnz_max.reserve(1));
+    ASL_TRY(nnz_max.reserve(2));
     ASL_TRY(count_nnz(ix->vecs.p, ix->d, n, nnz.p, nnz_max.p));
-    int32_t h_max = 0;
-    ASL_TRY(nnz_max.download(&h_max, 1));
+    int32_t h_nm[2] = {0, 0};
+    ASL_TRY(nnz_max.download(h_nm, 2));
     ASL_TRY(sync_stream());
+    const int32_t h_max = h_nm[0];
+    // every non-zero on the 2^-22 grid inside (0, 1): posting words (flat_scan.hip, FX)
+    const bool fixed_point = h_nm[1] == 0 && ix->d <= 1024 && FI_BLK <= 1024;
     // dimension-major postings (the default IVF-Flat scan)
     if (h_max > 0 && (size_t)h_max * 8 < (size_t)ix->d) {
       std::vector<int32_t> blk_off((size_t)ix->nlist + 1, 0), pos_blk((size_t)n);
@@ -362,6 +373,45 @@ static int build_lists(asl_index *ix) {
       std::vector<uint32_t> h_cnt(ncell);
       ASL_TRY(cnt_dev.download(h_cnt.data(), ncell));
       ASL_TRY(sync_stream());
+      ix->inv_layout = 0;
+      if (fixed_point) {
+        // whole lines of 32 posting words per (block, dimension); the table byte is the line count
+        const int stride = (ix->d + 127) & ~127;
+        std::vector<uint8_t> h_tab8(nblk * (size_t)stride, 0);
+        std::vector<uint16_t> h_c16(ncell);
+        std::vector<uint32_t> h_line(ncell), h_base(nblk);
+        uint64_t run = 0;     // 128-byte lines
+        for (size_t b = 0; b < nblk; b++) {
+          h_base[b] = (uint32_t)run;
+          for (int j = 0; j < ix->d; j++) {
+            const uint32_t c = h_cnt[b * (size_t)ix->d + j];       // <= FI_BLK: at most 26 lines
+            h_line[b * (size_t)ix->d + j] = (uint32_t)run;
+            h_c16[b * (size_t)ix->d + j] = (uint16_t)c;
+            h_tab8[b * (size_t)stride + j] = (uint8_t)((c + 31) / 32);
+            run += (c + 31) / 32;
+          }
+        }
+        if (run < (1ull << 32)) {
+          const size_t bytes = (size_t)std::max<uint64_t>(run, 1) * 128 + 512;
+          DevBuf<uint32_t> line_dev;
+          ASL_TRY(line_dev.upload(h_line.data(), ncell));
+          ASL_TRY(ix->blk_offsets.upload(blk_off.data(), blk_off.size()));
+          ASL_TRY(ix->blk_base.upload(h_base.data(), nblk));
+          ASL_TRY(ix->inv_tab8.upload(h_tab8.data(), h_tab8.size()));
+          ASL_TRY(ix->inv_cnt16.upload(h_c16.data(), ncell));
+          ASL_TRY(ix->inv_data.reserve(bytes));
+          HIP_TRY(hipMemsetAsync(ix->inv_data.p, 0, bytes, stream()));
+          HIP_TRY(hipMemsetAsync(cnt_dev.p, 0, ncell * 4, stream()));
+          ASL_TRY(fx_fill(ix->vecs.p, ix->d, order.p, pos_blk_dev.p, pos_loc_dev.p, n, line_dev.p,
+                          cnt_dev.p, reinterpret_cast<uint32_t *>(ix->inv_data.p)));
+          ASL_TRY(fx_order((int64_t)ncell, line_dev.p, cnt_dev.p, reinterpret_cast<uint32_t *>(ix->inv_data.p)));
+          ASL_TRY(sync_stream());
+          ix->tab_stride = stride;
+          ix->has_inv = true;
+          ix->inv_layout = 2;
+        }
+      }
+      if (!ix->has_inv) {
       // segments placed block by block (flat_scan.hip: inv_place_block)
       std::vector<uint32_t> h_tab(ncell), h_base(nblk);
       uint64_t run = 0;     // 64-byte units
@@ -385,6 +435,8 @@ static int build_lists(asl_index *ix) {
         ASL_TRY(inv_order((int64_t)nblk, ix->d, ix->blk_base.p, ix->inv_tab.p, ix->inv_data.p));
         ASL_TRY(sync_stream());
         ix->has_inv = true;
+        ix->inv_layout = 1;
+      }
       }
     }
   }
@@ -454,8 +506,8 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   const int d = ix->d;
   const int64_t n = ix->n_store;
   if (ix->kind == ASL_INDEX_FLAT || ix->kind == ASL_INDEX_IVFFLAT) {
-    if (ix->unordered == 2) return fail(ASL_ERR_STATE, "packed-key rows need an IVF-PQ index");
     const bool ivf = ix->kind == ASL_INDEX_IVFFLAT;
+    if (ix->unordered == 2 && !ivf) return fail(ASL_ERR_STATE, "packed-key rows need an IVF index");
     int words = 0;
     if (ivf) {
       nprobe = std::max(1, std::min(nprobe, ix->nlist));
@@ -469,6 +521,8 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       ASL_TRY(build_lists(ix));
       // variant 0: dimension-major postings; 1 (or an unsupported shape): dense GEMM + masked top-k
       const bool use_inv = ix->has_inv && ix->scan_variant == 0 && flat_inv_supported(d, k, nprobe);
+      if (ix->unordered == 2 && !(use_inv && I64 && k + FLAT_KEYS_SLACK <= TK_MAX_K))
+        return fail(ASL_ERR_STATE, "packed-key rows need the postings scan of IVF-Flat (sparse vectors, k <= 1280) and an int64 output");
       if (use_inv) {
         {
           ProfScope ps("scan");
@@ -476,10 +530,12 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
           ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
           ASL_TRY(ix->scan_over.reserve(1));
           ASL_TRY(list_nonzeros(xq, nq, d, d, ix->scan_ent.p, ix->scan_cnt.p, ix->scan_over.p));
-          ASL_TRY(flat_inv_scan(xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
-                                ix->blk_offsets.p, ix->blk_base.p, ix->inv_tab.p, ix->inv_data.p,
-                                ix->ids.p, k, D, I64, I32, set_mode || ix->unordered == 1,
-                                ix->scan_ent.p, ix->scan_cnt.p));
+          const bool fx = ix->inv_layout == 2;
+          ASL_TRY(flat_inv_scan(ix->inv_layout, xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
+                                ix->blk_offsets.p, ix->blk_base.p,
+                                fx ? (const void *)ix->inv_tab8.p : (const void *)ix->inv_tab.p,
+                                ix->tab_stride, ix->inv_data.p, ix->ids.p, k, D, I64, I32,
+                                ix->unordered ? ix->unordered : (set_mode ? 1 : 0), ix->scan_ent.p, ix->scan_cnt.p));
         }
         if (prof_enabled()) {
           // vectors scored by this launch, summed on the device (nothing waits inside a step)
@@ -666,6 +722,28 @@ int asl_index_set_unordered(asl_index_t *ix, int32_t unordered) {
   return ASL_OK;
 }
 
+int asl_index_set_flat_storage(asl_index_t *ix, int32_t mode) {
+  clear_error();
+  if (!ix || ix->kind != ASL_INDEX_IVFFLAT) return fail(ASL_ERR_INVALID, "set_flat_storage: an IVF-Flat index is required");
+  if (mode != ASL_FLAT_FX22 && mode != ASL_FLAT_F32) return fail(ASL_ERR_INVALID, "set_flat_storage: ASL_FLAT_FX22 or ASL_FLAT_F32");
+  if (ix->ntotal > 0 && mode != ix->flat_storage)
+    return fail(ASL_ERR_STATE, "set_flat_storage: set before add() (stored components are rounded as they arrive)");
+  ix->flat_storage = mode;
+  return ASL_OK;
+}
+
+int asl_index_get_flat_storage(const asl_index_t *ix) { return ix ? ix->flat_storage : 0; }
+
+int asl_index_flat_layout(asl_index_t *ix) {
+  clear_error();
+  if (!ix || ix->kind != ASL_INDEX_IVFFLAT) return fail(ASL_ERR_INVALID, "flat_layout: an IVF-Flat index is required");
+  if (ix->trained && ix->n_store > 0) {
+    ASL_TRY(ensure_device());
+    ASL_TRY(build_lists(ix));
+  }
+  return ix->has_inv ? ix->inv_layout : 0;
+}
+
 int asl_index_set_scan_variant(asl_index_t *ix, int32_t variant) {
   clear_error();
   if (!ix || variant < 0 || variant > 1)
@@ -678,8 +756,12 @@ int asl_index_set_scan_variant(asl_index_t *ix, int32_t variant) {
 // index at (k, nprobe): the predicate index_search_device applies, for callers that must
 // choose the exchange format up front (ann_solo_amd/distributed.py).
 int asl_index_supports_keys(const asl_index_t *ix, int32_t k, int32_t nprobe) {
-  if (!ix || ix->kind != ASL_INDEX_IVFPQ) return 0;
+  if (!ix) return 0;
   nprobe = std::max(1, std::min(nprobe, ix->nlist));
+  if (ix->kind == ASL_INDEX_IVFFLAT)      // the postings scan's set finish (flat_scan.hip)
+    return ix->scan_variant == 0 && (ix->lists_dirty || ix->has_inv) && flat_inv_supported(ix->d, k, nprobe) &&
+           k + 768 <= TK_MAX_K;
+  if (ix->kind != ASL_INDEX_IVFPQ) return 0;
   return ix->scan_variant == 0 && pq_scan_tiled_supported(ix->pq_m, ix->ksub, k, nprobe) &&
          k + 768 <= TK_MAX_K;
 }
@@ -805,6 +887,8 @@ static int index_add_impl(asl_index_t *ix, int64_t n, const float *x, const int3
     }
   } else {
     ASL_TRY(dev_append(ix->vecs, (size_t)ix->n_store * ix->d, dx.d, (size_t)n * ix->d));
+    if (ix->kind == ASL_INDEX_IVFFLAT && ix->flat_storage == 0)      // stored components: 22-bit fixed point
+      ASL_TRY(quantize_fx22(ix->vecs.p + (size_t)ix->n_store * ix->d, n * ix->d));
   }
   ASL_TRY(sync_stream());
   ix->n_store += n;
@@ -1114,7 +1198,11 @@ int asl_index_postings_work(asl_index_t *ix, int32_t nq, const float *xq, int32_
   DevBuf<unsigned long long> acc;
   ASL_TRY(acc.reserve(2));
   HIP_TRY(hipMemsetAsync(acc.p, 0, 16, stream()));
-  ASL_TRY(flat_inv_work(dq.d, nq, ix->d, ix->coarse_I.p, nprobe, ix->blk_offsets.p, ix->inv_tab.p, acc.p));
+  if (ix->inv_layout == 2)
+    ASL_TRY(flat_fx_work(dq.d, nq, ix->d, ix->coarse_I.p, nprobe, ix->blk_offsets.p, ix->inv_tab8.p,
+                         ix->tab_stride, ix->inv_cnt16.p, acc.p));
+  else
+    ASL_TRY(flat_inv_work(dq.d, nq, ix->d, ix->coarse_I.p, nprobe, ix->blk_offsets.p, ix->inv_tab.p, acc.p));
   unsigned long long h[2] = {0, 0};
   ASL_TRY(acc.download(h, 2));
   ASL_TRY(sync_stream());
@@ -1254,7 +1342,8 @@ int asl_index_save(const asl_index_t *ix, const char *path) {
   h.shard_rank = ix->shard_rank;
   h.shard_world = ix->shard_world;
   h.has_vids = ix->has_vids;
-  h.pad = ix->refine_rows ? (1 | (ix->refine_k << 1)) : 0;   // exact rows follow the payload
+  h.pad = ix->refine_rows ? (1 | (ix->refine_k << 1)) : 0;   // IVF-PQ: exact rows follow the payload
+  if (ix->kind == ASL_INDEX_IVFFLAT) h.pad = ix->flat_storage;   // IVF-Flat: component storage mode
   bool ok = fwrite(&h, sizeof h, 1, f) == 1;
   auto dump = [&](const void *dev, size_t bytes) {
     if (!ok || bytes == 0) return;
@@ -1318,7 +1407,9 @@ asl_index_t *asl_index_load(const char *path) {
     else if (h.niter < 0 || (h.trained != 0 && h.trained != 1) || (h.has_vids != 0 && h.has_vids != 1)) bad = "bad flags";
     else if (h.shard_world < 1 || h.shard_rank < 0 || h.shard_rank >= h.shard_world) bad = "bad shard fields";
     else if (!h.trained && h.n_store > 0 && ivf) bad = "vectors in an untrained index";
-    else if (h.pad < 0 || ((h.pad & 1) && h.kind != ASL_INDEX_IVFPQ) || (h.pad >> 1) > TK_MAX_K) bad = "bad refine fields";
+    else if (h.kind == ASL_INDEX_IVFFLAT ? (h.pad != ASL_FLAT_FX22 && h.pad != ASL_FLAT_F32)
+                                         : (h.pad < 0 || ((h.pad & 1) && h.kind != ASL_INDEX_IVFPQ) || (h.pad >> 1) > TK_MAX_K))
+      bad = "bad refine / storage fields";
     if (!bad) {  // the payload must be exactly what the header announces
       const uint64_t ksub = h.kind == ASL_INDEX_IVFPQ ? (1ull << h.pq_bits) : 0;
       uint64_t want = sizeof h;
@@ -1327,7 +1418,7 @@ asl_index_t *asl_index_load(const char *path) {
       if (ivf) want += (uint64_t)h.n_store * 4;
       if (h.has_vids) want += (uint64_t)h.n_store * 4;
       want += h.kind == ASL_INDEX_IVFPQ ? (uint64_t)h.n_store * h.pq_m : (uint64_t)h.n_store * h.d * 4;
-      if (h.pad & 1) want += (uint64_t)h.ntotal * (1 + (uint64_t)refine_stride() * 6);
+      if (h.kind == ASL_INDEX_IVFPQ && (h.pad & 1)) want += (uint64_t)h.ntotal * (1 + (uint64_t)refine_stride() * 6);
       const long here = ftell(f);
       if (fseek(f, 0, SEEK_END) != 0 || (uint64_t)ftell(f) != want) bad = "file size does not match the header";
       fseek(f, here, SEEK_SET);
@@ -1377,7 +1468,8 @@ asl_index_t *asl_index_load(const char *path) {
     slurp(ix->codes_add, n * ix->pq_m);
   else
     slurp(ix->vecs, n * ix->d);
-  if (h.pad & 1) {
+  if (ix->kind == ASL_INDEX_IVFFLAT) ix->flat_storage = h.pad;
+  if (ix->kind == ASL_INDEX_IVFPQ && (h.pad & 1)) {
     const size_t rn = (size_t)ix->ntotal, S = (size_t)refine_stride();
     ix->refine_rows = true;
     ix->refine_k = h.pad >> 1;

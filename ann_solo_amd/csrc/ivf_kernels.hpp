@@ -64,11 +64,13 @@ int tile_codes(const uint8_t *codes, const int32_t *ids, const int32_t *dst_slot
 // FI_BLK measured (scan ms at nprobe 128): 512 7.69 | 640 7.14 | 768 6.81 | 832 6.71 | 864 6.70 (the LDS limit of three workgroups per CU) | 1024: two workgroups per CU
 constexpr int FI_BLK = 832;
 bool flat_inv_supported(int d, int k, int nprobe);
-int flat_inv_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
+// layout 1: float postings (seg_tab u32 [nblocks, d]); 2: fixed-point posting words behind a byte
+// table (seg_tab u8 [nblocks, tab_stride]); see flat_scan.hip
+int flat_inv_scan(int layout, const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *list_offsets, const int32_t *blk_offsets,
-                  const uint32_t *blk_base, const uint32_t *seg_tab, const char *seg_bytes,
+                  const uint32_t *blk_base, const void *seg_tab, int tab_stride, const char *seg_bytes,
                   const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode,
-                  const uint2 *ent = nullptr, const int32_t *ent_cnt = nullptr);
+                  const uint2 *ent, const int32_t *ent_cnt);
 int flat_inv_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *blk_offsets, const uint32_t *seg_tab, unsigned long long *out_dev);
 uint32_t inv_place_block(const uint32_t *cnt, int d, uint32_t *tab, bool *ok);
@@ -84,6 +86,31 @@ int inv_count(const float *vecs, int d, const int32_t *order, const int32_t *pos
 int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk,
              const uint16_t *pos_loc, int64_t n, const uint32_t *blk_base,
              const uint32_t *seg_tab, uint32_t *cursor, char *seg_bytes);
+// fixed-point storage (22 fractional bits) of IVF-Flat components in [0, 1)
+__host__ __device__ inline float fx22_round(float x) {
+  if (!(x >= 0.0f && x < 1.0f)) return x;
+  const float m = rintf(x * 4194304.0f);          // a power of two: exact; ties to even
+  return (m < 4194303.0f ? m : 4194303.0f) * (1.0f / 4194304.0f);
+}
+__host__ __device__ inline bool fx22_on_grid(float x) {
+  return x > 0.0f && x < 1.0f && x * 4194304.0f == rintf(x * 4194304.0f);
+}
+int quantize_fx22(float *x, int64_t n);
+// the two-phase exact exchange of a sharded search (exchange.hip)
+int keys_split(const unsigned long long *K, int64_t nrows, int k, int kp, unsigned long long *head,
+               unsigned long long *rest);
+int keys_merge(const unsigned long long *heads, int S, int nq, int kp, int k, const unsigned long long *xbuf,
+               long long xcap, const unsigned long long *prev_keys, int32_t *need,
+               unsigned long long *out_keys, unsigned long long *bounds, int64_t *I, float *D, int sorted);
+int keys_extras(const unsigned long long *rest, int64_t nrows, int k, const unsigned long long *bounds, int nq,
+                long long xcap, unsigned long long *xbuf, unsigned int *cursor, int32_t *overflow);
+int flat_fx_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
+                 const int32_t *blk_offsets, const uint8_t *tab8, int tab_stride,
+                 const uint16_t *cnt16, unsigned long long *out_dev);
+int fx_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk,
+            const uint16_t *pos_loc, int64_t n, const uint32_t *seg_line, uint32_t *cursor,
+            uint32_t *words);
+int fx_order(int64_t ncell, const uint32_t *seg_line, const uint32_t *count, uint32_t *words);
 int inv_order(int64_t nblocks, int d, const uint32_t *blk_base, const uint32_t *seg_tab,
               char *seg_bytes);
 int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_max_dev);

@@ -85,8 +85,10 @@ using namespace asl;
 // asl_index_shard(idx, rank, world) on an index holding the same vectors everywhere:
 //   all-gather of the hashed queries -> coarse quantiser on the own slice, probe lists
 //   all-gathered -> scan of the local inverted lists for all world x nq queries (exact top-k
-//   sets) -> all-to-all of the per-shard rows (grouped send/recv: direct peer copies over xGMI)
-//   -> k-way merge under (score desc, id asc).
+//   sets) -> the two-phase exact exchange of exchange.hip (heads of ~2k / world packed keys,
+//   the owners' bounds, the held-back keys above them; grouped send/recv = direct peer copies
+//   over xGMI) -> merge under (score desc, id asc). The full rows travel instead when the scan
+//   cannot emit packed keys, with the exact re-rank on, or after a phase-2 buffer ran full.
 // With the exact re-rank on (asl_index_set_refine, k' > k) every shard returns its k' best ADC
 // hits, the merge yields the k' best of the whole index -- the unsharded short-list -- and the
 // owner of the query re-ranks that against the exact rows (replicated on every rank).
@@ -137,6 +139,76 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
   ASL_TRY(index_coarse_device(ix, nq, xq, np, cD.p, cI.p));
   RCCL_TRY(R.AllGather(cD.p, cD_all.p, (size_t)nq * np, NCCL_FLOAT32, comm, st));
   RCCL_TRY(R.AllGather(cI.p, cI_all.p, (size_t)nq * np, NCCL_INT32, comm, st));
+  // 2'. the two-phase exact exchange (exchange.hip) whenever the scan can emit packed keys: heads
+  //     of ~2k / world keys, the owners' bounds, the held-back keys above them; the full rows
+  //     below remain the path for everything else and the fallback when a phase-2 buffer runs full
+  if (!refine && asl_index_supports_keys(ix, k, np)) {
+    typedef unsigned long long u64k;
+    static DevBuf<int64_t> &Kp = *new DevBuf<int64_t>(), &Hs = *new DevBuf<int64_t>(), &Hr = *new DevBuf<int64_t>(),
+                           &Rs = *new DevBuf<int64_t>(), &Ko = *new DevBuf<int64_t>(), &Bs = *new DevBuf<int64_t>(),
+                           &Br = *new DevBuf<int64_t>(), &Xs = *new DevBuf<int64_t>(), &Xr = *new DevBuf<int64_t>();
+    static DevBuf<int32_t> &need = *new DevBuf<int32_t>(), &flag = *new DevBuf<int32_t>();
+    static DevBuf<unsigned int> &cursor = *new DevBuf<unsigned int>();
+    const int keys = std::min(k, (2 * k + world - 1) / world), kp = keys + 1;
+    const bool second = kp - 1 < k;
+    const long long xcap = (long long)nq * std::max(8, k / 16);
+    ASL_TRY(Kp.reserve(all * k));
+    ASL_TRY(Hs.reserve(all * kp));
+    ASL_TRY(Hr.reserve(all * kp));
+    ASL_TRY(Rs.reserve(all * k));
+    ASL_TRY(Ko.reserve((size_t)nq * k));
+    ASL_TRY(Bs.reserve(all));
+    ASL_TRY(Br.reserve(all));
+    ASL_TRY(need.reserve((size_t)nq));
+    ASL_TRY(flag.reserve(1));
+    int prev = 0;
+    ASL_TRY(index_swap_unordered(ix, 2, &prev));
+    const int rc = index_search_device(ix, (int)all, x_all.p, k, np, nullptr, Kp.p, nullptr, cD_all.p, cI_all.p, true);
+    ASL_TRY(index_swap_unordered(ix, prev, nullptr));
+    ASL_TRY(rc);
+    ASL_TRY(keys_split(reinterpret_cast<const u64k *>(Kp.p), (int64_t)all, k, kp, reinterpret_cast<u64k *>(Hs.p),
+                       reinterpret_cast<u64k *>(Rs.p)));
+    auto all_to_all = [&](const int64_t *src, int64_t *dst, size_t per_rank) -> int {
+      RCCL_TRY(R.GroupStart());
+      for (int r = 0; r < world; ++r) {
+        RCCL_TRY(R.Send(src + (size_t)r * per_rank, per_rank, NCCL_INT64, r, comm, st));
+        RCCL_TRY(R.Recv(dst + (size_t)r * per_rank, per_rank, NCCL_INT64, r, comm, st));
+      }
+      RCCL_TRY(R.GroupEnd());
+      return ASL_OK;
+    };
+    ASL_TRY(all_to_all(Hs.p, Hr.p, (size_t)nq * kp));
+    ASL_TRY(keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, nullptr, 0, nullptr, need.p,
+                       reinterpret_cast<u64k *>(Ko.p), reinterpret_cast<u64k *>(Bs.p), nullptr, nullptr, 0));
+    bool overflow = false;
+    const int64_t *xr = nullptr;
+    if (second) {
+      ASL_TRY(Xs.reserve((size_t)world * ((size_t)nq + (size_t)xcap)));
+      ASL_TRY(Xr.reserve((size_t)world * ((size_t)nq + (size_t)xcap)));
+      ASL_TRY(cursor.reserve((size_t)world));
+      ASL_TRY(all_to_all(Bs.p, Br.p, (size_t)nq));
+      HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)world * sizeof(unsigned int), st));
+      HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int32_t), st));
+      ASL_TRY(keys_extras(reinterpret_cast<const u64k *>(Rs.p), (int64_t)all, k, reinterpret_cast<const u64k *>(Br.p),
+                          nq, xcap, reinterpret_cast<u64k *>(Xs.p), cursor.p, flag.p));
+      ASL_TRY(all_to_all(Xs.p, Xr.p, (size_t)nq + (size_t)xcap));
+      // a full phase-2 buffer ANYWHERE sends every rank down the full exchange: the flags are
+      // gathered (world ints) so that all ranks take the same branch
+      static DevBuf<int32_t> &flags = *new DevBuf<int32_t>();
+      ASL_TRY(flags.reserve((size_t)world));
+      RCCL_TRY(R.AllGather(flag.p, flags.p, 1, NCCL_INT32, comm, st));
+      std::vector<int32_t> h((size_t)world);
+      ASL_TRY(flags.download(h.data(), (size_t)world));
+      ASL_TRY(sync_stream());
+      for (int32_t f : h) overflow |= f != 0;
+      xr = Xr.p;
+    }
+    if (!overflow) {
+      float *Dout2 = D;
+      return keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, reinterpret_cast<const u64k *>(xr),
+                        xr ? xcap : 0, reinterpret_cast<const u64k *>(Ko.p), need.p, nullptr, nullptr, I, Dout2, 1);
+    }
+  }
   // 2. the local lists, for all queries (rank-major rows), as exact top-k sets
   //    (unordered mode: un-refined ADC rows, see annsolo_mi.h at asl_index_set_refine)
   int prev_unordered = 0;

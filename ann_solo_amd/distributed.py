@@ -10,15 +10,21 @@ addition. Per batch and charge partition:
   2. every rank searches its own inverted lists for ALL queries: coarse quantiser is
      replicated (identical probe lists everywhere, bit-exact fp32 MFMA chain), the
      PQ/flat scan touches only locally owned lists -> per-shard top-k;
-  3. the exchange: all-to-all of the per-shard top-k (IVF-PQ: one packed 8-byte key per hit
-     = order-preserving score bits << 32 | ~id) so that rank r receives the
-     ``world`` partial lists of its own query slice (1/world of an all-gather's
-     inbound bytes; xGMI is point-to-point, so this maps to direct peer copies). The
-     scan runs in a few query chunks and the all-to-all of one chunk is in flight on
-     RCCL's stream while the next chunk is scanned;
-  4. k-way merge under (score desc, id asc) -- identical to the unsharded result by
-     construction -- then precursor post-filter + shifted-dot rescoring data-parallel
-     over the rank's own queries (the packed peak store is replicated: ~1 GB of 288).
+  3. the exchange (round 4: two phases, exact; csrc/exchange.hip has the argument). Hits are
+     packed 8-byte keys (order-preserving score bits << 32 | ~id). Phase 1: an all-to-all of the
+     HEAD of every per-shard row -- about 2 k / world of its best keys plus its best held-back
+     key T -- so that rank r receives ``world`` heads for each query of its own slice (~2 k keys
+     per query instead of world * k). The owner merges them, takes the k-th best key it has seen
+     as a bound B and asks exactly those shards whose T beats B for what they hold above B
+     (all-to-all of 8 bytes per (query, shard), then an all-to-all of one small fixed-size
+     buffer per pair of ranks: usually empty). xGMI is point-to-point, so an all-to-all maps to
+     direct peer copies. The scan runs in a few query chunks and the collectives of one chunk
+     are in flight on RCCL's stream while the next chunk is scanned;
+  4. merge under (score desc, id asc) -- identical to the unsharded result by construction
+     (a key that is never shipped lies below a bound that k shipped keys reach) -- then precursor
+     post-filter + shifted-dot rescoring data-parallel over the rank's own queries (the packed
+     peak store is replicated: ~1 GB of 288). If a phase-2 buffer overflows (a flag, checked
+     once per batch) the batch is repeated with the full world * k exchange.
 
 List ownership is the greedy heaviest-first balancing of ``asl_lpt_owner`` over the
 expected scan load of each list (size squared: populous lists are also probed more often);
@@ -148,6 +154,44 @@ class HipShardBackend:
         from . import faiss_compat
         return faiss_compat.topk_merge_keys(Ks, unordered=True)   # rescoring consumes a set
 
+    # ---- the two-phase exchange (csrc/exchange.hip); every tensor lives on the device
+    def keys_split(self, K: torch.Tensor, kp: int):
+        rows, k = K.shape
+        head = torch.empty((rows, kp), dtype=torch.int64, device=K.device)
+        rest = torch.empty((rows, k), dtype=torch.int64, device=K.device)
+        _lib.check(_lib.lib().asl_keys_split(rows, k, kp, _lib.ptr(K), _lib.ptr(head), _lib.ptr(rest)))
+        return head, rest
+
+    def keys_merge_heads(self, heads: torch.Tensor, k: int):
+        S, n, kp = heads.shape
+        dev = heads.device
+        out = torch.empty((n, k), dtype=torch.int64, device=dev)
+        bounds = torch.empty((S, n), dtype=torch.int64, device=dev)
+        need = torch.empty((n,), dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().asl_keys_merge_heads(S, n, kp, k, _lib.ptr(heads), _lib.ptr(out),
+                                                   _lib.ptr(bounds), _lib.ptr(need)))
+        return out, bounds, need
+
+    def keys_extras(self, rest: torch.Tensor, bounds: torch.Tensor, world: int, xcap: int,
+                    overflow: torch.Tensor):
+        rows, k = rest.shape
+        n = rows // world
+        xbuf = torch.empty((world, n + xcap), dtype=torch.int64, device=rest.device)
+        _lib.check(_lib.lib().asl_keys_extras(world, n, k, _lib.ptr(rest), _lib.ptr(bounds), int(xcap),
+                                              _lib.ptr(xbuf), _lib.ptr(overflow)))
+        return xbuf
+
+    def keys_merge_final(self, heads: torch.Tensor, xbuf: Optional[torch.Tensor], out_keys, need, k: int):
+        S, n, kp = heads.shape
+        I = torch.empty((n, k), dtype=torch.int64, device=heads.device)
+        xcap = 0 if xbuf is None else xbuf.shape[1] - n
+        _lib.check(_lib.lib().asl_keys_merge_final(S, n, kp, k, _lib.ptr(heads), _lib.ptr(xbuf), int(xcap),
+                                                   _lib.ptr(out_keys), _lib.ptr(need), None, _lib.ptr(I)))
+        return I
+
+    def new_flag(self):
+        return torch.zeros(1, dtype=torch.int32, device=self.device)
+
     def refine(self, vectors: torch.Tensor, knn: torch.Tensor):
         """Merged k' short-list of the own queries -> the k best by exact inner product."""
         if self.k_scan == self.k:
@@ -224,6 +268,53 @@ def exchange_partials(D: torch.Tensor, I: torch.Tensor, world: int, group=None,
     return out + ([], None) if async_op else out
 
 
+class CommLog:
+    """Bytes this rank hands to every collective of the sharded search, by name (bench.py prints
+    it as the ``comm`` block; ``sharded_search_batch(..., comm=CommLog())``)."""
+
+    def __init__(self):
+        self.calls = {}
+
+    def add(self, name: str, t: torch.Tensor, world: int, kind: str):
+        b = t.numel() * t.element_size()
+        # all-to-all: (world - 1) / world of the buffer leaves the rank; all-gather: the buffer goes
+        # to every other rank
+        out = b * (world - 1) // world if kind == 'all_to_all' else b * (world - 1)
+        c = self.calls.setdefault(name, {'kind': kind, 'calls': 0, 'buffer_bytes': 0, 'bytes_out': 0})
+        c['calls'] += 1
+        c['buffer_bytes'] += b
+        c['bytes_out'] += out
+
+    def summary(self, steps: int = 1):
+        out = {}
+        for name, c in self.calls.items():
+            out[name] = {'kind': c['kind'], 'calls_per_step': c['calls'] / steps,
+                         'bytes_out_per_rank_per_step': c['bytes_out'] // max(steps, 1),
+                         'buffer_bytes_per_call': c['buffer_bytes'] // max(c['calls'], 1)}
+        out['total_bytes_out_per_rank_per_step'] = sum(c['bytes_out'] for c in self.calls.values()) // max(steps, 1)
+        return out
+
+
+def _all_to_all(x: torch.Tensor, world: int, group=None, comm: Optional[CommLog] = None, name: str = ''):
+    """x [world * m, ...] (block r goes to rank r) -> ([world, m, ...] the blocks the ranks sent
+    here, work handles). RCCL: one all_to_all_single, enqueued asynchronously; gloo (CPU tests):
+    all-gather of host copies and a slice."""
+    m = x.shape[0] // world
+    rank = dist.get_rank(group)
+    if comm is not None:
+        comm.add(name, x, world, 'all_to_all')
+    if dist.get_backend(group) == 'nccl':
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        w = dist.all_to_all_single(out, x, group=group, async_op=True)
+        return out.view((world, m) + tuple(x.shape[1:])), [w], x
+    xc = x.cpu().contiguous()
+    parts = [torch.empty_like(xc) for _ in range(world)]
+    dist.all_gather(parts, xc, group=group)
+    sl = slice(rank * m, (rank + 1) * m)
+    return torch.stack([p_[sl] for p_ in parts]).to(x.device), [], None
+
+
 def exchange_keys(K: torch.Tensor, world: int, group=None):
     """Packed-key variant of ``exchange_partials``: ONE all-to-all of 8 bytes per hit.
     Returns ([world, n, k] keys of this rank's n queries, work handles, keep-alive)."""
@@ -287,7 +378,8 @@ def _peak_row_width(queries: PackedSpectra, world: int, group=None,
     return -(-m // PEAK_ROW_ALIGN) * PEAK_ROW_ALIGN
 
 
-def _all_gather_peaks(queries: PackedSpectra, world: int, group=None, agreed: Optional[int] = None):
+def _all_gather_peaks(queries: PackedSpectra, world: int, group=None, agreed: Optional[int] = None,
+                      comm: Optional['CommLog'] = None):
     """All-gather of the local queries' peaks as fixed-width rows [n, 2 W + 1] of 4-byte words
     (W m/z values, W intensities, the peak count). Returns (gathered [world * n, 2 W + 1], work)."""
     W = _peak_row_width(queries, world, group, agreed)
@@ -303,6 +395,8 @@ def _all_gather_peaks(queries: PackedSpectra, world: int, group=None, agreed: Op
         buf[:, :W] = torch.where(have, queries.mz[pos], buf[:, :W])
         buf[:, W:2 * W] = torch.where(have, queries.intensity[pos], buf[:, W:2 * W])
     buf[:, 2 * W] = cnt.to(torch.int32).view(torch.float32)          # bit pattern, not a value
+    if comm is not None:
+        comm.add('query_peaks_all_gather', buf, world, 'all_gather')
     return _all_gather_rows(buf, world, group, async_op=True)
 
 
@@ -347,10 +441,19 @@ def _concat_results(parts):
                        None if first.knn is None else cat([p.knn for p in parts]))
 
 
+def head_width(k: int, world: int, head_keys: Optional[int] = None) -> int:
+    """Row width kp of the phase-1 exchange: ``min(k, ceil(2 k / world))`` key slots (or
+    ``head_keys``) + the slot of the best held-back key."""
+    keys = head_keys if head_keys is not None else -(-2 * k // max(world, 1))
+    return max(1, min(int(keys), k)) + 1
+
+
 def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, device_out=False,
                          chunks: Optional[int] = None, _force_exchange: bool = False,
                          pm_stride: Optional[int] = None, check_sizes: bool = False,
-                         peak_width: Optional[int] = None):
+                         peak_width: Optional[int] = None, two_phase: Optional[bool] = None,
+                         head_keys: Optional[int] = None, extras_per_query: Optional[int] = None,
+                         comm: Optional['CommLog'] = None, stats: Optional[dict] = None):
     """One batch: ``queries_local`` is this rank's equally sized slice of the global
     batch. Returns the BatchResult of the local slice (library rows are global).
     ``peak_width``: a bound on the peaks per query that is IDENTICAL on every rank (e.g.
@@ -358,9 +461,16 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     width of the peak exchange by an all-reduce.
 
     The shard scan runs in ``chunks`` pieces (the same sub-slice of every rank's queries per
-    piece) so that the all-to-all of one piece travels over xGMI while the next piece is
-    being scanned; merge and rescoring of piece c are issued after the scan of piece c+1, so
-    the last piece's exchange hides behind the rescoring of the one before."""
+    piece) so that the collectives of one piece travel over xGMI while the next piece is being
+    scanned: every piece walks through the stages head exchange -> merge + bounds -> held-back
+    keys -> final merge + rescoring, one stage per scan that is issued behind it.
+
+    ``two_phase`` (default: whenever the backend emits packed keys): the exact two-phase
+    exchange of csrc/exchange.hip; ``head_keys`` overrides the keys per head (default
+    ``ceil(2 k / world)``), ``extras_per_query`` the capacity of the phase-2 buffers (slots per
+    query and pair of ranks, default ``max(8, k // 16)``). A full phase-2 buffer repeats the
+    batch with the full exchange (``stats['fallback']``). ``comm``: a ``CommLog`` that receives
+    the bytes of every collective."""
     world = dist.get_world_size(group)
     if queries_local.n == 0:
         # every rank must bring the same, non-zero number of queries (the collectives below are
@@ -384,9 +494,12 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     # peaks (8 B each) but 800 floats once hashed, so the PEAKS travel (fixed-width rows,
     # ~0.5 KB per query instead of 3.2 KB) while the coarse quantiser runs on the own slice, and
     # every rank hashes the foreign queries itself (encode: ~6 us per 1000 queries)
-    packed, w_vec = _all_gather_peaks(queries_local, world, group, peak_width)
+    packed, w_vec = _all_gather_peaks(queries_local, world, group, peak_width, comm)
     co = backend.coarse(vec) if getattr(backend, 'supports_preassigned', False) else None
     if co is not None:
+        if comm is not None:
+            comm.add('probe_lists_all_gather', co[0], world, 'all_gather')
+            comm.add('probe_lists_all_gather', co[1], world, 'all_gather')
         cD, cI = _all_gather_rows(co[0], world, group), _all_gather_rows(co[1], world, group)
     if w_vec is not None:
         w_vec.wait()
@@ -398,45 +511,136 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     chunks = max(1, min(chunks, n_local))
     bounds = [(n_local * c) // chunks for c in range(chunks + 1)]
     rank_base = torch.arange(world, device=allvec.device).unsqueeze(1) * n_local
-    results, pending = [], None
 
-    use_keys = co is not None and getattr(backend, 'supports_keys', False)
+    use_keys = bool(getattr(backend, 'supports_keys', False)) and \
+        (co is not None or not getattr(backend, 'supports_preassigned', False))
+    if two_phase is None:
+        two_phase = use_keys and hasattr(backend, 'keys_split')
+    two_phase = bool(two_phase and use_keys)
+    k_scan = int(getattr(backend, 'k_scan', getattr(backend, 'k', 0)))
+    kp = head_width(k_scan, world, head_keys) if two_phase else 0
+    second = two_phase and kp - 1 < k_scan            # heads can hold something back
+    flag = backend.new_flag() if second else None
 
-    def finish(p):
-        payload, lo, hi = p
-        for w in payload[-2]:
-            w.wait()
-        if use_keys:
-            knn = backend.merge_keys(payload[0].contiguous())[1]
-        else:
-            knn = backend.merge(payload[0].contiguous(), payload[1].contiguous())[1]
+    def rescore(lo, hi, knn):
         if hasattr(backend, 'refine'):       # exact re-rank of the merged short-list (k' -> k)
             knn = backend.refine(vec[lo:hi], knn)
         sub = queries_local if (lo, hi) == (0, n_local) else queries_local.select(
             torch.arange(lo, hi, device=queries_local.device))
-        results.append(backend.rescore_knn(sub, knn, device_out, **kw))
+        return backend.rescore_knn(sub, knn, device_out, **kw)
 
-    for c in range(chunks):
-        lo, hi = bounds[c], bounds[c + 1]
-        if hi == lo:
-            continue
+    def scan(lo, hi):
+        """shard scan of rows [lo, hi) of every rank's slice, rank-major"""
         if chunks == 1:
             xv, pre = allvec, (cD, cI) if co is not None else None
-        else:   # rows [lo, hi) of every rank's slice, rank-major
+        else:
             rows = (rank_base + torch.arange(lo, hi, device=allvec.device).unsqueeze(0)).reshape(-1)
             xv = allvec.index_select(0, rows)
             pre = (cD.index_select(0, rows), cI.index_select(0, rows)) if co is not None else None
         if use_keys:
-            nxt = (exchange_keys(backend.shard_search_keys(xv, *pre), world, group), lo, hi)
-        else:
-            D, I = (backend.shard_search_preassigned(xv, *pre) if pre is not None
-                    else backend.shard_search(xv))
-            nxt = (exchange_partials(D, I, world, group, async_op=True), lo, hi)
-        if pending is not None:
-            finish(pending)
-        pending = nxt
-    finish(pending)
-    return _concat_results(results)
+            return backend.shard_search_keys(xv, *(pre if pre is not None else (None, None)))
+        return (backend.shard_search_preassigned(xv, *pre) if pre is not None
+                else backend.shard_search(xv))
+
+    def wait(works):
+        for w in works:
+            w.wait()
+
+    # every piece is a little state machine; `step` advances it by one stage and returns True
+    # when its result has been appended
+    def piece(lo, hi, out):
+        st = {'stage': 0}
+
+        def step():
+            n = hi - lo
+            if st['stage'] == 0:
+                if not two_phase:             # the full rows travel (one collective)
+                    if use_keys:
+                        st['x'] = _all_to_all(out, world, group, comm, 'topk_rows_all_to_all')
+                    else:
+                        if comm is not None:
+                            comm.add('topk_rows_all_to_all', out[0], world, 'all_to_all')
+                            comm.add('topk_rows_all_to_all', out[1], world, 'all_to_all')
+                        st['x'] = exchange_partials(out[0], out[1], world, group, async_op=True)
+                    st['stage'] = 10
+                    return False
+                head, st['rest'] = backend.keys_split(out, kp)
+                st['x'] = _all_to_all(head, world, group, comm, 'heads_all_to_all')
+                st['stage'] = 1
+                return False
+            if st['stage'] == 10:             # full exchange: merge, rescore
+                if use_keys:
+                    wait(st['x'][1])
+                    knn = backend.merge_keys(st['x'][0].contiguous())[1]
+                else:
+                    wait(st['x'][2])
+                    knn = backend.merge(st['x'][0].contiguous(), st['x'][1].contiguous())[1]
+                results.append((lo, rescore(lo, hi, knn)))
+                return True
+            if st['stage'] == 1:              # heads are here: merge, bound, questions to the shards
+                wait(st['x'][1])
+                st['heads'] = st['x'][0].contiguous()
+                st['keys'], bnd, st['need'] = backend.keys_merge_heads(st['heads'], k_scan)
+                if not second:
+                    knn = backend.keys_merge_final(st['heads'], None, st['keys'], st['need'], k_scan)
+                    results.append((lo, rescore(lo, hi, knn)))
+                    return True
+                st['x'] = _all_to_all(bnd.reshape(world * n), world, group, comm, 'bounds_all_to_all')
+                st['stage'] = 2
+                return False
+            if st['stage'] == 2:              # the owners' bounds are here: what was held back above them
+                wait(st['x'][1])
+                xcap = n * (extras_per_query if extras_per_query is not None else max(8, k_scan // 16))
+                xbuf = backend.keys_extras(st['rest'], st['x'][0].reshape(world * n).contiguous(), world,
+                                           xcap, flag)
+                st['rest'] = None
+                st['x'] = _all_to_all(xbuf.reshape(world * (n + xcap)), world, group, comm,
+                                      'held_back_keys_all_to_all')
+                st['xcap'] = xcap
+                st['stage'] = 3
+                return False
+            wait(st['x'][1])                  # stage 3: final merge, rescoring
+            xr = st['x'][0].reshape(world, n + st['xcap']).contiguous()
+            knn = backend.keys_merge_final(st['heads'], xr, st['keys'], st['need'], k_scan)
+            results.append((lo, rescore(lo, hi, knn)))
+            return True
+        return step
+
+    def run():
+        pending = []
+        for c in range(chunks):
+            lo, hi = bounds[c], bounds[c + 1]
+            if hi == lo:
+                continue
+            out = scan(lo, hi)
+            for p_ in list(pending):          # older pieces: one stage each, behind this scan
+                if p_():
+                    pending.remove(p_)
+            new = piece(lo, hi, out)
+            new()                             # split + first collective, right behind its scan
+            pending.append(new)
+        while pending:
+            for p_ in list(pending):
+                if p_():
+                    pending.remove(p_)
+
+    results = []
+    run()
+    if second:
+        # one flag per batch: did any destination buffer of phase 2 run full anywhere?
+        f = flag if dist.get_backend(group) == 'nccl' else flag.cpu()
+        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)
+        if int(f.item()):
+            if stats is not None:
+                stats['fallback'] = stats.get('fallback', 0) + 1
+            two_phase = second = False
+            results = []
+            run()
+    if stats is not None:
+        stats['two_phase'] = bool(kp)
+        stats['head_width'] = kp
+    results.sort(key=lambda t: t[0])
+    return _concat_results([r for _, r in results])
 
 
 # ---------------------------------------------------------------------------- cascade batches

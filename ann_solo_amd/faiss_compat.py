@@ -192,6 +192,24 @@ class Index:
                                                       int(nprobe or self.nprobe), C.byref(b), C.byref(l)))
         return b.value, l.value
 
+    def set_storage(self, storage: str):
+        """IVF-Flat component storage, before the first ``add``: 'fx22' | 'fp32'."""
+        mode = {'fx22': 0, 'fp32': 1}[storage]
+        _lib.check(_lib.lib().asl_index_set_flat_storage(self._h, mode))
+
+    @property
+    def storage(self) -> str:
+        return ('fx22', 'fp32')[_lib.lib().asl_index_get_flat_storage(self._h)]
+
+    @property
+    def flat_layout(self) -> int:
+        """IVF-Flat scan layout the stored data allowed: 0 dense rows only, 1 float postings,
+        2 fixed-point postings (builds the lists if they are stale)."""
+        r = _lib.lib().asl_index_flat_layout(self._h)
+        if r < 0:
+            _lib.check(r)
+        return r
+
     def set_refine(self, kprime: int):
         """IVF-PQ: re-rank the ``kprime`` best ADC candidates with the exact inner product and
         return the k best (FAISS ``IndexRefineFlat``); call before ``add``. 0 switches it off."""
@@ -258,12 +276,18 @@ class IndexFlatIP(Index):
 
 
 class IndexIVFFlat(Index):
-    def __init__(self, quantizer, d, nlist, metric=METRIC_INNER_PRODUCT):
+    """``storage``: 'fx22' (default) -- ``add`` stores every component in [0, 1) as the nearest
+    multiple of 2^-22, which lets the inverted lists hold 4-byte postings -- or 'fp32' (components
+    as given); ``asl_index_set_flat_storage``. Not a FAISS argument: FAISS' CPU index stores
+    float32, the GPU clone the reference makes stores float16 (spectral_library.py:490-497)."""
+
+    def __init__(self, quantizer, d, nlist, metric=METRIC_INNER_PRODUCT, storage='fx22'):
         if metric != METRIC_INNER_PRODUCT:
             raise ValueError('only METRIC_INNER_PRODUCT is implemented (the reference uses no other)')
         self.quantizer = quantizer
         self.nlist = nlist
         super().__init__(_lib.lib().asl_index_create(d, nlist, _KIND_IVFFLAT, 0, 0), d)
+        self.set_storage(storage)
 
 
 class IndexIVFPQ(Index):
@@ -347,10 +371,11 @@ def write_index_faiss(index: Index, path: str):
                 f.write(ids[a:b].astype('<i8').tobytes())
 
 
-def read_index_faiss(path: str) -> 'IndexIVFFlat':
-    """Load a FAISS IVF-Flat / inner-product file (e.g. a ``.idxann`` the reference cached):
-    FAISS' centroids and FAISS' own list assignments are kept; ids must be 0..ntotal-1 (what
-    ``index.add`` gives and the reference relies on). Raises ValueError on anything else."""
+def parse_index_faiss(path: str) -> dict:
+    """The content of a FAISS IVF-Flat / inner-product file as host arrays (no device involved):
+    ``d, nlist, nprobe, ntotal, centroids [nlist, d], x [ntotal, d]`` (vector of id i in row i),
+    ``lists [ntotal]`` (the inverted list FAISS filed every vector under). Raises ValueError on
+    anything that is not such a file, damaged or not."""
     import struct
     with open(path, 'rb') as f:
         buf = f.read()
@@ -435,7 +460,18 @@ def read_index_faiss(path: str) -> 'IndexIVFFlat':
         raise ValueError(f'{path}: truncated ({e})') from None
     except (IndexError, OverflowError, MemoryError) as e:      # a damaged header: sizes, counts
         raise ValueError(f'{path}: corrupt ({type(e).__name__}: {e})') from None
-    idx = IndexIVFFlat(IndexFlatIP(d), d, int(nlist), METRIC_INNER_PRODUCT)
+    return {'d': int(d), 'nlist': int(nlist), 'nprobe': int(nprobe), 'ntotal': int(ntotal),
+            'centroids': cen, 'x': x, 'lists': lists}
+
+
+def read_index_faiss(path: str, storage: str = 'fx22') -> 'IndexIVFFlat':
+    """Load a FAISS IVF-Flat / inner-product file (e.g. a ``.idxann`` the reference cached):
+    FAISS' centroids and FAISS' own list assignments are kept; ids must be 0..ntotal-1 (what
+    ``index.add`` gives and the reference relies on). Raises ValueError on anything else."""
+    f = parse_index_faiss(path)
+    d, nlist, nprobe, ntotal, cen, x, lists = (f['d'], f['nlist'], f['nprobe'], f['ntotal'],
+                                               f['centroids'], f['x'], f['lists'])
+    idx = IndexIVFFlat(IndexFlatIP(d), d, int(nlist), METRIC_INNER_PRODUCT, storage=storage)
     idx.set_trained(cen)
     if ntotal:
         _lib.check(_lib.lib().asl_index_add_preassigned(idx._h, int(ntotal), _lib.ptr(x), _lib.ptr(lists)))

@@ -252,10 +252,13 @@ class SpectralLibrary:
         (index kind, PQ shape, trainer settings) is hashed in as well, so switching it can never
         pick up a stale file."""
         cfg = self.config
-        if cfg.index == 'ivfflat' and cfg.kmeans_niter == 25 and cfg.seed == 1234:
+        if (cfg.index == 'ivfflat' and cfg.kmeans_niter == 25 and cfg.seed == 1234 and
+                cfg.flat_storage == 'fx22'):
             return self._get_hyperparameter_hash()
         d = {hp: cfg[hp] for hp in self._hyperparameters}
         d.update(index=cfg.index, kmeans_niter=cfg.kmeans_niter, seed=cfg.seed)
+        if cfg.index == 'ivfflat' and cfg.flat_storage != 'fx22':
+            d.update(flat_storage=cfg.flat_storage)
         if cfg.index == 'ivfpq':
             d.update(pq_m=cfg.pq_m, pq_bits=cfg.pq_bits)
             if cfg.refine_k:
@@ -280,7 +283,7 @@ class SpectralLibrary:
                                              cfg.pq_bits, faiss.METRIC_INNER_PRODUCT)
             else:
                 ann_index = faiss.IndexIVFFlat(quantizer, cfg.hash_len, cfg.num_list,
-                                               faiss.METRIC_INNER_PRODUCT)
+                                               faiss.METRIC_INNER_PRODUCT, storage=cfg.flat_storage)
             ann_index.seed = cfg.seed
             ann_index.set_niter(cfg.kmeans_niter)
             if cfg.index == 'ivfpq' and cfg.refine_k:
@@ -297,7 +300,8 @@ class SpectralLibrary:
         kind = 2 if cfg.index == 'ivfpq' else 1
         return (i.kind == kind and i.d == cfg.hash_len and i.nlist == cfg.num_list and
                 i.ntotal == len(part.ids) and bool(i.trained) and i.shard_world == 1 and
-                (kind != 2 or (i.pq_m == cfg.pq_m and i.pq_ksub == (1 << cfg.pq_bits))))
+                (kind != 2 or (i.pq_m == cfg.pq_m and i.pq_ksub == (1 << cfg.pq_bits))) and
+                (kind != 1 or idx.storage == cfg.flat_storage))
 
     def _get_ann_index(self, charge: int) -> faiss.Index:
         part = self.partitions[charge]
@@ -306,7 +310,8 @@ class SpectralLibrary:
             imported = False
             if not os.path.isfile(self._ann_filenames[charge]) and charge in self._faiss_filenames:
                 try:        # the reference's FAISS cache: its centroids, its list assignments
-                    idx = faiss.read_index_faiss(self._faiss_filenames[charge])
+                    idx = faiss.read_index_faiss(self._faiss_filenames[charge],
+                                                 storage=self.config.flat_storage)
                     imported = True
                     logging.info('Imported the FAISS index %s', self._faiss_filenames[charge])
                 except (ValueError, OSError, _lib.AnnSoloMiError) as e:

@@ -76,6 +76,22 @@ def main():
                     help='N > 1: ranks per shard group (lists sharded inside a group, groups are '
                          'replicas); 0 = N, the fully list-sharded layout of the north star; '
                          '1 = replicas only')
+    ap.add_argument('--exchange', default='two-phase', choices=['two-phase', 'full'],
+                    help="N > 1: 'two-phase' (default) = heads of ~2k/N keys per (query, shard), a "
+                         "bound, then the held-back keys above it (exact; csrc/exchange.hip); 'full' "
+                         "= every shard's whole top-k row")
+    ap.add_argument('--head-keys', type=int, default=None,
+                    help='N > 1, two-phase exchange: keys per head instead of ceil(2k / N) (diagnostic: '
+                         'small heads force the bound / held-back-keys round at any N)')
+    ap.add_argument('--extras-per-query', type=int, default=None,
+                    help='N > 1, two-phase exchange: phase-2 buffer slots per query and pair of ranks '
+                         '(default max(8, k / 16); diagnostic: 0 forces the fallback to the full exchange)')
+    ap.add_argument('--preflight-seconds', type=float, default=120.0,
+                    help='N > 1: every collective of the sharded path is first run at a tiny size '
+                         'under a watchdog that ends the process (exit code 17, a diagnostic line on '
+                         'stderr) if it has not finished within this many seconds; 0 = skip')
+    ap.add_argument('--no-cascade', action='store_true',
+                    help='skip the configs[4] cascade pass of the default N = 1 run (JSON field `cascade`)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0,
                     help='target core-seconds of the CPU baseline sample (0 = skip)')
     args = ap.parse_args()
@@ -95,7 +111,7 @@ def main():
     from ann_solo_amd import _lib, synthetic
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     from ann_solo_amd import faiss_compat as faiss
-    from ann_solo_amd.distributed import (HipShardBackend, make_shard_groups,
+    from ann_solo_amd.distributed import (CommLog, HipShardBackend, make_shard_groups,
                                           sharded_search_batch)
 
     if not torch.cuda.is_available():
@@ -113,6 +129,8 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
+        if args.preflight_seconds > 0:
+            preflight(args, world, rank, dev, backend)
 
     t_build = time.time()
     charge = 2
@@ -168,11 +186,24 @@ def main():
         mod = mod_local[:nr]
         top1 = (r.best_row.to(torch.int64) == src)
         rec = overlap(knn) / float(nr * args.k)
+        ehit = (Ie == src.unsqueeze(1)).any(1)        # the notebook's metric, on EXACT inner-product search
         recall = {'queries': nr, 'k': args.k,
                   'recall_at_k_vs_exact_ip': rec,
                   'hit_at_k_source_spectrum': float(hit.float().mean()),
                   'hit_at_k_modified_only': float(hit[mod].float().mean()) if mod.any() else None,
-                  'top1_is_source_spectrum': float(top1.float().mean())}
+                  'top1_is_source_spectrum': float(top1.float().mean()),
+                  # the reference's one behavioural number at this boundary: with EXACT inner-product
+                  # search the true match is inside the top 1024 for 75.1 % of the modified SSMs of
+                  # iPRG2012 (notebooks/iprg2012_num_candidates.ipynb:282-288). The same quantity on
+                  # this synthetic library (source spectrum of a query inside the exact top-k):
+                  'exact_hit_at_k_source': float(ehit.float().mean()),
+                  'exact_hit_at_k_modified_only': float(ehit[mod].float().mean()) if mod.any() else None,
+                  'reference_exact_hit_at_1024_modified_iprg2012': 0.751,
+                  'generator_note': 'synthetic queries are one library spectrum each with 10 % of the peaks '
+                                    'dropped, 10 noise peaks, 5 mDa fragment jitter and (half of them) one '
+                                    'mass shift on the ions that contain the modified residue (SURVEY.md 8d): '
+                                    'cleaner than real spectra of modified peptides, so the synthetic hit@k '
+                                    'is an upper bound on what the iPRG2012 figure measures, not a reproduction'}
         if args.index == 'ivfpq':
             # SURVEY.md 8(d) operating point: IVF-Flat over the SAME coarse quantiser and nprobe =
             # exact scores inside the probed lists, the ceiling of this index geometry
@@ -249,9 +280,13 @@ def main():
             dist.all_reduce(wmax, op=dist.ReduceOp.MAX, group=group)
             peak_width = int(wmax.item())
 
+            comm_log, xstats = CommLog(), {}
+
             def step():
                 return sharded_search_batch(shard_backend, q, group=group, device_out=True,
-                                            peak_width=peak_width)
+                                            peak_width=peak_width, comm=comm_log, stats=xstats,
+                                            two_phase=None if args.exchange == 'two-phase' else False,
+                                            head_keys=args.head_keys, extras_per_query=args.extras_per_query)
         else:
             step = unsharded_step
         got = step()
@@ -263,6 +298,7 @@ def main():
     else:
         step = unsharded_step
 
+    comm = None
     L = _lib.lib()
     # consecutive steps are independent batches: the encoder + coarse quantiser of step i+1 run
     # on one stream under the list scan of step i on another (bit-identical results)
@@ -271,10 +307,21 @@ def main():
     for _ in range(args.warmup):
         step()
     sl.synchronize()
+    if world > 1 and degree > 1:
+        comm_log.calls.clear()
+        xstats.clear()
     L.asl_profile_enable(1)
     L.asl_profile_reset()
     elapsed, res = timed(step, args.steps)
     sl.synchronize()            # reports any error a pipelined batch deferred
+    if world > 1 and degree > 1:
+        # bytes every collective of a step moved (counted inside the timed steps) and what each
+        # costs on its own at its real per-chunk size (outside the timed region, after it)
+        comm = comm_log.summary(args.steps)
+        comm['exchange'] = args.exchange if xstats.get('two_phase') or args.exchange == 'full' else 'full (rows)'
+        comm['head_width'] = xstats.get('head_width')
+        comm['fallbacks_to_full_exchange'] = xstats.get('fallback', 0)
+        comm['collective_ms_alone'] = time_collectives(comm_log, group, degree, dev, backend, args.steps)
     L.asl_profile_enable(0)
     sl.set_pipeline(False)
 
@@ -429,9 +476,25 @@ def main():
         feat_ms = (time.perf_counter() - t1) * 1e3
         n_ssm = int((res.pm_count > 0).sum())
         del feats
-        cpu = None
+        cpu, ctx = None, None
         if world == 1 and args.cpu_seconds > 0:
-            cpu = cpu_baseline(args, sl, part, idx, q, res, charge, cfg)
+            ctx = oracle_context(sl, part, idx)
+            cpu = cpu_baseline(args, sl, part, idx, q, res, charge, cfg, ctx=ctx)
+        stages_gbs = stage_rates(args, sl, part, q, charge, stages, lib) if world == 1 else None
+        # configs[4] in the same run: one pass of the two-level cascade over
+        # cascade_batches x batch queries through the same engine and index, with oracle parity
+        cascade = None
+        if world == 1 and not args.no_cascade:
+            from argparse import Namespace
+            a_c = Namespace(**{**vars(args), 'steps': max(1, min(args.steps, 3)), 'warmup': 1})
+            c = cascade_pass(a_c, 1, 0, dev, backend, sl, lib, aux, charge, cfg,
+                             parity_seconds=min(args.cpu_seconds, 8.0), oracle_ctx=ctx)
+            cascade = {'workload': c['config']['workload'], 'value': c['value'], 'unit': c['unit'],
+                       'queries_per_pass': c['identifications']['queries'], 'ms_per_pass': c['ms_per_step'],
+                       'passes': c['steps'], 'levels': c['levels'],
+                       'identifications': c['identifications'],
+                       'parity_vs_oracle': c.get('parity_vs_oracle'),
+                       'device_stages_ms_per_pass': c['device_stages_ms_per_step']}
         out = {
             'metric': 'query spectra/sec + recall@k vs brute-force, open-mod search on MassIVE-KB',
             'value': round(total_queries / elapsed, 2),
@@ -466,9 +529,12 @@ def main():
                             'fixed_recall.value (IVF-Flat over the same quantiser, measured in this run '
                             'with its own roofline and oracle parity)'),
             'fixed_recall': fixed_recall,
+            'cascade': cascade,
             'shard_check': shard_check,
+            'comm': comm,
             'alt_layouts': alt,
             'stages_ms_per_step': {k: round(v['ms_total'] / args.steps, 3) for k, v in stages.items()},
+            'stages_gbs': stages_gbs,
             'post_path': {'ssm_features_ms_per_batch': round(feat_ms, 3), 'ssms': n_ssm},
             'roofline': roofline,
             'cpu_baseline': cpu,
@@ -495,6 +561,14 @@ class _LibraryMeta:
 
 
 def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
+    out = cascade_pass(args, world, rank, dev, backend, sl, lib, aux, charge, cfg,
+                       parity_seconds=min(args.cpu_seconds, 10.0) if world == 1 else 0.0)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def cascade_pass(args, world, rank, dev, backend, sl, lib, aux, charge, cfg, parity_seconds=0.0,
+                 oracle_ctx=None, index_name=None, nprobe=None):
     """BASELINE configs[4]: the reference's two-level cascade (spectral_library.py:237-259) --
     standard search (20 ppm window, no ANN) of every query, a gate standing for the mokapot FDR
     filter, then the open search (ANN + +-open Da window, shifted dot) of the unidentified
@@ -502,11 +576,15 @@ def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
     reference-shaped SSM records are materialised after the timed pass and reported). With N > 1 the
     library's IVF lists are sharded over the ranks (``enable_sharding``): level 1 is data-parallel
     over the queries, level 2 is the list-sharded search. One "step" = one pass over
-    ``cascade_batches`` x 16 384 queries per GPU."""
+    ``cascade_batches`` x 16 384 queries per GPU. Returns the JSON object (rank 0; None elsewhere);
+    ``parity_seconds`` > 0 adds ``parity_vs_oracle``: a sample of the pass's queries through the
+    oracle's two levels (``cascade_parity``)."""
     import numpy as np
     import torch
     import torch.distributed as dist
     from ann_solo_amd import synthetic
+    index_name = index_name or args.index
+    nprobe = nprobe or args.nprobe
     part = sl.partitions[charge]
     sl.pipeline_cascade = not args.no_pipeline      # open-search batches through the two-stream pipeline
     nq = world * args.cascade_batches * args.batch
@@ -565,7 +643,7 @@ def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     if rank != 0:
-        return
+        return None
     stages = {}
     for name in ('encode', 'coarse_gemm', 'coarse_select', 'scan', 'filter', 'rescore',
                  'rescore_matches'):
@@ -591,8 +669,8 @@ def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
         'config': {'workload': f'configs[4]: cascade over a MassIVE-KB-scale synthetic library '
                                f'({args.library_size} spectra): standard search 20 ppm -> gate '
                                f'(cosine >= {thr:g}, stands for the mokapot FDR filter) -> open search '
-                               f'+-{args.open_da:g} Da of the remainder, {args.index} nlist={args.nlist} '
-                               f'nprobe={args.nprobe} k={args.k}, shifted dot; results as a columnar SSM table',
+                               f'+-{args.open_da:g} Da of the remainder, {index_name} nlist={args.nlist} '
+                               f'nprobe={nprobe} k={args.k}, shifted dot; results as a columnar SSM table',
                    'queries_per_gpu': args.cascade_batches * args.batch, 'batch': args.batch,
                    'parallelism': 'single' if world == 1 else
                    f'level 1 query-parallel x{world}, level 2 ivf-list-shard x{world}'},
@@ -604,7 +682,238 @@ def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
         'cascade_check': check,
         'device_stages_ms_per_step': stages,
     }
-    print(json.dumps(out), flush=True)
+    if parity_seconds > 0 and world == 1:
+        out['parity_vs_oracle'] = cascade_parity(args, sl, part, charge, cfg, q, ids, thr, parity_seconds,
+                                                 oracle_ctx, nprobe)
+    return out
+
+
+def stage_rates(args, sl, part, q, charge, stages, lib):
+    """GB/s of the two stages SURVEY.md 8(d) lists without a roofline claim. Encoder: the peaks
+    read (8 B each) + the hashed vectors written (4 B x hash_len per query). Rescoring: per
+    candidate that reaches it (it passed the precursor window) its packed peak record (9 B per
+    peak: m/z, intensity, fragment charge) + the 32-byte row record; the candidates are counted
+    exactly, outside the timed region: the neighbour ids of this batch through the same window
+    test, whose count must equal the kernel's own ``n_candidates``."""
+    import torch
+    r = sl._search_batch(q, charge, 'open', want_knn=True, device_out=True)
+    knn = r.knn
+    ok = knn >= 0
+    rows = knn.clamp(min=0)
+    lp = torch.as_tensor(part.precursor_mz, device=knn.device).to(torch.float32).to(torch.float64)
+    qp = q.precursor_mz.to(knn.device).to(torch.float64).unsqueeze(1)
+    ok &= (qp - lp[rows]).abs() * charge <= float(args.open_da)
+    valid = torch.as_tensor(part.valid, device=knn.device) if getattr(part, 'valid', None) is not None else None
+    if valid is not None:
+        ok &= valid[rows].bool()
+    off = part.spectra.offsets.to(knn.device).to(torch.int64)
+    npk = (off[1:] - off[:-1])[rows]
+    n_cand = int(ok.sum())
+    cand_peaks = int((npk * ok).sum())
+    same = int(r.n_candidates.to(torch.int64).sum()) == n_cand
+    enc_ms = stages['encode']['ms_total'] / max(stages['encode']['launches'], 1)
+    res_ms = (stages['rescore']['ms_total'] + stages['filter']['ms_total']) / max(stages['rescore']['launches'], 1)
+    enc_b = int(q.mz.numel()) * 8 + q.n * sl.config.hash_len * 4
+    res_b = cand_peaks * 9 + n_cand * 32
+    return {'encode': {'bytes_per_batch': enc_b, 'ms': round(enc_ms, 4),
+                       'GBps': round(enc_b / (enc_ms * 1e-3) / 1e9, 2) if enc_ms > 0 else None,
+                       'bytes': '8 B per query peak + 4 B x hash_len per vector written'},
+            'rescore': {'bytes_per_batch': res_b, 'ms': round(res_ms, 4),
+                        'GBps': round(res_b / (res_ms * 1e-3) / 1e9, 2) if res_ms > 0 else None,
+                        'candidates': n_cand, 'candidate_peaks': cand_peaks,
+                        'bytes_per_candidate': round(res_b / max(n_cand, 1), 1),
+                        'bytes': '9 B per candidate peak (packed record) + 32-B row record per candidate that '
+                                 'passed the precursor window',
+                        'candidate_count_equals_the_kernels': same,
+                        'note': 'stage time inside the pipelined step (filter + rescoring launches); '
+                                'latency / gather bound: no roofline claim (SURVEY.md 8d)'}}
+
+
+def oracle_context(sl, part, idx):
+    """Host copies the oracle legs share: the library's peaks and the index as the oracle reads it
+    (inverted lists from the device, in list order). IVF-Flat: the stored vectors as sparse rows
+    (``HostIVF.to_csr``) -- the sparse-aware CPU scan, same chain, same bits as the dense one."""
+    from oracle import oracle_py as O
+    Lh = O.Spectra(*part.spectra.to('cpu').numpy())
+    off, ids, payload = idx.lists()
+    info = idx.info()
+    ivf = O.HostIVF.__new__(O.HostIVF)
+    ivf.centroids, ivf.nlist, ivf.d = idx.centroids(), info.nlist, info.d
+    ivf.list_offsets, ivf.ids, ivf.payload = off, ids, payload
+    ivf.codebooks = idx.codebooks() if info.kind == 2 else None
+    ivf.kind = 1 if info.kind == 2 else 0
+    dense = None
+    if ivf.kind == 0:
+        dense = ivf
+        ivf = ivf.to_csr()
+    return {'O': O, 'Lh': Lh, 'ivf': ivf, 'ivf_dense': dense}
+
+
+def cascade_parity(args, sl, part, charge, cfg, q, ids, thr, seconds, ctx, nprobe):
+    """A sample of the cascade pass's queries through the ORACLE's two levels: standard search
+    (every library spectrum inside the standard window, best shifted dot, cosine over its peak
+    matches), the gate (cosine >= thr), then for the rest the oracle's open search over the same
+    index. Compared with what the pass filed for those queries: library row, score, q."""
+    import numpy as np
+    import torch
+    t0 = time.time()
+    ctx = ctx or oracle_context(sl, part, sl._get_ann_index(charge))
+    O, Lh, ivf = ctx['O'], ctx['Lh'], ctx['ivf']
+    lib_pmz32 = np.asarray(part.precursor_mz, np.float32)
+    lib_pmz = lib_pmz32.astype(np.float64)
+    order = np.argsort(lib_pmz, kind='stable')
+    sorted_pmz = lib_pmz[order]
+    tol, mode = cfg.precursor_tolerance_mass, cfg.precursor_tolerance_mode
+    nq = q.n
+    # bounded sample, spread over the pass: ~1 ms (std) + ~4 ms / cores (open) per query
+    n_s = int(max(64, min(nq, seconds * 150)))
+    rows = np.unique(np.linspace(0, nq - 1, n_s).astype(np.int64))
+    qs = q.select(torch.as_tensor(rows, device=q.device)).to('cpu')
+    Q = O.Spectra(*qs.numpy())
+    qpmz = np.asarray(qs.precursor_mz, np.float64)
+    qo, qmz, qit = Q.offsets, Q.mz, Q.intensity
+
+    def cosine(i, row, pm):
+        a, b = Lh.offsets[row], Lh.offsets[row + 1]
+        return float(O.ssm_features(qmz[qo[i]:qo[i + 1]], qit[qo[i]:qo[i + 1]], Lh.mz[a:b],
+                                    Lh.intensity[a:b], pm)[0])
+    want = {}
+    rest = []
+    for i in range(len(rows)):
+        if mode == 'ppm':        # |q - l| / l * 1e6 <= tol (spectral_library.py:421-427): a slightly wider
+            lo = np.searchsorted(sorted_pmz, qpmz[i] / (1 + tol * 1.001e-6) - 1e-9)       # range, then the formula
+            hi = np.searchsorted(sorted_pmz, qpmz[i] / (1 - tol * 1.001e-6) + 1e-9)
+            c = order[lo:hi]
+            c = c[np.abs(qpmz[i] - lib_pmz[c]) / lib_pmz[c] * 10 ** 6 <= tol]
+        else:
+            lo = np.searchsorted(sorted_pmz, qpmz[i] - tol / charge - 1e-6)
+            hi = np.searchsorted(sorted_pmz, qpmz[i] + tol / charge + 1e-6)
+            c = order[lo:hi]
+            c = c[np.abs(qpmz[i] - lib_pmz[c]) * charge <= tol]
+        c = np.sort(c).astype(np.int64)
+        if len(c):
+            b, sc, pm = O.best_match(Q, i, Lh, c, cfg.fragment_mz_tolerance, cfg.allow_peak_shifts)
+            if b >= 0:
+                cs = cosine(i, int(c[b]), pm)
+                if cs >= thr:
+                    want[int(rows[i])] = (int(c[b]), cs, 0.0)
+                    continue
+        rest.append(i)
+    if rest:                     # level 2: the oracle's open search of the remainder, all host threads
+        sub = qs.select(torch.as_tensor(np.asarray(rest)))
+        Qr = O.Spectra(*sub.numpy())
+        r = O.search_batch(Qr, Lh, lib_pmz32, charge, ivf, args.k, nprobe, args.open_da, 'Da',
+                           cfg.fragment_mz_tolerance, cfg.allow_peak_shifts, pm_stride=64)
+        for j, i in enumerate(rest):
+            row = int(r['best_row'][j])
+            if row >= 0:
+                cs = cosine(i, row, r['pm_pairs'][j][:int(r['pm_count'][j])])
+                want[int(rows[i])] = (row, cs, 0.0 if cs >= thr else 1.0)
+    got = {}
+    sel = np.isin(ids.qrow, rows)
+    for qr, lr, sc, qq in zip(ids.qrow[sel], ids.lib_row[sel], ids.score[sel], ids.q[sel]):
+        got[int(qr)] = (int(lr), float(sc), float(qq))
+    rows_equal = sum(1 for k_ in want if k_ in got and got[k_][0] == want[k_][0] and got[k_][2] == want[k_][2])
+    dmax = max([abs(got[k_][1] - want[k_][1]) for k_ in want if k_ in got] or [0.0])
+    return {'queries': int(len(rows)), 'kept_at_level_1': int(len(rows) - len(rest)),
+            'open_search_of_the_rest': int(len(rest)),
+            'same_queries_identified': bool(set(want) == set(got)),
+            'library_row_and_q_equal': int(rows_equal), 'identified_by_oracle': int(len(want)),
+            'cosine_max_abs_diff': float(dmax),
+            'all_equal': bool(set(want) == set(got) and rows_equal == len(want) and dmax <= 1e-9),
+            'seconds': round(time.time() - t0, 1)}
+
+
+def preflight(args, world, rank, dev, backend):
+    """Every collective the sharded path uses, once, at a tiny size, under a watchdog: a job whose
+    RCCL / xGMI set-up hangs ends here with a diagnostic line and exit code 17 instead of running
+    into the driver's limit with nothing to read. The watchdog is a thread that leaves through
+    ``os._exit`` -- the process is never replaced by another program."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    state = {'at': 'start'}
+
+    def bark():
+        sys.stderr.write(f'[bench] PREFLIGHT TIMEOUT on rank {rank}/{world}: collective '
+                         f'"{state["at"]}" did not finish within {args.preflight_seconds:g} s '
+                         f'(backend {backend}); MASTER_ADDR={os.environ.get("MASTER_ADDR")} '
+                         f'LOCAL_RANK={os.environ.get("LOCAL_RANK")} '
+                         f'HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}\n')
+        sys.stderr.flush()
+        os._exit(17)
+    dog = threading.Timer(args.preflight_seconds, bark)
+    dog.daemon = True
+    dog.start()
+    t0 = time.perf_counter()
+    cdev = dev if backend == 'nccl' else torch.device('cpu')
+    took = {}
+
+    def run(name, fn):
+        state['at'] = name
+        t = time.perf_counter()
+        fn()
+        if backend == 'nccl':
+            torch.cuda.synchronize()
+        took[name] = round((time.perf_counter() - t) * 1e3, 2)
+    x = torch.full((world * 8,), rank, dtype=torch.int64, device=cdev)
+    run('barrier', dist.barrier)
+    run('all_reduce(max)', lambda: dist.all_reduce(x.clone(), op=dist.ReduceOp.MAX))
+    if backend == 'nccl':
+        out = torch.empty(world * x.numel(), dtype=torch.int64, device=cdev)
+        run('all_gather_into_tensor', lambda: dist.all_gather_into_tensor(out, x))
+        y = torch.empty_like(x)
+        run('all_to_all_single', lambda: dist.all_to_all_single(y, x))
+        ok = bool((y.view(world, 8) == torch.arange(world, device=cdev).unsqueeze(1)).all())
+    else:
+        parts = [torch.empty_like(x) for _ in range(world)]
+        run('all_gather', lambda: dist.all_gather(parts, x))
+        ok = all(int(p_[0]) == r for r, p_ in enumerate(parts))
+    dog.cancel()
+    if not ok:
+        sys.stderr.write(f'[bench] PREFLIGHT: rank {rank} received wrong data from a collective\n')
+        os._exit(18)
+    if rank == 0:
+        log(f'[bench] preflight ok in {time.perf_counter() - t0:.2f}s: {took} ms (first call of each)')
+
+
+def time_collectives(comm_log, group, world, dev, backend, steps, reps=5):
+    """Every collective of the step on its own, at the buffer size the step used per call: ms per
+    call (max over ranks, synchronised) and the rate at which a rank's outgoing bytes left."""
+    import torch
+    import torch.distributed as dist
+    out = {}
+    for name, c in comm_log.calls.items():
+        nbytes = c['buffer_bytes'] // max(c['calls'], 1)
+        n = max(world, (nbytes // 8) // world * world)
+        cdev = dev if backend == 'nccl' else torch.device('cpu')
+        x = torch.zeros(n, dtype=torch.int64, device=cdev)
+        if c['kind'] == 'all_to_all' and backend == 'nccl':
+            y = torch.empty_like(x)
+            fn = lambda: dist.all_to_all_single(y, x, group=group)
+        elif backend == 'nccl':
+            y = torch.empty(n * world, dtype=torch.int64, device=cdev)
+            fn = lambda: dist.all_gather_into_tensor(y, x, group=group)
+        else:
+            parts = [torch.empty_like(x) for _ in range(world)]
+            fn = lambda: dist.all_gather(parts, x, group=group)
+        fn()
+        if backend == 'nccl':
+            torch.cuda.synchronize()
+        dist.barrier(group=group)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        if backend == 'nccl':
+            torch.cuda.synchronize()
+        el = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=cdev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX, group=group)
+        ms = float(el.item()) * 1e3
+        leaving = n * 8 * (world - 1) // world if c['kind'] == 'all_to_all' else n * 8 * (world - 1)
+        out[name] = {'buffer_bytes': n * 8, 'ms_per_call': round(ms, 4),
+                     'GBps_out_per_rank': round(leaving / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
+                     'calls_per_step': c['calls'] / max(steps, 1)}
+    return out
 
 
 def _lib_handle():
@@ -679,12 +988,17 @@ def postings_roofline(sl, idx, q, nprobe, avg_ms, args=None):
                                       if traffic else None)}
 
 
-def faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_queries):
+def faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_queries, knn_gpu=None):
     """when ``import faiss`` succeeds on this box, time the reference's own
     retrieval library on the host cores -- ``IndexIVFFlat`` / ``IndexIVFPQ`` (inner product) over
     the same hashed vectors, with THIS index's coarse centroids as the quantiser (so nothing but
     the PQ codebooks is trained), same nlist / nprobe / k, ``omp_set_num_threads(cores)``.
-    Retrieval only (FAISS has no rescoring). Returns a dict, or the string 'unavailable'."""
+    Retrieval only (FAISS has no rescoring). For IVF-Flat the ids FAISS returns are compared with
+    the GPU's for the same queries (``knn_gpu``: rows of the same index): same quantiser, same
+    lists, exact inner products on both sides, so the sets differ only where scores tie within
+    float rounding at the k-th place (FAISS sums in SIMD-lane order, the GPU in ascending
+    dimension) -- ``knn_id_overlap_vs_gpu`` and the largest |difference| of the sorted score rows
+    say by how much. Returns a dict, or the string 'unavailable'."""
     try:
         import faiss as F
     except Exception:
@@ -716,31 +1030,40 @@ def faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_queries):
         xq = sl._encode(q.select(torch.arange(nq, device=q.device))).cpu().numpy()
         fx.search(xq[:min(nq, 64)], args.k)                      # warm-up
         t0 = time.perf_counter()
-        _, I = fx.search(xq, args.k)
+        Df, I = fx.search(xq, args.k)
         dt = time.perf_counter() - t0
-        return {'value': round(nq / dt, 2), 'unit': 'query spectra/s (retrieval only)',
-                'index': 'IndexIVFPQ' if info.kind == 2 else 'IndexIVFFlat', 'threads': int(cores),
-                'queries': nq, 'build_s': round(t_build, 1), 'version': getattr(F, '__version__', '?')}
+        out = {'value': round(nq / dt, 2), 'unit': 'query spectra/s (retrieval only)',
+               'index': 'IndexIVFPQ' if info.kind == 2 else 'IndexIVFFlat', 'threads': int(cores),
+               'queries': nq, 'build_s': round(t_build, 1), 'version': getattr(F, '__version__', '?')}
+        if info.kind != 2 and knn_gpu is not None:
+            g = np.asarray(knn_gpu)[:nq]
+            m = min(len(g), len(I))
+            inter = sum(len(np.intersect1d(g[i][g[i] >= 0], I[i][I[i] >= 0])) for i in range(m))
+            total = sum(int((g[i] >= 0).sum()) for i in range(m))
+            idx.nprobe = int(args.nprobe)
+            Dg, _ = idx.search(xq[:m], args.k)
+            out.update({'knn_id_overlap_vs_gpu': round(inter / max(total, 1), 6), 'queries_compared': m,
+                        'max_abs_score_diff_sorted_rows': float(np.abs(np.asarray(Dg) - Df[:m]).max()),
+                        'tie_rule': 'GPU / oracle: (score desc, id asc) on fp32 scores of the ascending-'
+                                    'dimension fmaf chain over the stored (2^-22 grid) components; FAISS: '
+                                    'its own summation order on the float32 vectors'})
+        return out
     except Exception as e:             # a FAISS build without these classes, out of memory, ...
         return f'importable, leg failed: {type(e).__name__}: {e}'
 
 
-def cpu_baseline(args, sl, part, idx, q, res, charge, cfg, faiss_leg=True):
+def cpu_baseline(args, sl, part, idx, q, res, charge, cfg, faiss_leg=True, ctx=None):
     """The oracle (plain-C port of the reference path, oracle/) on the host cores of this
     box, on a bounded sample of the SAME batch against the SAME index; doubles as a
-    full-size parity check of the GPU results."""
+    full-size parity check of the GPU results. IVF-Flat: the oracle scans a SPARSE copy of the
+    stored vectors (per-list CSR, the same ascending fmaf chain: what a sparse-aware CPU
+    implementation does), and a few queries also go through its dense rows -- the definition --
+    to show both give the same bits."""
     import numpy as np
     import torch
-    from oracle import oracle_py as O
     t0 = time.time()
-    Lh = O.Spectra(*part.spectra.to('cpu').numpy())
-    off, ids, payload = idx.lists()
-    info = idx.info()
-    ivf = O.HostIVF.__new__(O.HostIVF)
-    ivf.centroids, ivf.nlist, ivf.d = idx.centroids(), info.nlist, info.d
-    ivf.list_offsets, ivf.ids, ivf.payload = off, ids, payload
-    ivf.codebooks = idx.codebooks() if info.kind == 2 else None
-    ivf.kind = 1 if info.kind == 2 else 0
+    ctx = ctx or oracle_context(sl, part, idx)
+    O, Lh, ivf = ctx['O'], ctx['Lh'], ctx['ivf']
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -753,10 +1076,20 @@ def cpu_baseline(args, sl, part, idx, q, res, charge, cfg, faiss_leg=True):
         t = time.perf_counter()
         r = O.search_batch(Q, Lh, part.precursor_mz, charge, ivf, args.k, args.nprobe,
                            args.open_da, 'Da', cfg.fragment_mz_tolerance, cfg.allow_peak_shifts,
-                           pm_stride=64, nthreads=threads, want_knn=True)
+                           pm_stride=64, nthreads=threads, want_knn=True)   # (`ivf`: the binding at call time)
         return time.perf_counter() - t, r
     n1 = min(q.n, 64)
     t1, r1 = run(n1, 1)                       # single core, also calibrates the sample size
+    dense_check = None
+    if ctx.get('ivf_dense') is not None:      # the dense rows (the definition) on the same queries
+        sparse_ivf, ivf = ivf, ctx['ivf_dense']
+        td, rd = run(n1, 1)
+        ivf = sparse_ivf
+        dense_check = {'queries': n1, 'ms_per_query_dense_rows': round(td / n1 * 1e3, 2),
+                       'ms_per_query_sparse_rows': round(t1 / n1 * 1e3, 2),
+                       'knn_ids_and_winners_equal': bool(np.array_equal(rd['knn_I'], r1['knn_I']) and
+                                                         np.array_equal(rd['best_row'], r1['best_row']) and
+                                                         np.array_equal(rd['best_score'], r1['best_score']))}
     per_q = t1 / n1
     n_all = int(min(q.n, max(cores, args.cpu_seconds / max(per_q, 1e-6))))
     t_all, r_all = run(n_all, cores)
@@ -773,13 +1106,15 @@ def cpu_baseline(args, sl, part, idx, q, res, charge, cfg, faiss_leg=True):
               'knn_ids_compared': int(knn_gpu.size),
               'best_row_equal': bool(np.array_equal(best_row, r_all['best_row'])),
               'best_score_max_abs_diff': float(np.abs(best_score - r_all['best_score']).max())}
-    faiss_note = faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_all) if faiss_leg else None
+    faiss_note = faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_all, g.knn) if faiss_leg else None
     log(f'[bench] cpu baseline: {n_all} queries on {cores} threads in {t_all:.2f}s, '
         f'single core {per_q * 1e3:.2f} ms/query (setup {time.time() - t0:.1f}s)')
     return {'value': round(n_all / t_all, 2), 'unit': 'query spectra/s', 'cores': cores,
             'kind': 'port', 'faiss': faiss_note,
             'sample': f'{n_all} queries of the same batch, same index, all {cores} host threads '
-                      f'(OpenMP over queries)',
+                      f'(OpenMP over queries)' + ('; IVF-Flat lists as sparse rows (CSR), same fmaf chain'
+                                                  if dense_check else ''),
+            'dense_definition_check': dense_check,
             'single_core_value': round(1.0 / per_q, 2),
             'single_core_sample': f'{n1} queries, 1 thread',
             'parity_vs_gpu': parity}

@@ -122,6 +122,24 @@ int asl_index_get_refine(const asl_index_t *idx);
 int asl_index_refine(asl_index_t *idx, int32_t nq, const float *xq, int32_t kprime,
                      const int64_t *I_in /* [nq,kprime], -1 = empty */, int32_t k, float *D, int64_t *I);
 
+/* IVF-Flat component storage (no FAISS counterpart on the CPU; FAISS' GPU clone of the reference
+ * stores float16, spectral_library.py:490-497). ASL_FLAT_FX22 (the default): add() rounds every
+ * component in [0, 1) to the nearest multiple of 2^-22 (ties to even, at most 1 - 2^-22;
+ * |dx| <= 1.2e-7) and stores anything else as given. When ALL stored non-zeros are such values --
+ * unit-norm hashed spectra always are -- the inverted lists are kept as 4-byte postings
+ * (22-bit numerator | 10-bit local index) in whole 128-byte lines behind a one-byte-per-dimension
+ * table (csrc/flat_scan.hip) instead of 6-byte postings behind 4-byte table words. Scores are
+ * the canonical ascending-dimension fp32 fmaf chain over the STORED components either way, so
+ * both layouts (and the generic kernels of asl_index_set_scan_variant) return identical ids and
+ * score bits for the same stored vectors. ASL_FLAT_F32 keeps every component as given. Set
+ * before the first add(); saved with the index. asl_index_flat_layout: 0 = dense rows only (no
+ * postings: vectors too dense), 1 = float postings, 2 = fixed-point postings. */
+#define ASL_FLAT_FX22 0
+#define ASL_FLAT_F32 1
+int asl_index_set_flat_storage(asl_index_t *idx, int32_t mode);
+int asl_index_get_flat_storage(const asl_index_t *idx);
+int asl_index_flat_layout(asl_index_t *idx);
+
 /* Scan kernel selection (identical results either way; the switch exists for A/B measurements
  * and for the parity tests): 0 = the layout-specific kernels (IVF-PQ: the tiled
  * sub-quantiser-per-lane scan with the histogram top-k when m = 32, 8 bits, nprobe <= 256;
@@ -177,6 +195,30 @@ int asl_index_search_sharded(asl_index_t *idx, void *rccl_comm, int32_t nq, cons
  * (k, nprobe) -- the tiled IVF-PQ scan: m = 32, 8-bit codes, automatic scan variant, nprobe
  * within the tiled kernel's limit, k + 768 <= 2048 --, else 0 (exchange (D, I) rows then). */
 int asl_index_supports_keys(const asl_index_t *idx, int32_t k, int32_t nprobe);
+/* The two-phase exact exchange of a sharded search (csrc/exchange.hip; device pointers only; what
+ * ann_solo_amd/distributed.py and asl_index_search_sharded run between their collectives). Rows
+ * of packed keys as asl_index_set_unordered mode 2 emits them (0 = empty, any order).
+ *   asl_keys_split: K [nrows, k] -> head [nrows, kp] (slots 0 .. kp-2: the row's best keys, all
+ *     those at or above a score-bucket floor that admits at most kp - 1; slot kp-1: T, the best
+ *     key held back, 0 if none) and rest [nrows, k] (the keys held back, 0 padded).
+ *   asl_keys_merge_heads: heads [S, nq, kp] of the S shards -> out_keys [nq, k] (the best k keys
+ *     seen, a set), bounds [S, nq] (B = the k-th best key seen if shard s must send what it holds
+ *     above B -- its T beats B --, else ~0: send nothing), need [nq] (some shard was asked).
+ *   asl_keys_extras: on the shard, rows destination-major (row = dst * nq + q): rest [W * nq, k],
+ *     bounds [W * nq] -> xbuf [W, nq + xcap]: per destination nq header words (count << 32 |
+ *     start) then the payload; *overflow = 1 when a destination's xcap slots do not suffice (the
+ *     caller must then repeat the batch with the full exchange). *overflow is never cleared here.
+ *   asl_keys_merge_final: heads + the xbuf [S, nq + xcap] received (NULL: none) + out_keys/need of
+ *     asl_keys_merge_heads -> I [nq, k] ids (a set, -1 padded) and D (may be NULL): the exact
+ *     top-k of the union of the shards' rows. k <= 1280. */
+int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, const int64_t *K, int64_t *head, int64_t *rest);
+int asl_keys_merge_heads(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
+                         int64_t *out_keys, int64_t *bounds, int32_t *need);
+int asl_keys_extras(int32_t W, int32_t nq, int32_t k, const int64_t *rest, const int64_t *bounds,
+                    int64_t xcap, int64_t *xbuf, int32_t *overflow);
+int asl_keys_merge_final(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
+                         const int64_t *xbuf, int64_t xcap, const int64_t *prev_keys, const int32_t *need,
+                         float *D, int64_t *I);
 /* list -> owner rank map of the balancing above, for inspection. */
 int asl_index_shard_map(const asl_index_t *idx, int32_t world, int32_t *owner /* [nlist] */);
 
@@ -201,8 +243,10 @@ int asl_topk_merge(int32_t S, int32_t nq, int32_t k, const float *Ds, const int6
 
 /* Algorithmic work of the IVF-Flat postings scan for these queries at this nprobe (measurement;
  * no reference counterpart): *bytes = sum over (query, probed block, non-zero query dimension)
- * of the 4-byte table word + 6 bytes per posting; *lines = the 128-byte lines those bytes lie
- * in (segments are placed by line). What bench.py prices the scan kernel's roofline with. */
+ * of the 4-byte table word + 6 bytes per posting (fixed-point layout: 1-byte table entry + 4
+ * bytes per posting); *lines = the 128-byte lines the scan touches for them (segments are placed
+ * by line; fixed-point layout: the block's whole table row + the lines of the wanted segments).
+ * What bench.py prices the scan kernel's roofline with. */
 int asl_index_postings_work(asl_index_t *idx, int32_t nq, const float *xq, int32_t nprobe,
                             int64_t *bytes, int64_t *lines);
 

@@ -964,6 +964,92 @@ void orc_ivfflat_search(const float *xq, int32_t nq, int32_t d, const float *cen
   }
 }
 
+/* Fixed-point storage of IVF-Flat components (asl_index_set_flat_storage, ASL_FLAT_FX22; no
+ * FAISS CPU counterpart -- the reference's GPU clone stores float16, spectral_library.py:490-497):
+ * a component in [0, 1) is stored as the nearest multiple of 2^-22 (ties to even, at most
+ * 1 - 2^-22), anything else as given. add() applies it; the scores are the same ascending fmaf
+ * chain over the STORED components. */
+float orc_fx22(float x) {
+  if (!(x >= 0.0f && x < 1.0f)) return x;
+  float m = rintf(x * 4194304.0f);
+  return (m < 4194303.0f ? m : 4194303.0f) * (1.0f / 4194304.0f);
+}
+void orc_quantize_fx22(float *x, int64_t n) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) x[i] = orc_fx22(x[i]);
+}
+
+/* ---- the same IVF-Flat search over a SPARSE copy of the stored vectors (CSR in list order:
+ * row i = the non-zeros of the vector at list position i, dimensions ascending). A hashed
+ * spectrum has <= ~50 non-zeros of 800: the score of a stored vector is the ascending chain
+ * acc = fmaf(q[dim], val, acc) over ITS non-zeros -- a zero query component leaves the
+ * accumulator unchanged bit for bit (the accumulator is never -0), so this equals
+ * ivfflat_one's chain over the query's non-zeros, which equals the dense chain. What a
+ * sparse-aware CPU implementation does: 6 bytes per stored non-zero instead of a 3 200-byte
+ * row per scanned vector (bench.py: the CPU baseline of the IVF-Flat leg). */
+int64_t orc_csr_count(const float *x, int64_t n, int32_t d) {
+  int64_t c = 0;
+#pragma omp parallel for schedule(static) reduction(+ : c)
+  for (int64_t i = 0; i < n * (int64_t)d; i++) c += x[i] != 0.0f;
+  return c;
+}
+void orc_csr_fill(const float *x, int64_t n, int32_t d, int64_t *indptr, uint16_t *dims,
+                  float *vals) {
+  indptr[0] = 0;
+  for (int64_t i = 0; i < n; i++) {
+    int64_t c = 0;
+    for (int32_t j = 0; j < d; j++) c += x[(size_t)i * d + j] != 0.0f;
+    indptr[i + 1] = indptr[i] + c;
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    int64_t o = indptr[i];
+    for (int32_t j = 0; j < d; j++)
+      if (x[(size_t)i * d + j] != 0.0f) {
+        dims[o] = (uint16_t)j;
+        vals[o] = x[(size_t)i * d + j];
+        o++;
+      }
+  }
+}
+
+static void ivfflat_csr_one(const float *q, int32_t d, const float *centroids, int32_t nlist,
+                            const int32_t *list_offsets, const int32_t *ids,
+                            const orc_csr_t *csr, int32_t k, int32_t nprobe, ivf_ws_t *w,
+                            float *D, int64_t *I) {
+  coarse_one(q, d, centroids, nlist, nprobe, w->cheap, w->idx, w->val, w->cD, w->cI);
+  orc_topk_t t = {w->heap, 0, k};
+  for (int32_t p = 0; p < nprobe; p++) {
+    int32_t l = w->cI[p];
+    if (l < 0) continue;
+    for (int32_t i = list_offsets[l]; i < list_offsets[l + 1]; i++) {
+      float acc = 0.0f;
+      for (int64_t o = csr->indptr[i]; o < csr->indptr[i + 1]; o++)
+        acc = fmaf(q[csr->dims[o]], csr->vals[o], acc);
+      topk_push(&t, acc, ids[i]);
+    }
+  }
+  topk_finish(&t, D, I);
+}
+
+void orc_ivfflat_csr_search(const float *xq, int32_t nq, int32_t d, const float *centroids,
+                            int32_t nlist, const int32_t *list_offsets, const int32_t *ids,
+                            const int64_t *indptr, const uint16_t *dims, const float *vals,
+                            int32_t k, int32_t nprobe, float *D, int64_t *I) {
+  if (nprobe > nlist) nprobe = nlist;
+  orc_csr_t csr = {indptr, dims, vals};
+#pragma omp parallel
+  {
+    ivf_ws_t w;
+    ivf_ws_alloc(&w, d, k, nprobe, 0, 0);
+#pragma omp for schedule(dynamic, 4)
+    for (int32_t q = 0; q < nq; q++)
+      ivfflat_csr_one(xq + (size_t)q * d, d, centroids, nlist, list_offsets, ids, &csr, k,
+                      nprobe, &w, D + (size_t)q * k, I + (size_t)q * k);
+    ivf_ws_free(&w);
+  }
+}
+
 static void ivfpq_one(const float *q, int32_t d, const float *centroids, int32_t nlist,
                       const int32_t *list_offsets, const int32_t *ids, const uint8_t *codes,
                       const float *codebooks, int32_t m, int32_t ksub, int32_t k,
@@ -1068,6 +1154,9 @@ void orc_search_batch(const orc_peaks_t *Q, const orc_peaks_t *L, const float *l
       if (kind == 1)
         ivfpq_one(vec, d, centroids, nlist, list_offsets, ids, (const uint8_t *)payload,
                   codebooks, m, ksub, k, nprobe, &w, Dk, Ik);
+      else if (kind == 2)
+        ivfflat_csr_one(vec, d, centroids, nlist, list_offsets, ids, (const orc_csr_t *)payload,
+                        k, nprobe, &w, Dk, Ik);
       else
         ivfflat_one(vec, d, centroids, nlist, list_offsets, ids, (const float *)payload, k,
                     nprobe, &w, Dk, Ik);

@@ -134,6 +134,22 @@ void orc_coarse(const float *xq, int32_t nq, int32_t d, const float *centroids,
 void orc_ivfflat_search(const float *xq, int32_t nq, int32_t d, const float *centroids,
                         int32_t nlist, const int32_t *list_offsets, const int32_t *ids,
                         const float *vecs, int32_t k, int32_t nprobe, float *D, int64_t *I);
+/* fixed-point storage of IVF-Flat components (the rule add() applies in ASL_FLAT_FX22 mode) */
+float orc_fx22(float x);
+void orc_quantize_fx22(float *x, int64_t n);
+/* the same search over a sparse (CSR, list order, dimensions ascending) copy of the stored vectors */
+typedef struct {
+  const int64_t *indptr; /* [ntotal+1] */
+  const uint16_t *dims;  /* [nnz] */
+  const float *vals;     /* [nnz] */
+} orc_csr_t;
+int64_t orc_csr_count(const float *x, int64_t n, int32_t d);
+void orc_csr_fill(const float *x, int64_t n, int32_t d, int64_t *indptr, uint16_t *dims,
+                  float *vals);
+void orc_ivfflat_csr_search(const float *xq, int32_t nq, int32_t d, const float *centroids,
+                            int32_t nlist, const int32_t *list_offsets, const int32_t *ids,
+                            const int64_t *indptr, const uint16_t *dims, const float *vals,
+                            int32_t k, int32_t nprobe, float *D, int64_t *I);
 void orc_pq_lut(const float *xq, int32_t d, const float *codebooks, int32_t m,
                 int32_t ksub, float *lut /* [m,ksub] */);
 float orc_adc(const float *lut, int32_t m, int32_t ksub, const uint8_t *code, float coarse);
@@ -153,7 +169,8 @@ int orc_precursor_ok(double q_mz, float lib_mz, int32_t charge, double tol, int 
 /* ---- whole hot path for one batch (CPU baseline leg) ------------------- */
 /* encode -> IVF(-PQ|-Flat) top-k -> precursor post-filter -> best match.
  * lib_pmz_f32[library->n] is spec_info's float32 precursor m/z column.
- * kind: 0 flat (payload = vecs), 1 pq (payload = codes). Outputs per query:
+ * kind: 0 flat (payload = vecs), 1 pq (payload = codes), 2 flat over a sparse copy (payload =
+ * const orc_csr_t *). Outputs per query:
  * best_row (library row, -1 if no candidate), best_score, n_cand. pm_* may be
  * NULL; otherwise pm_pairs has capacity pm_stride pairs per query. */
 void orc_search_batch(const orc_peaks_t *queries, const orc_peaks_t *library,

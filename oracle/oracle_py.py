@@ -60,6 +60,9 @@ def lib():
         L.orc_precursor_ok.restype = C.c_int
         L.orc_precursor_ok.argtypes = [C.c_double, C.c_float, C.c_int32, C.c_double, C.c_int]
         L.orc_max_threads.restype = C.c_int
+        L.orc_csr_count.restype = C.c_int64
+        L.orc_fx22.restype = C.c_float
+        L.orc_fx22.argtypes = [C.c_float]
     return _LIB
 
 
@@ -328,6 +331,18 @@ def coarse(xq, centroids, nprobe):
     return D, I
 
 
+class OrcCsr(C.Structure):
+    _fields_ = [('indptr', C.c_void_p), ('dims', C.c_void_p), ('vals', C.c_void_p)]
+
+
+def quantize_fx22(x):
+    """The fixed-point storage rule of IVF-Flat (``asl_index_set_flat_storage``, FX22): a copy of
+    ``x`` with every component in [0, 1) on the grid of 2^-22."""
+    out = np.array(x, np.float32, copy=True, order='C')
+    lib().orc_quantize_fx22(_p(out, c_f32p), C.c_int64(out.size))
+    return out
+
+
 class HostIVF:
     """Inverted lists laid out for the oracle (list order, ascending id in list)."""
 
@@ -343,12 +358,38 @@ class HostIVF:
         self.codebooks = None if codebooks is None else _c(codebooks, np.float32)
         self.kind = 0 if codebooks is None else 1
 
+    def to_csr(self):
+        """Sparse copy of an IVF-Flat payload (CSR in list order): ``kind`` becomes 2 and
+        ``search`` / ``search_batch`` run the sparse-aware scan -- same chain, same bits."""
+        assert self.kind == 0
+        x = _c(self.payload, np.float32)
+        n, d = x.shape
+        nnz = int(lib().orc_csr_count(_p(x, c_f32p), C.c_int64(n), C.c_int32(d)))
+        out = HostIVF.__new__(HostIVF)
+        out.__dict__.update(self.__dict__)
+        out.indptr = np.empty(n + 1, np.int64)
+        out.dims = np.empty(max(nnz, 1), np.uint16)
+        out.vals = np.empty(max(nnz, 1), np.float32)
+        lib().orc_csr_fill(_p(x, c_f32p), C.c_int64(n), C.c_int32(d), _p(out.indptr, c_i64p),
+                           out.dims.ctypes.data_as(C.c_void_p), _p(out.vals, c_f32p))
+        out.payload = None
+        out.kind = 2
+        out._csr = OrcCsr(out.indptr.ctypes.data, out.dims.ctypes.data, out.vals.ctypes.data)
+        return out
+
     def search(self, xq, k, nprobe):
         xq = _c(xq, np.float32)
         nq = len(xq)
         D = np.empty((nq, k), np.float32)
         I = np.empty((nq, k), np.int64)
-        if self.kind == 0:
+        if self.kind == 2:
+            lib().orc_ivfflat_csr_search(
+                _p(xq, c_f32p), C.c_int32(nq), C.c_int32(self.d), _p(self.centroids, c_f32p),
+                C.c_int32(self.nlist), _p(self.list_offsets, c_i32p), _p(self.ids, c_i32p),
+                _p(self.indptr, c_i64p), self.dims.ctypes.data_as(C.c_void_p),
+                _p(self.vals, c_f32p), C.c_int32(k), C.c_int32(nprobe), _p(D, c_f32p),
+                _p(I, c_i64p))
+        elif self.kind == 0:
             lib().orc_ivfflat_search(
                 _p(xq, c_f32p), C.c_int32(nq), C.c_int32(self.d), _p(self.centroids, c_f32p),
                 C.c_int32(self.nlist), _p(self.list_offsets, c_i32p), _p(self.ids, c_i32p),
@@ -412,7 +453,7 @@ def search_batch(queries: Spectra, library: Spectra, lib_pmz_f32, charge, ivf: H
         C.c_double(min_bound), C.c_double(bin_size), C.c_int32(ivf.d), C.c_uint32(seed),
         C.c_int(ivf.kind), _p(ivf.centroids, c_f32p), C.c_int32(ivf.nlist),
         _p(ivf.list_offsets, c_i32p), _p(ivf.ids, c_i32p),
-        ivf.payload.ctypes.data_as(C.c_void_p),
+C.cast(C.pointer(ivf._csr), C.c_void_p) if ivf.kind == 2 else ivf.payload.ctypes.data_as(C.c_void_p),
         _p(ivf.codebooks, c_f32p) if ivf.codebooks is not None else None, C.c_int32(m),
         C.c_int32(ksub), C.c_int32(k), C.c_int32(nprobe), C.c_double(prec_tol),
         C.c_int(0 if prec_mode == 'Da' else 1), C.c_double(frag_tol),

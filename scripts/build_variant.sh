@@ -1,7 +1,10 @@
 #!/bin/bash
 # Build a VARIANT of libannsolo_mi.so for same-box A/B runs (ASL_LIB_PATH, scripts/ab_*.sh):
 #
-#   scripts/build_variant.sh <out.so> [NAME=VALUE ...] [-- extra hipcc flags]
+#   scripts/build_variant.sh <out.so> [NAME=VALUE ...] [sed:<file>:<expression> ...] [-- extra hipcc flags]
+#
+# `sed:flat_scan.hip:s/a/b/` applies a sed expression to one file of the COPY (timing-only
+# experiments that are not a constant).
 #
 # The product sources carry their tuning values as plain `constexpr` constants; a variant is
 # made from a COPY of csrc/ (scripts/tmp/variant_<hash>/csrc, git-ignored) in which every
@@ -23,6 +26,13 @@ rm -rf "$root"; mkdir -p "$root/ann_solo_amd" "$root/include"
 cp -r ann_solo_amd/csrc "$root/ann_solo_amd/csrc"; rm -rf "$root/ann_solo_amd/csrc/build"
 cp include/annsolo_mi.h "$root/include/"
 for d in "${defs[@]}"; do
+  if [[ "$d" == sed:* ]]; then
+    rest=${d#sed:}; file=${rest%%:*}; expr=${rest#*:}
+    before=$(md5sum < "$root/ann_solo_amd/csrc/$file")
+    sed -i -E "$expr" "$root/ann_solo_amd/csrc/$file"
+    [ "$before" != "$(md5sum < "$root/ann_solo_amd/csrc/$file")" ] || { echo "build_variant: '$expr' changed nothing in $file" >&2; exit 1; }
+    continue
+  fi
   name=${d%%=*}; val=${d#*=}
   hits=$(grep -lE "constexpr .*\\b$name = [^,;]+[,;]" "$root"/ann_solo_amd/csrc/*.h* || true)
   [ -n "$hits" ] || { echo "build_variant: no 'constexpr ... $name = ...' in csrc/" >&2; exit 1; }

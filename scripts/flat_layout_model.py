@@ -134,5 +134,79 @@ def main():
                lambda c: 1 + (torch.clamp(c - 32, min=0) + 63) // 64, 1)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and not (len(sys.argv) > 4 and sys.argv[4] == 'pair'):
     main()
+
+
+def pairing_model():
+    """Passes and rows per query when two blocks whose sizes sum to <= 832 share a wave pass
+    (half-wave each; an unpaired block keeps 64-lane rows of two lines): two-pointer pairing of
+    the size-sorted probed blocks."""
+    import numpy as np
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    dev = torch.device('cuda', 0)
+    lib, aux = synthetic.make_library(N, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
+    cfg = Config(num_list=NLIST, num_probe=NPROBE, num_candidates=1024, index='ivfpq', pq_m=32,
+                 kmeans_niter=25, mode='ann', precursor_tolerance_mass_open=500.0,
+                 precursor_tolerance_mode_open='Da', batch_size=16384, seed=1234)
+    sl = SpectralLibrary(lib, config=cfg, device=dev)
+    part = sl.partitions[2]
+    idx = sl._get_ann_index(2)
+    q_all, _ = synthetic.make_queries(lib, aux, 16384, seed=42, open_range=500.0, charge=2)
+    nq = 256
+    q = q_all.select(torch.arange(nq, device=dev))
+    off, ids, _ = idx.lists()
+    llen = np.diff(off)
+    xq = sl._encode(q)
+    _, probes = idx.coarse(xq, NPROBE)
+    probes = probes.cpu().numpy()
+    qnz = (xq != 0).cpu().numpy()
+    vec = sl._encode(part.spectra)
+    ids_t = torch.from_numpy(ids).to(dev).long()
+    # blocks of 832 in list order, per-(block, dim) line counts
+    nb = (llen + 831) // 832
+    boff = np.concatenate([[0], np.cumsum(nb)])
+    bsize, bstart = [], []
+    for l in range(NLIST):
+        for j in range(nb[l]):
+            bstart.append(off[l] + j * 832)
+            bsize.append(min(832, llen[l] - j * 832))
+    bsize = np.array(bsize)
+    nblk = len(bsize)
+    blk_of_pos = np.repeat(np.arange(nblk), bsize)
+    c = torch.zeros(nblk * D, dtype=torch.int32, device=dev)
+    blk_t = torch.from_numpy(blk_of_pos).to(dev)
+    for a in range(0, N, 262144):
+        nz = (vec[ids_t[a:a + 262144]] != 0).nonzero()
+        key = blk_t[a + nz[:, 0]] * D + nz[:, 1]
+        c.index_add_(0, key, torch.ones_like(key, dtype=torch.int32))
+    nl = ((c.view(nblk, D) + 31) // 32).cpu().numpy()
+    tot = dict(passes=0, rows_pair=0, rows_now=0, visits=0, lines=0)
+    for i in range(nq):
+        blks = np.concatenate([np.arange(boff[l], boff[l + 1]) for l in probes[i]])
+        dims = np.nonzero(qnz[i])[0]
+        order = blks[np.argsort(bsize[blks], kind='stable')]
+        lo, hi = 0, len(order) - 1
+        tot['visits'] += len(order)
+        while lo <= hi:
+            A = order[hi]
+            nlA = nl[A][dims]
+            tot['rows_now'] += int(((nlA + 1) // 2).sum())
+            tot['lines'] += int(nlA.sum())
+            if lo < hi and bsize[order[lo]] + bsize[A] <= 832:
+                B = order[lo]
+                nlB = nl[B][dims]
+                tot['rows_now'] += int(((nlB + 1) // 2).sum())
+                tot['lines'] += int(nlB.sum())
+                tot['rows_pair'] += int(np.maximum(nlA, nlB).sum())
+                lo += 1
+            else:
+                tot['rows_pair'] += int(((nlA + 1) // 2).sum())
+            hi -= 1
+            tot['passes'] += 1
+    print({k: v / nq for k, v in tot.items()})
+
+
+if __name__ == '__main__' and len(sys.argv) > 4 and sys.argv[4] == 'pair':
+    pairing_model()

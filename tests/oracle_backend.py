@@ -5,6 +5,11 @@ import torch
 
 from oracle import oracle_py as O
 
+try:                                   # the workers of the gloo tests put tests/ itself on sys.path
+    import exchange_ref as X
+except ImportError:
+    from tests import exchange_ref as X
+
 
 class OracleShardBackend:
     def __init__(self, lib_np, lib_pmz32, centroids, assign, payload, codebooks, rank, world,
@@ -42,6 +47,47 @@ class OracleShardBackend:
     def merge(self, Ds, Is):
         D, I = O.topk_merge(Ds.numpy(), Is.numpy())
         return torch.from_numpy(D), torch.from_numpy(I)
+
+    # ---- packed keys + the two-phase exchange (tests/exchange_ref.py restates csrc/exchange.hip);
+    # ``keys = False`` makes the driver take the (D, I) exchange instead
+    keys = True
+
+    @property
+    def supports_keys(self):
+        return self.keys
+
+    def shard_search_keys(self, vectors, coarse_D=None, coarse_I=None):
+        D, I = self.ivf.search(vectors.numpy(), self.k, self.nprobe)
+        return torch.from_numpy(X.pack_keys(D, I))
+
+    def merge_keys(self, Ks):
+        S, n, k = Ks.shape
+        K = Ks.numpy().view(np.uint64)
+        I = np.full((n, k), -1, np.int64)
+        for q in range(n):
+            best = X._topk_set(K[:, q, :].reshape(-1), k)
+            I[q, :len(best)] = X.key_id(best)
+        return None, torch.from_numpy(I)
+
+    def keys_split(self, K, kp):
+        head, rest = X.keys_split(K.numpy(), kp)
+        return torch.from_numpy(head), torch.from_numpy(rest)
+
+    def keys_merge_heads(self, heads, k):
+        out, bounds, need = X.keys_merge_heads(heads.numpy(), k)
+        return torch.from_numpy(out), torch.from_numpy(bounds), torch.from_numpy(need)
+
+    def keys_extras(self, rest, bounds, world, xcap, overflow):
+        xbuf, ov = X.keys_extras(rest.numpy(), bounds.numpy(), world, xcap)
+        overflow[0] = max(int(overflow[0]), ov)
+        return torch.from_numpy(xbuf)
+
+    def keys_merge_final(self, heads, xbuf, out_keys, need, k):
+        return torch.from_numpy(X.keys_merge_final(heads.numpy(), None if xbuf is None else xbuf.numpy(),
+                                                   out_keys.numpy(), need.numpy(), k))
+
+    def new_flag(self):
+        return torch.zeros(1, dtype=torch.int32)
 
     def _window_ok(self, q_pmz, tol, mode):
         """spectral_library.py:421-427 in float64 over the float32 library column."""

@@ -86,13 +86,35 @@ def _worker(rank, world, port, kind, out_dir):
             raise AssertionError('a spectrum wider than the agreed row must be refused')
         except ValueError:
             pass
-    res = sharded_search_batch(be, q)
     # unsharded reference for my slice
     D, I = be.full.search(be.encode(q).numpy(), 64, 4)
     ref = OracleShardBackend(lib_np, pmz32, cen, a, payload, cb, 0, 1, 2, 64, 4, 300, 'Da', 0.02,
                              True, lpt_owner).rescore_knn(q, torch.from_numpy(I))
-    ok = (np.array_equal(res['knn'], I) and np.array_equal(res['best_row'], ref['best_row'])
-          and np.array_equal(res['best_score'], ref['best_score']))
+    from ann_solo_amd.distributed import CommLog
+    # every exchange the driver knows must give the unsharded rows: the two-phase exchange with
+    # the default head (at world 2: ceil(2k / 2) = k keys, nothing is ever held back), with small
+    # heads (40 of k = 64 keys per shard: the bound / held-back-keys round runs; 1 key per shard:
+    # the owner sees fewer than k keys and asks for everything), with phase-2 buffers too small (the
+    # flag repeats the batch with the full exchange), the full packed-key rows, the (D, I) rows
+    ok, seen = True, {}
+    for name, kw in (('two_phase', {}), ('small_heads', dict(head_keys=40, extras_per_query=32)),
+                     ('tiny_heads', dict(head_keys=1, extras_per_query=64)),
+                     ('overflow', dict(head_keys=9, extras_per_query=0)),
+                     ('full_keys', dict(two_phase=False)), ('rows', None)):
+        be.keys = kw is not None
+        stats, comm = {}, CommLog()
+        res = sharded_search_batch(be, q, stats=stats, comm=comm, **(kw or {}))
+        same = (np.array_equal(res['knn'], I) and np.array_equal(res['best_row'], ref['best_row'])
+                and np.array_equal(res['best_score'], ref['best_score']))
+        ok = ok and same
+        seen[name] = (same, stats.get('fallback', 0), sorted(comm.calls))
+    be.keys = True
+    ok = (ok and seen['overflow'][1] == 1 and seen['small_heads'][1] == 0 and
+          'held_back_keys_all_to_all' in seen['small_heads'][2] and
+          'held_back_keys_all_to_all' not in seen['two_phase'][2] and
+          seen['rows'][2].count('topk_rows_all_to_all') == 1)
+    if not ok:
+        print('exchange modes:', seen, flush=True)
     owner_ok = set(be.owner.tolist()) == set(range(world))
     with open(os.path.join(out_dir, f'rank{rank}.txt'), 'w') as f:
         f.write(f'{int(ok)} {int(owner_ok)} {int((res["best_row"] >= 0).sum())}')

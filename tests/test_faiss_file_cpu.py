@@ -37,3 +37,20 @@ def test_absurd_header_counts_raise_value_error(tmp_path):
     open(p, 'wb').write(b'IwFl' + hdr + struct.pack('<QQ', 6, 5) + b'IxFI' + b'\0' * 64)
     with pytest.raises(ValueError):
         faiss.read_index_faiss(p)
+
+
+@pytest.mark.parametrize('name', ['', '_sprs'])
+def test_reader_parses_the_independent_byte_fixture(name):
+    """tests/golden/faiss_ivfflat_kat*.idxann were written by tests/golden/make_faiss_fixture.py,
+    which restates FAISS' writer (faiss/impl/index_write.cpp) field by field and imports nothing
+    of this repository: the parser must recover exactly the content that script put in."""
+    from ann_solo_amd import faiss_compat as faiss
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    want = np.load(os.path.join(g, 'faiss_ivfflat_kat.npz'))
+    f = faiss.parse_index_faiss(os.path.join(g, f'faiss_ivfflat_kat{name}.idxann'))
+    pre = 'sprs_' if name else ''
+    assert f['d'] == int(want['d']) and f['nlist'] == int(want['nlist'])
+    assert f['nprobe'] == int(want[pre + 'nprobe']) and f['ntotal'] == len(want[pre + 'x'])
+    assert np.array_equal(f['centroids'].view(np.uint32), want['centroids'].view(np.uint32))
+    assert np.array_equal(f['x'].view(np.uint32), want[pre + 'x'].view(np.uint32))
+    assert np.array_equal(f['lists'], want[pre + 'lists'])

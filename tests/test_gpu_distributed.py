@@ -14,9 +14,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('degree,index', [(0, 'ivfpq'), (1, 'ivfpq'), (0, 'ivfflat')])
-def test_two_rank_sharded_bench_path(degree, index):
-    """degree 0 = lists sharded over both ranks; degree 1 = two replicas (no exchange)"""
+@pytest.mark.parametrize('degree,index,extra', [
+    (0, 'ivfpq', []), (1, 'ivfpq', []), (0, 'ivfflat', []),
+    (0, 'ivfpq', ['--head-keys', '700']),                             # phase 2 of the exchange runs
+    (0, 'ivfflat', ['--head-keys', '600', '--extras-per-query', '0']),   # ... and overflows: fallback
+    (0, 'ivfpq', ['--exchange', 'full'])])
+def test_two_rank_sharded_bench_path(degree, index, extra):
+    """degree 0 = lists sharded over both ranks; degree 1 = two replicas (no exchange). The
+    exchange: two-phase by default (at two ranks a head holds the whole row), with smaller heads
+    (the owners ask for held-back keys), with no room for the answers (one fallback to the full
+    exchange per step), and the full rows."""
     env = dict(os.environ, ASL_BENCH_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port',
@@ -24,7 +31,8 @@ def test_two_rank_sharded_bench_path(degree, index):
            os.path.join(ROOT, 'bench.py'),
            '--gpus', '2', '--steps', '1', '--warmup', '1', '--library-size', '60000', '--nlist',
            '256', '--niter', '4', '--batch', '1024', '--recall-queries', '64',
-           '--shard-degree', str(degree), '--index', index]
+           '--shard-degree', str(degree), '--index', index] + extra
+    cmd[cmd.index('--master-port') + 1] = str(int(cmd[cmd.index('--master-port') + 1]) + 20 * len(extra))
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     line = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert line, out.stderr[-2000:]
@@ -35,6 +43,16 @@ def test_two_rank_sharded_bench_path(degree, index):
     if degree == 0:
         assert d['config']['parallelism'] == 'ivf-list-shard x2'
         assert d['alt_layouts']['replicas_only']['value'] > 0
+        c = d['comm']
+        assert c['total_bytes_out_per_rank_per_step'] > 0 and c['collective_ms_alone']
+        if '--exchange' in extra:
+            assert 'topk_rows_all_to_all' in c and 'heads_all_to_all' not in c
+        else:
+            assert c['exchange'] == 'two-phase' and 'heads_all_to_all' in c
+            assert ('held_back_keys_all_to_all' in c) == ('--head-keys' in extra)
+            assert c['fallbacks_to_full_exchange'] == (1 if '--extras-per-query' in extra else 0)
+            # k = 1024 at two ranks: heads of ceil(2k / 2) + 1 slots unless overridden
+            assert c['head_width'] == (int(extra[1]) + 1 if '--head-keys' in extra else 1025)
     else:
         assert d['config']['parallelism'] == 'replicas x2' and d['alt_layouts'] is None
 

@@ -1,0 +1,111 @@
+"""The device kernels of the two-phase exact top-k exchange (ann_solo_amd/csrc/exchange.hip)
+against their numpy restatement (tests/exchange_ref.py) and against the definition: the ids the
+owner ends up with are the top-k of the union of all shards' rows, whatever the head width."""
+import numpy as np
+import pytest
+
+import exchange_ref as X
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(rng, nrows, k, fill=1.0, lo=-0.1, hi=0.95, grid=None, id_base=0, id_span=1 << 20):
+    """[nrows, k] packed keys: random scores (optionally on a coarse grid: many ties and crowded
+    buckets), unique ids per row, a ragged number of valid entries, shuffled (rows are sets)."""
+    K = np.zeros((nrows, k), np.uint64)
+    for r in range(nrows):
+        n = k if fill >= 1.0 else int(rng.integers(0, k + 1) if rng.random() < 0.5 else k)
+        s = rng.uniform(lo, hi, n).astype(np.float32)
+        if grid:
+            s = (np.round(s * grid) / grid).astype(np.float32)
+        ids = id_base + rng.choice(id_span, n, replace=False)
+        keys = X.pack_keys(s, ids).view(np.uint64)
+        rng.shuffle(keys)
+        K[r, :n] = keys
+    return K.view(np.int64)
+
+
+def _sets(a):
+    a = np.asarray(a).view(np.uint64)
+    return [set(r[r != 0].tolist()) for r in a]
+
+
+@pytest.mark.parametrize('k,kp', [(1024, 257), (1024, 513), (64, 17), (100, 101), (1280, 2), (256, 33)])
+def test_keys_split_equals_the_restatement(k, kp):
+    import torch
+    from ann_solo_amd.distributed import HipShardBackend
+    be = HipShardBackend.__new__(HipShardBackend)
+    rng = np.random.default_rng(k + kp)
+    K = np.concatenate([_rows(rng, 40, k, fill=0.5), _rows(rng, 24, k, grid=50),
+                        np.zeros((2, k), np.int64)])
+    head, rest = be.keys_split(torch.from_numpy(K).cuda(), kp)
+    head, rest = head.cpu().numpy(), rest.cpu().numpy()
+    h0, r0 = X.keys_split(K, kp)
+    assert np.array_equal(head[:, kp - 1], h0[:, kp - 1])                     # best held-back key
+    assert _sets(head[:, :kp - 1]) == _sets(h0[:, :kp - 1]) and _sets(rest) == _sets(r0)
+    for r in range(len(K)):                                                   # zero padding is at the end
+        for row in (head[r, :kp - 1], rest[r]):
+            nz = np.nonzero(row)[0]
+            assert len(nz) == 0 or nz[-1] == len(nz) - 1
+        a, h = _sets(head[r:r + 1, :kp - 1])[0], _sets(rest[r:r + 1])[0]
+        assert not h or not a or max(h) < min(a)                              # kept keys beat held-back ones
+        assert len(a) <= kp - 1 and a | h == _sets(K[r:r + 1])[0]
+
+
+@pytest.mark.parametrize('S,k,head_keys,xper,grid', [(8, 1024, 256, 64, None), (4, 256, 40, 256, None),
+                                                     (3, 100, 100, 0, None), (8, 512, 16, 512, 40),
+                                                     (2, 64, 1, 64, None), (5, 1280, 300, 8, None)])
+def test_two_phase_exchange_is_the_top_k_of_the_union(S, k, head_keys, xper, grid):
+    """One owner, S shards, all on one device: split -> merge of the heads -> bounds -> held-back
+    keys -> final merge. Every step equals the restatement; the result equals the definition."""
+    import torch
+    from ann_solo_amd.distributed import HipShardBackend, head_width
+    be = HipShardBackend.__new__(HipShardBackend)
+    rng = np.random.default_rng(S * k + head_keys)
+    n = 37
+    # shard s owns ids [s << 20, (s + 1) << 20): keys are unique across shards; skewed scores so that
+    # some shards hold far more than their share of a query's best hits
+    rows = [_rows(rng, n, k, fill=0.7, hi=0.5 + 0.45 * rng.random(), grid=grid, id_base=s << 20) for s in range(S)]
+    kp = head_width(k, S, head_keys)
+    heads, rests = [], []
+    for s in range(S):
+        h, r = be.keys_split(torch.from_numpy(rows[s]).cuda(), kp)
+        heads.append(h)
+        rests.append(r)
+    heads = torch.stack(heads)                                   # what the owner receives [S, n, kp]
+    out, bounds, need = be.keys_merge_heads(heads, k)
+    o0, b0, n0 = X.keys_merge_heads(heads.cpu().numpy(), k)
+    assert _sets(out.cpu().numpy()) == _sets(o0)
+    assert np.array_equal(bounds.cpu().numpy(), b0) and np.array_equal(need.cpu().numpy(), n0)
+    union = np.concatenate(rows, axis=1).view(np.uint64)
+    want = [set(X.key_id(np.sort(u[u != 0])[::-1][:k]).tolist()) for u in union]
+    if kp - 1 >= k:                                              # nothing can be held back
+        assert not need.any()
+        I = be.keys_merge_final(heads, None, out, need, k)
+    else:
+        # every shard answers the questions addressed to it: "destination" = the one owner, so
+        # the shard-side call runs with world = 1 rows-per-destination = n
+        xcap = n * xper
+        flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+        xbufs = [be.keys_extras(rests[s], bounds[s].contiguous(), 1, xcap, flag)[0] for s in range(S)]
+        overflow = int(flag.item())
+        ref_over = 0
+        for s in range(S):
+            xb0, ov = X.keys_extras(rests[s].cpu().numpy(), b0[s], 1, xcap)
+            ref_over |= ov
+            got, exp = xbufs[s].cpu().numpy().view(np.uint64), xb0[0].view(np.uint64)
+            if not ov:
+                for q in range(n):                               # same keys per query, wherever they sit
+                    c, st = int(got[q] >> np.uint64(32)), int(got[q] & np.uint64(0xFFFFFFFF))
+                    c0, st0 = int(exp[q] >> np.uint64(32)), int(exp[q] & np.uint64(0xFFFFFFFF))
+                    assert c == c0 and set(got[n + st:n + st + c].tolist()) == set(exp[n + st0:n + st0 + c0].tolist())
+        assert overflow == ref_over
+        if overflow:
+            assert xper < k            # only a buffer smaller than a row can run full here
+            return
+        I = be.keys_merge_final(heads, torch.stack(xbufs), out, need, k)
+    I = I.cpu().numpy()
+    for q in range(n):
+        got = I[q][I[q] >= 0]
+        assert len(got) == len(set(got.tolist())) == len(want[q]) and set(got.tolist()) == want[q], q
+        assert (I[q][len(got):] == -1).all()

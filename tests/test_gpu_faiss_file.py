@@ -82,15 +82,18 @@ def test_hand_assembled_files_and_rejections(tmp_path):
     rng = np.random.default_rng(2)
     d, nlist = 16, 6
     cen = _sparse_rows(rng, nlist, d, 4)
-    x = _sparse_rows(rng, 40, d, 5)
+    x_file = _sparse_rows(rng, 40, d, 5)
     # an assignment FAISS might have made (NOT the arg-max one everywhere), ids scattered over lists
     assign = rng.integers(0, nlist, 40)
     assign[assign == 4] = 1                                   # list 4 stays empty
-    lists = {int(l): (np.nonzero(assign == l)[0], x[assign == l]) for l in np.unique(assign)}
-    for sparse in (False, True):
+    lists = {int(l): (np.nonzero(assign == l)[0], x_file[assign == l]) for l in np.unique(assign)}
+    from oracle import oracle_py as O
+    for sparse, storage in ((False, 'fx22'), (True, 'fx22'), (False, 'fp32')):
         p = str(tmp_path / f'h{int(sparse)}.idxann')
         _hand_made(p, d, cen, lists, sparse=sparse)
-        idx = faiss.read_index_faiss(p)
+        idx = faiss.read_index_faiss(p, storage=storage)
+        # (the default storage of IVF-Flat keeps components in [0, 1) on the 2^-22 grid)
+        x = x_file if storage == 'fp32' else O.quantize_fx22(x_file)
         off, ids, vecs = idx.lists()
         assert idx.ntotal == 40 and idx.nprobe == 5
         for l in range(nlist):
@@ -147,3 +150,34 @@ def test_engine_imports_an_existing_reference_cache(tmp_path):
     dmg = SpectralLibrary(lib, config=ref_cfg, index_dir=str(tmp_path / 'y'), basename='lib')
     r = dmg._search_batch(q, 2, 'open')
     assert (r.best_row >= 0).any() and dmg._get_ann_index(2).ntotal == lib.n
+
+
+@pytest.mark.parametrize('name', ['', '_sprs'])
+@pytest.mark.parametrize('storage', ['fx22', 'fp32'])
+def test_writer_reproduces_the_independent_byte_fixture(tmp_path, name, storage):
+    """The fixture of tests/golden/make_faiss_fixture.py (FAISS' writer restated field by field,
+    nothing of this repository imported) through the device and back: import, search, export --
+    the exported file must be the fixture's bytes (its components are multiples of 2^-12, so the
+    fixed-point storage keeps them bit for bit as well)."""
+    from ann_solo_amd import faiss_compat as faiss
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    src = os.path.join(g, f'faiss_ivfflat_kat{name}.idxann')
+    want = np.load(os.path.join(g, 'faiss_ivfflat_kat.npz'))
+    pre = 'sprs_' if name else ''
+    idx = faiss.read_index_faiss(src, storage=storage)
+    assert idx.ntotal == len(want[pre + 'x']) and idx.nprobe == int(want[pre + 'nprobe'])
+    assert idx.flat_layout == (2 if storage == 'fx22' else 1)
+    x = want[pre + 'x']
+    off, ids, vecs = idx.lists()
+    stored = np.empty_like(x)
+    stored[ids] = vecs
+    assert np.array_equal(stored.view(np.uint32), x.view(np.uint32))  # the file's vectors, bit for bit
+    assert np.array_equal(want[pre + 'lists'][ids], np.repeat(np.arange(int(want['nlist'])), np.diff(off)))
+    idx.nprobe = int(want['nlist'])
+    D, I = idx.search(x[:8], 5)
+    exact = (x[:8].astype(np.float64) @ x.astype(np.float64).T)
+    assert np.allclose(np.sort(exact, 1)[:, ::-1][:, :5], D, rtol=0, atol=1e-6)
+    idx.nprobe = int(want[pre + 'nprobe'])
+    out = str(tmp_path / 'back.idxann')
+    faiss.write_index_faiss(idx, out)
+    assert open(out, 'rb').read() == open(src, 'rb').read()

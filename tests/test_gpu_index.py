@@ -218,12 +218,30 @@ def test_packed_key_rows_and_their_merge(vecs, trained):
     o, ou = np.argsort(I, 1), np.argsort(Iu, 1)
     assert np.array_equal(np.take_along_axis(I, o, 1), np.take_along_axis(Iu, ou, 1))
     assert np.array_equal(np.take_along_axis(D, o, 1).view(np.uint32), np.take_along_axis(Du, ou, 1).view(np.uint32))
-    flat = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
-    flat.set_trained(cen)
-    flat.add(xb)
-    flat.set_unordered(2)
+    # IVF-Flat emits the same packed rows from its postings scan (round 4: both index kinds share
+    # the two-phase exchange); a brute-force index has no such rows
+    for storage in ('fx22', 'fp32'):
+        flat = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16, storage=storage)
+        flat.set_trained(cen)
+        flat.add(xb)
+        flat.nprobe = 8
+        for k in (1024, 33):
+            D, I = flat.search(xq, k)
+            cD, cI = flat.coarse(xq, 8)
+            K = flat.search_preassigned_keys(xq, k, cD, cI).view(np.uint64)
+            ids = np.where(K != 0, 0xFFFFFFFF - (K & np.uint64(0xFFFFFFFF)).astype(np.int64), -1)
+            ordb = (K >> np.uint64(32)).astype(np.uint32)
+            bits = np.where(ordb & 0x80000000, ordb & 0x7fffffff, ~ordb).astype(np.uint32)
+            for r in range(len(xq)):
+                n = int((I[r] >= 0).sum())
+                o, ok = np.argsort(I[r, :n]), np.argsort(np.where(ids[r] >= 0, ids[r], 1 << 40))[:n]
+                assert (ids[r] >= 0).sum() == n and np.array_equal(I[r, :n][o], ids[r][ok])
+                assert np.array_equal(D[r, :n][o].view(np.uint32), bits[r][ok])
+    brute = faiss.IndexFlatIP(800)
+    brute.add(xb[:100])
+    brute.set_unordered(2)
     with pytest.raises(_lib.AnnSoloMiError):
-        flat.search(xq, 10)
+        brute.search(xq, 10)
 
 
 def test_coarse_and_lut_bit_exact(O, vecs, pq_index):
@@ -268,18 +286,30 @@ def test_ivfpq_recall_against_exact(O, vecs, pq_index):
     assert recall > 0.5, recall
 
 
-def test_ivfflat_search_identical_to_oracle(O, vecs, trained):
+@pytest.mark.parametrize('storage', ['fx22', 'fp32'])
+def test_ivfflat_search_identical_to_oracle(O, vecs, trained, storage):
+    """Both storage modes: 'fx22' stores every component on the 2^-22 grid (the oracle's
+    ``quantize_fx22`` is the same rule) and scans 4-byte posting words behind the byte table
+    (layout 2); 'fp32' keeps the components as given and scans float postings (layout 1). Ids and
+    score bits equal the oracle's over the same stored vectors, for both scan variants."""
     from ann_solo_amd import faiss_compat as faiss
     xb, xq = vecs
     cen, _ = trained
-    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16, storage=storage)
     idx.set_trained(cen)
     idx.add(xb)
+    assert idx.storage == storage and idx.flat_layout == (2 if storage == 'fx22' else 1)
     a = O.assign(xb, cen, 0)
+    xb = O.quantize_fx22(xb) if storage == 'fx22' else xb
     ivf = O.HostIVF(cen, a, xb)
     off, ids, v = idx.lists()
     assert np.array_equal(off, ivf.list_offsets) and np.array_equal(ids, ivf.ids)
     assert np.array_equal(v, ivf.payload)
+    # the sparse-aware CPU scan (bench.py's IVF-Flat baseline) is the same chain: same bits
+    csr = ivf.to_csr()
+    Dd, Id = ivf.search(xq[:32], 100, 4)
+    Dc, Ic = csr.search(xq[:32], 100, 4)
+    assert np.array_equal(Id, Ic) and np.array_equal(Dd.view(np.uint32), Dc.view(np.uint32))
     # scan variants: 0 = per-dimension postings (default), 1 = dense GEMM + masked top-k
     for variant in (0, 1):
         idx.set_scan_variant(variant)
@@ -333,28 +363,95 @@ def test_sparse_coarse_quantiser_equals_the_gemm(d, nlist):
         assert np.array_equal(D0.view(np.uint32), D1.view(np.uint32)), name
 
 
-def test_postings_work_counter(vecs, trained):
+@pytest.mark.parametrize('storage', ['fx22', 'fp32'])
+def test_postings_work_counter(vecs, trained, storage):
     """asl_index_postings_work (the roofline bytes of the postings scan) against numpy: per
-    (query, probed block of 832 vectors, non-zero query dimension) 4 bytes + 6 per posting."""
+    (query, probed block of 832 vectors, non-zero query dimension) 4 bytes + 6 per posting
+    (float postings) / 1 byte + 4 per posting and the lines = the block's 7-line byte table +
+    ceil(postings / 32) per wanted segment (fixed-point postings)."""
     from ann_solo_amd import faiss_compat as faiss
     xb, xq = vecs
     cen, _ = trained
-    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16, storage=storage)
     idx.set_trained(cen)
     idx.add(xb)
     off, ids, v = idx.lists()
     nq, nprobe = 24, 5
     _, cI = idx.coarse(xq[:nq], nprobe)
-    want = 0
+    want = want_lines = 0
     for i in range(nq):
         dims = np.nonzero(xq[i])[0]
         for l in cI[i]:
             for b0 in range(off[l], off[l + 1], 832):
                 blk = v[b0:min(b0 + 832, off[l + 1])][:, dims]
-                want += 4 * len(dims) + 6 * int(np.count_nonzero(blk))
+                if storage == 'fx22':
+                    c = np.count_nonzero(blk, axis=0)
+                    want += len(dims) + 4 * int(c.sum())
+                    want_lines += 7 + int(((c + 31) // 32).sum())
+                else:
+                    want += 4 * len(dims) + 6 * int(np.count_nonzero(blk))
     got, lines = idx.postings_work(xq[:nq], nprobe)
     assert got == want
-    assert lines * 128 >= got - 4 * 0 and lines > 0
+    assert lines > 0 and (storage != 'fx22' or lines == want_lines)
+
+
+def test_flat_storage_fx22_against_fp32_and_float64(O, vecs, trained):
+    """What the fixed-point storage changes (VERDICT r3 item 3's rule): ids equal the fp32-storage
+    result except for candidates within 1e-6 of the k-th score; scores within 1e-5 of the float64
+    inner product of the ORIGINAL vectors. Data outside [0, 1) keeps float postings."""
+    from ann_solo_amd import faiss_compat as faiss
+    xb, xq = vecs
+    cen, _ = trained
+    res = {}
+    for storage in ('fx22', 'fp32'):
+        idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16, storage=storage)
+        idx.set_trained(cen)
+        idx.add(xb)
+        idx.nprobe = 6
+        res[storage] = idx.search(xq[:64], 256)
+    (Dx, Ix), (Df, If) = res['fx22'], res['fp32']
+    xq = xq[:64]
+    exact = np.einsum('qkd,qd->qk', xb[np.maximum(Ix, 0)].astype(np.float64), xq.astype(np.float64))
+    assert np.abs(np.where(Ix >= 0, Dx - exact, 0.0)).max() <= 1e-5
+    for r in range(len(xq)):
+        only = np.setxor1d(Ix[r][Ix[r] >= 0], If[r][If[r] >= 0])
+        if len(only):            # swapped candidates sit at the k-th score
+            kth = min(Dx[r][Ix[r] >= 0].min(), Df[r][If[r] >= 0].min())
+            sc = xb[only].astype(np.float64) @ xq[r].astype(np.float64)
+            assert np.abs(sc - kth).max() <= 1e-6, (r, only, sc, kth)
+    # signed components: stored as given, float postings, exact chain
+    rng = np.random.default_rng(3)
+    xs = xb.copy()
+    xs[:, ::7] *= -1.0
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    idx.set_trained(cen)
+    idx.add(xs)
+    assert idx.flat_layout == 1
+    off, ids, v = idx.lists()
+    stored = np.empty_like(xs)
+    stored[ids] = v
+    assert np.array_equal(stored, np.where(xs >= 0, O.quantize_fx22(xs), xs))
+    with pytest.raises(Exception):
+        idx.set_storage('fp32')          # after add(): refused
+
+
+def test_flat_storage_survives_save_and_load(vecs, trained, tmp_path):
+    from ann_solo_amd import faiss_compat as faiss
+    xb, xq = vecs
+    cen, _ = trained
+    for storage in ('fx22', 'fp32'):
+        idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16, storage=storage)
+        idx.set_trained(cen)
+        idx.add(xb[:1500])
+        path = str(tmp_path / f'{storage}.idxmi')
+        faiss.write_index(idx, path)
+        back = faiss.read_index(path)
+        assert back.storage == storage and back.flat_layout == idx.flat_layout
+        back.add(xb[1500:])
+        idx.add(xb[1500:])
+        idx.nprobe = back.nprobe = 5
+        (D0, I0), (D1, I1) = idx.search(xq[:64], 100), back.search(xq[:64], 100)
+        assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
 
 
 def test_ivfflat_postings_scan_many_small_lists():
