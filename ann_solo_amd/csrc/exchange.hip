@@ -35,68 +35,94 @@ constexpr u64 XK_NONE = ~0ull;      // bound meaning "send nothing"
 // padded), slot kp-1 = T; rest [nrows, k]: the keys held back, compacted, 0 padded.
 // The kept set = all keys whose score bucket (hist_topk.hpp: 512 buckets over [-0.25, 1)) is at
 // or above the lowest bucket floor that admits at most kp - 1 keys.
-__global__ __launch_bounds__(256) void keys_split_kernel(const u64 *__restrict__ K, int k, int kp,
-                                                         u64 *__restrict__ head,
-                                                         u64 *__restrict__ rest) {
-  __shared__ int hist[HT_NB];
-  __shared__ int part[8];
-  __shared__ int s_floor, s_na, s_nr;
-  __shared__ u64 s_best_rest;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const size_t row = blockIdx.x;
-  constexpr int PER = 8;            // k <= 2048
+// One WAVE per row, no barrier: PER keys per lane in registers, a 512-bucket histogram of the
+// wave in LDS (ds_add), cumulative counts from the top by a DPP scan of eight buckets per lane,
+// ballots for the compaction. (The first version -- a 256-thread workgroup per row with three
+// barriers -- took 13.6 us per row: 1.78 ms for the 131 072 rows of a rank at 8 GPUs.)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t xk_dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ uint32_t xk_scan(uint32_t x) {      // inclusive, 64 lanes
+  uint32_t t = x + xk_dpp<0x111, 0xf, 0xf>(x);
+  t += xk_dpp<0x112, 0xf, 0xf>(x);
+  t += xk_dpp<0x113, 0xf, 0xf>(x);
+  t += xk_dpp<0x114, 0xf, 0xe>(t);
+  t += xk_dpp<0x118, 0xf, 0xc>(t);
+  t += xk_dpp<0x142, 0xa, 0xf>(t);
+  t += xk_dpp<0x143, 0xc, 0xf>(t);
+  return t;
+}
+
+constexpr int XS_WAVES = 4;
+template <int PER>
+__global__ __launch_bounds__(64 * XS_WAVES) void keys_split_kernel(const u64 *__restrict__ K, int64_t nrows,
+                                                                   int k, int kp, u64 *__restrict__ head,
+                                                                   u64 *__restrict__ rest) {
+  __shared__ int s_hist[XS_WAVES][HT_NB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * XS_WAVES + wave;
+  if (row >= nrows) return;
+  int *hist = s_hist[wave];
   u64 kk[PER];
-  int bk[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    const int i = tid + u * 256;
+    const int i = lane + u * 64;
     kk[u] = i < k ? K[row * k + i] : 0ull;
-    bk[u] = kk[u] ? score_bucket(key_score(kk[u])) : -1;
   }
-  for (int i = tid; i < HT_NB; i += 256) hist[i] = 0;
-  if (tid == 0) {
-    s_floor = HT_NB;
-    s_na = s_nr = 0;
-    s_best_rest = 0ull;
-  }
-  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < HT_NB / 64; ++u) hist[lane + u * 64] = 0;
 #pragma unroll
   for (int u = 0; u < PER; ++u)
-    if (bk[u] >= 0) atomicAdd(&hist[bk[u]], 1);
-  __syncthreads();
-  {  // thread t owns buckets 511 - 2t, 510 - 2t; cumulative counts from the top
-    const int h0 = hist[HT_NB - 1 - 2 * tid], h1 = hist[HT_NB - 2 - 2 * tid];
-    int tot;
-    const int above = block_excl_scan<4>(h0 + h1, part, tid, tot);
-    const int cap = kp - 1;
-    if (above + h0 + h1 <= cap) atomicMin(&s_floor, HT_NB - 2 - 2 * tid);
-    else if (above + h0 <= cap) atomicMin(&s_floor, HT_NB - 1 - 2 * tid);
+    if (kk[u]) atomicAdd(&hist[score_bucket(key_score(kk[u]))], 1);
+  // lane L owns buckets 511 - 8 L .. 504 - 8 L (descending); `above` = keys in higher buckets
+  int h[8], mine = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    h[u] = hist[HT_NB - 1 - (lane * 8 + u)];
+    mine += h[u];
   }
-  __syncthreads();
-  const int fl = s_floor;
+  int cum = (int)xk_scan((uint32_t)mine) - mine;
+  const int cap = kp - 1;
+  int fl = HT_NB;                       // the lowest bucket of mine that still admits <= cap keys
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    cum += h[u];
+    if (cum <= cap) fl = HT_NB - 1 - (lane * 8 + u);
+  }
+  // the wave's floor = the lowest such bucket of the LAST lane whose first bucket still fits
+  // (cumulative counts only grow): lanes are ordered from the top bucket down
+  const unsigned long long okm = __ballot(fl < HT_NB);
+  int floor_b = HT_NB;
+  if (okm) {
+    const int last = 63 - __builtin_clzll(okm);      // ok lanes form a prefix 0 .. last
+    floor_b = __builtin_amdgcn_readlane(fl, last);
+  }
+  int na = 0, nr = 0;
+  u64 best = 0ull;
+  const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    const bool a = bk[u] >= fl, r = bk[u] >= 0 && bk[u] < fl;
+    const bool valid = kk[u] != 0ull;
+    const bool a = valid && score_bucket(key_score(kk[u])) >= floor_b;
+    const bool r = valid && !a;
     const unsigned long long ma = __ballot(a), mr = __ballot(r);
-    int ba = 0, br = 0;
-    if (lane == 0) {
-      if (ma) ba = atomicAdd(&s_na, __popcll(ma));
-      if (mr) br = atomicAdd(&s_nr, __popcll(mr));
-    }
-    ba = __builtin_amdgcn_readfirstlane(ba);
-    br = __builtin_amdgcn_readfirstlane(br);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (a) head[row * kp + ba + __popcll(ma & below)] = kk[u];
+    if (a) head[row * kp + na + __popcll(ma & below)] = kk[u];
     if (r) {
-      rest[row * k + br + __popcll(mr & below)] = kk[u];
-      atomicMax(&s_best_rest, kk[u]);
+      rest[row * k + nr + __popcll(mr & below)] = kk[u];
+      best = kk[u] > best ? kk[u] : best;
     }
+    na += __popcll(ma);
+    nr += __popcll(mr);
   }
-  __syncthreads();
-  const int na = s_na, nr = s_nr;
-  for (int i = na + tid; i < kp - 1; i += 256) head[row * kp + i] = 0ull;
-  for (int i = nr + tid; i < k; i += 256) rest[row * k + i] = 0ull;
-  if (tid == 0) head[row * kp + kp - 1] = s_best_rest;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const u64 o = (u64)__shfl_xor((unsigned long long)best, off);
+    best = o > best ? o : best;
+  }
+  for (int i = na + lane; i < kp - 1; i += 64) head[row * kp + i] = 0ull;
+  for (int i = nr + lane; i < k; i += 64) rest[row * k + i] = 0ull;
+  if (lane == 0) head[row * kp + kp - 1] = best;
 }
 
 // ---- owner: merge of the heads (+ phase-2 answers) ------------------------------------------
@@ -258,7 +284,13 @@ __global__ __launch_bounds__(256) void keys_extras_kernel(const u64 *__restrict_
 
 int keys_split(const u64 *K, int64_t nrows, int k, int kp, u64 *head, u64 *rest) {
   if (nrows <= 0) return ASL_OK;
-  hipLaunchKernelGGL(keys_split_kernel, dim3((unsigned)nrows), dim3(256), 0, stream(), K, k, kp, head, rest);
+  const dim3 grid((unsigned)cdiv(nrows, XS_WAVES)), block(64 * XS_WAVES);
+  if (k <= 256)
+    hipLaunchKernelGGL(keys_split_kernel<4>, grid, block, 0, stream(), K, nrows, k, kp, head, rest);
+  else if (k <= 1024)
+    hipLaunchKernelGGL(keys_split_kernel<16>, grid, block, 0, stream(), K, nrows, k, kp, head, rest);
+  else
+    hipLaunchKernelGGL(keys_split_kernel<32>, grid, block, 0, stream(), K, nrows, k, kp, head, rest);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }

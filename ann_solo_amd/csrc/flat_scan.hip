@@ -96,6 +96,26 @@ constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = 256, FI_U = 8;   // FI_U
 constexpr int FI_ROWS = (FI_BLK + 63) / 64;      // rows of accumulators in a block
 static_assert(64 % FI_U == 0, "a batch of dimensions must not straddle the 64 lanes of a chunk");
 
+// inclusive prefix sum over the 64 lanes of a wave in seven DPP adds (row_shr 1 / 2 / 3 of the
+// input, row_shr 4 and 8 of the running sums inside each row of 16, then row_bcast 15 / 31 across
+// the rows) instead of six ds_bpermute round trips with a select and an add each: the per-block
+// bookkeeping of the scan runs two of these per block, and the kernel is VALU-bound
+// (profiles/r04_ivfflat_np112_pmc_summary.txt: SQ_ACTIVE_INST_VALU 89 % of the SIMD cycles)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t fi_dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  uint32_t t = x + fi_dpp<0x111, 0xf, 0xf>(x);
+  t += fi_dpp<0x112, 0xf, 0xf>(x);
+  t += fi_dpp<0x113, 0xf, 0xf>(x);
+  t += fi_dpp<0x114, 0xf, 0xe>(t);
+  t += fi_dpp<0x118, 0xf, 0xc>(t);
+  t += fi_dpp<0x142, 0xa, 0xf>(t);
+  t += fi_dpp<0x143, 0xc, 0xf>(t);
+  return t;
+}
+
 struct FiUnit {
   uint32_t blk;   // block index into the per-dimension table
   int32_t pos0;   // list-order position of the block's first vector
@@ -244,13 +264,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
           if (lane * 16 < tab_stride) tb = *reinterpret_cast<const uint4 *>(trow + lane * 16);
           const uint32_t mine = __builtin_amdgcn_sad_u8(tb.x, 0u, 0u) + __builtin_amdgcn_sad_u8(tb.y, 0u, 0u) +
                                 __builtin_amdgcn_sad_u8(tb.z, 0u, 0u) + __builtin_amdgcn_sad_u8(tb.w, 0u, 0u);
-          uint32_t in = mine;
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)in, o, 64);
-            if (lane >= o) in += t;
-          }
-          tpre = in - mine;
+          tpre = wave_incl_scan(mine) - mine;
         }
         for (int kk0 = 0; kk0 < K; kk0 += 64) {
           const int kk = kk0 + lane;
@@ -287,12 +301,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
           // prefix sums, ds_bpermute pulls), then start, count and query value of that
           // dimension. More than 64 rows in a chunk (dense data): further passes.
           const uint32_t rows_j = (e.y + 63u) >> 6;
-          uint32_t incl = rows_j;
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-            if (lane >= o) incl += t;
-          }
+          const uint32_t incl = wave_incl_scan(rows_j);
           const uint32_t pre = incl - rows_j;      // first row of my dimension
           const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
           for (uint32_t r0 = 0; r0 < R; r0 += 64) {

@@ -468,7 +468,8 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     ``two_phase`` (default: whenever the backend emits packed keys): the exact two-phase
     exchange of csrc/exchange.hip; ``head_keys`` overrides the keys per head (default
     ``ceil(2 k / world)``), ``extras_per_query`` the capacity of the phase-2 buffers (slots per
-    query and pair of ranks, default ``max(8, k // 16)``). A full phase-2 buffer repeats the
+    query and pair of ranks, default ``max(8, k // 16)``). With heads as wide as the rows (two
+    ranks) the rows travel whole. A full phase-2 buffer repeats the
     batch with the full exchange (``stats['fallback']``). ``comm``: a ``CommLog`` that receives
     the bytes of every collective."""
     world = dist.get_world_size(group)
@@ -519,7 +520,9 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     two_phase = bool(two_phase and use_keys)
     k_scan = int(getattr(backend, 'k_scan', getattr(backend, 'k', 0)))
     kp = head_width(k_scan, world, head_keys) if two_phase else 0
-    second = two_phase and kp - 1 < k_scan            # heads can hold something back
+    if two_phase and kp - 1 >= k_scan:       # (two ranks: a head of ceil(2k / 2) keys IS the row) the
+        two_phase, kp = False, 0             # rows travel whole: no split, no bound, one merge
+    second = two_phase                       # heads hold something back
     flag = backend.new_flag() if second else None
 
     def rescore(lo, hi, knn):

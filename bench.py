@@ -318,7 +318,7 @@ def main():
         # bytes every collective of a step moved (counted inside the timed steps) and what each
         # costs on its own at its real per-chunk size (outside the timed region, after it)
         comm = comm_log.summary(args.steps)
-        comm['exchange'] = args.exchange if xstats.get('two_phase') or args.exchange == 'full' else 'full (rows)'
+        comm['exchange'] = 'two-phase' if xstats.get('two_phase') else 'full rows'
         comm['head_width'] = xstats.get('head_width')
         comm['fallbacks_to_full_exchange'] = xstats.get('fallback', 0)
         comm['collective_ms_alone'] = time_collectives(comm_log, group, degree, dev, backend, args.steps)
@@ -424,7 +424,8 @@ def main():
             a_f = Namespace(**{**vars(args), 'nprobe': best, 'cpu_seconds': min(args.cpu_seconds, 8.0)})
             cb = cpu_baseline(a_f, sl_f, sl_f.partitions[charge], idx_f, q, res_f, charge, cfg, faiss_leg=False)
             fixed_recall['parity_vs_gpu'] = cb['parity_vs_gpu']
-            fixed_recall['cpu_baseline'] = {k_: cb[k_] for k_ in ('value', 'unit', 'cores', 'kind', 'sample')}
+            fixed_recall['cpu_baseline'] = {k_: cb[k_] for k_ in ('value', 'unit', 'cores', 'kind', 'sample',
+                                                                     'single_core_value', 'dense_definition_check')}
         sl_f.shutdown()
         del sl_f, idx_f
         torch.cuda.empty_cache()
@@ -921,8 +922,8 @@ def _lib_handle():
     return _lib.lib()
 
 
-PMC_TRAFFIC_FILE = 'profiles/r03_pmc_traffic.json'
-PMC_TRAFFIC_FILE_FLAT = 'profiles/r03_ivfflat_np112_pmc_traffic.json'     # IVF-Flat, nprobe 112
+PMC_TRAFFIC_FILE = 'profiles/r04_pmc_traffic.json'
+PMC_TRAFFIC_FILE_FLAT = 'profiles/r04_ivfflat_np112_pmc_traffic.json'     # IVF-Flat (fixed-point postings), nprobe 112
 
 
 def pmc_traffic(args, world):
@@ -974,12 +975,16 @@ def postings_roofline(sl, idx, q, nprobe, avg_ms, args=None):
     the timed region; ``lines`` = the 128-byte lines those bytes occupy (what a cold scan has to
     move). HBM-bound: every (query, block) pair touches its own lines."""
     b, l = idx.postings_work(sl._encode(q), nprobe)
-    traffic, src = flat_pmc_traffic(args, nprobe) if args is not None else (None, None)
+    layout = idx.flat_layout
+    traffic, src = flat_pmc_traffic(args, nprobe) if args is not None and layout == 2 else (None, None)
     achieved = b / (avg_ms * 1e-3) / 1e9
     by_line = l * 128 / (avg_ms * 1e-3) / 1e9
     return {'bound': 'hbm', 'kernel': 'flat_inv_scan_kernel', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
-            'bytes': '4-B table word + 6 B per posting, per (probed block, non-zero query dimension)',
+            'layout': {1: 'float postings (6 B) behind 4-byte table words', 2: 'fixed-point posting words (4 B) '
+                       'in whole 128-byte lines behind a one-byte-per-dimension table'}.get(layout),
+            'bytes': ('1-B table entry + 4 B per posting' if layout == 2 else '4-B table word + 6 B per posting') +
+                     ', per (probed block, non-zero query dimension)',
             'algorithmic_bytes_per_launch': int(b), 'avg_launch_ms': round(avg_ms, 4),
             'lines_128B_per_launch': int(l), 'achieved_by_lines': round(by_line, 2),
             'frac_by_lines': round(by_line / HBM_PEAK_GBS, 5), 'traffic': traffic,

@@ -30,6 +30,19 @@ q = q_all.select(torch.arange(batch, device=dev)).contiguous()
 be = HipShardBackend(sl, 2, 'open')
 allvec = be.encode(q_all)
 cD, cI = be.coarse(allvec)
+# the W shards of the index, side by side on this GPU (copies through a file): the rows every shard
+# holds for this rank's own `batch` queries are what the exchange statistics need
+import tempfile
+from ann_solo_amd import faiss_compat as faiss
+tmp = os.path.join(tempfile.mkdtemp(), 'sim.idxmi')
+faiss.write_index(idx, tmp)
+own_rows = []
+for s_ in range(1, W):
+    other = faiss.read_index(tmp)
+    other.shard(s_, W)
+    own_rows.append(other.search_preassigned_keys(allvec[:batch], be.k_scan, cD[:batch], cI[:batch]))
+    del other
+os.remove(tmp)
 idx.shard(0, W)
 
 
@@ -46,16 +59,41 @@ def timed(fn, reps=3):
 t_enc, _ = timed(lambda: be.encode(q_all))      # every rank hashes ALL queries (peaks travel)
 vec = be.encode(q)
 t_coarse, _ = timed(lambda: be.coarse(vec))     # ... and quantises its own slice
-if index == 'ivfpq':
-    t_scan, K = timed(lambda: be.shard_search_keys(allvec, cD, cI))
-    Ks = K.view(W, batch, -1).contiguous()
-    t_merge, (_, knn) = timed(lambda: be.merge_keys(Ks))
+from ann_solo_amd.distributed import head_width
+# the two-phase exchange's compute on this rank: split of the W x batch local rows, merge of the
+# heads this rank would own (here: the heads of its own rows for the first `batch` queries of
+# every "shard" -- the same work), the held-back keys above the bounds, the final merge
+t_scan, K = timed(lambda: be.shard_search_keys(allvec, cD, cI))
+kp = head_width(be.k_scan, W)
+t_split, (head, rest) = timed(lambda: be.keys_split(K, kp))
+# what this rank receives: the heads of its own queries' rows from every shard
+heads = torch.stack([head[:batch]] + [be.keys_split(r_, kp)[0] for r_ in own_rows]).contiguous()
+rests = [rest[:batch]] + [be.keys_split(r_, kp)[1] for r_ in own_rows]
+t_m1, (okeys, bnd, need) = timed(lambda: be.keys_merge_heads(heads, be.k_scan))
+t_x = t_m2 = 0.0
+if kp - 1 < be.k_scan:
+    flag = be.new_flag()
+    xcap = batch * max(8, be.k_scan // 16)
+    # shard side: this rank answers W x batch rows (timed on its own rows against the bounds its
+    # own queries got -- the same amount of work); owner side: the real answers of the W shards
+    t_x, _ = timed(lambda: be.keys_extras(rest, bnd.reshape(-1).contiguous(), W, xcap, be.new_flag()))
+    xbuf = torch.stack([be.keys_extras(rests[s_].contiguous(), bnd[s_].contiguous(), 1, xcap, flag)[0]
+                        for s_ in range(W)])
+    t_m2, knn = timed(lambda: be.keys_merge_final(heads, xbuf, okeys, need, be.k_scan))
+    want = be.merge_keys(torch.stack([K[:batch]] + own_rows).contiguous())[1]
+    exact = bool(torch.equal(torch.sort(knn, 1).values, torch.sort(want, 1).values))
+    held = float(((xbuf[:, :batch] >> 32).sum()).item()) / batch
+    asked = float(need.float().mean())
 else:
-    t_scan, (D, I) = timed(lambda: be.shard_search_preassigned(allvec, cD, cI))
-    Ds, Is = D.view(W, batch, -1).contiguous(), I.view(W, batch, -1).contiguous()
-    t_merge, (_, knn) = timed(lambda: be.merge(Ds, Is))
+    t_m2, knn = timed(lambda: be.keys_merge_final(heads, None, okeys, need, be.k_scan))
+    flag, asked, exact, held = None, 0.0, True, 0.0
+t_old, _ = timed(lambda: be.merge_keys(K.view(W, batch, -1).contiguous()))
 t_resc, _ = timed(lambda: be.rescore_knn(q, knn, True))
+t_merge = t_split + t_m1 + t_x + t_m2
 tot = t_enc + t_coarse + t_scan + t_merge + t_resc
 print(f'{index} W={W} batch/rank={batch} variant={variant}: encode (all {W * batch}) {t_enc:.2f} coarse {t_coarse:.2f} '
-      f'shard scan ({W * batch} queries) {t_scan:.2f} merge {t_merge:.2f} rescore {t_resc:.2f} '
+      f'shard scan ({W * batch} queries) {t_scan:.2f} exchange compute {t_merge:.2f} (split {t_split:.2f} + heads {t_m1:.2f} + '
+      f'held-back {t_x:.2f} + final {t_m2:.2f}; head width {kp}, queries asking {asked:.3f}, held-back keys per query {held:.1f}, '
+      f'equals the full merge: {exact}, overflow '
+      f'{int(flag.item()) if flag is not None else 0}; the full-row merge it replaces {t_old:.2f}) rescore {t_resc:.2f} '
       f'| compute per step {tot:.2f} ms (collectives excluded)')

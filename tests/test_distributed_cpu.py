@@ -111,7 +111,7 @@ def _worker(rank, world, port, kind, out_dir):
     be.keys = True
     ok = (ok and seen['overflow'][1] == 1 and seen['small_heads'][1] == 0 and
           'held_back_keys_all_to_all' in seen['small_heads'][2] and
-          'held_back_keys_all_to_all' not in seen['two_phase'][2] and
+          'heads_all_to_all' not in seen['two_phase'][2] and    # two ranks: the rows travel whole
           seen['rows'][2].count('topk_rows_all_to_all') == 1)
     if not ok:
         print('exchange modes:', seen, flush=True)

@@ -47,12 +47,12 @@ def test_two_rank_sharded_bench_path(degree, index, extra):
         assert c['total_bytes_out_per_rank_per_step'] > 0 and c['collective_ms_alone']
         if '--exchange' in extra:
             assert 'topk_rows_all_to_all' in c and 'heads_all_to_all' not in c
-        else:
-            assert c['exchange'] == 'two-phase' and 'heads_all_to_all' in c
-            assert ('held_back_keys_all_to_all' in c) == ('--head-keys' in extra)
+        elif '--head-keys' in extra:
+            assert c['exchange'] == 'two-phase' and 'heads_all_to_all' in c and 'held_back_keys_all_to_all' in c
             assert c['fallbacks_to_full_exchange'] == (1 if '--extras-per-query' in extra else 0)
-            # k = 1024 at two ranks: heads of ceil(2k / 2) + 1 slots unless overridden
-            assert c['head_width'] == (int(extra[1]) + 1 if '--head-keys' in extra else 1025)
+            assert c['head_width'] == int(extra[1]) + 1
+        else:       # two ranks: a head of ceil(2k / 2) keys is the whole row -- the rows travel as they are
+            assert 'topk_rows_all_to_all' in c and 'heads_all_to_all' not in c
     else:
         assert d['config']['parallelism'] == 'replicas x2' and d['alt_layouts'] is None
 
