@@ -169,12 +169,35 @@ __global__ __launch_bounds__(HT_NT) void keys_merge_kernel(
       top.end_round(appended);
     }
   };
-  // heads: 64-entry chunks of the S lists interleaved (as topk_merge_hist_kernel), slot kp-1 skipped
-  const int kin = kp - 1, kc = (kin + 63) >> 6;
-  stream([&](int v) -> u64 {
-    const int c = v >> 6, s = c % S, j = (c / S) * 64 + (v & 63);
-    return j < kin ? heads[((size_t)s * nq + q) * kp + j] : 0ull;
-  }, kc * S * 64);
+  // heads: slot kp-1 (the held-back key) skipped. When all S * (kp - 1) slots fit the key buffer
+  // (the two-phase exchange's own shape: ceil(2k / S) keys from each of S shards) they go straight
+  // into it, counted in the histogram -- no rounds, no per-key reservations; empty slots stay
+  // (every consumer of the buffer skips zeros). Otherwise 64-entry chunks of the S lists
+  // interleaved through the streaming offers, as topk_merge_hist_kernel does.
+  const int kin = kp - 1;
+  if (S * kin <= CAP) {
+    const int total = S * kin;
+    for (int i = tid; i < total; i += HT_NT) {
+      const int s = i / kin, j = i - s * kin;
+      const u64 key = heads[((size_t)s * nq + q) * kp + j];
+      top.keys[i] = key;
+      if (key) atomicAdd(&top.hist[score_bucket(key_score(key))], 1);
+    }
+    __syncthreads();
+    top.fill = total;
+    if (tid == 0) top.ctl[TopK::C_FILL] = total;
+    __syncthreads();
+    if (round2 && xbuf) {      // answers follow through the streaming offers: they need a round's worth of room
+      top.begin_round();
+      top.end_round(0);
+    }
+  } else {
+    const int kc = (kin + 63) >> 6;
+    stream([&](int v) -> u64 {
+      const int c = v >> 6, s = c % S, j = (c / S) * 64 + (v & 63);
+      return j < kin ? heads[((size_t)s * nq + q) * kp + j] : 0ull;
+    }, kc * S * 64);
+  }
   if (round2 && xbuf) {
     for (int s = 0; s < S; ++s) {                // block-uniform
       const u64 *src = xbuf + (size_t)s * ((size_t)nq + (size_t)xcap);

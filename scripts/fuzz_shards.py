@@ -12,12 +12,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import numpy as np
 import torch
 from ann_solo_amd import _lib, faiss_compat as faiss, synthetic
+from ann_solo_amd.distributed import HipShardBackend, head_width
 from ann_solo_amd.spectral_library import Config, SpectralLibrary
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 t_end = time.time() + budget
-trials = bad = 0
+trials = bad = two_phase = 0
 dev = torch.device('cuda', 0)
 tmp = tempfile.mkdtemp()
 while time.time() < t_end:
@@ -60,9 +61,28 @@ while time.time() < t_end:
     if use_keys:
         Dk, Ik = faiss.topk_merge_keys(torch.stack(keys))
         ok &= torch.equal(Ik, I) and torch.equal(Dk.view(torch.int32), D.view(torch.int32))
+        if k + 768 <= 2048:
+            # the two-phase exchange (csrc/exchange.hip) over the same rows, a random head width: heads
+            # -> bounds -> held-back keys -> final merge must give the unsharded ids as a set
+            be = HipShardBackend.__new__(HipShardBackend)
+            kp = head_width(k, W, int(rng.integers(1, k + 1)) if rng.random() < 0.7 else None)
+            split = [be.keys_split(K_, kp) for K_ in keys]
+            heads = torch.stack([h for h, _ in split])
+            okeys, bnd, need = be.keys_merge_heads(heads, k)
+            if kp - 1 < k:
+                flag = torch.zeros(1, dtype=torch.int32, device=dev)
+                xcap = nq * int(rng.choice([k, max(8, k // 16)]))
+                xb = torch.stack([be.keys_extras(split[r][1], bnd[r].contiguous(), 1, xcap, flag)[0]
+                                  for r in range(W)])
+                If = None if int(flag.item()) else be.keys_merge_final(heads, xb, okeys, need, k)
+            else:
+                If = be.keys_merge_final(heads, None, okeys, need, k)
+            if If is not None:
+                ok &= torch.equal(torch.sort(If, 1).values, torch.sort(I, 1).values)
+                two_phase += 1
     trials += 1
     if not ok:
         bad += 1
         print('MISMATCH', desc, flush=True)
     sl.shutdown()
-print(f'{trials} trials, {bad} mismatches')
+print(f'{trials} trials ({two_phase} also through the two-phase exchange), {bad} mismatches')
