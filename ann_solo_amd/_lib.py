@@ -241,6 +241,16 @@ def ptr(a):
     raise TypeError(type(a))
 
 
+_DEFAULT_RAW = {}
+
+
+def _default_raw_stream(idx: int) -> int:
+    import torch
+    if idx not in _DEFAULT_RAW:
+        _DEFAULT_RAW[idx] = int(torch.cuda.default_stream(idx).cuda_stream)
+    return _DEFAULT_RAW[idx]
+
+
 def _require_default_stream(device):
     """The library issues its kernels on the null stream (and, in pipeline mode, on streams of
     its own that it orders against the null stream). That is ordered with PyTorch only while
@@ -249,7 +259,14 @@ def _require_default_stream(device):
     before the library has finished. Every device tensor crosses ``ptr()``, so the check lives
     here and such a call fails instead of racing."""
     import torch
-    if torch.cuda.current_stream(device) != torch.cuda.default_stream(device):
+    # (every device tensor of every call passes here: the raw-handle query is a C call of well
+    # under a microsecond; the stream objects of the public API cost ~10 us a pair)
+    try:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        ok = torch._C._cuda_getCurrentRawStream(idx) == _default_raw_stream(idx)
+    except AttributeError:      # a PyTorch without the private hook
+        ok = torch.cuda.current_stream(device) == torch.cuda.default_stream(device)
+    if not ok:
         raise AnnSoloMiError(
             'libannsolo_mi issues its work on the default HIP stream: call it with '
             "PyTorch's default stream current (not inside torch.cuda.stream(...)), or "
