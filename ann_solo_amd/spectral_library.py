@@ -638,11 +638,12 @@ class SpectralLibrary:
         finally:
             if piped:
                 self.set_pipeline(False)         # synchronises first
-        for charge, sel, q, res in pending:
-            part = self.partitions[charge]
-            # default search-engine score: the cosine over the winner's peak matches
-            cos = spectrum_similarity.ssm_cosine(q, part.spectra, res.best_row, res.pm_pairs,
-                                                 res.pm_count)
+        # default search-engine score: the cosine over the winner's peak matches -- every batch's
+        # kernel is enqueued before the first result is copied back (a copy waits for its kernel)
+        cosines = [spectrum_similarity.ssm_cosine(q, self.partitions[charge].spectra, res.best_row,
+                                                  res.pm_pairs, res.pm_count)
+                   for charge, sel, q, res in pending]
+        for (charge, sel, q, res), cos in zip(pending, cosines):
             table.add_batch(charge, sel, _to_np(res.best_row), _to_np(cos), res)
         if uid is not None:
             table = table.first_per_uid(uid)

@@ -487,7 +487,7 @@ def main():
         cascade = None
         if world == 1 and not args.no_cascade:
             from argparse import Namespace
-            a_c = Namespace(**{**vars(args), 'steps': max(1, min(args.steps, 3)), 'warmup': 1})
+            a_c = Namespace(**{**vars(args), 'steps': max(1, min(args.steps, 10)), 'warmup': max(1, min(args.warmup, 2))})
             c = cascade_pass(a_c, 1, 0, dev, backend, sl, lib, aux, charge, cfg,
                              parity_seconds=min(args.cpu_seconds, 8.0), oracle_ctx=ctx)
             cascade = {'workload': c['config']['workload'], 'value': c['value'], 'unit': c['unit'],
