@@ -217,6 +217,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   top.init(smem, k, ids, tid);
   top.out_keys = set_mode == 2 && I64 != nullptr;     // rows of packed keys (sharded exchange)
   float *acc = s_acc + wave * FI_BLK;
+  const uint32_t lane4 = (uint32_t)lane * 4u;
   int chunks_done = 0;
   auto sync = [&]() {             // raise the flag, meet the other waves, compact
     if (lane == 0) *s_flag = 1;
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
             const uint32_t rc1 = min(64u, cnj - 64u * t) - 1u;    // last lane of my row with a posting of its own
             const uint32_t rvo = stj + 256u * t;                  // its values (FX: its posting words) ...
             const uint32_t rlo = stj + 4u * cnj + 128u * t;       // ... and local indices
+            const uint32_t rfx = rvo | (rc1 >> 5);                // FX: offset | (two lines wide)
             // Software pipeline over the rows, FI_U deep: row r + FI_U is requested as soon as
             // row r has been applied, so FI_U - 1 rows are always in flight (loads return in
             // order: the wait before applying r is "all but the 2 (FI_U - 1) youngest"). Loads
@@ -343,12 +345,16 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
             float qj[FI_U], val[FI_U];
 #define FI_FETCH(u, r)                                                                            \
   {                                                                                               \
-    const uint32_t vo_ = (uint32_t)__builtin_amdgcn_readlane((int)rvo, (r));                      \
-    const uint32_t c1_ = (uint32_t)__builtin_amdgcn_readlane((int)rc1, (r));                      \
     qj[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rq), (r))); \
     if constexpr (FX) {                                                                           \
-      loc[u] = *reinterpret_cast<const uint32_t *>(bptr + (vo_ + 4u * ((uint32_t)lane & c1_)));   \
+      /* one descriptor word: the row's byte offset (a multiple of 128) | 1 when it is two lines \
+         wide; the offset goes into the scalar base, the width into the mask of my word index */  \
+      const uint32_t s_ = (uint32_t)__builtin_amdgcn_readlane((int)rfx, (r));                     \
+      const char *row_ = bptr + (s_ & ~1u);                                                       \
+      loc[u] = *reinterpret_cast<const uint32_t *>(row_ + (lane4 & ((s_ & 1u) ? 255u : 127u)));   \
     } else {                                                                                      \
+      const uint32_t vo_ = (uint32_t)__builtin_amdgcn_readlane((int)rvo, (r));                    \
+      const uint32_t c1_ = (uint32_t)__builtin_amdgcn_readlane((int)rc1, (r));                    \
       const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)rlo, (r));                    \
       const uint32_t l_ = min((uint32_t)lane, c1_);                                               \
       val[u] = *reinterpret_cast<const float *>(bptr + (vo_ + 4u * l_));                          \

@@ -95,3 +95,38 @@ def test_config1_ivfflat_default_parameters(O, iprg):
         Ie = Ie.cpu().numpy()
         rec = np.mean([len(set(res.knn[i]) & set(Ie[i])) / 10 for i in range(q.n)])
         assert rec > 0.8, rec
+
+
+def test_default_bench_line_at_small_size():
+    """The driver's `python bench.py` line, at a size that takes seconds: every block the round-4
+    line carries must be there and its parity flags true -- recall with the exact hit@k fields,
+    the fixed-recall leg with its own roofline / parity / CPU baseline, the configs[4] cascade
+    pass with oracle parity, the stage rates with the candidate count the kernel reports."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--library-size', '60000', '--nlist', '256',
+           '--niter', '4', '--batch', '1024', '--steps', '2', '--warmup', '1', '--cpu-seconds', '2',
+           '--recall-queries', '64', '--cascade-batches', '2', '--nprobe', '32', '--k', '256']
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert line, out.stderr[-3000:]
+    d = json.loads(line[-1])
+    assert d['metric'].startswith('query spectra/sec') and d['value'] > 0 and d['n_gpus'] == 1
+    assert d['roofline']['bound'] == 'hbm' and d['roofline']['frac'] > 0 and d['dtype'] == 'f32'
+    r = d['recall']
+    assert 0 < r['exact_hit_at_k_source'] <= 1 and r['reference_exact_hit_at_1024_modified_iprg2012'] == 0.751
+    cb = d['cpu_baseline']
+    assert cb['value'] > 0 and cb['cores'] >= 1 and cb['parity_vs_gpu']['knn_id_sets_equal'] and \
+        cb['parity_vs_gpu']['best_row_equal'] and cb['parity_vs_gpu']['best_score_max_abs_diff'] == 0.0
+    f = d['fixed_recall']
+    assert f['index'] == 'ivfflat' and f['value'] > 0 and f['roofline']['layout'].startswith('fixed-point')
+    assert f['parity_vs_gpu']['knn_id_sets_equal'] and f['parity_vs_gpu']['best_row_equal']
+    assert f['cpu_baseline']['dense_definition_check']['knn_ids_and_winners_equal'] is True
+    c = d['cascade']
+    assert c['value'] > 0 and c['levels']['std']['queries_in_per_step'] == 2048
+    assert c['parity_vs_oracle']['all_equal'] is True and c['parity_vs_oracle']['queries'] >= 64
+    g = d['stages_gbs']
+    assert g['rescore']['candidate_count_equals_the_kernels'] is True and g['encode']['GBps'] > 0
