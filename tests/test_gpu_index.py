@@ -46,7 +46,7 @@ def test_flat_search_exact(O, vecs):
         assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))   # fmaf chain == MFMA chain
 
 
-@pytest.mark.parametrize('n', [4096, 4095, 1000, 257])
+@pytest.mark.parametrize('n', [4096, 4095, 1000, 257, 100])
 def test_short_row_select_matches_oracle(O, n):
     """The register-resident top-k of short rows (coarse top-nprobe of nlist): random rows,
     duplicated vectors (equal scores -> lowest id first), an all-zero query (every score
