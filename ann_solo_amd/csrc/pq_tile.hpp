@@ -64,8 +64,14 @@ __device__ __forceinline__ float tile_adc(const char *lut_bytes, const uint4 A, 
 // Per-query LUT image lut[c*32 + m]. Thread c owns code word c; the codebooks are read
 // from the TRANSPOSED copy cbT[m][t][c] so that a wave's load is one contiguous 256-B
 // line (the [m][c][t] original makes every lane touch its own cache line: measured 4x
-// slower). The 32 stores of a wave all hit bank m (64-way conflict, 64 LDS cycles each) --
-// cheaper than any scheme that scatters the codebook reads.
+// slower). The image's bank is the sub-quantiser (that is what makes the scan's reads
+// conflict-free), so a wave that stores ONE sub-quantiser's 64 entries hits one bank 64 times:
+// until round 4 that was ~13 such stores per thread, ~6 k LDS cycles per table -- nothing next to
+// a 16 384-query scan, a third of the per-(query, shard) fixed cost of a sharded one. Now a
+// thread keeps its 16 (32) finished sums in registers and stores them as 16-byte groups, the
+// lanes of one instruction rotated over the groups (lane l stores group (i + l) & 3 in
+// instruction i): 4 (8) stores per thread, 16 banks busy at a time. The table needs no zeroing
+// pass either: every entry is written.
 //
 // Zero query components are SKIPPED: fmaf(0, cb, acc) == acc bit for bit (finite
 // codebooks), so the chain over the non-zero components in ascending t is the canonical
@@ -94,10 +100,6 @@ __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, 
   if (!fast) {
     for (int i = tid; i < d; i += NT) s_q[i] = xq_row[i];
     __syncthreads();
-  }
-  if (tid >= 64) {  // the other waves zero the table meanwhile (sub-quantisers without non-zeros)
-    float4 *z = reinterpret_cast<float4 *>(s_lut);
-    for (int i = tid - 64; i < PQT_KSUB * PQT_M / 4; i += NT - 64) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (fast) {
     if (tid < 64) {   // wave 0: one entry per lane (ascending dimension = ascending (m, t))
@@ -152,11 +154,16 @@ __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, 
   const int Kall = reinterpret_cast<const int *>(s_nz)[0];
   const int K16 = reinterpret_cast<const int *>(s_nz)[1];
   const int c = tid & (PQT_KSUB - 1);
-  const int kbeg = (NT > PQT_KSUB && tid >= PQT_KSUB) ? K16 : 0;
-  const int K = (NT > PQT_KSUB && tid < PQT_KSUB) ? K16 : Kall;   // wave-uniform
+  // wave-uniform values, kept in scalar registers (the register file below is indexed by them)
+  const int kbeg = __builtin_amdgcn_readfirstlane((NT > PQT_KSUB && tid >= PQT_KSUB) ? K16 : 0);
+  const int K = __builtin_amdgcn_readfirstlane((NT > PQT_KSUB && tid < PQT_KSUB) ? K16 : Kall);
   constexpr int U = 8;   // codebook loads in flight per thread
+  constexpr int MS = NT > PQT_KSUB ? PQT_M / 2 : PQT_M;   // sub-quantisers per thread
+  const int mbase = __builtin_amdgcn_readfirstlane((NT > PQT_KSUB && tid >= PQT_KSUB) ? PQT_M / 2 : 0);
+  typedef float lut_regs __attribute__((ext_vector_type(MS)));
+  lut_regs r = 0.0f;     // indexed by a scalar below (v_movrel / gpr-index mode, no scratch)
   float acc = 0.0f;
-  int cur = -1;
+  int cur = mbase;       // "the run of sub-quantiser mbase, nothing summed yet"
   for (int k0 = kbeg; k0 < K; k0 += U) {
     float cbv[U], qv[U];
     int mm[U];
@@ -171,16 +178,31 @@ __device__ __forceinline__ void build_lut_cbt(const float *__restrict__ xq_row, 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (k0 + u < K) {               // block-uniform
-        if (mm[u] != cur) {           // block-uniform: a sub-quantiser's run ends
-          if (cur >= 0) s_lut[c * PQT_M + cur] = acc;
+        const int m_u = __builtin_amdgcn_readfirstlane(mm[u]);
+        if (m_u != cur) {             // block-uniform: a sub-quantiser's run ends
+          asm volatile("; a run ends" ::: "memory");   // keeps this a (scalar) branch: as a select it is 16 v_cndmask per entry
+          r[cur - mbase] = acc;
           acc = 0.0f;
-          cur = mm[u];
+          cur = m_u;
         }
         acc = __builtin_fmaf(qv[u], cbv[u], acc);
       }
     }
   }
-  if (cur >= 0) s_lut[c * PQT_M + cur] = acc;
+  r[cur - mbase] = acc;
+  // groups of four sub-quantisers, 16 bytes each; lane l stores group (i + l) mod NG in
+  // instruction i
+  constexpr int NG = MS / 4;
+  float4 *row = reinterpret_cast<float4 *>(s_lut + c * PQT_M + mbase);
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int g = (i + tid) & (NG - 1);
+    float4 v = make_float4(r[0], r[1], r[2], r[3]);
+#pragma unroll
+    for (int h = 1; h < NG; ++h)
+      if (g == h) v = make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]);
+    row[g] = v;
+  }
   __syncthreads();
 }
 
