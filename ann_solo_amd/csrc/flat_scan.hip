@@ -96,25 +96,9 @@ constexpr int FI_NW = 8, FI_NT = 64 * FI_NW, FI_CHUNK = 256, FI_U = 8;   // FI_U
 constexpr int FI_ROWS = (FI_BLK + 63) / 64;      // rows of accumulators in a block
 static_assert(64 % FI_U == 0, "a batch of dimensions must not straddle the 64 lanes of a chunk");
 
-// inclusive prefix sum over the 64 lanes of a wave in seven DPP adds (row_shr 1 / 2 / 3 of the
-// input, row_shr 4 and 8 of the running sums inside each row of 16, then row_bcast 15 / 31 across
-// the rows) instead of six ds_bpermute round trips with a select and an add each: the per-block
-// bookkeeping of the scan runs two of these per block, and the kernel is VALU-bound
-// (profiles/r04_ivfflat_np112_pmc_summary.txt: SQ_ACTIVE_INST_VALU 89 % of the SIMD cycles)
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ uint32_t fi_dpp(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
-  uint32_t t = x + fi_dpp<0x111, 0xf, 0xf>(x);
-  t += fi_dpp<0x112, 0xf, 0xf>(x);
-  t += fi_dpp<0x113, 0xf, 0xf>(x);
-  t += fi_dpp<0x114, 0xf, 0xe>(t);
-  t += fi_dpp<0x118, 0xf, 0xc>(t);
-  t += fi_dpp<0x142, 0xa, 0xf>(t);
-  t += fi_dpp<0x143, 0xc, 0xf>(t);
-  return t;
-}
+// (wave_incl_scan -- the seven-DPP-add prefix sum of hist_topk.hpp -- runs twice per block in the
+// per-block bookkeeping: the kernel is VALU-bound, profiles/r04_ivfflat_np112_pmc_summary.txt:
+// SQ_ACTIVE_INST_VALU 89 % of the SIMD cycles)
 
 struct FiUnit {
   uint32_t blk;   // block index into the per-dimension table

@@ -45,15 +45,29 @@ __device__ __forceinline__ float bucket_floor(int b) {
 
 // exclusive prefix sum of one int per thread over a workgroup of NW waves; `part` = NW LDS
 // ints reserved for this call site. Total in `total`.
+// Inclusive prefix sum over the 64 lanes of a wave in seven DPP adds (row_shr 1 / 2 / 3, row_shr 4
+// and 8 under bank masks, row_bcast 15 and 31 under row masks) -- no LDS crossbar round trips:
+// the ds_bpermute chain this replaces (six dependent __shfl_up) was ~0.3 us of latency per scan,
+// and a top-k finish runs three of them. All 64 lanes must be active.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t scan_dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  uint32_t t = x + scan_dpp<0x111, 0xf, 0xf>(x);
+  t += scan_dpp<0x112, 0xf, 0xf>(x);
+  t += scan_dpp<0x113, 0xf, 0xf>(x);
+  t += scan_dpp<0x114, 0xf, 0xe>(t);
+  t += scan_dpp<0x118, 0xf, 0xc>(t);
+  t += scan_dpp<0x142, 0xa, 0xf>(t);
+  t += scan_dpp<0x143, 0xc, 0xf>(t);
+  return t;
+}
+
 template <int NW>
 __device__ __forceinline__ int block_excl_scan(int v, int *part, int tid, int &total) {
   const int lane = tid & 63, wave = tid >> 6;
-  int incl = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(incl, off);
-    if (lane >= off) incl += o;
-  }
+  const int incl = (int)wave_incl_scan((uint32_t)v);
   if (lane == 63) part[wave] = incl;
   __syncthreads();
   int base = 0;
@@ -320,7 +334,9 @@ struct HistTopK {
       tk.finish(out_keys ? nullptr : D, I64, out_keys ? nullptr : I32, tid);
       return;
     }
-    fill = compact();
+    // the last compaction, fused: keys below the threshold bucket are dropped in registers (no
+    // write-back, no second pass over the buffer)
+    update_bstar();
     const int bs = ctl[C_BSTAR];
     u64 kk[PER];
     int32_t idv[PER];
@@ -328,6 +344,7 @@ struct HistTopK {
     for (int u = 0; u < PER; ++u) {
       const int i = tid + u * NT;
       kk[u] = i < fill ? keys[i] : 0ull;
+      if (kk[u] != 0ull && score_bucket(ord2f((uint32_t)(kk[u] >> 32))) < bs) kk[u] = 0ull;
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u)   // all gathers of a thread in flight together
@@ -370,14 +387,35 @@ struct HistTopK {
     __syncthreads();
     const int r = k - n_above;          // > 0
     const int take = n_bound < r ? n_bound : r;
-    for (int i = tid; i < n_bound; i += NT) {
-      const u64 key = scratch[i];
-      int rank = i;
-      if (n_bound > r) {                 // block-uniform
-        rank = 0;
-        for (int j = 0; j < n_bound; ++j) rank += scratch[j] > key;
+    if (n_bound <= r) {                  // block-uniform: the whole threshold bucket is in
+      for (int i = tid; i < n_bound; i += NT) emit(n_above + i, scratch[i]);
+    } else if (n_bound <= NT) {          // block-uniform
+      // rank = number of larger keys, counted by ALL threads: the bucket's keys padded to a power
+      // of two n_pad, the NT / n_pad groups of n_pad threads each count over their share of the
+      // keys (a wave reads one key at a time: LDS broadcasts), partial counts through the dead
+      // histogram. (One thread per key walking the whole bucket left most of the workgroup idle:
+      // 0.43 ms of a 131 072-row shard scan.)
+      int n_pad = 64;
+      while (n_pad < n_bound) n_pad <<= 1;
+      const int P = NT / n_pad, i = tid & (n_pad - 1), p = tid / n_pad;
+      const int seg = (n_bound + P - 1) / P, j0 = p * seg, j1 = min(n_bound, j0 + seg);
+      const u64 mine = i < n_bound ? scratch[i] : ~0ull;
+      int c = 0;
+      for (int j = j0; j < j1; ++j) c += scratch[j] > mine;
+      hist[p * n_pad + i] = c;
+      __syncthreads();
+      if (tid < n_bound) {
+        int rank = 0;
+        for (int pp = 0; pp < P; ++pp) rank += hist[pp * n_pad + tid];
+        if (rank < take) emit(n_above + rank, scratch[tid]);
       }
-      if (rank < take) emit(n_above + rank, key);
+    } else {
+      for (int i = tid; i < n_bound; i += NT) {
+        const u64 key = scratch[i];
+        int rank = 0;
+        for (int j = 0; j < n_bound; ++j) rank += scratch[j] > key;
+        if (rank < take) emit(n_above + rank, key);
+      }
     }
     for (int i = n_above + take + tid; i < k; i += NT) {
       if (out_keys) {
