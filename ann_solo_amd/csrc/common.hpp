@@ -200,4 +200,35 @@ struct PeaksStage {  // stages an asl_peaks_t whose arrays may be on the host
 };
 bool peaks_on_device(const asl_peaks_t *p);
 
+// Inclusive prefix sum over the 64 lanes of a wave in seven DPP adds (row_shr 1 / 2 / 3, row_shr 4
+// and 8 under bank masks, row_bcast 15 and 31 under row masks) -- no LDS crossbar round trips:
+// the ds_bpermute chain this replaces (six dependent __shfl_up) was ~0.3 us of latency per scan,
+// and a top-k finish runs three of them. All 64 lanes must be active.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t scan_dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  uint32_t t = x + scan_dpp<0x111, 0xf, 0xf>(x);
+  t += scan_dpp<0x112, 0xf, 0xf>(x);
+  t += scan_dpp<0x113, 0xf, 0xf>(x);
+  t += scan_dpp<0x114, 0xf, 0xe>(t);
+  t += scan_dpp<0x118, 0xf, 0xc>(t);
+  t += scan_dpp<0x142, 0xa, 0xf>(t);
+  t += scan_dpp<0x143, 0xc, 0xf>(t);
+  return t;
+}
+// Maximum over the 64 lanes of a wave, valid in lane 63 (same ladder with max for +).
+__device__ __forceinline__ int wave_max_to_lane63(int x) {
+  auto mx = [](int a, uint32_t b) { return a > (int)b ? a : (int)b; };   // values >= 0: the DPP fill 0 is neutral
+  int t = mx(x, scan_dpp<0x111, 0xf, 0xf>((uint32_t)x));
+  t = mx(t, scan_dpp<0x112, 0xf, 0xf>((uint32_t)x));
+  t = mx(t, scan_dpp<0x113, 0xf, 0xf>((uint32_t)x));
+  t = mx(t, scan_dpp<0x114, 0xf, 0xe>((uint32_t)t));
+  t = mx(t, scan_dpp<0x118, 0xf, 0xc>((uint32_t)t));
+  t = mx(t, scan_dpp<0x142, 0xa, 0xf>((uint32_t)t));
+  t = mx(t, scan_dpp<0x143, 0xc, 0xf>((uint32_t)t));
+  return t;
+}
+
 }  // namespace asl

@@ -45,25 +45,7 @@ __device__ __forceinline__ float bucket_floor(int b) {
 
 // exclusive prefix sum of one int per thread over a workgroup of NW waves; `part` = NW LDS
 // ints reserved for this call site. Total in `total`.
-// Inclusive prefix sum over the 64 lanes of a wave in seven DPP adds (row_shr 1 / 2 / 3, row_shr 4
-// and 8 under bank masks, row_bcast 15 and 31 under row masks) -- no LDS crossbar round trips:
-// the ds_bpermute chain this replaces (six dependent __shfl_up) was ~0.3 us of latency per scan,
-// and a top-k finish runs three of them. All 64 lanes must be active.
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ uint32_t scan_dpp(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
-  uint32_t t = x + scan_dpp<0x111, 0xf, 0xf>(x);
-  t += scan_dpp<0x112, 0xf, 0xf>(x);
-  t += scan_dpp<0x113, 0xf, 0xf>(x);
-  t += scan_dpp<0x114, 0xf, 0xe>(t);
-  t += scan_dpp<0x118, 0xf, 0xc>(t);
-  t += scan_dpp<0x142, 0xa, 0xf>(t);
-  t += scan_dpp<0x143, 0xc, 0xf>(t);
-  return t;
-}
-
+// (wave_incl_scan: common.hpp)
 template <int NW>
 __device__ __forceinline__ int block_excl_scan(int v, int *part, int tid, int &total) {
   const int lane = tid & 63, wave = tid >> 6;

@@ -987,12 +987,10 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
       const bool def_bs = okr && (m_cn > 64 || m_chg >= 31);
       const bool def_pair = okr && !def_bs && S > RF_SMAX;
       const int cn_eff = (okr && !def_bs && !def_pair && qn > 0) ? m_cn : 0;
-      int incl = cn_eff;
-#pragma unroll
-      for (int o = 1; o < 32; o <<= 1) {
-        const int v = __shfl_up(incl, o, 32);
-        if (t >= o) incl += v;
-      }
+      // prefix sums over the 32 candidates: both halves of the wave hold the same values, so the
+      // 64-lane DPP scan (common.hpp) is the 32-lane one plus, in the upper half, the total
+      int incl = (int)wave_incl_scan((uint32_t)cn_eff);
+      incl -= hi ? rl_i(incl, 31) : 0;
       // the chunk ends where the owner table is full (the prefix sums ascend)
       const uint32_t fit = (uint32_t)__ballot(okr && incl <= RF_PMAX);
       const int ntake = __popc(fit);          // >= 1: a candidate has <= 64 peaks here
@@ -1000,13 +998,8 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
       const int excl = incl - cn_eff;
       const int P = rl_i(incl, ntake - 1);
       int cmaxw = take ? cn_eff : 0, Smaxw = (take && cn_eff > 0) ? S : 0;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        cmaxw = max(cmaxw, __shfl_xor(cmaxw, o, 32));
-        Smaxw = max(Smaxw, __shfl_xor(Smaxw, o, 32));
-      }
-      cmaxw = rl_i(cmaxw, 0);
-      Smaxw = rl_i(Smaxw, 0);
+      cmaxw = rl_i(wave_max_to_lane63(cmaxw), 63);     // (both >= 0)
+      Smaxw = rl_i(wave_max_to_lane63(Smaxw), 63);
       if (take && hi == 0) {
         Wv.base[t] = m_co;
         Wv.rec[t] = (uint32_t)cn_eff | ((uint32_t)S << 8) | ((uint32_t)m_chg << 16);

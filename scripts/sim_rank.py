@@ -97,3 +97,16 @@ print(f'{index} W={W} batch/rank={batch} variant={variant}: encode (all {W * bat
       f'equals the full merge: {exact}, overflow '
       f'{int(flag.item()) if flag is not None else 0}; the full-row merge it replaces {t_old:.2f}) rescore {t_resc:.2f} '
       f'| compute per step {tot:.2f} ms (collectives excluded)')
+
+# how the final top-k spreads over the shards: per query the largest number of its k best hits
+# that ONE shard holds (what a shard-side k smaller than k would have to cover)
+rows = torch.stack([K[:batch]] + own_rows)                      # [W, batch, k] packed keys
+flip = torch.tensor(-2 ** 63, dtype=torch.int64, device=dev)   # unsigned order as signed order
+allk = (rows ^ flip).permute(1, 0, 2).reshape(batch, -1)
+kth = torch.topk(allk, be.k_scan, dim=1).values[:, -1:]         # the k-th best key of the union
+share = ((rows ^ flip) >= kth.unsqueeze(0)).sum(2)              # [W, batch]
+mx = share.max(0).values.float()
+qs = torch.quantile(mx, torch.tensor([0.5, 0.9, 0.99, 0.999, 1.0], device=dev)).tolist()
+print(f'largest share of a query\'s top {be.k_scan} in one shard: median {qs[0]:.0f}, 90 % {qs[1]:.0f}, 99 % {qs[2]:.0f}, '
+      f'99.9 % {qs[3]:.0f}, max {qs[4]:.0f}; queries with a shard holding more than 512: {(mx > 512).float().mean():.5f}, '
+      f'more than 384: {(mx > 384).float().mean():.5f}, more than 640: {(mx > 640).float().mean():.5f}')
