@@ -115,12 +115,12 @@ struct StageProf {
   int64_t launches = 0;
 };
 static std::map<std::string, StageProf> g_prof;
-static bool g_prof_on = false;
+static int g_prof_on = 0;   // 0 off, 1 every stage, 2 the list scan only (two events per step)
 static int64_t g_scanned = 0;
 static std::vector<std::pair<StageProf *, std::pair<hipEvent_t, hipEvent_t>>> g_open;
 
 ProfScope::ProfScope(const char *stage) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || (g_prof_on == 2 && std::strcmp(stage, "scan") != 0)) return;
   StageProf &sp = g_prof[stage];
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (!sp.pool.empty()) {
@@ -142,7 +142,7 @@ ProfScope::~ProfScope() {
   o.first->launches++;
   if (slot == (int)g_open.size() - 1) g_open.pop_back();
 }
-bool prof_enabled() { return g_prof_on; }
+bool prof_enabled() { return g_prof_on != 0; }
 void prof_add_scanned(int64_t v) {
   if (g_prof_on) g_scanned += v;
 }
@@ -213,7 +213,7 @@ int asl_set_pipeline(int on) {
 }
 
 int asl_profile_enable(int on) {
-  g_prof_on = on != 0;
+  g_prof_on = on == 2 ? 2 : (on != 0);
   return ASL_OK;
 }
 
