@@ -9,6 +9,21 @@ python3 bench.py "$@" > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o x -- python3 bench.py --cpu-seconds 0 "$@" > gpurun_out/$tag/bench_under_rocprof.json 2> /tmp/prof_$tag.err
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/$tag/kernel_stats.csv
+# the default run launches the scan at several sizes (recall sample, cascade tail): the per-dispatch
+# trace grouped by grid size gives the FULL-SIZE launches' average that roofline.avg_launch_ms must match
+t=$(find /tmp/prof_$tag -name "*kernel_trace.csv" | head -1)
+[ -n "$t" ] && python3 - "$t" > gpurun_out/$tag/scan_launches.txt <<'PY'
+import csv, sys, collections
+g = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r['Kernel_Name']
+    if 'pq_scan_v3_kernel' in n or 'flat_inv_scan_kernel' in n:
+        wg = int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1)
+        g[(n.split('(')[0].replace('void asl::', ''), wg)].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
+print('scan-kernel dispatches of the run under rocprofv3 --kernel-trace, by kernel and workgroups (= queries) per launch')
+for (n, wg), v in sorted(g.items()):
+    print(f'{n:45s} queries {wg:6d}  launches {len(v):3d}  avg {sum(v) / len(v):7.3f} ms  min {min(v):7.3f}  max {max(v):7.3f}')
+PY
 bash scripts/pmc.sh $tag/pmc "$@" > /dev/null 2>&1
 cp gpurun_out/$tag/pmc/summary.txt gpurun_out/$tag/pmc_summary.txt
 # HBM-side bytes of the dominant scan kernel per launch (FETCH_SIZE is in KiB; x2 on gfx950 for a
