@@ -1,7 +1,7 @@
 """Measurement helper: the compute one rank of a W-GPU sharded search performs per step,
 emulated on ONE GPU (shard 0 of W, W x batch queries). Collectives are not included.
 
-  python scripts/sim_rank.py W [library_size] [batch] [scan_variant] [ivfpq|ivfflat]
+  python scripts/sim_rank.py W [library_size] [batch] [scan_variant] [ivfpq|ivfflat] [shard_k (timing only)]
 """
 import os
 import sys
@@ -28,6 +28,8 @@ idx.set_scan_variant(variant)
 q_all, _ = synthetic.make_queries(lib, aux, W * batch, seed=42, open_range=500.0, charge=2)
 q = q_all.select(torch.arange(batch, device=dev)).contiguous()
 be = HipShardBackend(sl, 2, 'open')
+if len(sys.argv) > 6:          # what-if: a shard-side k smaller than k (results are NOT exact then: timing only)
+    be.k_scan = int(sys.argv[6])
 allvec = be.encode(q_all)
 cD, cI = be.coarse(allvec)
 # the W shards of the index, side by side on this GPU (copies through a file): the rows every shard
