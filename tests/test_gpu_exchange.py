@@ -55,7 +55,12 @@ def test_keys_split_equals_the_restatement(k, kp):
 @pytest.mark.parametrize('S,k,head_keys,xper,grid', [(8, 1024, 256, 64, None), (4, 256, 40, 256, None),
                                                      (3, 100, 100, 0, None), (8, 512, 16, 512, 40),
                                                      (2, 64, 1, 64, None), (5, 1280, 300, 8, None),
-                                                     (3, 1024, 800, 256, None), (16, 1024, 128, 128, 60)])
+                                                     (3, 1024, 800, 256, None), (16, 1024, 128, 128, 60),
+                                                     # threshold buckets of ~800 / ~340 / ~160 keys: the finish's
+                                                     # serial ranking (more keys than threads) and its parallel
+                                                     # one at several group sizes
+                                                     (8, 512, 64, 512, 5), (8, 1024, 256, 1024, 12),
+                                                     (4, 1024, 512, 1024, 25)])
 def test_two_phase_exchange_is_the_top_k_of_the_union(S, k, head_keys, xper, grid):
     """One owner, S shards, all on one device: split -> merge of the heads -> bounds -> held-back
     keys -> final merge. Every step equals the restatement; the result equals the definition.
