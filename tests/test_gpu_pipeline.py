@@ -110,3 +110,37 @@ def test_callers_may_drop_their_tensors_before_the_batches_finish(world):
     for i, row, score in got:
         assert torch.equal(row.cpu(), want[i][0]) and torch.equal(score.cpu(), want[i][1])
     sl.set_pipeline(False)
+
+
+def test_profile_levels_scope_the_stage_events(world):
+    """asl_profile_enable(1) brackets every stage with HIP events, (2) only the list scan (what
+    bench.py keeps inside its timed region), (0) nothing; the batch results do not depend on it."""
+    import ctypes as C
+    from ann_solo_amd import _lib
+    engines, batches = world
+    sl = engines['ivfpq']
+    sl.set_pipeline(True)
+    L = _lib.lib()
+
+    def launches(name):
+        ms, n = C.c_double(), C.c_int64()
+        L.asl_profile_get(name.encode(), C.byref(ms), C.byref(n))
+        return n.value, ms.value
+    ref = None
+    try:
+        for level, want in ((2, {'scan'}), (1, {'scan', 'encode', 'rescore', 'rescore_matches', 'coarse_select'}),
+                            (0, set())):
+            L.asl_profile_reset()
+            L.asl_profile_enable(level)
+            r = sl._search_batch(batches[0], 2, 'open', device_out=True)
+            sl.synchronize()
+            L.asl_profile_enable(0)
+            for name in ('scan', 'encode', 'rescore', 'rescore_matches', 'coarse_select'):
+                n, ms = launches(name)
+                assert (n > 0) == (name in want), (level, name, n)
+                assert ms > 0 or n == 0
+            assert ref is None or _same(r, ref)
+            ref = r
+    finally:
+        L.asl_profile_enable(0)
+        sl.set_pipeline(False)
