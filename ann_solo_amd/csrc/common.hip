@@ -143,8 +143,9 @@ ProfScope::~ProfScope() {
   if (slot == (int)g_open.size() - 1) g_open.pop_back();
 }
 bool prof_enabled() { return g_prof_on != 0; }
+bool prof_counts() { return g_prof_on == 1; }   // the scanned-vector count costs a kernel per scan: not at level 2
 void prof_add_scanned(int64_t v) {
-  if (g_prof_on) g_scanned += v;
+  if (g_prof_on == 1) g_scanned += v;
 }
 // device-side accumulator of scanned vectors: kernels add to it, nothing waits inside a step
 static unsigned long long *g_scanned_dev = nullptr;

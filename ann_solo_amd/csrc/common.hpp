@@ -169,6 +169,7 @@ struct ProfScope {
 void prof_add_scanned(int64_t vectors);
 unsigned long long *prof_scanned_dev();   // device accumulator (nullptr on allocation failure)
 bool prof_enabled();
+bool prof_counts();
 
 // Device copy of a packed spectra set (pointers are device pointers).
 struct DevPeaks {

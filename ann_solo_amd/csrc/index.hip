@@ -514,45 +514,44 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
       if (!pre_I) {
         ASL_TRY(coarse_search(ix, xq, nq, nprobe));
-      } else {  // search_preassigned: adopt the caller's probe lists (coarse scores are unused)
-        ASL_TRY(ix->coarse_I.reserve((size_t)nq * nprobe));
-        HIP_TRY(hipMemcpyAsync(ix->coarse_I.p, pre_I, (size_t)nq * nprobe * 4, hipMemcpyDeviceToDevice, stream()));
       }
+      // search_preassigned: the caller's probe lists are read where they lie (device memory that
+      // stays valid until the scan has run: the pipeline's per-parity buffers, a caller's tensor on
+      // this stream); the coarse scores are unused
+      const int32_t *cI = pre_I ? pre_I : ix->coarse_I.p;
       ASL_TRY(build_lists(ix));
       // variant 0: dimension-major postings; 1 (or an unsupported shape): dense GEMM + masked top-k
       const bool use_inv = ix->has_inv && ix->scan_variant == 0 && flat_inv_supported(d, k, nprobe);
       if (ix->unordered == 2 && !(use_inv && I64 && k + FLAT_KEYS_SLACK <= TK_MAX_K))
         return fail(ASL_ERR_STATE, "packed-key rows need the postings scan of IVF-Flat (sparse vectors, k <= 1280) and an int64 output");
       if (use_inv) {
+        ASL_TRY(ix->scan_ent.reserve((size_t)nq * 64));
+        ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
+        ASL_TRY(ix->scan_over.reserve(1));
+        ASL_TRY(list_nonzeros(xq, nq, d, d, ix->scan_ent.p, ix->scan_cnt.p, ix->scan_over.p));
         {
-          ProfScope ps("scan");
-          ASL_TRY(ix->scan_ent.reserve((size_t)nq * 64));
-          ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
-          ASL_TRY(ix->scan_over.reserve(1));
-          ASL_TRY(list_nonzeros(xq, nq, d, d, ix->scan_ent.p, ix->scan_cnt.p, ix->scan_over.p));
+          ProfScope ps("scan");     // the scan kernel itself
           const bool fx = ix->inv_layout == 2;
-          ASL_TRY(flat_inv_scan(ix->inv_layout, xq, nq, d, ix->coarse_I.p, nprobe, ix->list_offsets.p,
+          ASL_TRY(flat_inv_scan(ix->inv_layout, xq, nq, d, cI, nprobe, ix->list_offsets.p,
                                 ix->blk_offsets.p, ix->blk_base.p,
                                 fx ? (const void *)ix->inv_tab8.p : (const void *)ix->inv_tab.p,
                                 ix->tab_stride, ix->inv_data.p, ix->ids.p, k, D, I64, I32,
                                 ix->unordered ? ix->unordered : (set_mode ? 1 : 0), ix->scan_ent.p, ix->scan_cnt.p));
         }
-        if (prof_enabled()) {
+        if (prof_counts()) {
           // vectors scored by this launch, summed on the device (nothing waits inside a step)
-    if (unsigned long long *acc = prof_scanned_dev())
-      ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
+          if (unsigned long long *acc = prof_scanned_dev())
+            ASL_TRY(scanned_count(cI, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
         }
         return ASL_OK;
       }
       words = (ix->nlist + 31) / 32;
       ASL_TRY(ix->bitmap.reserve((size_t)nq * words));
-      ASL_TRY(probe_bitmap(ix->coarse_I.p, nq, nprobe, ix->bitmap.p, words));
-      if (n > 0 && prof_enabled()) {
-                // algorithmic work: vectors in probed lists (needs list sizes)
-        ASL_TRY(build_lists(ix));
-// vectors scored by this launch, summed on the device (nothing waits inside a step)
-    if (unsigned long long *acc = prof_scanned_dev())
-      ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
+      ASL_TRY(probe_bitmap(cI, nq, nprobe, ix->bitmap.p, words));
+      if (n > 0 && prof_counts()) {
+        // algorithmic work: vectors in probed lists, summed on the device (nothing waits inside a step)
+        if (unsigned long long *acc = prof_scanned_dev())
+          ASL_TRY(scanned_count(cI, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
       }
     }
     const int64_t ncol = std::max<int64_t>(n, 1);
@@ -574,14 +573,10 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   nprobe = std::max(1, std::min(nprobe, ix->nlist));
   if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
   ASL_TRY(build_lists(ix));
-  if (!pre_D) {
-    ASL_TRY(coarse_search(ix, xq, nq, nprobe));
-  } else {  // search_preassigned: adopt the caller's probe lists
-    ASL_TRY(ix->coarse_D.reserve((size_t)nq * nprobe));
-    ASL_TRY(ix->coarse_I.reserve((size_t)nq * nprobe));
-    HIP_TRY(hipMemcpyAsync(ix->coarse_D.p, pre_D, (size_t)nq * nprobe * 4, hipMemcpyDeviceToDevice, stream()));
-    HIP_TRY(hipMemcpyAsync(ix->coarse_I.p, pre_I, (size_t)nq * nprobe * 4, hipMemcpyDeviceToDevice, stream()));
-  }
+  if (!pre_D) ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+  // search_preassigned: the caller's probe lists, read where they lie (see the IVF-Flat branch)
+  const float *cD = pre_D ? pre_D : ix->coarse_D.p;
+  const int32_t *cI = pre_D ? pre_I : ix->coarse_I.p;
   // exact re-rank: the ADC scan returns k' > k candidates as a set, refine.hip keeps the k best
   const bool refine = ix->refine_k > k && ix->refine_rows && ix->unordered == 0;
   float *fin_D = D;
@@ -603,7 +598,6 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
     set_mode = true;
   }
   {
-    ProfScope ps("scan");
     const bool tiled = ix->has_tiles && ix->scan_variant == 0 &&
                        pq_scan_tiled_supported(ix->pq_m, ix->ksub, k, nprobe);
     if (ix->unordered == 2 && !(tiled && I64))
@@ -629,20 +623,22 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
       ASL_TRY(ix->scan_over.reserve(1));
       ASL_TRY(list_nonzeros(xq, nq, d, d, ix->scan_ent.p, ix->scan_cnt.p, ix->scan_over.p));
-      ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks_t.p, ix->dsub, ix->coarse_D.p, ix->coarse_I.p,
+      ProfScope ps("scan");     // the scan kernel itself
+      ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks_t.p, ix->dsub, cD, cI,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
                          ix->ids_tiled.p, k, D, I64, I32, ix->unordered ? ix->unordered : (set_mode ? 1 : 0),
                          ix->scan_ent.p, ix->scan_cnt.p));
-    }
-    else
-      ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, ix->coarse_D.p,
-                      ix->coarse_I.p, nprobe, ix->list_offsets.p, ix->ids.p, ix->codes.p, k, D,
+    } else {
+      ProfScope ps("scan");
+      ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, cD,
+                      cI, nprobe, ix->list_offsets.p, ix->ids.p, ix->codes.p, k, D,
                       I64, I32));
+    }
   }
-  if (prof_enabled()) {
+  if (prof_counts()) {
     // vectors scored by this launch, summed on the device (nothing waits inside a step)
     if (unsigned long long *acc = prof_scanned_dev())
-      ASL_TRY(scanned_count(ix->coarse_I.p, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
+      ASL_TRY(scanned_count(cI, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
   }
   if (refine) {
     ProfScope ps("refine");

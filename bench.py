@@ -331,13 +331,14 @@ def main():
     ms, n = C.c_double(), C.c_int64()
     L.asl_profile_get(b'scan', C.byref(ms), C.byref(n))
     scan_timed = {'ms_total': ms.value, 'launches': n.value}
-    scanned = L.asl_profile_scanned_vectors()
-    # second pass, every stage bracketed (not part of `value`)
+    # second pass over the same batches, every stage bracketed and the scanned vectors counted on
+    # the device (not part of `value`; the count is a property of the batch, the same in both passes)
     L.asl_profile_reset()
     L.asl_profile_enable(1)
     timed(step, args.steps)
     sl.synchronize()
     L.asl_profile_enable(0)
+    scanned = L.asl_profile_scanned_vectors()
     sl.set_pipeline(False)
 
     stages = {}

@@ -404,7 +404,8 @@ int asl_window_candidates(asl_library_t *lib, int32_t nq, const double *query_pm
  * "coarse_select","scan","filter","rescore","rescore_matches".
  * on = 1: every stage (two events around each: ~16 per batch, which keep the stages of a
  * pipelined batch from being dispatched back to back -- measured 0.3 ms of a 7.9 ms step);
- * on = 2: the list scan only (the dominant kernel, two events per batch); 0: off. */
+ * on = 2: the list scan kernel only (the dominant kernel, two events per batch; the
+ * scanned-vector counter, which costs a small kernel per scan, is not fed either); 0: off. */
 int asl_profile_enable(int on);
 int asl_profile_reset(void);
 /* Accumulated milliseconds and launch count for a stage since the last reset. */
