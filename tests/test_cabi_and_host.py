@@ -279,3 +279,18 @@ def test_ssm_table_columnar_bookkeeping():
     ids = both.library_identifiers({2: SimpleNamespace(ids=np.arange(200, 205)),
                                     3: SimpleNamespace(ids=np.arange(300, 305))})
     assert ids.tolist() == [204, 200, 303, 202]
+
+
+def test_measurement_scripts_and_bench_compile():
+    """bench.py, __graft_entry__.py and every helper under scripts/ are at least valid Python (they
+    only run on a GPU box), and the shell helpers parse."""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, 'bench.py'), os.path.join(root, '__graft_entry__.py')] + \
+        sorted(glob.glob(os.path.join(root, 'scripts', '*.py')))
+    assert len(files) > 10
+    for f in files:
+        compile(open(f).read(), f, 'exec')
+    for f in sorted(glob.glob(os.path.join(root, 'scripts', '*.sh'))):
+        assert subprocess.run(['bash', '-n', f]).returncode == 0, f
