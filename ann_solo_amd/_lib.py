@@ -170,8 +170,8 @@ def lib():
         L.asl_index_get_flat_storage.argtypes = [C.c_void_p]
         L.asl_keys_split.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.asl_keys_merge_heads.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 4
-        L.asl_keys_extras.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
-                                      C.c_void_p, C.c_void_p]
+        L.asl_keys_extras.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_void_p, C.c_void_p]
         L.asl_keys_merge_final.argtypes = [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                                              C.c_void_p, C.c_void_p, C.c_void_p]
         L.asl_index_postings_work.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, c_i64p, c_i64p]

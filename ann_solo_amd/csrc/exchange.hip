@@ -32,9 +32,13 @@ constexpr u64 XK_NONE = ~0ull;      // bound meaning "send nothing"
 
 // ---- phase 1: head of a row ---------------------------------------------------------------
 // K [nrows, k] (0 = empty, any order) -> head [nrows, kp]: slots 0 .. kp-2 the kept keys (0
-// padded), slot kp-1 = T; rest [nrows, k]: the keys held back, compacted, 0 padded.
+// padded), slot kp-1 = T (the best key held back); floor_out [nrows]: the row's bucket floor.
 // The kept set = all keys whose score bucket (hist_topk.hpp: 512 buckets over [-0.25, 1)) is at
-// or above the lowest bucket floor that admits at most kp - 1 keys.
+// or above the lowest bucket floor that admits at most kp - 1 keys. The held-back keys are not
+// copied anywhere: they are the keys of K below the floor, and phase 2 (keys_extras_kernel) reads
+// them from K itself -- only for the rows an owner asks about. (Until the second half of round 4
+// the split also wrote them out as a second [nrows, k] array: the kernel is HBM-bound, and that
+// was 1.07 of its 2.4 GB per 131 072 rows.)
 // One WAVE per row, no barrier: PER keys per lane in registers, a 512-bucket histogram of the
 // wave in LDS (ds_add), cumulative counts from the top by a DPP scan of eight buckets per lane,
 // ballots for the compaction. (The first version -- a 256-thread workgroup per row with three
@@ -58,7 +62,7 @@ constexpr int XS_WAVES = 4;
 template <int PER>
 __global__ __launch_bounds__(64 * XS_WAVES) void keys_split_kernel(const u64 *__restrict__ K, int64_t nrows,
                                                                    int k, int kp, u64 *__restrict__ head,
-                                                                   u64 *__restrict__ rest) {
+                                                                   int32_t *__restrict__ floor_out) {
   __shared__ int s_hist[XS_WAVES][HT_NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * XS_WAVES + wave;
@@ -98,22 +102,17 @@ __global__ __launch_bounds__(64 * XS_WAVES) void keys_split_kernel(const u64 *__
     const int last = 63 - __builtin_clzll(okm);      // ok lanes form a prefix 0 .. last
     floor_b = __builtin_amdgcn_readlane(fl, last);
   }
-  int na = 0, nr = 0;
+  int na = 0;
   u64 best = 0ull;
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const bool valid = kk[u] != 0ull;
     const bool a = valid && score_bucket(key_score(kk[u])) >= floor_b;
-    const bool r = valid && !a;
-    const unsigned long long ma = __ballot(a), mr = __ballot(r);
+    const unsigned long long ma = __ballot(a);
     if (a) head[row * kp + na + __popcll(ma & below)] = kk[u];
-    if (r) {
-      rest[row * k + nr + __popcll(mr & below)] = kk[u];
-      best = kk[u] > best ? kk[u] : best;
-    }
+    if (valid && !a) best = kk[u] > best ? kk[u] : best;
     na += __popcll(ma);
-    nr += __popcll(mr);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -121,8 +120,10 @@ __global__ __launch_bounds__(64 * XS_WAVES) void keys_split_kernel(const u64 *__
     best = o > best ? o : best;
   }
   for (int i = na + lane; i < kp - 1; i += 64) head[row * kp + i] = 0ull;
-  for (int i = nr + lane; i < k; i += 64) rest[row * k + i] = 0ull;
-  if (lane == 0) head[row * kp + kp - 1] = best;
+  if (lane == 0) {
+    head[row * kp + kp - 1] = best;
+    floor_out[row] = floor_b;
+  }
 }
 
 // ---- owner: merge of the heads (+ phase-2 answers) ------------------------------------------
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(HT_NT) void keys_merge_kernel(
 // rows are destination-major: row = dst * nq + q. xbuf [W, nq + xcap]: per destination nq
 // header words (count << 32 | start) followed by xcap payload slots; cursor [W] (zeroed by the
 // caller) hands out the payload; *overflow is raised when a destination's payload is full.
-__global__ __launch_bounds__(256) void keys_extras_kernel(const u64 *__restrict__ rest, int k,
+__global__ __launch_bounds__(256) void keys_extras_kernel(const u64 *__restrict__ K, int k,
+                                                          const int32_t *__restrict__ floor_in,
                                                           const u64 *__restrict__ bounds, int nq,
                                                           long long xcap, u64 *__restrict__ xbuf,
                                                           unsigned int *__restrict__ cursor,
@@ -277,13 +279,15 @@ __global__ __launch_bounds__(256) void keys_extras_kernel(const u64 *__restrict_
     return;
   }
   constexpr int PER = 8;
+  const int floor_b = floor_in[row];
   u64 kk[PER];
   int c = 0;
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const int i = tid + u * 256;
-    kk[u] = i < k ? rest[row * k + i] : 0ull;
-    if (kk[u] <= B) kk[u] = 0ull;
+    kk[u] = i < k ? K[row * k + i] : 0ull;
+    // held back = below the row's bucket floor (the split's own test); wanted = above the bound
+    if (kk[u] <= B || score_bucket(key_score(kk[u])) >= floor_b) kk[u] = 0ull;
     c += kk[u] != 0ull;
   }
   int tot;
@@ -305,15 +309,15 @@ __global__ __launch_bounds__(256) void keys_extras_kernel(const u64 *__restrict_
     if (kk[u]) pay[st + pos++] = kk[u];
 }
 
-int keys_split(const u64 *K, int64_t nrows, int k, int kp, u64 *head, u64 *rest) {
+int keys_split(const u64 *K, int64_t nrows, int k, int kp, u64 *head, int32_t *floor_out) {
   if (nrows <= 0) return ASL_OK;
   const dim3 grid((unsigned)cdiv(nrows, XS_WAVES)), block(64 * XS_WAVES);
   if (k <= 256)
-    hipLaunchKernelGGL(keys_split_kernel<4>, grid, block, 0, stream(), K, nrows, k, kp, head, rest);
+    hipLaunchKernelGGL(keys_split_kernel<4>, grid, block, 0, stream(), K, nrows, k, kp, head, floor_out);
   else if (k <= 1024)
-    hipLaunchKernelGGL(keys_split_kernel<16>, grid, block, 0, stream(), K, nrows, k, kp, head, rest);
+    hipLaunchKernelGGL(keys_split_kernel<16>, grid, block, 0, stream(), K, nrows, k, kp, head, floor_out);
   else
-    hipLaunchKernelGGL(keys_split_kernel<32>, grid, block, 0, stream(), K, nrows, k, kp, head, rest);
+    hipLaunchKernelGGL(keys_split_kernel<32>, grid, block, 0, stream(), K, nrows, k, kp, head, floor_out);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -329,10 +333,10 @@ int keys_merge(const u64 *heads, int S, int nq, int kp, int k, const u64 *xbuf, 
   return ASL_OK;
 }
 
-int keys_extras(const u64 *rest, int64_t nrows, int k, const u64 *bounds, int nq, long long xcap,
-                u64 *xbuf, unsigned int *cursor, int32_t *overflow) {
+int keys_extras(const u64 *K, const int32_t *floor_in, int64_t nrows, int k, const u64 *bounds, int nq,
+                long long xcap, u64 *xbuf, unsigned int *cursor, int32_t *overflow) {
   if (nrows <= 0) return ASL_OK;
-  hipLaunchKernelGGL(keys_extras_kernel, dim3((unsigned)nrows), dim3(256), 0, stream(), rest, k, bounds,
+  hipLaunchKernelGGL(keys_extras_kernel, dim3((unsigned)nrows), dim3(256), 0, stream(), K, k, floor_in, bounds,
                      nq, xcap, xbuf, cursor, overflow);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
@@ -345,13 +349,12 @@ using namespace asl;
 extern "C" {
 
 // see include/annsolo_mi.h
-int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, const int64_t *K, int64_t *head, int64_t *rest) {
+int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, const int64_t *K, int64_t *head, int32_t *floor_out) {
   clear_error();
-  if (nrows < 0 || k < 1 || k > 2048 || kp < 2 || kp > k + 1 || !K || !head || !rest)
+  if (nrows < 0 || k < 1 || k > 2048 || kp < 2 || kp > k + 1 || !K || !head || !floor_out)
     return fail(ASL_ERR_INVALID, "keys_split: need 1 <= k <= 2048, 2 <= kp <= k + 1 and non-null device arrays");
   ASL_TRY(ensure_device());
-  return keys_split(reinterpret_cast<const u64 *>(K), nrows, k, kp, reinterpret_cast<u64 *>(head),
-                    reinterpret_cast<u64 *>(rest));
+  return keys_split(reinterpret_cast<const u64 *>(K), nrows, k, kp, reinterpret_cast<u64 *>(head), floor_out);
 }
 
 int asl_keys_merge_heads(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
@@ -364,16 +367,17 @@ int asl_keys_merge_heads(int32_t S, int32_t nq, int32_t kp, int32_t k, const int
                     reinterpret_cast<u64 *>(out_keys), reinterpret_cast<u64 *>(bounds), nullptr, nullptr, 0);
 }
 
-int asl_keys_extras(int32_t W, int32_t nq, int32_t k, const int64_t *rest, const int64_t *bounds,
-                    int64_t xcap, int64_t *xbuf, int32_t *overflow) {
+int asl_keys_extras(int32_t W, int32_t nq, int32_t k, const int64_t *K, const int32_t *floor_in,
+                    const int64_t *bounds, int64_t xcap, int64_t *xbuf, int32_t *overflow) {
   clear_error();
-  if (W < 1 || nq < 0 || k < 1 || k > 2048 || xcap < 0 || xcap >= 0xFFFFFFFFLL || !rest || !bounds || !xbuf || !overflow)
+  if (W < 1 || nq < 0 || k < 1 || k > 2048 || xcap < 0 || xcap >= 0xFFFFFFFFLL || !K || !floor_in || !bounds || !xbuf ||
+      !overflow)
     return fail(ASL_ERR_INVALID, "keys_extras: bad argument");
   ASL_TRY(ensure_device());
   DevBuf<unsigned int> cursor;
   ASL_TRY(cursor.reserve((size_t)W));
   HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)W * sizeof(unsigned int), stream()));
-  ASL_TRY(keys_extras(reinterpret_cast<const u64 *>(rest), (int64_t)W * nq, k,
+  ASL_TRY(keys_extras(reinterpret_cast<const u64 *>(K), floor_in, (int64_t)W * nq, k,
                       reinterpret_cast<const u64 *>(bounds), nq, xcap, reinterpret_cast<u64 *>(xbuf), cursor.p,
                       overflow));
   return sync_stream();       // the cursor is a temporary of this call

@@ -98,12 +98,13 @@ __host__ __device__ inline bool fx22_on_grid(float x) {
 int quantize_fx22(float *x, int64_t n);
 // the two-phase exact exchange of a sharded search (exchange.hip)
 int keys_split(const unsigned long long *K, int64_t nrows, int k, int kp, unsigned long long *head,
-               unsigned long long *rest);
+               int32_t *floor_out);
 int keys_merge(const unsigned long long *heads, int S, int nq, int kp, int k, const unsigned long long *xbuf,
                long long xcap, const unsigned long long *prev_keys, int32_t *need,
                unsigned long long *out_keys, unsigned long long *bounds, int64_t *I, float *D, int sorted);
-int keys_extras(const unsigned long long *rest, int64_t nrows, int k, const unsigned long long *bounds, int nq,
-                long long xcap, unsigned long long *xbuf, unsigned int *cursor, int32_t *overflow);
+int keys_extras(const unsigned long long *K, const int32_t *floor_in, int64_t nrows, int k,
+                const unsigned long long *bounds, int nq, long long xcap, unsigned long long *xbuf,
+                unsigned int *cursor, int32_t *overflow);
 int flat_fx_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                  const int32_t *blk_offsets, const uint8_t *tab8, int tab_stride,
                  const uint16_t *cnt16, unsigned long long *out_dev);

@@ -145,9 +145,9 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
   if (!refine && asl_index_supports_keys(ix, k, np)) {
     typedef unsigned long long u64k;
     static DevBuf<int64_t> &Kp = *new DevBuf<int64_t>(), &Hs = *new DevBuf<int64_t>(), &Hr = *new DevBuf<int64_t>(),
-                           &Rs = *new DevBuf<int64_t>(), &Ko = *new DevBuf<int64_t>(), &Bs = *new DevBuf<int64_t>(),
+                           &Ko = *new DevBuf<int64_t>(), &Bs = *new DevBuf<int64_t>(),
                            &Br = *new DevBuf<int64_t>(), &Xs = *new DevBuf<int64_t>(), &Xr = *new DevBuf<int64_t>();
-    static DevBuf<int32_t> &need = *new DevBuf<int32_t>(), &flag = *new DevBuf<int32_t>();
+    static DevBuf<int32_t> &need = *new DevBuf<int32_t>(), &flag = *new DevBuf<int32_t>(), &Fl = *new DevBuf<int32_t>();
     static DevBuf<unsigned int> &cursor = *new DevBuf<unsigned int>();
     const int keys = std::min(k, (2 * k + world - 1) / world), kp = keys + 1;
     const bool second = kp - 1 < k;
@@ -155,7 +155,7 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
     ASL_TRY(Kp.reserve(all * k));
     ASL_TRY(Hs.reserve(all * kp));
     ASL_TRY(Hr.reserve(all * kp));
-    ASL_TRY(Rs.reserve(all * k));
+    ASL_TRY(Fl.reserve(all));
     ASL_TRY(Ko.reserve((size_t)nq * k));
     ASL_TRY(Bs.reserve(all));
     ASL_TRY(Br.reserve(all));
@@ -167,7 +167,7 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
     ASL_TRY(index_swap_unordered(ix, prev, nullptr));
     ASL_TRY(rc);
     ASL_TRY(keys_split(reinterpret_cast<const u64k *>(Kp.p), (int64_t)all, k, kp, reinterpret_cast<u64k *>(Hs.p),
-                       reinterpret_cast<u64k *>(Rs.p)));
+                       Fl.p));
     auto all_to_all = [&](const int64_t *src, int64_t *dst, size_t per_rank) -> int {
       RCCL_TRY(R.GroupStart());
       for (int r = 0; r < world; ++r) {
@@ -189,7 +189,7 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
       ASL_TRY(all_to_all(Bs.p, Br.p, (size_t)nq));
       HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)world * sizeof(unsigned int), st));
       HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int32_t), st));
-      ASL_TRY(keys_extras(reinterpret_cast<const u64k *>(Rs.p), (int64_t)all, k, reinterpret_cast<const u64k *>(Br.p),
+      ASL_TRY(keys_extras(reinterpret_cast<const u64k *>(Kp.p), Fl.p, (int64_t)all, k, reinterpret_cast<const u64k *>(Br.p),
                           nq, xcap, reinterpret_cast<u64k *>(Xs.p), cursor.p, flag.p));
       ASL_TRY(all_to_all(Xs.p, Xr.p, (size_t)nq + (size_t)xcap));
       // a full phase-2 buffer ANYWHERE sends every rank down the full exchange: the flags are

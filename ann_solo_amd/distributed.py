@@ -156,11 +156,13 @@ class HipShardBackend:
 
     # ---- the two-phase exchange (csrc/exchange.hip); every tensor lives on the device
     def keys_split(self, K: torch.Tensor, kp: int):
+        """-> head [rows, kp] and the rows' bucket floors [rows]: the keys held back are the keys of
+        ``K`` below its row's floor -- ``keys_extras`` reads them from ``K`` itself."""
         rows, k = K.shape
         head = torch.empty((rows, kp), dtype=torch.int64, device=K.device)
-        rest = torch.empty((rows, k), dtype=torch.int64, device=K.device)
-        _lib.check(_lib.lib().asl_keys_split(rows, k, kp, _lib.ptr(K), _lib.ptr(head), _lib.ptr(rest)))
-        return head, rest
+        floor = torch.empty((rows,), dtype=torch.int32, device=K.device)
+        _lib.check(_lib.lib().asl_keys_split(rows, k, kp, _lib.ptr(K), _lib.ptr(head), _lib.ptr(floor)))
+        return head, floor
 
     def keys_merge_heads(self, heads: torch.Tensor, k: int):
         S, n, kp = heads.shape
@@ -172,13 +174,13 @@ class HipShardBackend:
                                                    _lib.ptr(bounds), _lib.ptr(need)))
         return out, bounds, need
 
-    def keys_extras(self, rest: torch.Tensor, bounds: torch.Tensor, world: int, xcap: int,
+    def keys_extras(self, K: torch.Tensor, floor: torch.Tensor, bounds: torch.Tensor, world: int, xcap: int,
                     overflow: torch.Tensor):
-        rows, k = rest.shape
+        rows, k = K.shape
         n = rows // world
-        xbuf = torch.empty((world, n + xcap), dtype=torch.int64, device=rest.device)
-        _lib.check(_lib.lib().asl_keys_extras(world, n, k, _lib.ptr(rest), _lib.ptr(bounds), int(xcap),
-                                              _lib.ptr(xbuf), _lib.ptr(overflow)))
+        xbuf = torch.empty((world, n + xcap), dtype=torch.int64, device=K.device)
+        _lib.check(_lib.lib().asl_keys_extras(world, n, k, _lib.ptr(K), _lib.ptr(floor), _lib.ptr(bounds),
+                                              int(xcap), _lib.ptr(xbuf), _lib.ptr(overflow)))
         return xbuf
 
     def keys_merge_final(self, heads: torch.Tensor, xbuf: Optional[torch.Tensor], out_keys, need, k: int):
@@ -567,7 +569,8 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
                         st['x'] = exchange_partials(out[0], out[1], world, group, async_op=True)
                     st['stage'] = 10
                     return False
-                head, st['rest'] = backend.keys_split(out, kp)
+                head, floor = backend.keys_split(out, kp)
+                st['rest'] = (out, floor)          # the held-back keys stay in the scan's rows
                 st['x'] = _all_to_all(head, world, group, comm, 'heads_all_to_all')
                 st['stage'] = 1
                 return False
@@ -594,8 +597,8 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
             if st['stage'] == 2:              # the owners' bounds are here: what was held back above them
                 wait(st['x'][1])
                 xcap = n * (extras_per_query if extras_per_query is not None else max(8, k_scan // 16))
-                xbuf = backend.keys_extras(st['rest'], st['x'][0].reshape(world * n).contiguous(), world,
-                                           xcap, flag)
+                xbuf = backend.keys_extras(st['rest'][0], st['rest'][1],
+                                           st['x'][0].reshape(world * n).contiguous(), world, xcap, flag)
                 st['rest'] = None
                 st['x'] = _all_to_all(xbuf.reshape(world * (n + xcap)), world, group, comm,
                                       'held_back_keys_all_to_all')

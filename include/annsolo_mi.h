@@ -200,22 +200,23 @@ int asl_index_supports_keys(const asl_index_t *idx, int32_t k, int32_t nprobe);
  * of packed keys as asl_index_set_unordered mode 2 emits them (0 = empty, any order).
  *   asl_keys_split: K [nrows, k] -> head [nrows, kp] (slots 0 .. kp-2: the row's best keys, all
  *     those at or above a score-bucket floor that admits at most kp - 1; slot kp-1: T, the best
- *     key held back, 0 if none) and rest [nrows, k] (the keys held back, 0 padded).
+ *     key held back, 0 if none) and floor [nrows] (that bucket floor: the keys held back are the
+ *     keys of K below it, which stay where they are).
  *   asl_keys_merge_heads: heads [S, nq, kp] of the S shards -> out_keys [nq, k] (the best k keys
  *     seen, a set), bounds [S, nq] (B = the k-th best key seen if shard s must send what it holds
  *     above B -- its T beats B --, else ~0: send nothing), need [nq] (some shard was asked).
- *   asl_keys_extras: on the shard, rows destination-major (row = dst * nq + q): rest [W * nq, k],
- *     bounds [W * nq] -> xbuf [W, nq + xcap]: per destination nq header words (count << 32 |
+ *   asl_keys_extras: on the shard, rows destination-major (row = dst * nq + q): K [W * nq, k] and
+ *     floor [W * nq] as asl_keys_split saw / wrote them, bounds [W * nq] -> xbuf [W, nq + xcap]: per destination nq header words (count << 32 |
  *     start) then the payload; *overflow = 1 when a destination's xcap slots do not suffice (the
  *     caller must then repeat the batch with the full exchange). *overflow is never cleared here.
  *   asl_keys_merge_final: heads + the xbuf [S, nq + xcap] received (NULL: none) + out_keys/need of
  *     asl_keys_merge_heads -> I [nq, k] ids (a set, -1 padded) and D (may be NULL): the exact
  *     top-k of the union of the shards' rows. k <= 1280. */
-int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, const int64_t *K, int64_t *head, int64_t *rest);
+int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, const int64_t *K, int64_t *head, int32_t *floor);
 int asl_keys_merge_heads(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
                          int64_t *out_keys, int64_t *bounds, int32_t *need);
-int asl_keys_extras(int32_t W, int32_t nq, int32_t k, const int64_t *rest, const int64_t *bounds,
-                    int64_t xcap, int64_t *xbuf, int32_t *overflow);
+int asl_keys_extras(int32_t W, int32_t nq, int32_t k, const int64_t *K, const int32_t *floor,
+                    const int64_t *bounds, int64_t xcap, int64_t *xbuf, int32_t *overflow);
 int asl_keys_merge_final(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
                          const int64_t *xbuf, int64_t xcap, const int64_t *prev_keys, const int32_t *need,
                          float *D, int64_t *I);

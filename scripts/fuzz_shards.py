@@ -72,7 +72,7 @@ while time.time() < t_end:
             if kp - 1 < k:
                 flag = torch.zeros(1, dtype=torch.int32, device=dev)
                 xcap = nq * int(rng.choice([k, max(8, k // 16)]))
-                xb = torch.stack([be.keys_extras(split[r][1], bnd[r].contiguous(), 1, xcap, flag)[0]
+                xb = torch.stack([be.keys_extras(keys[r], split[r][1], bnd[r].contiguous(), 1, xcap, flag)[0]
                                   for r in range(W)])
                 If = None if int(flag.item()) else be.keys_merge_final(heads, xb, okeys, need, k)
             else:

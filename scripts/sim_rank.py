@@ -67,10 +67,11 @@ from ann_solo_amd.distributed import head_width
 # every "shard" -- the same work), the held-back keys above the bounds, the final merge
 t_scan, K = timed(lambda: be.shard_search_keys(allvec, cD, cI))
 kp = head_width(be.k_scan, W)
-t_split, (head, rest) = timed(lambda: be.keys_split(K, kp))
+t_split, (head, floor) = timed(lambda: be.keys_split(K, kp))
 # what this rank receives: the heads of its own queries' rows from every shard
 heads = torch.stack([head[:batch]] + [be.keys_split(r_, kp)[0] for r_ in own_rows]).contiguous()
-rests = [rest[:batch]] + [be.keys_split(r_, kp)[1] for r_ in own_rows]
+rows_own = [K[:batch].contiguous()] + own_rows          # every shard's rows for this rank's own queries ...
+floors = [floor[:batch].contiguous()] + [be.keys_split(r_, kp)[1] for r_ in own_rows]     # ... and their floors
 t_m1, (okeys, bnd, need) = timed(lambda: be.keys_merge_heads(heads, be.k_scan))
 t_x = t_m2 = 0.0
 if kp - 1 < be.k_scan:
@@ -78,8 +79,8 @@ if kp - 1 < be.k_scan:
     xcap = batch * max(8, be.k_scan // 16)
     # shard side: this rank answers W x batch rows (timed on its own rows against the bounds its
     # own queries got -- the same amount of work); owner side: the real answers of the W shards
-    t_x, _ = timed(lambda: be.keys_extras(rest, bnd.reshape(-1).contiguous(), W, xcap, be.new_flag()))
-    xbuf = torch.stack([be.keys_extras(rests[s_].contiguous(), bnd[s_].contiguous(), 1, xcap, flag)[0]
+    t_x, _ = timed(lambda: be.keys_extras(K, floor, bnd.reshape(-1).contiguous(), W, xcap, be.new_flag()))
+    xbuf = torch.stack([be.keys_extras(rows_own[s_], floors[s_], bnd[s_].contiguous(), 1, xcap, flag)[0]
                         for s_ in range(W)])
     t_m2, knn = timed(lambda: be.keys_merge_final(heads, xbuf, okeys, need, be.k_scan))
     want = be.merge_keys(torch.stack([K[:batch]] + own_rows).contiguous())[1]

@@ -47,13 +47,13 @@ def score_bucket(s):
 
 
 def keys_split(K, kp):
-    """K [rows, k] -> head [rows, kp] (kept keys, then 0; last slot = best held-back key), rest
-    [rows, k] (held-back keys, then 0). Kept = every key whose bucket is at or above the lowest
-    bucket floor that admits at most kp - 1 keys."""
+    """K [rows, k] -> head [rows, kp] (kept keys, then 0; last slot = best held-back key), floor
+    [rows] (int32). Kept = every key whose bucket is at or above the lowest bucket floor that admits
+    at most kp - 1 keys; the held-back keys are the keys of K below the floor (``held_back``)."""
     K = np.asarray(K).view(np.uint64)
     rows, k = K.shape
     head = np.zeros((rows, kp), np.uint64)
-    rest = np.zeros((rows, k), np.uint64)
+    floors = np.zeros(rows, np.int32)
     for r in range(rows):
         keys = K[r][K[r] != 0]
         b = score_bucket(key_score(keys))
@@ -63,8 +63,20 @@ def keys_split(K, kp):
         a, h = keys[b >= floor], keys[b < floor]
         head[r, :len(a)] = a
         head[r, kp - 1] = h.max() if len(h) else 0
+        floors[r] = floor
+    return head.view(np.int64), floors
+
+
+def held_back(K, floors):
+    """The keys of every row of K below the row's bucket floor, compacted and 0 padded [rows, k]
+    (what the split holds back; test helper)."""
+    K = np.asarray(K).view(np.uint64)
+    rest = np.zeros_like(K)
+    for r in range(len(K)):
+        keys = K[r][K[r] != 0]
+        h = keys[score_bucket(key_score(keys)) < floors[r]]
         rest[r, :len(h)] = h
-    return head.view(np.int64), rest.view(np.int64)
+    return rest.view(np.int64)
 
 
 def _topk_set(cands, k):
@@ -90,12 +102,12 @@ def keys_merge_heads(heads, k):
     return out.view(np.int64), bounds.view(np.int64), need
 
 
-def keys_extras(rest, bounds, world, xcap):
-    """rest [world * n, k] (destination-major rows), bounds [world * n] -> xbuf [world, n + xcap]
+def keys_extras(K, floors, bounds, world, xcap):
+    """K [world * n, k] (destination-major rows) and the floors of ``keys_split``, bounds [world * n] -> xbuf [world, n + xcap]
     (n header words count << 32 | start, then the payload) and the overflow flag. Payload order
     inside a destination is the row order here (the device's is whatever its atomics gave: the
     headers say where each row's keys are)."""
-    rest = np.asarray(rest).view(np.uint64)
+    rest = held_back(K, floors).view(np.uint64)
     bounds = np.asarray(bounds).view(np.uint64)
     rows, k = rest.shape
     n = rows // world

@@ -70,15 +70,15 @@ class OracleShardBackend:
         return None, torch.from_numpy(I)
 
     def keys_split(self, K, kp):
-        head, rest = X.keys_split(K.numpy(), kp)
-        return torch.from_numpy(head), torch.from_numpy(rest)
+        head, floors = X.keys_split(K.numpy(), kp)
+        return torch.from_numpy(head), torch.from_numpy(floors)
 
     def keys_merge_heads(self, heads, k):
         out, bounds, need = X.keys_merge_heads(heads.numpy(), k)
         return torch.from_numpy(out), torch.from_numpy(bounds), torch.from_numpy(need)
 
-    def keys_extras(self, rest, bounds, world, xcap, overflow):
-        xbuf, ov = X.keys_extras(rest.numpy(), bounds.numpy(), world, xcap)
+    def keys_extras(self, K, floors, bounds, world, xcap, overflow):
+        xbuf, ov = X.keys_extras(K.numpy(), floors.numpy(), bounds.numpy(), world, xcap)
         overflow[0] = max(int(overflow[0]), ov)
         return torch.from_numpy(xbuf)
 

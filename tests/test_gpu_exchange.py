@@ -38,15 +38,16 @@ def test_keys_split_equals_the_restatement(k, kp):
     rng = np.random.default_rng(k + kp)
     K = np.concatenate([_rows(rng, 40, k, fill=0.5), _rows(rng, 24, k, grid=50),
                         np.zeros((2, k), np.int64)])
-    head, rest = be.keys_split(torch.from_numpy(K).cuda(), kp)
-    head, rest = head.cpu().numpy(), rest.cpu().numpy()
-    h0, r0 = X.keys_split(K, kp)
+    head, floors = be.keys_split(torch.from_numpy(K).cuda(), kp)
+    head, floors = head.cpu().numpy(), floors.cpu().numpy()
+    h0, f0 = X.keys_split(K, kp)
     assert np.array_equal(head[:, kp - 1], h0[:, kp - 1])                     # best held-back key
-    assert _sets(head[:, :kp - 1]) == _sets(h0[:, :kp - 1]) and _sets(rest) == _sets(r0)
+    assert np.array_equal(floors, f0)                                         # the bucket floor of every row
+    assert _sets(head[:, :kp - 1]) == _sets(h0[:, :kp - 1])
+    rest = X.held_back(K, floors)                                             # what stays behind in K
     for r in range(len(K)):                                                   # zero padding is at the end
-        for row in (head[r, :kp - 1], rest[r]):
-            nz = np.nonzero(row)[0]
-            assert len(nz) == 0 or nz[-1] == len(nz) - 1
+        nz = np.nonzero(head[r, :kp - 1])[0]
+        assert len(nz) == 0 or nz[-1] == len(nz) - 1
         a, h = _sets(head[r:r + 1, :kp - 1])[0], _sets(rest[r:r + 1])[0]
         assert not h or not a or max(h) < min(a)                              # kept keys beat held-back ones
         assert len(a) <= kp - 1 and a | h == _sets(K[r:r + 1])[0]
@@ -74,11 +75,11 @@ def test_two_phase_exchange_is_the_top_k_of_the_union(S, k, head_keys, xper, gri
     # some shards hold far more than their share of a query's best hits
     rows = [_rows(rng, n, k, fill=0.7, hi=0.5 + 0.45 * rng.random(), grid=grid, id_base=s << 20) for s in range(S)]
     kp = head_width(k, S, head_keys)
-    heads, rests = [], []
+    heads, floors = [], []
     for s in range(S):
         h, r = be.keys_split(torch.from_numpy(rows[s]).cuda(), kp)
         heads.append(h)
-        rests.append(r)
+        floors.append(r)
     heads = torch.stack(heads)                                   # what the owner receives [S, n, kp]
     out, bounds, need = be.keys_merge_heads(heads, k)
     o0, b0, n0 = X.keys_merge_heads(heads.cpu().numpy(), k)
@@ -94,11 +95,12 @@ def test_two_phase_exchange_is_the_top_k_of_the_union(S, k, head_keys, xper, gri
         # the shard-side call runs with world = 1 rows-per-destination = n
         xcap = n * xper
         flag = torch.zeros(1, dtype=torch.int32, device='cuda')
-        xbufs = [be.keys_extras(rests[s], bounds[s].contiguous(), 1, xcap, flag)[0] for s in range(S)]
+        dev_rows = [torch.from_numpy(rows[s]).cuda() for s in range(S)]
+        xbufs = [be.keys_extras(dev_rows[s], floors[s], bounds[s].contiguous(), 1, xcap, flag)[0] for s in range(S)]
         overflow = int(flag.item())
         ref_over = 0
         for s in range(S):
-            xb0, ov = X.keys_extras(rests[s].cpu().numpy(), b0[s], 1, xcap)
+            xb0, ov = X.keys_extras(rows[s], floors[s].cpu().numpy(), b0[s], 1, xcap)
             ref_over |= ov
             got, exp = xbufs[s].cpu().numpy().view(np.uint64), xb0[0].view(np.uint64)
             if not ov:
