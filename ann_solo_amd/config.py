@@ -73,8 +73,9 @@ class Config:
     kmeans_niter: int = 25                  # FAISS' ClusteringParameters.niter default
     seed: int = 1234                        # flag --ann_seed; FAISS' ClusteringParameters.seed default
     num_gpus: int = 0                       # > 1: list-shard the ANN indexes over that many ranks
-    flat_storage: str = 'fx22'              # IVF-Flat component storage: 'fx22' (22-bit fixed point
-                                            # for components in [0, 1): 4-byte postings) | 'fp32'
+    flat_storage: str = 'fp32'              # IVF-Flat component storage: 'fp32' (as given: the reference's
+                                            # CPU index) | 'fx22' (opt-in: 22-bit fixed point for
+                                            # components in [0, 1), 4-byte postings, |dx| <= 1.2e-7)
 
     MAX_PEAKS = 256      # peaks per spectrum the preprocessing / rescoring kernels hold (csrc/process.hip)
     MAX_TOPK = 2048      # largest k / nprobe of the LDS top-k (csrc/ivf_kernels.hpp: TK_MAX_K)
@@ -157,8 +158,9 @@ def add_arguments(parser) -> None:
     parser.add_argument('--ann_seed', default=d.seed, type=int,
                         help='random seed of the ANN index trainer (default: %(default)s)')
     parser.add_argument('--flat_storage', default=d.flat_storage, type=str, choices=['fx22', 'fp32'],
-                        help='IVF-Flat: store vector components in [0, 1) as 22-bit fixed point '
-                             '(4-byte postings, |dx| <= 1.2e-7) or as float32 (default: %(default)s)')
+                        help='IVF-Flat: store vector components as float32 (what FAISS stores) or, '
+                             'opt-in, those in [0, 1) as 22-bit fixed point (4-byte postings, '
+                             '|dx| <= 1.2e-7) (default: %(default)s)')
     parser.add_argument('--num_gpus', default=d.num_gpus, type=int,
                         help='shard the ANN index by inverted list over this many GPUs; the job '
                              'runs one process per GPU (torchrun --nproc-per-node N) and N must '

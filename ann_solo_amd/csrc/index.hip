@@ -101,7 +101,8 @@ struct asl_index {
   bool has_inv = false;
   // the fixed-point layout (inv_layout 2): blk_base in 128-byte lines, one byte per (block,
   // dimension) = lines of the segment, posting words (numerator << 10 | local index) in inv_data
-  int flat_storage = 0;          // 0: add() rounds components in [0, 1) to 22 fractional bits; 1: float32 as given
+  int flat_storage = ASL_FLAT_F32;   // ASL_FLAT_F32 (default): components as given; ASL_FLAT_FX22: add() rounds
+                                     // components in [0, 1) to 22 fractional bits
   int inv_layout = 0;            // what build_lists found the data fit for: 0 none, 1 float postings, 2 fixed-point words
   int tab_stride = 0;            // bytes per block of inv_tab8 (d rounded up to a 128-byte line)
   DevBuf<uint8_t> inv_tab8;
@@ -728,7 +729,7 @@ int asl_index_set_flat_storage(asl_index_t *ix, int32_t mode) {
   return ASL_OK;
 }
 
-int asl_index_get_flat_storage(const asl_index_t *ix) { return ix ? ix->flat_storage : 0; }
+int asl_index_get_flat_storage(const asl_index_t *ix) { return ix ? ix->flat_storage : ASL_FLAT_F32; }
 
 int asl_index_flat_layout(asl_index_t *ix) {
   clear_error();
@@ -751,15 +752,30 @@ int asl_index_set_scan_variant(asl_index_t *ix, int32_t variant) {
 // 1 when asl_index_search_preassigned can emit packed 64-bit keys (unordered mode 2) for this
 // index at (k, nprobe): the predicate index_search_device applies, for callers that must
 // choose the exchange format up front (ann_solo_amd/distributed.py).
-int asl_index_supports_keys(const asl_index_t *ix, int32_t k, int32_t nprobe) {
+// IVF-Flat: the answer depends on the vectors THIS handle stores (has_inv: an empty or dense shard
+// has no postings), so a stale layout is rebuilt first -- the value is then what a search meets --
+// and sharded drivers agree on it across ranks before they pick the exchange format.
+int asl_index_supports_keys(asl_index_t *ix, int32_t k, int32_t nprobe) {
   if (!ix) return 0;
   nprobe = std::max(1, std::min(nprobe, ix->nlist));
-  if (ix->kind == ASL_INDEX_IVFFLAT)      // the postings scan's set finish (flat_scan.hip)
-    return ix->scan_variant == 0 && (ix->lists_dirty || ix->has_inv) && flat_inv_supported(ix->d, k, nprobe) &&
+  if (ix->kind == ASL_INDEX_IVFFLAT) {    // the postings scan's set finish (flat_scan.hip)
+    if (ix->lists_dirty && ix->trained && (ensure_device() != ASL_OK || build_lists(ix) != ASL_OK)) return 0;
+    return ix->scan_variant == 0 && ix->has_inv && flat_inv_supported(ix->d, k, nprobe) &&
            k + 768 <= TK_MAX_K;
+  }
   if (ix->kind != ASL_INDEX_IVFPQ) return 0;
   return ix->scan_variant == 0 && pq_scan_tiled_supported(ix->pq_m, ix->ksub, k, nprobe) &&
          k + 768 <= TK_MAX_K;
+}
+
+// shard-side k of the third exchange phase (exchange.hip; measured in profiles/r04_shard_scan_probe.txt:
+// k / 2 at 8 ranks takes ~1 ms off the shard scan, 0.06-0.8 % of the queries need the third phase)
+int32_t asl_shard_k(int32_t k, int32_t world) {
+  if (k < 1 || world < 4) return k;
+  const int raw = world >= 8 ? (k + 1) / 2 : (5 * k + 7) / 8;
+  const int ks = std::min(k, (raw + 63) / 64 * 64);
+  const int head = std::min(k, (2 * k + world - 1) / world);
+  return ks > head ? ks : k;
 }
 
 int asl_index_set_niter(asl_index_t *ix, int32_t niter) {
@@ -883,7 +899,7 @@ static int index_add_impl(asl_index_t *ix, int64_t n, const float *x, const int3
     }
   } else {
     ASL_TRY(dev_append(ix->vecs, (size_t)ix->n_store * ix->d, dx.d, (size_t)n * ix->d));
-    if (ix->kind == ASL_INDEX_IVFFLAT && ix->flat_storage == 0)      // stored components: 22-bit fixed point
+    if (ix->kind == ASL_INDEX_IVFFLAT && ix->flat_storage == ASL_FLAT_FX22)      // stored components: 22-bit fixed point
       ASL_TRY(quantize_fx22(ix->vecs.p + (size_t)ix->n_store * ix->d, n * ix->d));
   }
   ASL_TRY(sync_stream());
@@ -1325,7 +1341,7 @@ int asl_index_save(const asl_index_t *ix, const char *path) {
   IdxHeader h;
   memset(&h, 0, sizeof h);
   memcpy(h.magic, "ASLIDX01", 8);
-  h.version = 1;
+  h.version = 2;      // 2: the storage field of an IVF-Flat header is authoritative (see asl_index_load)
   h.d = ix->d;
   h.nlist = ix->nlist;
   h.kind = ix->kind;
@@ -1392,7 +1408,7 @@ asl_index_t *asl_index_load(const char *path) {
   {  // never trust a file: every count below sizes a host vector or a device allocation
     const char *bad = nullptr;
     const bool ivf = h.kind == ASL_INDEX_IVFFLAT || h.kind == ASL_INDEX_IVFPQ;
-    if (h.version != 1) bad = "unsupported version";
+    if (h.version != 1 && h.version != 2) bad = "unsupported version";
     else if (h.kind < ASL_INDEX_FLAT || h.kind > ASL_INDEX_IVFPQ) bad = "unknown index kind";
     else if (h.d <= 0 || h.d > (1 << 20)) bad = "bad dimension";
     else if (ivf && (h.nlist <= 0 || h.nlist > (1 << 24))) bad = "bad nlist";
@@ -1464,7 +1480,19 @@ asl_index_t *asl_index_load(const char *path) {
     slurp(ix->codes_add, n * ix->pq_m);
   else
     slurp(ix->vecs, n * ix->d);
-  if (ix->kind == ASL_INDEX_IVFFLAT) ix->flat_storage = h.pad;
+  if (ix->kind == ASL_INDEX_IVFFLAT) {
+    ix->flat_storage = h.pad;
+    // version 1: the field was 0 both for fixed-point files and for the unrounded float32 files
+    // of the builds before the storage modes existed -- the components say which
+    if (ok && h.version == 1 && h.pad == ASL_FLAT_FX22 && n > 0) {
+      DevBuf<int32_t> nnz, nnz_max;
+      int32_t h_nm[2] = {0, 0};
+      ok = nnz.reserve(n) == ASL_OK && nnz_max.reserve(2) == ASL_OK &&
+           count_nnz(ix->vecs.p, ix->d, (int64_t)n, nnz.p, nnz_max.p) == ASL_OK &&
+           nnz_max.download(h_nm, 2) == ASL_OK && sync_stream() == ASL_OK;
+      if (ok && h_nm[1] != 0) ix->flat_storage = ASL_FLAT_F32;
+    }
+  }
   if (ix->kind == ASL_INDEX_IVFPQ && (h.pad & 1)) {
     const size_t rn = (size_t)ix->ntotal, S = (size_t)refine_stride();
     ix->refine_rows = true;

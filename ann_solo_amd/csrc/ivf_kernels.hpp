@@ -96,15 +96,24 @@ __host__ __device__ inline bool fx22_on_grid(float x) {
   return x > 0.0f && x < 1.0f && x * 4194304.0f == rintf(x * 4194304.0f);
 }
 int quantize_fx22(float *x, int64_t n);
-// the two-phase exact exchange of a sharded search (exchange.hip)
+// the exact top-k exchange of a sharded search (exchange.hip): heads, bounds, held-back keys,
+// and (with_min) the third phase for shard-side k_s < k
 int keys_split(const unsigned long long *K, int64_t nrows, int k, int kp, unsigned long long *head,
-               int32_t *floor_out);
+               int32_t *floor_out, int with_min = 0);
 int keys_merge(const unsigned long long *heads, int S, int nq, int kp, int k, const unsigned long long *xbuf,
                long long xcap, const unsigned long long *prev_keys, int32_t *need,
-               unsigned long long *out_keys, unsigned long long *bounds, int64_t *I, float *D, int sorted);
+               unsigned long long *out_keys, unsigned long long *bounds, int64_t *I, float *D, int sorted,
+               int with_min = 0, unsigned long long *fin_keys = nullptr, unsigned long long *req = nullptr,
+               int32_t *need3 = nullptr, unsigned int *n3 = nullptr);
+int keys_merge3(const unsigned long long *fin_keys, int W, int nq, int k, const unsigned long long *xbuf,
+                long long xcap, const int32_t *need3, int64_t *I, float *D, int sorted);
 int keys_extras(const unsigned long long *K, const int32_t *floor_in, int64_t nrows, int k,
                 const unsigned long long *bounds, int nq, long long xcap, unsigned long long *xbuf,
                 unsigned int *cursor, int32_t *overflow);
+int keys_rescan(const unsigned long long *K3, int64_t n3, int k, const int64_t *rowidx,
+                const unsigned long long *req, int nq, long long xcap, unsigned long long *xbuf,
+                unsigned int *cursor, int32_t *overflow);
+int req_rows(const unsigned long long *req, int64_t nrows, int64_t *rowidx, unsigned int *count);
 int flat_fx_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                  const int32_t *blk_offsets, const uint8_t *tab8, int tab_stride,
                  const uint16_t *cnt16, unsigned long long *out_dev);

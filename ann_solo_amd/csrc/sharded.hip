@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 #include "ivf_kernels.hpp"
@@ -127,10 +128,6 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
   ASL_TRY(cI.reserve((size_t)nq * np));
   ASL_TRY(cD_all.reserve(all * np));
   ASL_TRY(cI_all.reserve(all * np));
-  ASL_TRY(Dp.reserve(all * k));
-  ASL_TRY(Ip.reserve(all * k));
-  ASL_TRY(Dr.reserve(all * k));
-  ASL_TRY(Ir.reserve(all * k));
   hipStream_t st = stream();
   nccl_comm_t comm = rccl_comm;
   // 1. everybody's queries; the coarse quantiser runs on the own slice meanwhile (same stream:
@@ -139,20 +136,49 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
   ASL_TRY(index_coarse_device(ix, nq, xq, np, cD.p, cI.p));
   RCCL_TRY(R.AllGather(cD.p, cD_all.p, (size_t)nq * np, NCCL_FLOAT32, comm, st));
   RCCL_TRY(R.AllGather(cI.p, cI_all.p, (size_t)nq * np, NCCL_INT32, comm, st));
-  // 2'. the two-phase exact exchange (exchange.hip) whenever the scan can emit packed keys: heads
-  //     of ~2k / world keys, the owners' bounds, the held-back keys above them; the full rows
-  //     below remain the path for everything else and the fallback when a phase-2 buffer runs full
-  if (!refine && asl_index_supports_keys(ix, k, np)) {
+  // a few ints every rank must see the same way: gathered, downloaded (one stream synchronisation)
+  static DevBuf<int32_t> &mine = *new DevBuf<int32_t>(), &everyone = *new DevBuf<int32_t>();
+  ASL_TRY(mine.reserve(4));
+  ASL_TRY(everyone.reserve((size_t)world * 4));
+  auto agree = [&](std::vector<int32_t> &h) -> int {      // mine[0..3] of every rank -> h [world * 4]
+    h.assign((size_t)world * 4, 0);
+    RCCL_TRY(R.AllGather(mine.p, everyone.p, 4, NCCL_INT32, comm, st));
+    ASL_TRY(everyone.download(h.data(), (size_t)world * 4));
+    return sync_stream();
+  };
+  std::vector<int32_t> h;
+  // 2'. the exact key exchange (exchange.hip) whenever EVERY shard's scan can emit packed keys (for
+  //     IVF-Flat that depends on the vectors a shard holds: agreed across the ranks, once per state
+  //     of the index): heads of ~2k / world keys, the owners' bounds, the held-back keys above
+  //     them, and -- the shards scanning with k_s < k -- the third phase; the full rows below
+  //     remain the path for everything else and the fallback when an answer buffer runs full
+  bool keys_everywhere = false;
+  if (!refine) {
+    const int32_t local = asl_index_supports_keys(ix, k, np) ? 1 : 0;
+    int32_t hm[4] = {local, 0, 0, 0};
+    ASL_TRY(mine.upload(hm, 4));
+    ASL_TRY(agree(h));
+    keys_everywhere = true;
+    for (int r = 0; r < world; ++r) keys_everywhere = keys_everywhere && h[(size_t)r * 4] != 0;
+  }
+  if (keys_everywhere) {
     typedef unsigned long long u64k;
     static DevBuf<int64_t> &Kp = *new DevBuf<int64_t>(), &Hs = *new DevBuf<int64_t>(), &Hr = *new DevBuf<int64_t>(),
                            &Ko = *new DevBuf<int64_t>(), &Bs = *new DevBuf<int64_t>(),
-                           &Br = *new DevBuf<int64_t>(), &Xs = *new DevBuf<int64_t>(), &Xr = *new DevBuf<int64_t>();
-    static DevBuf<int32_t> &need = *new DevBuf<int32_t>(), &flag = *new DevBuf<int32_t>(), &Fl = *new DevBuf<int32_t>();
+                           &Br = *new DevBuf<int64_t>(), &Xs = *new DevBuf<int64_t>(), &Xr = *new DevBuf<int64_t>(),
+                           &Kf = *new DevBuf<int64_t>(), &Rs = *new DevBuf<int64_t>(), &Rr = *new DevBuf<int64_t>(),
+                           &rowidx = *new DevBuf<int64_t>(), &K3 = *new DevBuf<int64_t>(), &If = *new DevBuf<int64_t>();
+    static DevBuf<int32_t> &need = *new DevBuf<int32_t>(), &flag = *new DevBuf<int32_t>(), &Fl = *new DevBuf<int32_t>(),
+                           &need3 = *new DevBuf<int32_t>(), &cI3 = *new DevBuf<int32_t>();
+    static DevBuf<float> &x3 = *new DevBuf<float>(), &cD3 = *new DevBuf<float>();
     static DevBuf<unsigned int> &cursor = *new DevBuf<unsigned int>();
-    const int keys = std::min(k, (2 * k + world - 1) / world), kp = keys + 1;
-    const bool second = kp - 1 < k;
+    const int keys = std::min(k, (2 * k + world - 1) / world);
+    const bool second = keys < k;                          // heads hold something back
+    const int ks = second ? asl_shard_k(k, world) : k;     // the shards' own k
+    const bool third = ks < k;
+    const int kp = keys + 1 + (third ? 1 : 0);
     const long long xcap = (long long)nq * std::max(8, k / 16);
-    ASL_TRY(Kp.reserve(all * k));
+    ASL_TRY(Kp.reserve(all * ks));
     ASL_TRY(Hs.reserve(all * kp));
     ASL_TRY(Hr.reserve(all * kp));
     ASL_TRY(Fl.reserve(all));
@@ -160,14 +186,15 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
     ASL_TRY(Bs.reserve(all));
     ASL_TRY(Br.reserve(all));
     ASL_TRY(need.reserve((size_t)nq));
-    ASL_TRY(flag.reserve(1));
+    ASL_TRY(flag.reserve(2));          // [0] an answer buffer ran full, [1] third-phase requests of my queries
+    HIP_TRY(hipMemsetAsync(flag.p, 0, 2 * sizeof(int32_t), st));
     int prev = 0;
     ASL_TRY(index_swap_unordered(ix, 2, &prev));
-    const int rc = index_search_device(ix, (int)all, x_all.p, k, np, nullptr, Kp.p, nullptr, cD_all.p, cI_all.p, true);
+    const int rc = index_search_device(ix, (int)all, x_all.p, ks, np, nullptr, Kp.p, nullptr, cD_all.p, cI_all.p, true);
     ASL_TRY(index_swap_unordered(ix, prev, nullptr));
     ASL_TRY(rc);
-    ASL_TRY(keys_split(reinterpret_cast<const u64k *>(Kp.p), (int64_t)all, k, kp, reinterpret_cast<u64k *>(Hs.p),
-                       Fl.p));
+    ASL_TRY(keys_split(reinterpret_cast<const u64k *>(Kp.p), (int64_t)all, ks, kp, reinterpret_cast<u64k *>(Hs.p),
+                       Fl.p, third ? 1 : 0));
     auto all_to_all = [&](const int64_t *src, int64_t *dst, size_t per_rank) -> int {
       RCCL_TRY(R.GroupStart());
       for (int r = 0; r < world; ++r) {
@@ -179,7 +206,8 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
     };
     ASL_TRY(all_to_all(Hs.p, Hr.p, (size_t)nq * kp));
     ASL_TRY(keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, nullptr, 0, nullptr, need.p,
-                       reinterpret_cast<u64k *>(Ko.p), reinterpret_cast<u64k *>(Bs.p), nullptr, nullptr, 0));
+                       reinterpret_cast<u64k *>(Ko.p), reinterpret_cast<u64k *>(Bs.p), nullptr, nullptr, 0,
+                       third ? 1 : 0));
     bool overflow = false;
     const int64_t *xr = nullptr;
     if (second) {
@@ -188,29 +216,92 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
       ASL_TRY(cursor.reserve((size_t)world));
       ASL_TRY(all_to_all(Bs.p, Br.p, (size_t)nq));
       HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)world * sizeof(unsigned int), st));
-      HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int32_t), st));
-      ASL_TRY(keys_extras(reinterpret_cast<const u64k *>(Kp.p), Fl.p, (int64_t)all, k, reinterpret_cast<const u64k *>(Br.p),
+      ASL_TRY(keys_extras(reinterpret_cast<const u64k *>(Kp.p), Fl.p, (int64_t)all, ks, reinterpret_cast<const u64k *>(Br.p),
                           nq, xcap, reinterpret_cast<u64k *>(Xs.p), cursor.p, flag.p));
       ASL_TRY(all_to_all(Xs.p, Xr.p, (size_t)nq + (size_t)xcap));
-      // a full phase-2 buffer ANYWHERE sends every rank down the full exchange: the flags are
-      // gathered (world ints) so that all ranks take the same branch
-      static DevBuf<int32_t> &flags = *new DevBuf<int32_t>();
-      ASL_TRY(flags.reserve((size_t)world));
-      RCCL_TRY(R.AllGather(flag.p, flags.p, 1, NCCL_INT32, comm, st));
-      std::vector<int32_t> h((size_t)world);
-      ASL_TRY(flags.download(h.data(), (size_t)world));
-      ASL_TRY(sync_stream());
-      for (int32_t f : h) overflow |= f != 0;
       xr = Xr.p;
     }
-    if (!overflow) {
-      float *Dout2 = D;
-      return keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, reinterpret_cast<const u64k *>(xr),
-                        xr ? xcap : 0, reinterpret_cast<const u64k *>(Ko.p), need.p, nullptr, nullptr, I, Dout2, 1);
+    // the result of phases 1-2: final rows when the shards scanned with the full k, else the
+    // keys + the third-phase requests. (If a phase-2 buffer ran full somewhere the rows written
+    // here are discarded below.)
+    if (third) {
+      ASL_TRY(Kf.reserve((size_t)nq * k));
+      ASL_TRY(If.reserve((size_t)nq * k));
+      ASL_TRY(Rs.reserve(all * 2));
+      ASL_TRY(Rr.reserve(all * 2));
+      ASL_TRY(need3.reserve((size_t)nq));
+      ASL_TRY(keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, reinterpret_cast<const u64k *>(xr),
+                         xr ? xcap : 0, reinterpret_cast<const u64k *>(Ko.p), need.p, nullptr, nullptr, If.p, nullptr, 0,
+                         1, reinterpret_cast<u64k *>(Kf.p), reinterpret_cast<u64k *>(Rs.p), need3.p,
+                         reinterpret_cast<unsigned int *>(flag.p + 1)));
+    } else {
+      ASL_TRY(keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, reinterpret_cast<const u64k *>(xr),
+                         xr ? xcap : 0, reinterpret_cast<const u64k *>(Ko.p), need.p, nullptr, nullptr, I, D, 1));
     }
+    if (second) {
+      // a full answer buffer ANYWHERE sends every rank down the full exchange, a third-phase
+      // request ANYWHERE sends every rank through the third phase: all ranks take the same branch
+      HIP_TRY(hipMemcpyAsync(mine.p, flag.p, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+      ASL_TRY(agree(h));
+      bool any3 = false;
+      for (int r = 0; r < world; ++r) {
+        overflow |= h[(size_t)r * 4] != 0;
+        any3 |= h[(size_t)r * 4 + 1] != 0;
+      }
+      if (!overflow && third) {
+        const long long xcap3 = xcap;
+        if (any3) {
+          // the requests travel; every shard lists the rows it was asked about, scans them again
+          // with the full k and answers with its keys strictly between B' and M
+          ASL_TRY(all_to_all(Rs.p, Rr.p, (size_t)nq * 2));
+          ASL_TRY(rowidx.reserve(all));
+          HIP_TRY(hipMemsetAsync(cursor.p, 0, sizeof(unsigned int), st));
+          ASL_TRY(req_rows(reinterpret_cast<const u64k *>(Rr.p), (int64_t)all, rowidx.p, cursor.p));
+          unsigned int n3 = 0;
+          ASL_TRY(cursor.download(&n3, 1));
+          ASL_TRY(sync_stream());
+          HIP_TRY(hipMemsetAsync(Xs.p, 0, (size_t)world * ((size_t)nq + (size_t)xcap3) * 8, st));
+          HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)world * sizeof(unsigned int), st));
+          HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int32_t), st));
+          if (n3 > 0) {
+            ASL_TRY(x3.reserve((size_t)n3 * d));
+            ASL_TRY(cD3.reserve((size_t)n3 * np));
+            ASL_TRY(cI3.reserve((size_t)n3 * np));
+            ASL_TRY(K3.reserve((size_t)n3 * k));
+            ASL_TRY(gather_rows_f32(x_all.p, d, rowidx.p, n3, d, x3.p, d));
+            ASL_TRY(gather_rows_f32(cD_all.p, np, rowidx.p, n3, np, cD3.p, np));
+            ASL_TRY(gather_rows_f32(reinterpret_cast<const float *>(cI_all.p), np, rowidx.p, n3, np,
+                                    reinterpret_cast<float *>(cI3.p), np));      // (4-byte words)
+            ASL_TRY(index_swap_unordered(ix, 2, &prev));
+            const int rc3 = index_search_device(ix, (int)n3, x3.p, k, np, nullptr, K3.p, nullptr, cD3.p, cI3.p, true);
+            ASL_TRY(index_swap_unordered(ix, prev, nullptr));
+            ASL_TRY(rc3);
+            ASL_TRY(keys_rescan(reinterpret_cast<const u64k *>(K3.p), n3, k, rowidx.p, reinterpret_cast<const u64k *>(Rr.p),
+                                nq, xcap3, reinterpret_cast<u64k *>(Xs.p), cursor.p, flag.p));
+          }
+          ASL_TRY(all_to_all(Xs.p, Xr.p, (size_t)nq + (size_t)xcap3));
+          HIP_TRY(hipMemcpyAsync(mine.p, flag.p, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+          ASL_TRY(agree(h));
+          for (int r = 0; r < world; ++r) overflow |= h[(size_t)r * 4] != 0;
+          if (!overflow)
+            return keys_merge3(reinterpret_cast<const u64k *>(Kf.p), world, nq, k, reinterpret_cast<const u64k *>(Xr.p),
+                               xcap3, need3.p, I, D, 1);
+        } else {
+          // nobody asked: the keys of phases 1-2 are the result; rows sorted as the unsharded index returns them
+          HIP_TRY(hipMemsetAsync(need3.p, 0, (size_t)nq * sizeof(int32_t), st));
+          return keys_merge3(reinterpret_cast<const u64k *>(Kf.p), world, nq, k, reinterpret_cast<const u64k *>(Xr.p),
+                             xcap3, need3.p, I, D, 1);
+        }
+      }
+    }
+    if (!overflow) return ASL_OK;
   }
   // 2. the local lists, for all queries (rank-major rows), as exact top-k sets
   //    (unordered mode: un-refined ADC rows, see annsolo_mi.h at asl_index_set_refine)
+  ASL_TRY(Dp.reserve(all * k));
+  ASL_TRY(Ip.reserve(all * k));
+  ASL_TRY(Dr.reserve(all * k));
+  ASL_TRY(Ir.reserve(all * k));
   int prev_unordered = 0;
   ASL_TRY(index_swap_unordered(ix, 1, &prev_unordered));
   const int rc_scan = index_search_device(ix, (int)all, x_all.p, k, np, Dp.p, Ip.p, nullptr, cD_all.p, cI_all.p, true);

@@ -24,7 +24,15 @@ addition. Per batch and charge partition:
      (a key that is never shipped lies below a bound that k shipped keys reach) -- then precursor
      post-filter + shifted-dot rescoring data-parallel over the rank's own queries (the packed
      peak store is replicated: ~1 GB of 288). If a phase-2 buffer overflows (a flag, checked
-     once per batch) the batch is repeated with the full world * k exchange.
+     once per batch) the batch is repeated with the full world * k exchange;
+  5. (round 5) from four ranks on the shards scan with a shard-side k_s < k (``shard_k``: 512 of
+     1024 at eight ranks -- a shard sees an eighth of a query's candidates, and the appends of a
+     k-deep row cost its scan ~1 ms per step). A head then also carries M, the smallest key of a
+     full row; after step 4 the owner knows B' = the k-th best key of its result, and only where
+     M_s > B' -- a fraction of a percent of the queries -- shard s may have dropped a key that
+     belongs there: the owner asks, the shard scans that query again with the full k and answers
+     with its keys between B' and M_s, the owner merges and rescores those queries again. One
+     host decision per batch (the flag of step 4 carries the number of requests).
 
 List ownership is the greedy heaviest-first balancing of ``asl_lpt_owner`` over the
 expected scan load of each list (size squared: populous lists are also probed more often);
@@ -141,36 +149,43 @@ class HipShardBackend:
     # packed 8-byte hits for the exchange (instead of 4-byte score + 8-byte id)
     @property
     def supports_keys(self):
-        """Packed-key rows exist only in the tiled IVF-PQ scan (index.hip: m = 32, 8-bit codes,
-        automatic scan variant, nprobe within the tiled kernel's limit, k + 768 <= 2048); every
-        other configuration exchanges (D, I) rows."""
+        """Packed-key rows come from the tiled IVF-PQ scan (index.hip: m = 32, 8-bit codes,
+        automatic scan variant, nprobe within the tiled kernel's limit, k + 768 <= 2048) and from
+        the postings scan of IVF-Flat -- which THIS shard has only if it stores sparse vectors;
+        every other configuration exchanges (D, I) rows. The value is local: the driver agrees
+        on it across the ranks (``sharded_search_batch``)."""
         return bool(_lib.lib().asl_index_supports_keys(self.index._h, int(self.k_scan),
                                                        int(self.sl._num_probe)))
 
-    def shard_search_keys(self, vectors, coarse_D, coarse_I):
-        return self.index.search_preassigned_keys(vectors, self.k_scan, coarse_D, coarse_I)
+    def shard_search_keys(self, vectors, coarse_D, coarse_I, k=None):
+        k = int(k or self.k_scan)
+        if vectors.shape[0] == 0:
+            return torch.zeros((0, k), dtype=torch.int64, device=vectors.device)
+        return self.index.search_preassigned_keys(vectors, k, coarse_D, coarse_I)
 
     def merge_keys(self, Ks: torch.Tensor):
         from . import faiss_compat
         return faiss_compat.topk_merge_keys(Ks, unordered=True)   # rescoring consumes a set
 
     # ---- the two-phase exchange (csrc/exchange.hip); every tensor lives on the device
-    def keys_split(self, K: torch.Tensor, kp: int):
+    def keys_split(self, K: torch.Tensor, kp: int, with_min: bool = False):
         """-> head [rows, kp] and the rows' bucket floors [rows]: the keys held back are the keys of
-        ``K`` below its row's floor -- ``keys_extras`` reads them from ``K`` itself."""
+        ``K`` below its row's floor -- ``keys_extras`` reads them from ``K`` itself. ``with_min``:
+        the head also carries the smallest key of a full row (third phase)."""
         rows, k = K.shape
         head = torch.empty((rows, kp), dtype=torch.int64, device=K.device)
         floor = torch.empty((rows,), dtype=torch.int32, device=K.device)
-        _lib.check(_lib.lib().asl_keys_split(rows, k, kp, _lib.ptr(K), _lib.ptr(head), _lib.ptr(floor)))
+        _lib.check(_lib.lib().asl_keys_split(rows, k, kp, int(with_min), _lib.ptr(K), _lib.ptr(head),
+                                             _lib.ptr(floor)))
         return head, floor
 
-    def keys_merge_heads(self, heads: torch.Tensor, k: int):
+    def keys_merge_heads(self, heads: torch.Tensor, k: int, with_min: bool = False):
         S, n, kp = heads.shape
         dev = heads.device
         out = torch.empty((n, k), dtype=torch.int64, device=dev)
         bounds = torch.empty((S, n), dtype=torch.int64, device=dev)
         need = torch.empty((n,), dtype=torch.int32, device=dev)
-        _lib.check(_lib.lib().asl_keys_merge_heads(S, n, kp, k, _lib.ptr(heads), _lib.ptr(out),
+        _lib.check(_lib.lib().asl_keys_merge_heads(S, n, kp, int(with_min), k, _lib.ptr(heads), _lib.ptr(out),
                                                    _lib.ptr(bounds), _lib.ptr(need)))
         return out, bounds, need
 
@@ -179,20 +194,60 @@ class HipShardBackend:
         rows, k = K.shape
         n = rows // world
         xbuf = torch.empty((world, n + xcap), dtype=torch.int64, device=K.device)
+        # the payload cursors are the caller's (a tensor on the stream): nothing waits in here, so
+        # the collectives of this piece really travel under the next piece's scan
+        cursor = torch.zeros(world, dtype=torch.int32, device=K.device)
         _lib.check(_lib.lib().asl_keys_extras(world, n, k, _lib.ptr(K), _lib.ptr(floor), _lib.ptr(bounds),
-                                              int(xcap), _lib.ptr(xbuf), _lib.ptr(overflow)))
+                                              int(xcap), _lib.ptr(xbuf), _lib.ptr(cursor), _lib.ptr(overflow)))
         return xbuf
 
-    def keys_merge_final(self, heads: torch.Tensor, xbuf: Optional[torch.Tensor], out_keys, need, k: int):
+    def keys_merge_final(self, heads: torch.Tensor, xbuf: Optional[torch.Tensor], out_keys, need, k: int,
+                         flag: Optional[torch.Tensor] = None):
+        """``flag`` (the batch's [overflow, requests] pair) arms the third phase: -> (I, fin_keys
+        [n, k], req [S, n, 2], need3 [n]) and ``flag[1]`` += the number of requests."""
         S, n, kp = heads.shape
-        I = torch.empty((n, k), dtype=torch.int64, device=heads.device)
+        dev = heads.device
+        I = torch.empty((n, k), dtype=torch.int64, device=dev)
         xcap = 0 if xbuf is None else xbuf.shape[1] - n
-        _lib.check(_lib.lib().asl_keys_merge_final(S, n, kp, k, _lib.ptr(heads), _lib.ptr(xbuf), int(xcap),
-                                                   _lib.ptr(out_keys), _lib.ptr(need), None, _lib.ptr(I)))
+        if flag is None:
+            _lib.check(_lib.lib().asl_keys_merge_final(S, n, kp, 0, k, _lib.ptr(heads), _lib.ptr(xbuf), int(xcap),
+                                                       _lib.ptr(out_keys), _lib.ptr(need), None, _lib.ptr(I),
+                                                       None, None, None, None))
+            return I
+        fin = torch.empty((n, k), dtype=torch.int64, device=dev)
+        req = torch.empty((S, n, 2), dtype=torch.int64, device=dev)
+        need3 = torch.empty((n,), dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().asl_keys_merge_final(S, n, kp, 1, k, _lib.ptr(heads), _lib.ptr(xbuf), int(xcap),
+                                                   _lib.ptr(out_keys), _lib.ptr(need), None, _lib.ptr(I),
+                                                   _lib.ptr(fin), _lib.ptr(req), _lib.ptr(need3),
+                                                   _lib.ptr(flag[1:])))
+        return I, fin, req, need3
+
+    def request_rows(self, req: torch.Tensor) -> torch.Tensor:
+        """req [rows, 2] -> the rows that carry a request (a host round trip: third phase only)."""
+        return torch.nonzero(req.reshape(-1, 2)[:, 0] != -1).reshape(-1)
+
+    def keys_rescan(self, K3: torch.Tensor, rowidx: torch.Tensor, req: torch.Tensor, world: int, n: int,
+                    xcap: int, flag: torch.Tensor):
+        k = K3.shape[1]
+        xbuf = torch.zeros((world, n + xcap), dtype=torch.int64, device=req.device)
+        cursor = torch.zeros(world, dtype=torch.int32, device=req.device)
+        n3 = int(rowidx.numel())
+        _lib.check(_lib.lib().asl_keys_rescan(world, n, k, n3, _lib.ptr(K3) if n3 else None,
+                                              _lib.ptr(rowidx) if n3 else None, _lib.ptr(req.contiguous()),
+                                              int(xcap), _lib.ptr(xbuf), _lib.ptr(cursor), _lib.ptr(flag)))
+        return xbuf
+
+    def keys_merge3(self, fin_keys: torch.Tensor, xbuf: torch.Tensor, need3: torch.Tensor, k: int):
+        n = fin_keys.shape[0]
+        I = torch.empty((n, k), dtype=torch.int64, device=fin_keys.device)
+        _lib.check(_lib.lib().asl_keys_merge3(xbuf.shape[0], n, k, _lib.ptr(fin_keys), _lib.ptr(xbuf),
+                                              int(xbuf.shape[1] - n), _lib.ptr(need3), None, _lib.ptr(I)))
         return I
 
     def new_flag(self):
-        return torch.zeros(1, dtype=torch.int32, device=self.device)
+        """[0]: an answer buffer ran full somewhere; [1]: third-phase requests of my queries."""
+        return torch.zeros(2, dtype=torch.int32, device=self.device)
 
     def refine(self, vectors: torch.Tensor, knn: torch.Tensor):
         """Merged k' short-list of the own queries -> the k best by exact inner product."""
@@ -445,9 +500,54 @@ def _concat_results(parts):
 
 def head_width(k: int, world: int, head_keys: Optional[int] = None) -> int:
     """Row width kp of the phase-1 exchange: ``min(k, ceil(2 k / world))`` key slots (or
-    ``head_keys``) + the slot of the best held-back key."""
+    ``head_keys``) + the slot of the best held-back key (the third phase adds one more)."""
     keys = head_keys if head_keys is not None else -(-2 * k // max(world, 1))
     return max(1, min(int(keys), k)) + 1
+
+
+def shard_k(k: int, world: int) -> int:
+    """The shards' own k of the third phase (``asl_shard_k``): k / 2 from 8 ranks on, 5 k / 8 from
+    4, rounded up to 64; k below 4 ranks or when that is not more than a head's key slots."""
+    return int(_lib.lib().asl_shard_k(int(k), int(world)))
+
+
+def _agreed_keys(backend, world: int, group, k_scan: int) -> bool:
+    """Can EVERY rank's shard emit packed keys? For IVF-Flat that depends on the vectors a shard
+    holds (an empty or dense shard scans dense rows), and ranks that disagreed would run
+    collectives of different shapes: all-reduce(MIN), once per (backend, group, k) -- the answer
+    only changes with the index."""
+    local = bool(getattr(backend, 'supports_keys', False))
+    if world == 1:
+        return local
+    cache = backend.__dict__.setdefault('_keys_agreed', {}) if hasattr(backend, '__dict__') else {}
+    key = (id(group), world, k_scan, getattr(backend, 'index_epoch', 0))
+    if key not in cache:
+        t = torch.tensor([int(local)], dtype=torch.int32)
+        if dist.get_backend(group) == 'nccl':
+            t = t.to(backend.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        cache[key] = bool(int(t.item()))
+    return cache[key]
+
+
+def _patch_rows(res, sel, new):
+    """Overwrite the rows ``sel`` of a batch result (``BatchResult`` / dict of a test backend)
+    with ``new``, a result of len(sel) rows."""
+    names = ('best_row', 'best_score', 'n_candidates', 'pm_count', 'pm_pairs', 'knn')
+    for name in names:
+        dst = res.get(name) if isinstance(res, dict) else getattr(res, name, None)
+        src = new.get(name) if isinstance(new, dict) else getattr(new, name, None)
+        if dst is None or src is None:
+            continue
+        if torch.is_tensor(dst):
+            idx = sel.to(dst.device)
+            src = torch.as_tensor(src).to(dst.device)
+            if name == 'pm_pairs' and src.dtype != dst.dtype:
+                src = src.view(dst.dtype) if src.element_size() == dst.element_size() else src.to(dst.dtype)
+            dst[idx] = src.to(dst.dtype) if src.dtype != dst.dtype else src
+        else:
+            src = src.cpu().numpy() if torch.is_tensor(src) else np.asarray(src)
+            dst[sel.cpu().numpy()] = src.astype(dst.dtype, copy=False)
 
 
 def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, device_out=False,
@@ -455,7 +555,8 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
                          pm_stride: Optional[int] = None, check_sizes: bool = False,
                          peak_width: Optional[int] = None, two_phase: Optional[bool] = None,
                          head_keys: Optional[int] = None, extras_per_query: Optional[int] = None,
-                         comm: Optional['CommLog'] = None, stats: Optional[dict] = None):
+                         comm: Optional['CommLog'] = None, stats: Optional[dict] = None,
+                         shard_keys: Optional[int] = None, answers_per_query: Optional[int] = None):
     """One batch: ``queries_local`` is this rank's equally sized slice of the global
     batch. Returns the BatchResult of the local slice (library rows are global).
     ``peak_width``: a bound on the peaks per query that is IDENTICAL on every rank (e.g.
@@ -467,13 +568,16 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     scanned: every piece walks through the stages head exchange -> merge + bounds -> held-back
     keys -> final merge + rescoring, one stage per scan that is issued behind it.
 
-    ``two_phase`` (default: whenever the backend emits packed keys): the exact two-phase
+    ``two_phase`` (default: whenever every rank's backend emits packed keys): the exact
     exchange of csrc/exchange.hip; ``head_keys`` overrides the keys per head (default
     ``ceil(2 k / world)``), ``extras_per_query`` the capacity of the phase-2 buffers (slots per
     query and pair of ranks, default ``max(8, k // 16)``). With heads as wide as the rows (two
-    ranks) the rows travel whole. A full phase-2 buffer repeats the
-    batch with the full exchange (``stats['fallback']``). ``comm``: a ``CommLog`` that receives
-    the bytes of every collective."""
+    ranks) the rows travel whole. ``shard_keys``: the shards' own k (default ``shard_k(k,
+    world)``; a value below k arms the third phase, k switches it off), ``answers_per_query``
+    the capacity of its answer buffers. A full answer buffer of phase 2 or 3 repeats the
+    batch with the full exchange of k-deep rows (``stats['fallback']``). ``comm``: a ``CommLog``
+    that receives the bytes of every collective; ``stats`` also gets ``shard_k`` and
+    ``third_phase_queries`` (own queries that were merged and rescored again)."""
     world = dist.get_world_size(group)
     if queries_local.n == 0:
         # every rank must bring the same, non-zero number of queries (the collectives below are
@@ -515,15 +619,24 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     bounds = [(n_local * c) // chunks for c in range(chunks + 1)]
     rank_base = torch.arange(world, device=allvec.device).unsqueeze(1) * n_local
 
-    use_keys = bool(getattr(backend, 'supports_keys', False)) and \
+    k_scan = int(getattr(backend, 'k_scan', getattr(backend, 'k', 0)))
+    # the exchange format is a COLLECTIVE choice (see _agreed_keys)
+    use_keys = _agreed_keys(backend, world, group, k_scan) and \
         (co is not None or not getattr(backend, 'supports_preassigned', False))
     if two_phase is None:
         two_phase = use_keys and hasattr(backend, 'keys_split')
     two_phase = bool(two_phase and use_keys)
-    k_scan = int(getattr(backend, 'k_scan', getattr(backend, 'k', 0)))
-    kp = head_width(k_scan, world, head_keys) if two_phase else 0
-    if two_phase and kp - 1 >= k_scan:       # (two ranks: a head of ceil(2k / 2) keys IS the row) the
-        two_phase, kp = False, 0             # rows travel whole: no split, no bound, one merge
+    nkeep = head_width(k_scan, world, head_keys) - 1 if two_phase else 0
+    if two_phase and nkeep >= k_scan:        # (two ranks: a head of ceil(2k / 2) keys IS the row) the
+        two_phase, nkeep = False, 0          # rows travel whole: no split, no bound, one merge
+    # third phase: the shards scan with k_row < k_scan keys per row
+    k_row = k_scan
+    if two_phase and hasattr(backend, 'keys_rescan'):
+        ks = int(shard_keys) if shard_keys is not None else shard_k(k_scan, world)
+        if nkeep < ks < k_scan:
+            k_row = ks
+    third = k_row < k_scan
+    kp = nkeep + 1 + int(third) if two_phase else 0
     second = two_phase                       # heads hold something back
     flag = backend.new_flag() if second else None
 
@@ -543,7 +656,10 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
             xv = allvec.index_select(0, rows)
             pre = (cD.index_select(0, rows), cI.index_select(0, rows)) if co is not None else None
         if use_keys:
-            return backend.shard_search_keys(xv, *(pre if pre is not None else (None, None)))
+            pre_ = pre if pre is not None else (None, None)
+            if two_phase and third:
+                return backend.shard_search_keys(xv, *pre_, k=k_row)
+            return backend.shard_search_keys(xv, *pre_)
         return (backend.shard_search_preassigned(xv, *pre) if pre is not None
                 else backend.shard_search(xv))
 
@@ -555,6 +671,16 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     # when its result has been appended
     def piece(lo, hi, out):
         st = {'stage': 0}
+
+        def final(xr):
+            if two_phase and third:
+                knn, fin, req, need3 = backend.keys_merge_final(st['heads'], xr, st['keys'], st['need'],
+                                                                k_scan, flag)
+                held3.append((lo, fin, req, need3))
+            else:
+                knn = backend.keys_merge_final(st['heads'], xr, st['keys'], st['need'], k_scan)
+            results.append((lo, rescore(lo, hi, knn)))
+            return True
 
         def step():
             n = hi - lo
@@ -569,7 +695,7 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
                         st['x'] = exchange_partials(out[0], out[1], world, group, async_op=True)
                     st['stage'] = 10
                     return False
-                head, floor = backend.keys_split(out, kp)
+                head, floor = (backend.keys_split(out, kp, True) if third else backend.keys_split(out, kp))
                 st['rest'] = (out, floor)          # the held-back keys stay in the scan's rows
                 st['x'] = _all_to_all(head, world, group, comm, 'heads_all_to_all')
                 st['stage'] = 1
@@ -586,11 +712,10 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
             if st['stage'] == 1:              # heads are here: merge, bound, questions to the shards
                 wait(st['x'][1])
                 st['heads'] = st['x'][0].contiguous()
-                st['keys'], bnd, st['need'] = backend.keys_merge_heads(st['heads'], k_scan)
+                st['keys'], bnd, st['need'] = (backend.keys_merge_heads(st['heads'], k_scan, True) if third
+                                               else backend.keys_merge_heads(st['heads'], k_scan))
                 if not second:
-                    knn = backend.keys_merge_final(st['heads'], None, st['keys'], st['need'], k_scan)
-                    results.append((lo, rescore(lo, hi, knn)))
-                    return True
+                    return final(None)
                 st['x'] = _all_to_all(bnd.reshape(world * n), world, group, comm, 'bounds_all_to_all')
                 st['stage'] = 2
                 return False
@@ -607,9 +732,7 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
                 return False
             wait(st['x'][1])                  # stage 3: final merge, rescoring
             xr = st['x'][0].reshape(world, n + st['xcap']).contiguous()
-            knn = backend.keys_merge_final(st['heads'], xr, st['keys'], st['need'], k_scan)
-            results.append((lo, rescore(lo, hi, knn)))
-            return True
+            return final(xr)
         return step
 
     def run():
@@ -630,21 +753,77 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
                 if p_():
                     pending.remove(p_)
 
-    results = []
-    run()
-    if second:
-        # one flag per batch: did any destination buffer of phase 2 run full anywhere?
+    def agree_flag():
+        """[overflow anywhere, third-phase requests anywhere]: one host round trip"""
         f = flag if dist.get_backend(group) == 'nccl' else flag.cpu()
         dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)
-        if int(f.item()):
+        v = f.cpu().tolist()
+        return int(v[0]) != 0, int(v[1]) != 0
+
+    def third_phase(res):
+        """Queries of which a shard's k_row-deep row may hide a key of the result: the requests
+        (B', M) travel, the shards scan those queries again with the full k and answer with
+        their keys in between, the owner merges and rescores them again. Returns the overflow
+        flag of the answer buffers (all-reduced)."""
+        held3.sort(key=lambda t: t[0])
+        fin = torch.cat([t[1] for t in held3])
+        req = torch.cat([t[2] for t in held3], dim=1).contiguous()          # [world, n_local, 2]
+        need3 = torch.cat([t[3] for t in held3])
+        rq, works, _keep = _all_to_all(req.reshape(world * n_local, 2), world, group, comm,
+                                       'rescan_requests_all_to_all')
+        wait(works)
+        rq = rq.reshape(world * n_local, 2).contiguous()       # row = owner * n_local + query
+        rows = backend.request_rows(rq)
+        pre = (cD.index_select(0, rows.to(cD.device)), cI.index_select(0, rows.to(cI.device))) \
+            if co is not None else (None, None)
+        K3 = backend.shard_search_keys(allvec.index_select(0, rows.to(allvec.device)), *pre, k=k_scan)
+        xcap3 = n_local * (answers_per_query if answers_per_query is not None else max(8, k_scan // 16))
+        flag.zero_()
+        xbuf = backend.keys_rescan(K3, rows, rq, world, n_local, xcap3, flag)
+        xr, works, _keep2 = _all_to_all(xbuf.reshape(world * (n_local + xcap3)), world, group, comm,
+                                        'rescan_answers_all_to_all')
+        wait(works)
+        knn3 = backend.keys_merge3(fin, xr.reshape(world, n_local + xcap3).contiguous(), need3, k_scan)
+        sel = torch.nonzero(need3).reshape(-1)
+        if stats is not None:
+            stats['third_phase_queries'] = stats.get('third_phase_queries', 0) + int(sel.numel())
+            stats['third_phase_rescans'] = stats.get('third_phase_rescans', 0) + int(rows.numel())
+        if sel.numel():
+            knn = knn3.index_select(0, sel.to(knn3.device))
+            if hasattr(backend, 'refine'):
+                knn = backend.refine(vec.index_select(0, sel.to(vec.device)), knn)
+            sub = queries_local.select(sel.to(queries_local.device))
+            _patch_rows(res, sel, backend.rescore_knn(sub, knn, device_out, **kw))
+        return agree_flag()[0]
+
+    results, held3 = [], []
+    run()
+    fallback = False
+    res = None
+    if second:
+        # one pair of flags per batch: did any answer buffer of phase 2 run full anywhere, and
+        # does any owner have a third-phase request?
+        fallback, any3 = agree_flag()
+        if not fallback and third:
+            results.sort(key=lambda t: t[0])
+            res = _concat_results([r for _, r in results])
+            if any3:
+                fallback = third_phase(res)
+        if fallback:
             if stats is not None:
                 stats['fallback'] = stats.get('fallback', 0) + 1
-            two_phase = second = False
-            results = []
+            two_phase = second = third = False
+            results, held3, res = [], [], None
             run()
     if stats is not None:
-        stats['two_phase'] = bool(kp)
+        stats['two_phase'] = bool(kp) and not fallback
+        stats['exchange_used'] = ('full rows (fallback)' if fallback else 'two-phase + third' if kp and k_row < k_scan
+                                  else 'two-phase' if kp else 'full rows')
         stats['head_width'] = kp
+        stats['shard_k'] = k_row if kp else k_scan
+        stats.setdefault('third_phase_queries', 0)
+    if res is not None:
+        return res
     results.sort(key=lambda t: t[0])
     return _concat_results([r for _, r in results])
 

@@ -276,12 +276,13 @@ class IndexFlatIP(Index):
 
 
 class IndexIVFFlat(Index):
-    """``storage``: 'fx22' (default) -- ``add`` stores every component in [0, 1) as the nearest
-    multiple of 2^-22, which lets the inverted lists hold 4-byte postings -- or 'fp32' (components
-    as given); ``asl_index_set_flat_storage``. Not a FAISS argument: FAISS' CPU index stores
-    float32, the GPU clone the reference makes stores float16 (spectral_library.py:490-497)."""
+    """``storage``: 'fp32' (default: the components as given -- what FAISS' CPU ``IndexIVFFlat``
+    of the reference stores, spectral_library.py:174-181) or 'fx22' (opt-in: ``add`` stores every
+    component in [0, 1) as the nearest multiple of 2^-22, which lets the inverted lists hold
+    4-byte postings); ``asl_index_set_flat_storage``. Not a FAISS argument (the GPU clone the
+    reference makes stores float16, spectral_library.py:490-497)."""
 
-    def __init__(self, quantizer, d, nlist, metric=METRIC_INNER_PRODUCT, storage='fx22'):
+    def __init__(self, quantizer, d, nlist, metric=METRIC_INNER_PRODUCT, storage='fp32'):
         if metric != METRIC_INNER_PRODUCT:
             raise ValueError('only METRIC_INNER_PRODUCT is implemented (the reference uses no other)')
         self.quantizer = quantizer
@@ -464,7 +465,7 @@ def parse_index_faiss(path: str) -> dict:
             'centroids': cen, 'x': x, 'lists': lists}
 
 
-def read_index_faiss(path: str, storage: str = 'fx22') -> 'IndexIVFFlat':
+def read_index_faiss(path: str, storage: str = 'fp32') -> 'IndexIVFFlat':
     """Load a FAISS IVF-Flat / inner-product file (e.g. a ``.idxann`` the reference cached):
     FAISS' centroids and FAISS' own list assignments are kept; ids must be 0..ntotal-1 (what
     ``index.add`` gives and the reference relies on). Raises ValueError on anything else."""

@@ -253,11 +253,11 @@ class SpectralLibrary:
         pick up a stale file."""
         cfg = self.config
         if (cfg.index == 'ivfflat' and cfg.kmeans_niter == 25 and cfg.seed == 1234 and
-                cfg.flat_storage == 'fx22'):
+                cfg.flat_storage == 'fp32'):
             return self._get_hyperparameter_hash()
         d = {hp: cfg[hp] for hp in self._hyperparameters}
         d.update(index=cfg.index, kmeans_niter=cfg.kmeans_niter, seed=cfg.seed)
-        if cfg.index == 'ivfflat' and cfg.flat_storage != 'fx22':
+        if cfg.index == 'ivfflat' and cfg.flat_storage != 'fp32':
             d.update(flat_storage=cfg.flat_storage)
         if cfg.index == 'ivfpq':
             d.update(pq_m=cfg.pq_m, pq_bits=cfg.pq_bits)

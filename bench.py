@@ -86,6 +86,13 @@ def main():
     ap.add_argument('--extras-per-query', type=int, default=None,
                     help='N > 1, two-phase exchange: phase-2 buffer slots per query and pair of ranks '
                          '(default max(8, k / 16); diagnostic: 0 forces the fallback to the full exchange)')
+    ap.add_argument('--shard-keys', type=int, default=None,
+                    help='N > 1: the shards\' own k (default asl_shard_k(k, N): k / 2 from 8 ranks on, 5 k / 8 '
+                         'from 4, k below); a value below k arms the third exchange phase (the owner asks a '
+                         'shard for a second scan with the full k where its row may hide a key of the result)')
+    ap.add_argument('--answers-per-query', type=int, default=None,
+                    help='N > 1, third phase: answer-buffer slots per query and pair of ranks (default '
+                         'max(8, k / 16); diagnostic: 0 forces the fallback to the full exchange)')
     ap.add_argument('--preflight-seconds', type=float, default=120.0,
                     help='N > 1: every collective of the sharded path is first run at a tiny size '
                          'under a watchdog that ends the process (exit code 17, a diagnostic line on '
@@ -286,7 +293,8 @@ def main():
                 return sharded_search_batch(shard_backend, q, group=group, device_out=True,
                                             peak_width=peak_width, comm=comm_log, stats=xstats,
                                             two_phase=None if args.exchange == 'two-phase' else False,
-                                            head_keys=args.head_keys, extras_per_query=args.extras_per_query)
+                                            head_keys=args.head_keys, extras_per_query=args.extras_per_query,
+                                            shard_keys=args.shard_keys, answers_per_query=args.answers_per_query)
         else:
             step = unsharded_step
         got = step()
@@ -322,9 +330,17 @@ def main():
         # bytes every collective of a step moved (counted inside the timed steps) and what each
         # costs on its own at its real per-chunk size (outside the timed region, after it)
         comm = comm_log.summary(args.steps)
-        comm['exchange'] = 'two-phase' if xstats.get('two_phase') else 'full rows'
+        comm['exchange'] = xstats.get('exchange_used') or ('two-phase' if xstats.get('two_phase') else 'full rows')
         comm['head_width'] = xstats.get('head_width')
+        comm['shard_k'] = xstats.get('shard_k')
         comm['fallbacks_to_full_exchange'] = xstats.get('fallback', 0)
+        # third phase: own queries merged and rescored again / rows this shard scanned again, per
+        # step, summed over the ranks of the job
+        t3 = torch.tensor([xstats.get('third_phase_queries', 0), xstats.get('third_phase_rescans', 0)],
+                          dtype=torch.int64, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t3, op=dist.ReduceOp.SUM)
+        comm['third_phase_queries'] = round(int(t3[0]) / max(args.steps, 1), 2)
+        comm['third_phase_rescans'] = round(int(t3[1]) / max(args.steps, 1), 2)
         comm['collective_ms_alone'] = time_collectives(comm_log, group, degree, dev, backend, args.steps)
     L.asl_profile_enable(0)
     scan_timed = {}
@@ -420,6 +436,9 @@ def main():
             if n_a.value > 0:
                 alone_f = ms_a.value / n_a.value
         fixed_recall = {'index': 'ivfflat', 'nlist': args.nlist, 'nprobe': best,
+                        # the reference's storage: float32 components as given (spectral_library.py:174-181):
+                        # ids / scores below are those of an index over the UNQUANTISED hashed vectors
+                        'storage': idx_f.storage,
                         'same_coarse_quantiser_as_the_ivfpq_index': same_q,
                         'recall_at_k_vs_exact_ip': best_rec,
                         'criterion': f'>= 0.95 x {ref_rec:.4f} (IVF-Flat, nprobe {args.nprobe})',
@@ -446,6 +465,39 @@ def main():
                                                                      'single_core_value', 'dense_definition_check')}
         sl_f.shutdown()
         del sl_f, idx_f
+        torch.cuda.empty_cache()
+        # the opt-in fixed-point storage at the same operating point, for the record (never `value`)
+        sl_x = SpectralLibrary(lib, config=replace(cfg, index='ivfflat', refine_k=None, flat_storage='fx22'),
+                               device=dev)
+        idx_x = sl_x._get_ann_index(charge)
+        sl_x._num_probe = best
+
+        def fx_step():
+            return sl_x._search_batch(q, charge, 'open', device_out=True)
+        sl_x.set_pipeline(pipelined)
+        for _ in range(args.warmup):
+            fx_step()
+        sl_x.synchronize()
+        L.asl_profile_enable(2)
+        L.asl_profile_reset()
+        n_x = max(2, min(args.steps, 10))
+        el_x, res_x = timed(fx_step, n_x)
+        sl_x.synchronize()
+        L.asl_profile_enable(0)
+        sl_x.set_pipeline(False)
+        ms_x, c_x = C.c_double(), C.c_int64()
+        L.asl_profile_get(b'scan', C.byref(ms_x), C.byref(c_x))
+        fixed_recall['alt_storage'] = {
+            'storage': idx_x.storage, 'value': round(args.batch * n_x / el_x, 2),
+            'ms_per_step': round(el_x / n_x * 1e3, 3), 'steps': n_x,
+            'scan_ms_per_step': round(ms_x.value / max(c_x.value, 1), 3),
+            'winners_equal_the_fp32_index': int((res_x.best_row == res_f.best_row).sum()),
+            'queries': int(res_x.best_row.numel()),
+            'note': "opt-in: components rounded to 2^-22 (|dx| <= 1.2e-7), 4-byte postings; ids differ from the "
+                    "float32 index only within 1e-6 of the k-th score (tests/test_gpu_fullscale.py bounds it "
+                    "at this size)"}
+        sl_x.shutdown()
+        del sl_x, idx_x
         torch.cuda.empty_cache()
 
 

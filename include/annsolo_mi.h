@@ -122,8 +122,11 @@ int asl_index_get_refine(const asl_index_t *idx);
 int asl_index_refine(asl_index_t *idx, int32_t nq, const float *xq, int32_t kprime,
                      const int64_t *I_in /* [nq,kprime], -1 = empty */, int32_t k, float *D, int64_t *I);
 
-/* IVF-Flat component storage (no FAISS counterpart on the CPU; FAISS' GPU clone of the reference
- * stores float16, spectral_library.py:490-497). ASL_FLAT_FX22 (the default): add() rounds every
+/* IVF-Flat component storage. ASL_FLAT_F32 (the default since round 5) keeps every component as
+ * given: the float32 vectors FAISS' CPU IndexIVFFlat stores (spectral_library.py:174-181) -- ids
+ * and scores are those of an index over the unquantised vectors. ASL_FLAT_FX22 (opt-in; no FAISS
+ * counterpart on the CPU, the reference's GPU clone stores float16, spectral_library.py:490-497):
+ * add() rounds every
  * component in [0, 1) to the nearest multiple of 2^-22 (ties to even, at most 1 - 2^-22;
  * |dx| <= 1.2e-7) and stores anything else as given. When ALL stored non-zeros are such values --
  * unit-norm hashed spectra always are -- the inverted lists are kept as 4-byte postings
@@ -131,8 +134,9 @@ int asl_index_refine(asl_index_t *idx, int32_t nq, const float *xq, int32_t kpri
  * table (csrc/flat_scan.hip) instead of 6-byte postings behind 4-byte table words. Scores are
  * the canonical ascending-dimension fp32 fmaf chain over the STORED components either way, so
  * both layouts (and the generic kernels of asl_index_set_scan_variant) return identical ids and
- * score bits for the same stored vectors. ASL_FLAT_F32 keeps every component as given. Set
- * before the first add(); saved with the index. asl_index_flat_layout: 0 = dense rows only (no
+ * score bits for the same stored vectors. Set
+ * before the first add(); saved with the index (file version 2; a version-1 file that says
+ * fixed point but holds off-grid components -- written before the modes existed -- loads as float32). asl_index_flat_layout: 0 = dense rows only (no
  * postings: vectors too dense), 1 = float postings, 2 = fixed-point postings. */
 #define ASL_FLAT_FX22 0
 #define ASL_FLAT_F32 1
@@ -192,34 +196,62 @@ int asl_index_shard(asl_index_t *idx, int32_t rank, int32_t world);
 int asl_index_search_sharded(asl_index_t *idx, void *rccl_comm, int32_t nq, const float *xq,
                              int32_t k, int32_t nprobe, float *D, int64_t *I);
 /* 1 if asl_index_search_preassigned can emit packed keys (unordered mode 2) for this index at
- * (k, nprobe) -- the tiled IVF-PQ scan: m = 32, 8-bit codes, automatic scan variant, nprobe
- * within the tiled kernel's limit, k + 768 <= 2048 --, else 0 (exchange (D, I) rows then). */
-int asl_index_supports_keys(const asl_index_t *idx, int32_t k, int32_t nprobe);
-/* The two-phase exact exchange of a sharded search (csrc/exchange.hip; device pointers only; what
- * ann_solo_amd/distributed.py and asl_index_search_sharded run between their collectives). Rows
- * of packed keys as asl_index_set_unordered mode 2 emits them (0 = empty, any order).
- *   asl_keys_split: K [nrows, k] -> head [nrows, kp] (slots 0 .. kp-2: the row's best keys, all
- *     those at or above a score-bucket floor that admits at most kp - 1; slot kp-1: T, the best
- *     key held back, 0 if none) and floor [nrows] (that bucket floor: the keys held back are the
+ * (k, nprobe) -- IVF-PQ: the tiled scan (m = 32, 8-bit codes, automatic scan variant, nprobe
+ * within the tiled kernel's limit, k + 768 <= 2048); IVF-Flat: the postings scan (sparse stored
+ * vectors, k <= 1280) --, else 0 (exchange (D, I) rows then). Builds the scan layout if it is
+ * out of date, so the answer is the one a search would meet. For IVF-Flat it depends on the
+ * vectors THIS shard holds (an empty or dense shard scans dense rows): a sharded driver must
+ * agree on it across ranks (MIN) before choosing the exchange format, as distributed.py and
+ * asl_index_search_sharded do. */
+int asl_index_supports_keys(asl_index_t *idx, int32_t k, int32_t nprobe);
+/* The exact top-k exchange of a sharded search (csrc/exchange.hip; device pointers only; what
+ * ann_solo_amd/distributed.py and asl_index_search_sharded run between their collectives; no
+ * reference counterpart: spectral_library.py:494 uses device 0 only). Rows of packed keys as
+ * asl_index_set_unordered mode 2 emits them (0 = empty, any order). with_min != 0 arms the third
+ * phase: the shards scan with a shard-side k_s < k and a head carries M, the smallest key of a
+ * FULL row (0 otherwise), in front of T; head layout [keys x (kp - 1 - with_min)][M][T].
+ *   asl_keys_split: K [nrows, k_s] -> head [nrows, kp] (the row's best keys, all those at or
+ *     above a score-bucket floor that admits at most the head's key slots; M; T = the best key
+ *     held back, 0 if none) and floor [nrows] (that bucket floor: the keys held back are the
  *     keys of K below it, which stay where they are).
  *   asl_keys_merge_heads: heads [S, nq, kp] of the S shards -> out_keys [nq, k] (the best k keys
  *     seen, a set), bounds [S, nq] (B = the k-th best key seen if shard s must send what it holds
  *     above B -- its T beats B --, else ~0: send nothing), need [nq] (some shard was asked).
- *   asl_keys_extras: on the shard, rows destination-major (row = dst * nq + q): K [W * nq, k] and
- *     floor [W * nq] as asl_keys_split saw / wrote them, bounds [W * nq] -> xbuf [W, nq + xcap]: per destination nq header words (count << 32 |
- *     start) then the payload; *overflow = 1 when a destination's xcap slots do not suffice (the
- *     caller must then repeat the batch with the full exchange). *overflow is never cleared here.
+ *   asl_keys_extras: on the shard, rows destination-major (row = dst * nq + q): K [W * nq, k_s]
+ *     and floor [W * nq] as asl_keys_split saw / wrote them, bounds [W * nq] -> xbuf
+ *     [W, nq + xcap]: per destination nq header words (count << 32 | start) then the payload;
+ *     cursor [W] int32, ZEROED BY THE CALLER (the payload cursors; the call returns without
+ *     waiting); *overflow = 1 when a destination's xcap slots do not suffice (the caller must
+ *     then repeat the batch with the full exchange). *overflow is never cleared here.
  *   asl_keys_merge_final: heads + the xbuf [S, nq + xcap] received (NULL: none) + out_keys/need of
  *     asl_keys_merge_heads -> I [nq, k] ids (a set, -1 padded) and D (may be NULL): the exact
- *     top-k of the union of the shards' rows. k <= 1280. */
-int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, const int64_t *K, int64_t *head, int32_t *floor);
-int asl_keys_merge_heads(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
+ *     top-k of the union of the shards' rows. k <= 1280. With with_min also fin_keys [nq, k] (the
+ *     keys behind I), req [S, nq, 2] = (B', M_s) for every shard that may have dropped a key of
+ *     the result (M_s > B' = the k-th best key of the result, 0 if fewer than k) else (~0, 0),
+ *     need3 [nq] (some shard is asked) and *n3 += the number of requests (never cleared here).
+ *   asl_keys_rescan: on the shard, after the requests travelled (req [W * nq, 2], destination-
+ *     major): K3 [n3, k] = the rows of a scan with the FULL k of the n3 requested (query, owner)
+ *     rows rowidx [n3] (= dst * nq + q, any order) -> xbuf [W, nq + xcap] (ZEROED BY THE CALLER):
+ *     the keys strictly between B' and M; cursor / overflow as above.
+ *   asl_keys_merge3: fin_keys + the answers xbuf [W, nq + xcap] + need3 -> I / D [nq, k]: the
+ *     exact top-k of the union of the shards' FULL rows. */
+int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, int32_t with_min, const int64_t *K, int64_t *head,
+                   int32_t *floor);
+int asl_keys_merge_heads(int32_t S, int32_t nq, int32_t kp, int32_t with_min, int32_t k, const int64_t *heads,
                          int64_t *out_keys, int64_t *bounds, int32_t *need);
 int asl_keys_extras(int32_t W, int32_t nq, int32_t k, const int64_t *K, const int32_t *floor,
-                    const int64_t *bounds, int64_t xcap, int64_t *xbuf, int32_t *overflow);
-int asl_keys_merge_final(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
+                    const int64_t *bounds, int64_t xcap, int64_t *xbuf, int32_t *cursor, int32_t *overflow);
+int asl_keys_merge_final(int32_t S, int32_t nq, int32_t kp, int32_t with_min, int32_t k, const int64_t *heads,
                          const int64_t *xbuf, int64_t xcap, const int64_t *prev_keys, const int32_t *need,
-                         float *D, int64_t *I);
+                         float *D, int64_t *I, int64_t *fin_keys, int64_t *req, int32_t *need3, int32_t *n3);
+int asl_keys_rescan(int32_t W, int32_t nq, int32_t k, int64_t n3, const int64_t *K3, const int64_t *rowidx,
+                    const int64_t *req, int64_t xcap, int64_t *xbuf, int32_t *cursor, int32_t *overflow);
+int asl_keys_merge3(int32_t W, int32_t nq, int32_t k, const int64_t *fin_keys, const int64_t *xbuf, int64_t xcap,
+                    const int32_t *need3, float *D, int64_t *I);
+/* The shard-side k of the third phase for a final k at `world` ranks: k / 2 from 8 ranks on,
+ * 5 k / 8 from 4 (rounded up to 64); k itself below 4 ranks or when that is not more than the
+ * head's ceil(2 k / world) key slots (pure host integer code). */
+int32_t asl_shard_k(int32_t k, int32_t world);
 /* list -> owner rank map of the balancing above, for inspection. */
 int asl_index_shard_map(const asl_index_t *idx, int32_t world, int32_t *owner /* [nlist] */);
 

@@ -18,7 +18,7 @@ from ann_solo_amd.spectral_library import Config, SpectralLibrary
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 t_end = time.time() + budget
-trials = bad = two_phase = 0
+trials = bad = two_phase = third_runs = third_asked = 0
 dev = torch.device('cuda', 0)
 tmp = tempfile.mkdtemp()
 while time.time() < t_end:
@@ -44,37 +44,63 @@ while time.time() < t_end:
     path = os.path.join(tmp, 'x.idxmi')
     faiss.write_index(idx, path)
     owner = idx.shard_map(W)
-    parts, keys, nloc = [], [], 0
+    parts, keys, keys_s, nloc = [], [], [], 0
     use_keys = bool(_lib.lib().asl_index_supports_keys(idx._h, k, nprobe))
+    # third phase: a random head and a random shard-side k between the head and k
+    hk = int(rng.integers(1, k + 1)) if rng.random() < 0.7 else min(k, -(-2 * k // W))
+    ks = int(rng.integers(hk + 1, k)) if hk + 1 < k and rng.random() < 0.6 else k
     for r in range(W):
         sh = faiss.read_index(path)
         sh.shard(r, W)
         nloc += sh.info().nlocal
         if use_keys:
+            use_keys = bool(_lib.lib().asl_index_supports_keys(sh._h, k, nprobe))      # (an empty / dense shard)
+        if use_keys:
             keys.append(sh.search_preassigned_keys(vec, k, cD, cI))
+            keys_s.append(sh.search_preassigned_keys(vec, ks, cD, cI) if ks < k else keys[-1])
         sh.set_unordered(True)
         parts.append(sh.search_preassigned(vec, k, cD, cI))
         del sh
     Dm, Im = faiss.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     ok = nloc == n and torch.equal(Im, I) and torch.equal(Dm.view(torch.int32), D.view(torch.int32))
     ok &= set(owner.tolist()) <= set(range(W))
-    if use_keys:
+    if use_keys and len(keys) == W:
         Dk, Ik = faiss.topk_merge_keys(torch.stack(keys))
         ok &= torch.equal(Ik, I) and torch.equal(Dk.view(torch.int32), D.view(torch.int32))
         if k + 768 <= 2048:
             # the two-phase exchange (csrc/exchange.hip) over the same rows, a random head width: heads
             # -> bounds -> held-back keys -> final merge must give the unsharded ids as a set
             be = HipShardBackend.__new__(HipShardBackend)
-            kp = head_width(k, W, int(rng.integers(1, k + 1)) if rng.random() < 0.7 else None)
-            split = [be.keys_split(K_, kp) for K_ in keys]
+            third = hk < ks < k
+            kp = head_width(k, W, hk) + int(third)
+            rows = keys_s if third else keys
+            split = [be.keys_split(K_, kp, third) for K_ in rows]
             heads = torch.stack([h for h, _ in split])
-            okeys, bnd, need = be.keys_merge_heads(heads, k)
-            if kp - 1 < k:
-                flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            okeys, bnd, need = be.keys_merge_heads(heads, k, third)
+            If = None
+            if hk < k:
+                flag = torch.zeros(2, dtype=torch.int32, device=dev)
                 xcap = nq * int(rng.choice([k, max(8, k // 16)]))
-                xb = torch.stack([be.keys_extras(keys[r], split[r][1], bnd[r].contiguous(), 1, xcap, flag)[0]
+                xb = torch.stack([be.keys_extras(rows[r], split[r][1], bnd[r].contiguous(), 1, xcap, flag)[0]
                                   for r in range(W)])
-                If = None if int(flag.item()) else be.keys_merge_final(heads, xb, okeys, need, k)
+                if not int(flag[0].item()):
+                    if third:
+                        # heads with M -> ... -> final merge + requests -> every shard answers from its
+                        # FULL row (what a second scan with k returns) -> last merge
+                        _, fin, req, need3 = be.keys_merge_final(heads, xb, okeys, need, k, flag)
+                        flag.zero_()
+                        xcap3 = nq * int(rng.choice([k, max(8, k // 16)]))
+                        ans = []
+                        for r in range(W):
+                            sel = be.request_rows(req[r].contiguous())
+                            ans.append(be.keys_rescan(keys[r].index_select(0, sel), sel, req[r].contiguous(), 1, nq,
+                                                      xcap3, flag)[0])
+                        if not int(flag[0].item()):
+                            If = be.keys_merge3(fin, torch.stack(ans), need3, k)
+                            third_runs += 1
+                            third_asked += int(need3.sum())
+                    else:
+                        If = be.keys_merge_final(heads, xb, okeys, need, k)
             else:
                 If = be.keys_merge_final(heads, None, okeys, need, k)
             if If is not None:
@@ -85,4 +111,5 @@ while time.time() < t_end:
         bad += 1
         print('MISMATCH', desc, flush=True)
     sl.shutdown()
-print(f'{trials} trials ({two_phase} also through the two-phase exchange), {bad} mismatches')
+print(f'{trials} trials ({two_phase} also through the two-phase exchange, {third_runs} of them with a shard-side '
+      f'k < k and the third phase: {third_asked} queries asked), {bad} mismatches')

@@ -56,8 +56,10 @@ class OracleShardBackend:
     def supports_keys(self):
         return self.keys
 
-    def shard_search_keys(self, vectors, coarse_D=None, coarse_I=None):
-        D, I = self.ivf.search(vectors.numpy(), self.k, self.nprobe)
+    def shard_search_keys(self, vectors, coarse_D=None, coarse_I=None, k=None):
+        if vectors.shape[0] == 0:
+            return torch.zeros((0, k or self.k), dtype=torch.int64)
+        D, I = self.ivf.search(vectors.numpy(), k or self.k, self.nprobe)
         return torch.from_numpy(X.pack_keys(D, I))
 
     def merge_keys(self, Ks):
@@ -69,12 +71,12 @@ class OracleShardBackend:
             I[q, :len(best)] = X.key_id(best)
         return None, torch.from_numpy(I)
 
-    def keys_split(self, K, kp):
-        head, floors = X.keys_split(K.numpy(), kp)
+    def keys_split(self, K, kp, with_min=False):
+        head, floors = X.keys_split(K.numpy(), kp, with_min)
         return torch.from_numpy(head), torch.from_numpy(floors)
 
-    def keys_merge_heads(self, heads, k):
-        out, bounds, need = X.keys_merge_heads(heads.numpy(), k)
+    def keys_merge_heads(self, heads, k, with_min=False):
+        out, bounds, need = X.keys_merge_heads(heads.numpy(), k, with_min)
         return torch.from_numpy(out), torch.from_numpy(bounds), torch.from_numpy(need)
 
     def keys_extras(self, K, floors, bounds, world, xcap, overflow):
@@ -82,12 +84,29 @@ class OracleShardBackend:
         overflow[0] = max(int(overflow[0]), ov)
         return torch.from_numpy(xbuf)
 
-    def keys_merge_final(self, heads, xbuf, out_keys, need, k):
-        return torch.from_numpy(X.keys_merge_final(heads.numpy(), None if xbuf is None else xbuf.numpy(),
-                                                   out_keys.numpy(), need.numpy(), k))
+    def keys_merge_final(self, heads, xbuf, out_keys, need, k, flag=None):
+        """``flag`` (the batch's [overflow, requests] pair) arms the third phase."""
+        r = X.keys_merge_final(heads.numpy(), None if xbuf is None else xbuf.numpy(),
+                               out_keys.numpy(), need.numpy(), k, with_min=flag is not None)
+        if flag is None:
+            return torch.from_numpy(r)
+        I, fin, req, need3, n3 = r
+        flag[1] += n3
+        return torch.from_numpy(I), torch.from_numpy(fin), torch.from_numpy(req), torch.from_numpy(need3)
+
+    def request_rows(self, req):
+        return torch.from_numpy(X.request_rows(req.numpy()))
+
+    def keys_rescan(self, K3, rowidx, req, world, n, xcap, flag):
+        xbuf, ov = X.keys_rescan(K3.numpy(), rowidx.numpy(), req.numpy(), world, n, xcap)
+        flag[0] = max(int(flag[0]), ov)
+        return torch.from_numpy(xbuf)
+
+    def keys_merge3(self, fin_keys, xbuf, need3, k):
+        return torch.from_numpy(X.keys_merge3(fin_keys.numpy(), xbuf.numpy(), need3.numpy(), k))
 
     def new_flag(self):
-        return torch.zeros(1, dtype=torch.int32)
+        return torch.zeros(2, dtype=torch.int32)
 
     def _window_ok(self, q_pmz, tol, mode):
         """spectral_library.py:421-427 in float64 over the float32 library column."""

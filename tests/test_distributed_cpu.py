@@ -58,7 +58,7 @@ def _worker(rank, world, port, kind, out_dir):
     xb = O.encode_batch(lib_np[1], lib_np[2], lib_np[0], 10.96, 0.04, 800)
     cen = O.kmeans(xb, 8, 4, 1234, 0, 256)
     a = O.assign(xb, cen, 0)
-    if kind == 'pq':
+    if kind.startswith('pq'):
         cb = O.pq_train(xb, cen, 8, 16, 4, 1241)
         payload = O.pq_encode(xb, cen, a, cb)
     else:      # 'flat', 'flat_wide'
@@ -96,22 +96,41 @@ def _worker(rank, world, port, kind, out_dir):
     # heads (40 of k = 64 keys per shard: the bound / held-back-keys round runs; 1 key per shard:
     # the owner sees fewer than k keys and asks for everything), with phase-2 buffers too small (the
     # flag repeats the batch with the full exchange), the full packed-key rows, the (D, I) rows
+    # Round 5, the third phase: the shards keep rows of shard_keys < k keys; a full row may hide a
+    # key of the result, the owner asks (B', M), the shard scans again with the full k. 'third':
+    # rows of 16 keys from 2-4 shards cannot even fill k = 64 -- B' = 0, every full row is asked
+    # about (a forced third phase); 'third_mid': some queries ask; 'third_overflow': answer buffers
+    # of zero slots send the batch down the full exchange. 'disagree': ONE rank's shard cannot
+    # emit packed keys (an empty / dense IVF-Flat shard): all ranks must take the (D, I) rows.
     ok, seen = True, {}
     for name, kw in (('two_phase', {}), ('small_heads', dict(head_keys=40, extras_per_query=32)),
                      ('tiny_heads', dict(head_keys=1, extras_per_query=64)),
                      ('overflow', dict(head_keys=9, extras_per_query=0)),
-                     ('full_keys', dict(two_phase=False)), ('rows', None)):
-        be.keys = kw is not None
+                     ('third', dict(head_keys=8, shard_keys=16, extras_per_query=64, answers_per_query=64)),
+                     ('third_mid', dict(head_keys=20, shard_keys=44, extras_per_query=64)),
+                     ('third_overflow', dict(head_keys=8, shard_keys=16, extras_per_query=64,
+                                             answers_per_query=0)),
+                     ('full_keys', dict(two_phase=False)), ('disagree', {}), ('rows', None)):
+        be.keys = kw is not None and (name != 'disagree' or rank == 0)
+        be.index_epoch = getattr(be, 'index_epoch', 0) + 1     # the agreed exchange format is cached per epoch
         stats, comm = {}, CommLog()
         res = sharded_search_batch(be, q, stats=stats, comm=comm, **(kw or {}))
-        same = (np.array_equal(res['knn'], I) and np.array_equal(res['best_row'], ref['best_row'])
+        same = (np.array_equal(np.sort(res['knn'], 1), np.sort(I, 1)) and
+                np.array_equal(res['best_row'], ref['best_row'])
                 and np.array_equal(res['best_score'], ref['best_score']))
         ok = ok and same
-        seen[name] = (same, stats.get('fallback', 0), sorted(comm.calls))
+        seen[name] = (same, stats.get('fallback', 0), sorted(comm.calls), stats.get('third_phase_queries', 0),
+                      stats.get('shard_k'), stats.get('exchange_used'))
     be.keys = True
     ok = (ok and seen['overflow'][1] == 1 and seen['small_heads'][1] == 0 and
           'held_back_keys_all_to_all' in seen['small_heads'][2] and
-          'heads_all_to_all' not in seen['two_phase'][2] and    # two ranks: the rows travel whole
+          ('heads_all_to_all' in seen['two_phase'][2]) == (world > 2) and    # two ranks: the rows travel whole
+          seen['third'][3] == nloc and seen['third'][4] == 16 and seen['third'][1] == 0 and
+          'rescan_answers_all_to_all' in seen['third'][2] and
+          seen['third_mid'][4] == 44 and seen['third_mid'][1] == 0 and
+          seen['third_overflow'][1] == 1 and seen['third_overflow'][5] == 'full rows (fallback)' and
+          seen['disagree'][2].count('topk_rows_all_to_all') == 1 and seen['disagree'][5] == 'full rows' and
+          'heads_all_to_all' not in seen['disagree'][2] and
           seen['rows'][2].count('topk_rows_all_to_all') == 1)
     if not ok:
         print('exchange modes:', seen, flush=True)
@@ -122,9 +141,10 @@ def _worker(rank, world, port, kind, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind', ['pq', 'flat', 'flat_wide'])
+@pytest.mark.parametrize('kind', ['pq', 'flat', 'flat_wide', 'pq4'])
 def test_two_rank_sharded_search_equals_unsharded(tmp_path, kind):
-    world = 2
+    """(kind 'pq4': the same through FOUR ranks -- heads really hold keys back by default)"""
+    world = 4 if kind == 'pq4' else 2
     port = _free_port()
     mp.spawn(_worker, args=(world, port, kind, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):

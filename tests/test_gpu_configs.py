@@ -122,7 +122,8 @@ def test_default_bench_line_at_small_size():
     assert cb['value'] > 0 and cb['cores'] >= 1 and cb['parity_vs_gpu']['knn_id_sets_equal'] and \
         cb['parity_vs_gpu']['best_row_equal'] and cb['parity_vs_gpu']['best_score_max_abs_diff'] == 0.0
     f = d['fixed_recall']
-    assert f['index'] == 'ivfflat' and f['value'] > 0 and f['roofline']['layout'].startswith('fixed-point')
+    assert f['index'] == 'ivfflat' and f['value'] > 0 and f['storage'] == 'fp32'
+    assert f['roofline']['layout'].startswith('float postings') and f['alt_storage']['storage'] == 'fx22'
     assert f['parity_vs_gpu']['knn_id_sets_equal'] and f['parity_vs_gpu']['best_row_equal']
     assert f['cpu_baseline']['dense_definition_check']['knn_ids_and_winners_equal'] is True
     c = d['cascade']

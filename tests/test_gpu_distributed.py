@@ -18,6 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (0, 'ivfpq', []), (1, 'ivfpq', []), (0, 'ivfflat', []),
     (0, 'ivfpq', ['--head-keys', '700']),                             # phase 2 of the exchange runs
     (0, 'ivfflat', ['--head-keys', '600', '--extras-per-query', '0']),   # ... and overflows: fallback
+    (0, 'ivfpq', ['--head-keys', '200', '--shard-keys', '448', '--extras-per-query', '512',
+                  '--answers-per-query', '1024']),                     # third phase: 2 x 448 < k, every query asks
+    (0, 'ivfflat', ['--head-keys', '300', '--shard-keys', '640', '--extras-per-query', '512']),   # some queries ask
     (0, 'ivfpq', ['--exchange', 'full'])])
 def test_two_rank_sharded_bench_path(degree, index, extra):
     """degree 0 = lists sharded over both ranks; degree 1 = two replicas (no exchange). The
@@ -47,8 +50,14 @@ def test_two_rank_sharded_bench_path(degree, index, extra):
         assert c['total_bytes_out_per_rank_per_step'] > 0 and c['collective_ms_alone']
         if '--exchange' in extra:
             assert 'topk_rows_all_to_all' in c and 'heads_all_to_all' not in c
+        elif '--shard-keys' in extra:
+            assert c['exchange'] == 'two-phase + third' and c['shard_k'] == int(extra[3])
+            assert c['head_width'] == int(extra[1]) + 2 and c['fallbacks_to_full_exchange'] == 0
+            if int(extra[3]) * 2 < 1024:          # two rows cannot fill k: every query with a full row asks
+                assert c['third_phase_queries'] > 1024 and 'rescan_answers_all_to_all' in c
         elif '--head-keys' in extra:
-            assert c['exchange'] == 'two-phase' and 'heads_all_to_all' in c and 'held_back_keys_all_to_all' in c
+            assert c['exchange'].startswith('two-phase' if '--extras-per-query' not in extra else 'full rows')
+            assert 'heads_all_to_all' in c and 'held_back_keys_all_to_all' in c
             assert c['fallbacks_to_full_exchange'] == (1 if '--extras-per-query' in extra else 0)
             assert c['head_width'] == int(extra[1]) + 1
         else:       # two ranks: a head of ceil(2k / 2) keys is the whole row -- the rows travel as they are

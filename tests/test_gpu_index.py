@@ -423,7 +423,7 @@ def test_flat_storage_fx22_against_fp32_and_float64(O, vecs, trained):
     rng = np.random.default_rng(3)
     xs = xb.copy()
     xs[:, ::7] *= -1.0
-    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16, storage='fx22')
     idx.set_trained(cen)
     idx.add(xs)
     assert idx.flat_layout == 1
@@ -433,6 +433,15 @@ def test_flat_storage_fx22_against_fp32_and_float64(O, vecs, trained):
     assert np.array_equal(stored, np.where(xs >= 0, O.quantize_fx22(xs), xs))
     with pytest.raises(Exception):
         idx.set_storage('fp32')          # after add(): refused
+    # the default is the reference's storage: float32 as given (spectral_library.py:174-181)
+    dflt = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    assert dflt.storage == 'fp32'
+    dflt.set_trained(cen)
+    dflt.add(xs)
+    _, ids_d, v_d = dflt.lists()
+    kept = np.empty_like(xs)
+    kept[ids_d] = v_d
+    assert np.array_equal(kept, xs)
 
 
 def test_flat_storage_survives_save_and_load(vecs, trained, tmp_path):
