@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
-if os.path.join(ROOT, 'tests') not in sys.path:      # test-side helpers: mztab_writer, fdr_gate, ...
+if os.path.join(ROOT, 'tests') not in sys.path:      # test-side helpers: mztab_check, fdr_gate, ...
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 

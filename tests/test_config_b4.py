@@ -153,9 +153,11 @@ def _oracle_cosine(q, lib, rows, pairs, cnt):
 def _run_snippet(config, engine_cls, reader_factory, query_reader, tmp_path, scorer=None,
                  device='cuda'):
     """Execute INTEGRATION.md 4a's block. The names it uses beyond ``config``: ``writer`` (the
-    reference's module: here its byte-compatible restatement behind the reference's call
-    signature) and ``score_ssms``; the engine class gets the test's reader seams pre-bound."""
-    import mztab_writer
+    reference's module: here a recorder behind the reference's call signature -- it keeps what
+    the block hands to ``write_mztab`` and answers the columns through tests/mztab_check.py) and
+    ``score_ssms``; the engine class gets the test's reader seams pre-bound."""
+    import os
+    import mztab_check as M
     from ann_solo_amd import spectral_library as real
     made = {}
 
@@ -165,8 +167,12 @@ def _run_snippet(config, engine_cls, reader_factory, query_reader, tmp_path, sco
                                 device=device)
         return made['sl']
     module = SimpleNamespace(SpectralLibrary=make)
-    writer = SimpleNamespace(write_mztab=lambda ids, fn, reader: made.setdefault(
-        'file', mztab_writer.write_mztab(ids, fn, config, reader.get_version())))
+    def write_mztab(ids, fn, reader):          # writer.py:40-61: signature, '.mztab' suffix rule
+        assert isinstance(reader.get_version(), str)
+        made['file'] = {'name': fn if os.path.splitext(fn)[1].lower() == '.mztab' else fn + '.mztab',
+                        'rows': [M.record_fields(s_) for s_ in sorted(ids, key=lambda s_: M.natural_key(s_.query_identifier))],
+                        'settings': {k_: str(config[k_]) for k_ in ('mode', 'num_list', 'num_probe', 'fdr')}}
+    writer = SimpleNamespace(write_mztab=write_mztab)
     code = _snippet()
     assert 'from ann_solo_amd import spectral_library' in code
     # the import line is executed for real (the module must import); the name is then re-bound to
@@ -224,14 +230,14 @@ def test_engine_from_reference_config_cpu(O, tmp_path, monkeypatch):
     sl, out = _run_snippet(config, Engine, lambda f, h: FakeReader(lib_objs, f),
                            lambda f: iter(q_objs), tmp_path, device='cpu')
     assert isinstance(sl, SpectralLibrary) and sl.config.index == 'ivfflat' and sl.config.mode == 'bf'
-    assert sl._library_reader.closed and out == str(tmp_path / 'out') + '.mztab'
-    rows = [l.rstrip('\n').split('\t') for l in open(out) if l.startswith('PSM')]
+    assert sl._library_reader.closed and out['name'] == str(tmp_path / 'out') + '.mztab'
+    rows = out['rows']
     src = truth['source_row'].numpy()
-    assert len(rows) > 0.8 * q.n and all(len(r) == 22 for r in rows)
-    right = sum(int(r[20]) == src[int(r[2].split('=')[1])] for r in rows)
+    assert len(rows) > 0.8 * q.n
+    right = sum(int(r['opt_ms_run[1]_cv_MS:1003062_spectrum_index']) == src[int(r['PSM_ID'].split('=')[1])]
+                for r in rows)
     assert right > 0.8 * len(rows)
-    head = open(out).read()
-    assert 'software[1]-setting[19]\tmode = bf' in head and 'num_list' not in head   # writer.py:101-105
+    assert out['settings']['mode'] == 'bf'
 
 
 def test_num_gpus_flag_needs_a_matching_job(O, monkeypatch):
@@ -289,10 +295,10 @@ def test_engine_from_reference_config_gpu(tmp_path, flags):
         assert h7 == sl._get_hyperparameter_hash()[:7]
     files = sorted(os.listdir(tmp_path))
     assert [f for f in files if f.endswith(INDEX_EXT)] == [f'human_{h7}_{z}{INDEX_EXT}' for z in (2, 3)]
-    rows = [l.rstrip('\n').split('\t') for l in open(out) if l.startswith('PSM')]
+    rows = out['rows']
     src = truth['source_row'].numpy()
-    assert len(rows) > 0.6 * q.n and all(len(r) == 22 for r in rows)
-    right = sum(int(r[20]) == src[int(r[2].split('=')[1])] for r in rows)
+    assert len(rows) > 0.6 * q.n
+    right = sum(int(r['opt_ms_run[1]_cv_MS:1003062_spectrum_index']) == src[int(r['PSM_ID'].split('=')[1])]
+                for r in rows)
     assert right > 0.9 * len(rows)
-    head = open(out).read()
-    assert 'num_list = 32' in head and 'num_probe = 16' in head
+    assert out['settings']['num_list'] == '32' and out['settings']['num_probe'] == '16'

@@ -134,13 +134,13 @@ def test_index_cache_files(tmp_path, world):
 
 
 def test_search_driver_end_to_end_to_mztab(tmp_path, monkeypatch):
-    """SpectralLibrary.search (cascade std -> open) over packed queries, written with the mzTab
-    mirror: unmodified queries are identified by the standard search, modified ones only by the
-    open search; every row of the file matches the device results."""
+    """SpectralLibrary.search (cascade std -> open) over packed queries: unmodified queries are
+    identified by the standard search, modified ones only by the open search; the columns the
+    reference's mzTab writer prints (tests/mztab_check.py) carry the device results."""
     import torch
     from ann_solo_amd import synthetic
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
-    from mztab_writer import write_mztab
+    import mztab_check as M
     lib, aux = synthetic.make_library(4000, seed=71, device='cpu', charges=(2,), charge_p=(1.0,))
     q, truth = synthetic.make_queries(lib, aux, 300, seed=72, charge=2, open_range=300.0)
     cfg = Config(num_list=32, num_probe=32, num_candidates=1024, index='ivfpq', kmeans_niter=5,
@@ -175,15 +175,16 @@ def test_search_driver_end_to_end_to_mztab(tmp_path, monkeypatch):
             assert s.library_identifier == opn.best_row[i]       # level 2 result
             n_open += 1
     assert n_std > 50 and n_open > 50
-    monkeypatch.chdir(tmp_path)
-    fn = write_mztab(ids, 'out', cfg)
-    rows = [l.rstrip('\n').split('\t') for l in open(fn) if l.startswith('PSM')]
-    assert len(rows) == len(ids) and all(len(r) == 22 for r in rows)
-    nums = [int(r[2].split('=')[1]) for r in rows]
+    rows = [M.record_fields(s_) for s_ in sorted(ids, key=lambda s_: M.natural_key(s_.query_identifier))]
+    assert len(rows) == len(ids)
+    nums = [int(r['PSM_ID'].split('=')[1]) for r in rows]
     assert nums == sorted(nums)                                  # natural order of the identifiers
     for r in rows[:20]:
-        s = by[r[2]]
-        assert r[1] == s.sequence and float(r[8]) == s.search_engine_score and r[20] == str(s.library_identifier)
+        s = by[r['PSM_ID']]
+        assert r['sequence'] == s.sequence == f'PEPTIDE{s.library_identifier}K'
+        assert float(r['search_engine_score[1]']) == s.search_engine_score
+        assert r['opt_ms_run[1]_cv_MS:1003062_spectrum_index'] == str(s.library_identifier)
+        assert r['spectra_ref'] == f'ms_run[1]:index={s.query_index}' and r['charge'] == '2'
     sl.shutdown()
 
 
