@@ -73,7 +73,7 @@ EXPORTS = [
     'asl_ssm_features_batch', 'asl_ssm_cosine_batch', 'asl_index_set_unordered', 'asl_topk_merge_keys',
     'asl_index_set_flat_storage', 'asl_index_get_flat_storage', 'asl_index_flat_layout',
     'asl_keys_split', 'asl_keys_merge_heads', 'asl_keys_extras', 'asl_keys_merge_final',
-    'asl_keys_rescan', 'asl_keys_merge3', 'asl_shard_k',
+    'asl_keys_rescan_list', 'asl_shard_k', 'asl_index_search_gated',
 ]
 
 
@@ -169,19 +169,20 @@ def lib():
         L.asl_index_set_flat_storage.argtypes = [C.c_void_p, C.c_int32]
         L.asl_index_flat_layout.argtypes = [C.c_void_p]
         L.asl_index_get_flat_storage.argtypes = [C.c_void_p]
-        L.asl_keys_split.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                     C.c_void_p]
-        L.asl_keys_merge_heads.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 4
+        L.asl_keys_split.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.asl_keys_merge_heads.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 4
+        L.asl_keys_rescan_list.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]
         L.asl_keys_extras.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.asl_keys_merge_final.argtypes = [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 8
-        L.asl_keys_rescan.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.asl_keys_merge3.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
-                                      C.c_void_p, C.c_void_p, C.c_void_p]
+                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int32]
+        L.asl_keys_merge_final.argtypes = [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.asl_shard_k.argtypes = [C.c_int32, C.c_int32]
         L.asl_shard_k.restype = C.c_int32
         L.asl_index_supports_keys.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.asl_index_search_gated.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.asl_index_postings_work.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, c_i64p, c_i64p]
         L.asl_index_get_refine.argtypes = [C.c_void_p]
         L.asl_index_get_refine.restype = C.c_int32

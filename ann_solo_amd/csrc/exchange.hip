@@ -23,17 +23,17 @@
 // that k shipped keys reach. If a destination's phase-2 buffer overflows, a flag is raised and
 // the caller repeats the batch with the full exchange (ann_solo_amd/distributed.py).
 //
-//   phase 3  (round 5) the shards may scan with a SHARD-SIDE k_s < k (512 of 1024 at 8 ranks): a
-//            shard sees an eighth of a query's candidates, its threshold rises late, and the
-//            appends of a k-deep row cost ~1 ms per step (profiles/r04_shard_scan_probe.txt).
-//            A row that is full (k_s keys) may have dropped keys; all of them are below M = the
-//            row's smallest key, which travels in the head next to T. After phase 2 the owner
-//            holds the exact top k of the union of the k_s-rows and B' = its k-th best key (0
-//            if fewer). If M_s < B' shard s dropped nothing that matters; otherwise -- a fraction
-//            of a percent of the queries -- the owner sends (B', M_s), the shard scans that query
-//            again with the full k and answers with its keys strictly between the two, and the
-//            owner merges once more. Still exact: a key that never travels is below a bound that
-//            k travelled keys reach.
+//   shard-side k_s < k (round 5). A shard sees 1 / world of a query's candidates, its top-k
+//   threshold rises late, and the appends of a k-deep row cost the scan ~0.5-0.9 ms per step at
+//   eight ranks (profiles/r05_sim_rank.txt). So the shards scan with k_s (asl_shard_k: 512 of
+//   1024 at 8 ranks). A FULL row of k_s keys may have dropped keys, all of them below M = the
+//   row's smallest key. Nothing changes for the owner: every key outside a head -- held back or
+//   dropped -- is <= T (a full row always holds something back, and M <= T), so "ask shard s iff
+//   T_s > B" still covers them. The SHARD completes its answer: where the bound it is sent lies
+//   below M (rescan_list_kernel; ~1 % of its rows) it scans that query again with the full k --
+//   a launch of fixed size gated by a device-side count, no host round trip -- and answers from
+//   that row instead: every key above B that is not in the head. Same collectives, same exact
+//   result: the top k of the union of the shards' FULL rows.
 #include "common.hpp"
 #include "hist_topk.hpp"
 #include "ivf_kernels.hpp"
@@ -43,10 +43,10 @@ namespace asl {
 constexpr u64 XK_NONE = ~0ull;      // bound meaning "send nothing"
 
 // ---- phase 1: head of a row ---------------------------------------------------------------
-// K [nrows, k] (0 = empty, any order) -> head [nrows, kp]: slots 0 .. nkeep-1 the kept keys (0
-// padded), slot kp-1 = T (the best key held back); with_min (phase 3): slot kp-2 = M, the row's
-// smallest key when the row is full (k keys: the scan may have dropped keys, all below M), else 0;
-// nkeep = kp - 1 - with_min. floor_out [nrows]: the row's bucket floor.
+// K [nrows, k] (0 = empty, any order) -> head [nrows, kp]: slots 0 .. kp-2 the kept keys (0
+// padded), slot kp-1 = T (the best key held back); floor_out [nrows]: the row's bucket floor;
+// rowmin_out [nrows] (may be null): M = the row's smallest key if the row is FULL (k keys: the
+// scan may have dropped keys, all of them below M), else 0.
 // The kept set = all keys whose score bucket (hist_topk.hpp: 512 buckets over [-0.25, 1)) is at
 // or above the lowest bucket floor that admits at most kp - 1 keys. The held-back keys are not
 // copied anywhere: they are the keys of K below the floor, and phase 2 (keys_extras_kernel) reads
@@ -75,9 +75,9 @@ __device__ __forceinline__ uint32_t xk_scan(uint32_t x) {      // inclusive, 64 
 constexpr int XS_WAVES = 4;
 template <int PER>
 __global__ __launch_bounds__(64 * XS_WAVES) void keys_split_kernel(const u64 *__restrict__ K, int64_t nrows,
-                                                                   int k, int kp, int with_min,
-                                                                   u64 *__restrict__ head,
-                                                                   int32_t *__restrict__ floor_out) {
+                                                                   int k, int kp, u64 *__restrict__ head,
+                                                                   int32_t *__restrict__ floor_out,
+                                                                   u64 *__restrict__ rowmin_out) {
   __shared__ int s_hist[XS_WAVES][HT_NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * XS_WAVES + wave;
@@ -104,8 +104,7 @@ __global__ __launch_bounds__(64 * XS_WAVES) void keys_split_kernel(const u64 *__
     mine += h[u];
   }
   int cum = (int)xk_scan((uint32_t)mine) - mine;
-  const int nkeep = kp - 1 - (with_min ? 1 : 0);
-  const int cap = nkeep;
+  const int cap = kp - 1;
   int fl = HT_NB;                       // the lowest bucket of mine that still admits <= cap keys
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
@@ -139,106 +138,45 @@ __global__ __launch_bounds__(64 * XS_WAVES) void keys_split_kernel(const u64 *__
     const u64 o = (u64)__shfl_xor((unsigned long long)best, off);
     best = o > best ? o : best;
   }
-  if (with_min) {
+  if (rowmin_out) {                     // wave-uniform
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const u64 o = (u64)__shfl_xor((unsigned long long)least, off);
       least = o < least ? o : least;
     }
   }
-  for (int i = na + lane; i < nkeep; i += 64) head[row * kp + i] = 0ull;
+  for (int i = na + lane; i < kp - 1; i += 64) head[row * kp + i] = 0ull;
   if (lane == 0) {
-    if (with_min) head[row * kp + kp - 2] = nv >= k ? least : 0ull;
     head[row * kp + kp - 1] = best;
     floor_out[row] = floor_b;
+    if (rowmin_out) rowmin_out[row] = nv >= k ? least : 0ull;
   }
 }
 
-// ---- owner: merge of the heads (+ phase-2 / phase-3 answers) ---------------------------------
-// heads [S, nq, kp]: kin key slots per head, then (mslot >= 0) M and (tslot >= 0) T; answers:
-// xbuf [XS, nq + xcap] as keys_extras_kernel / keys_rescan_kernel fill it (per source nq header
-// words count << 32 | start, then xcap payload slots).
+// ---- owner: merge of the heads (+ phase-2 answers) ------------------------------------------
+// heads [S, nq, kp]; extras (round 2): xbuf [S, nq + xcap] as keys_extras_kernel fills it (per
+// source nq header words count << 32 | start, then xcap payload slots).
 // Round 1 (bounds != null): out_keys [nq, k] = the best k keys seen (set, 0 padded);
 //   bounds [S, nq] = B if shard s must answer (T_s > B) else XK_NONE; need[q] = any shard asked.
 // Round 2 (I != null): I [nq, k] = ids of the exact top-k (set, -1 padded), D optional scores;
-//   queries with need[q] == 0 only convert prev_keys [nq, k]. With req != null (phase 3 armed):
-//   fin_keys [nq, k] = the keys behind I, req [S, nq, 2] = (B', M_s) where shard s must scan the
-//   query again with the full k (M_s > B' = the k-th best key of the result, 0 if fewer than k)
-//   else (XK_NONE, 0), need3[q] = any such shard, *n3 += the number of requests.
-struct MergeArgs {
-  const u64 *heads;
-  int S, nq, kp, kin, tslot, mslot, k;
-  const u64 *xbuf;
-  int XS;
-  long long xcap;
-  const u64 *prev_keys;
-  int32_t *need;
-  u64 *out_keys, *bounds;
-  int64_t *I;
-  float *D;
-  int sorted;
-  u64 *fin_keys, *req;
-  int32_t *need3;
-  unsigned int *n3;
-};
-
+//   queries with need[q] == 0 only convert prev_keys [nq, k].
 template <int CAP>
-__global__ __launch_bounds__(HT_NT) void keys_merge_kernel(const MergeArgs a) {
+__global__ __launch_bounds__(HT_NT) void keys_merge_kernel(
+    const u64 *__restrict__ heads, int S, int nq, int kp, int k, const u64 *__restrict__ xbuf,
+    long long xcap, const u64 *__restrict__ prev_keys,
+    int32_t *__restrict__ need, u64 *__restrict__ out_keys, u64 *__restrict__ bounds,
+    int64_t *__restrict__ I, float *__restrict__ D, int sorted) {
   using TopK = HistTopK<CAP, HT_NT * 2>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ u64 s_min;
   __shared__ int s_cnt, s_any;
   const int tid = threadIdx.x, q = blockIdx.x;
-  const int S = a.S, nq = a.nq, kp = a.kp, k = a.k;
-  const u64 *heads = a.heads;
-  const bool round2 = a.I != nullptr;
-  // B = the k-th best key of a row of <= k keys (0 when it holds fewer): every thread gets it
-  auto row_bound = [&](const u64 *row) -> u64 {
-    if (tid == 0) {
-      s_min = XK_NONE;
-      s_cnt = 0;
-      s_any = 0;
-    }
-    __syncthreads();
-    u64 m = XK_NONE;
-    int c = 0;
+  const bool round2 = I != nullptr;
+  if (round2 && need && need[q] == 0 && !sorted) {   // nothing was asked for: the round-1 set stands
     for (int i = tid; i < k; i += HT_NT) {
-      const u64 key = row[i];
-      if (key) {
-        m = key < m ? key : m;
-        ++c;
-      }
-    }
-    atomicMin(&s_min, m);
-    atomicAdd(&s_cnt, c);
-    __syncthreads();
-    return s_cnt >= k ? s_min : 0ull;
-  };
-  // phase 3: which shards may have dropped a key that belongs to the result?
-  auto third = [&](const u64 *row) {
-    const u64 B = row_bound(row);
-    for (int s = tid; s < S; s += HT_NT) {
-      const u64 M = heads[((size_t)s * nq + q) * kp + a.mslot];
-      const bool ask = M != 0ull && M > B;
-      a.req[((size_t)s * nq + q) * 2] = ask ? B : XK_NONE;
-      a.req[((size_t)s * nq + q) * 2 + 1] = ask ? M : 0ull;
-      if (ask) {
-        s_any = 1;
-        atomicAdd(a.n3, 1u);
-      }
-    }
-    if (a.fin_keys)
-      for (int i = tid; i < k; i += HT_NT) a.fin_keys[(size_t)q * k + i] = row[i];
-    __syncthreads();
-    if (tid == 0) a.need3[q] = s_any;
-  };
-  if (round2 && a.need && a.need[q] == 0 && !a.sorted) {   // nothing was asked for: the earlier set stands
-    const u64 *prev = a.prev_keys + (size_t)q * k;
-    if (a.req) third(prev);
-    for (int i = tid; i < k; i += HT_NT) {
-      const u64 key = prev[i];
-      a.I[(size_t)q * k + i] = key ? (int64_t)key_id(key) : -1;
-      if (a.D) a.D[(size_t)q * k + i] = key ? key_score(key) : -3.402823466e+38f;
+      const u64 key = prev_keys[(size_t)q * k + i];
+      I[(size_t)q * k + i] = key ? (int64_t)key_id(key) : -1;
+      if (D) D[(size_t)q * k + i] = key ? key_score(key) : -3.402823466e+38f;
     }
     return;
   }
@@ -259,13 +197,12 @@ __global__ __launch_bounds__(HT_NT) void keys_merge_kernel(const MergeArgs a) {
       top.end_round(appended);
     }
   };
-  // heads: the M / T slots skipped. When all S * kin slots fit the key buffer
+  // heads: slot kp-1 (the held-back key) skipped. When all S * (kp - 1) slots fit the key buffer
   // (the two-phase exchange's own shape: ceil(2k / S) keys from each of S shards) they go straight
   // into it, counted in the histogram -- no rounds, no per-key reservations; empty slots stay
   // (every consumer of the buffer skips zeros). Otherwise 64-entry chunks of the S lists
   // interleaved through the streaming offers, as topk_merge_hist_kernel does.
-  const int kin = a.kin;
-  const bool answers = round2 && a.xbuf && (!a.need || a.need[q] != 0);
+  const int kin = kp - 1;
   if (S * kin <= CAP) {
     const int total = S * kin;
     for (int i = tid; i < total; i += HT_NT) {
@@ -278,7 +215,7 @@ __global__ __launch_bounds__(HT_NT) void keys_merge_kernel(const MergeArgs a) {
     top.fill = total;
     if (tid == 0) top.ctl[TopK::C_FILL] = total;
     __syncthreads();
-    if (answers) {      // answers follow through the streaming offers: they need a round's worth of room
+    if (round2 && xbuf) {      // answers follow through the streaming offers: they need a round's worth of room
       top.begin_round();
       top.end_round(0);
     }
@@ -289,57 +226,141 @@ __global__ __launch_bounds__(HT_NT) void keys_merge_kernel(const MergeArgs a) {
       return j < kin ? heads[((size_t)s * nq + q) * kp + j] : 0ull;
     }, kc * S * 64);
   }
-  if (answers) {
-    for (int s = 0; s < a.XS; ++s) {                // block-uniform
-      const u64 *src = a.xbuf + (size_t)s * ((size_t)nq + (size_t)a.xcap);
+  if (round2 && xbuf) {
+    for (int s = 0; s < S; ++s) {                // block-uniform
+      const u64 *src = xbuf + (size_t)s * ((size_t)nq + (size_t)xcap);
       const u64 h = src[q];
       const int cnt = (int)(h >> 32);
       const u64 *pay = src + nq + (size_t)(uint32_t)h;
       if (cnt > 0) stream([&](int v) -> u64 { return v < cnt ? pay[v] : 0ull; }, cnt);
     }
   }
-  u64 *row = (round2 ? reinterpret_cast<u64 *>(a.I) : a.out_keys) + (size_t)q * k;
-  if (round2 && a.sorted)      // rows under (score desc, id asc), as the unsharded index returns them
+  u64 *row = (round2 ? reinterpret_cast<u64 *>(I) : out_keys) + (size_t)q * k;
+  if (round2 && sorted)      // rows under (score desc, id asc), as the unsharded index returns them
     top.finish(nullptr, reinterpret_cast<int64_t *>(row), nullptr);
   else
     top.finish_set(nullptr, reinterpret_cast<int64_t *>(row), nullptr,
                    reinterpret_cast<u64 *>(smem + TopK::lds_bytes()));
   __syncthreads();
-  __threadfence_block();
   if (round2) {                                  // keys -> ids in place (every thread its own slots)
-    if (a.req) {
-      third(row);
-      __syncthreads();
-    }
+    __threadfence_block();
     for (int i = tid; i < k; i += HT_NT) {
       const u64 key = row[i];
-      if (a.D) a.D[(size_t)q * k + i] = key ? key_score(key) : -3.402823466e+38f;
-      a.I[(size_t)q * k + i] = key ? (int64_t)key_id(key) : -1;
+      if (D) D[(size_t)q * k + i] = key ? key_score(key) : -3.402823466e+38f;
+      I[(size_t)q * k + i] = key ? (int64_t)key_id(key) : -1;
     }
     return;
   }
   // round 1: B = the k-th best key seen (0 when fewer than k were), then the question to every shard
-  const u64 B = row_bound(row);
+  if (tid == 0) {
+    s_min = XK_NONE;
+    s_cnt = 0;
+    s_any = 0;
+  }
+  __syncthreads();
+  __threadfence_block();
+  {
+    u64 m = XK_NONE;
+    int c = 0;
+    for (int i = tid; i < k; i += HT_NT) {
+      const u64 key = row[i];
+      if (key) {
+        m = key < m ? key : m;
+        ++c;
+      }
+    }
+    atomicMin(&s_min, m);
+    atomicAdd(&s_cnt, c);
+  }
+  __syncthreads();
+  const u64 B = s_cnt >= k ? s_min : 0ull;
   for (int s = tid; s < S; s += HT_NT) {
-    const u64 T = heads[((size_t)s * nq + q) * kp + a.tslot];
+    const u64 T = heads[((size_t)s * nq + q) * kp + kp - 1];
     const bool ask = T > B;                      // T == 0: nothing held back
-    a.bounds[(size_t)s * nq + q] = ask ? B : XK_NONE;
+    bounds[(size_t)s * nq + q] = ask ? B : XK_NONE;
     if (ask) s_any = 1;
   }
   __syncthreads();
-  if (tid == 0) a.need[q] = s_any;
+  if (tid == 0) need[q] = s_any;
 }
 
-// ---- phase 2 / phase 3 on the shard: answers into one buffer per destination ------------------
-// xbuf [W, nq + xcap]: per destination nq header words (count << 32 | start) followed by xcap
-// payload slots; cursor [W] (zeroed by the caller) hands out the payload; *overflow is raised when
-// a destination's payload is full. kk[PER]: this thread's keys of the row, 0 = not wanted.
-template <int PER>
-__device__ __forceinline__ void answer_row(u64 (&kk)[PER], int c, int dst, int q, int nq, long long xcap,
-                                           u64 *__restrict__ xbuf, unsigned int *__restrict__ cursor,
-                                           int32_t *__restrict__ overflow, int *part, unsigned int *s_start) {
+// ---- phase 2 on the shard: the keys outside the head above the owner's bound -----------------
+// Which rows need a second scan with the full k? Those whose bound lies below the smallest key
+// of a FULL row: a dropped key could be above the bound. rows destination-major. rowlist [R]
+// (zero-initialised by the caller: slots past the count stay valid row numbers) receives the
+// rows, rmap [nrows] their slot or -1, *count the number (the GATE of the scan launch that
+// follows: a device-side count, nothing returns to the host); more than R: *overflow = 1 (the
+// caller repeats the batch with k-deep rows) and the row keeps rmap = -1.
+__global__ void rescan_list_kernel(const u64 *__restrict__ bounds, const u64 *__restrict__ rowmin,
+                                   int64_t nrows, int R, int64_t *__restrict__ rowlist,
+                                   int32_t *__restrict__ rmap, int *__restrict__ count,
+                                   int32_t *__restrict__ overflow) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool need = false;
+  if (i < nrows) {
+    const u64 B = bounds[i], M = rowmin[i];
+    need = B != XK_NONE && M != 0ull && M > B;
+  }
+  const unsigned long long m = __ballot(need);
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (m && lane == 0) base = atomicAdd(count, __popcll(m));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (i < nrows) {
+    int slot = -1;
+    if (need) {
+      slot = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (slot < R) {
+        rowlist[slot] = i;
+      } else {
+        slot = -1;
+        *overflow = 1;
+      }
+    }
+    rmap[i] = slot;
+  }
+}
+
+// rows are destination-major: row = dst * nq + q. xbuf [W, nq + xcap]: per destination nq
+// header words (count << 32 | start) followed by xcap payload slots; cursor [W] (zeroed by the
+// caller) hands out the payload; *overflow is raised when a destination's payload is full.
+// rmap != null: a row with rmap[row] >= 0 answers from K3 [*, k3], its second scan with the
+// full k (every key above the bound that is not in the head: held back or dropped the first
+// time), the others from K [*, k] as before.
+__global__ __launch_bounds__(256) void keys_extras_kernel(const u64 *__restrict__ K, int k,
+                                                          const int32_t *__restrict__ floor_in,
+                                                          const u64 *__restrict__ bounds, int nq,
+                                                          long long xcap, u64 *__restrict__ xbuf,
+                                                          unsigned int *__restrict__ cursor,
+                                                          int32_t *__restrict__ overflow,
+                                                          const int32_t *__restrict__ rmap,
+                                                          const u64 *__restrict__ K3, int k3) {
+  __shared__ int part[8];
+  __shared__ unsigned int s_start;
   const int tid = threadIdx.x;
+  const size_t row = blockIdx.x;
+  const int dst = (int)(row / nq), q = (int)(row % nq);
   u64 *hdr = xbuf + (size_t)dst * (nq + xcap), *pay = hdr + nq;
+  const u64 B = bounds[row];
+  if (B == XK_NONE) {                            // block-uniform
+    if (tid == 0) hdr[q] = 0ull;
+    return;
+  }
+  constexpr int PER = 8;
+  const int floor_b = floor_in[row];
+  const int slot = rmap ? rmap[row] : -1;        // block-uniform
+  const u64 *src = slot >= 0 ? K3 + (size_t)slot * k3 : K + row * k;
+  const int width = slot >= 0 ? k3 : k;
+  u64 kk[PER];
+  int c = 0;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = tid + u * 256;
+    kk[u] = i < width ? src[i] : 0ull;
+    // outside the head = below the row's bucket floor (the split's own test); wanted = above the bound
+    if (kk[u] <= B || score_bucket(key_score(kk[u])) >= floor_b) kk[u] = 0ull;
+    c += kk[u] != 0ull;
+  }
   int tot;
   int pos = block_excl_scan<4>(c, part, tid, tot);
   if (tid == 0) {
@@ -348,195 +369,56 @@ __device__ __forceinline__ void answer_row(u64 (&kk)[PER], int c, int dst, int q
       *overflow = 1;
       st = 0xFFFFFFFFu;
     }
-    *s_start = st;
+    s_start = st;
     hdr[q] = st == 0xFFFFFFFFu ? 0ull : (((u64)tot << 32) | st);
   }
   __syncthreads();
-  const unsigned int st = *s_start;
+  const unsigned int st = s_start;
   if (st == 0xFFFFFFFFu) return;
 #pragma unroll
   for (int u = 0; u < PER; ++u)
     if (kk[u]) pay[st + pos++] = kk[u];
 }
 
-// phase 2: the held-back keys (below the row's bucket floor) above the owner's bound. Rows are
-// destination-major: row = dst * nq + q.
-__global__ __launch_bounds__(256) void keys_extras_kernel(const u64 *__restrict__ K, int k,
-                                                          const int32_t *__restrict__ floor_in,
-                                                          const u64 *__restrict__ bounds, int nq,
-                                                          long long xcap, u64 *__restrict__ xbuf,
-                                                          unsigned int *__restrict__ cursor,
-                                                          int32_t *__restrict__ overflow) {
-  __shared__ int part[8];
-  __shared__ unsigned int s_start;
-  const int tid = threadIdx.x;
-  const size_t row = blockIdx.x;
-  const int dst = (int)(row / nq), q = (int)(row % nq);
-  const u64 B = bounds[row];
-  if (B == XK_NONE) {                            // block-uniform
-    if (tid == 0) xbuf[(size_t)dst * (nq + xcap) + q] = 0ull;
-    return;
-  }
-  constexpr int PER = 8;
-  const int floor_b = floor_in[row];
-  u64 kk[PER];
-  int c = 0;
-#pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int i = tid + u * 256;
-    kk[u] = i < k ? K[row * k + i] : 0ull;
-    // held back = below the row's bucket floor (the split's own test); wanted = above the bound
-    if (kk[u] <= B || score_bucket(key_score(kk[u])) >= floor_b) kk[u] = 0ull;
-    c += kk[u] != 0ull;
-  }
-  answer_row<PER>(kk, c, dst, q, nq, xcap, xbuf, cursor, overflow, part, &s_start);
-}
-
-// phase 3: K3 [n3, k] = the FULL-k rows of the queries an owner asked about, rowidx [n3] = their
-// destination-major row (dst * nq + q), req [W * nq, 2] = (B', M) as the owners sent them. The
-// answer of a row = its keys strictly between B' and M (everything at or above M travelled in
-// phases 1-2). xbuf must be zeroed by the caller (rows nobody asked about keep an empty header).
-__global__ __launch_bounds__(256) void keys_rescan_kernel(const u64 *__restrict__ K3, int k,
-                                                          const int64_t *__restrict__ rowidx,
-                                                          const u64 *__restrict__ req, int nq,
-                                                          long long xcap, u64 *__restrict__ xbuf,
-                                                          unsigned int *__restrict__ cursor,
-                                                          int32_t *__restrict__ overflow) {
-  __shared__ int part[8];
-  __shared__ unsigned int s_start;
-  const int tid = threadIdx.x;
-  const size_t r = blockIdx.x;
-  const int64_t row = rowidx[r];
-  const int dst = (int)(row / nq), q = (int)(row % nq);
-  const u64 B = req[2 * row], M = req[2 * row + 1];
-  constexpr int PER = 8;
-  u64 kk[PER];
-  int c = 0;
-#pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int i = tid + u * 256;
-    kk[u] = i < k ? K3[r * k + i] : 0ull;
-    if (B == XK_NONE || kk[u] <= B || kk[u] >= M) kk[u] = 0ull;
-    c += kk[u] != 0ull;
-  }
-  answer_row<PER>(kk, c, dst, q, nq, xcap, xbuf, cursor, overflow, part, &s_start);
-}
-
-// rows of req [nrows, 2] that carry a request, compacted (ascending order is NOT guaranteed; the
-// answers are addressed through headers, so any order gives the same result): rowidx, *count
-__global__ void req_rows_kernel(const u64 *__restrict__ req, int64_t nrows, int64_t *__restrict__ rowidx,
-                                unsigned int *__restrict__ count) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool ask = i < nrows && req[2 * i] != XK_NONE;
-  const unsigned long long m = __ballot(ask);
-  if (!m) return;
-  const int lane = threadIdx.x & 63;
-  unsigned int base = 0;
-  if (lane == 0) base = atomicAdd(count, (unsigned int)__popcll(m));
-  base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-  if (ask) rowidx[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
-}
-
-int keys_split(const u64 *K, int64_t nrows, int k, int kp, u64 *head, int32_t *floor_out, int with_min) {
+int keys_split(const u64 *K, int64_t nrows, int k, int kp, u64 *head, int32_t *floor_out, u64 *rowmin_out) {
   if (nrows <= 0) return ASL_OK;
   const dim3 grid((unsigned)cdiv(nrows, XS_WAVES)), block(64 * XS_WAVES);
   if (k <= 256)
-    hipLaunchKernelGGL(keys_split_kernel<4>, grid, block, 0, stream(), K, nrows, k, kp, with_min, head, floor_out);
+    hipLaunchKernelGGL(keys_split_kernel<4>, grid, block, 0, stream(), K, nrows, k, kp, head, floor_out, rowmin_out);
   else if (k <= 1024)
-    hipLaunchKernelGGL(keys_split_kernel<16>, grid, block, 0, stream(), K, nrows, k, kp, with_min, head, floor_out);
+    hipLaunchKernelGGL(keys_split_kernel<16>, grid, block, 0, stream(), K, nrows, k, kp, head, floor_out, rowmin_out);
   else
-    hipLaunchKernelGGL(keys_split_kernel<32>, grid, block, 0, stream(), K, nrows, k, kp, with_min, head, floor_out);
+    hipLaunchKernelGGL(keys_split_kernel<32>, grid, block, 0, stream(), K, nrows, k, kp, head, floor_out, rowmin_out);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
 
-static int launch_merge(const MergeArgs &a) {
-  if (a.nq <= 0) return ASL_OK;
-  const size_t lds = HistTopK<2048, HT_NT * 2>::lds_bytes() + (size_t)2048 * 8;
-  hipLaunchKernelGGL((keys_merge_kernel<2048>), dim3(a.nq), dim3(HT_NT), lds, stream(), a);
-  ASL_CHECK_LAUNCH();
-  return ASL_OK;
-}
-
-// heads [S, nq, kp] with nkeep = kp - 1 - with_min key slots, then M (with_min), then T
 int keys_merge(const u64 *heads, int S, int nq, int kp, int k, const u64 *xbuf, long long xcap,
                const u64 *prev_keys, int32_t *need, u64 *out_keys, u64 *bounds, int64_t *I, float *D,
-               int sorted, int with_min, u64 *fin_keys, u64 *req, int32_t *need3, unsigned int *n3) {
-  MergeArgs a;
-  a.heads = heads;
-  a.S = S;
-  a.nq = nq;
-  a.kp = kp;
-  a.kin = kp - 1 - (with_min ? 1 : 0);
-  a.tslot = kp - 1;
-  a.mslot = with_min ? kp - 2 : -1;
-  a.k = k;
-  a.xbuf = xbuf;
-  a.XS = S;
-  a.xcap = xcap;
-  a.prev_keys = prev_keys;
-  a.need = need;
-  a.out_keys = out_keys;
-  a.bounds = bounds;
-  a.I = I;
-  a.D = D;
-  a.sorted = sorted;
-  a.fin_keys = with_min ? fin_keys : nullptr;
-  a.req = with_min ? req : nullptr;
-  a.need3 = need3;
-  a.n3 = n3;
-  return launch_merge(a);
-}
-
-// phase 3 on the owner: fin_keys [nq, k] (the result of phases 1-2) + the answers xbuf
-// [W, nq + xcap] of the W shards -> I / D [nq, k]; queries with need3[q] == 0 keep their set
-int keys_merge3(const u64 *fin_keys, int W, int nq, int k, const u64 *xbuf, long long xcap,
-                const int32_t *need3, int64_t *I, float *D, int sorted) {
-  MergeArgs a;
-  a.heads = fin_keys;
-  a.S = 1;
-  a.nq = nq;
-  a.kp = k;
-  a.kin = k;
-  a.tslot = a.mslot = -1;
-  a.k = k;
-  a.xbuf = xbuf;
-  a.XS = W;
-  a.xcap = xcap;
-  a.prev_keys = fin_keys;
-  a.need = const_cast<int32_t *>(need3);
-  a.out_keys = a.bounds = nullptr;
-  a.I = I;
-  a.D = D;
-  a.sorted = sorted;
-  a.fin_keys = a.req = nullptr;
-  a.need3 = nullptr;
-  a.n3 = nullptr;
-  return launch_merge(a);
+               int sorted) {
+  if (nq <= 0) return ASL_OK;
+  const size_t lds = HistTopK<2048, HT_NT * 2>::lds_bytes() + (size_t)2048 * 8;
+  hipLaunchKernelGGL((keys_merge_kernel<2048>), dim3(nq), dim3(HT_NT), lds, stream(), heads, S, nq, kp,
+                     k, xbuf, xcap, prev_keys, need, out_keys, bounds, I, D, sorted);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
 }
 
 int keys_extras(const u64 *K, const int32_t *floor_in, int64_t nrows, int k, const u64 *bounds, int nq,
-                long long xcap, u64 *xbuf, unsigned int *cursor, int32_t *overflow) {
+                long long xcap, u64 *xbuf, unsigned int *cursor, int32_t *overflow, const int32_t *rmap,
+                const u64 *K3, int k3) {
   if (nrows <= 0) return ASL_OK;
   hipLaunchKernelGGL(keys_extras_kernel, dim3((unsigned)nrows), dim3(256), 0, stream(), K, k, floor_in, bounds,
-                     nq, xcap, xbuf, cursor, overflow);
+                     nq, xcap, xbuf, cursor, overflow, rmap, K3, k3);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
 
-int keys_rescan(const u64 *K3, int64_t n3, int k, const int64_t *rowidx, const u64 *req, int nq, long long xcap,
-                u64 *xbuf, unsigned int *cursor, int32_t *overflow) {
-  if (n3 <= 0) return ASL_OK;
-  hipLaunchKernelGGL(keys_rescan_kernel, dim3((unsigned)n3), dim3(256), 0, stream(), K3, k, rowidx, req, nq,
-                     xcap, xbuf, cursor, overflow);
-  ASL_CHECK_LAUNCH();
-  return ASL_OK;
-}
-
-int req_rows(const u64 *req, int64_t nrows, int64_t *rowidx, unsigned int *count) {
+int rescan_list(const u64 *bounds, const u64 *rowmin, int64_t nrows, int R, int64_t *rowlist, int32_t *rmap,
+                int *count, int32_t *overflow) {
   if (nrows <= 0) return ASL_OK;
-  hipLaunchKernelGGL(req_rows_kernel, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, stream(), req, nrows,
-                     rowidx, count);
+  hipLaunchKernelGGL(rescan_list_kernel, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, stream(), bounds, rowmin,
+                     nrows, R, rowlist, rmap, count, overflow);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -548,74 +430,60 @@ using namespace asl;
 extern "C" {
 
 // see include/annsolo_mi.h
-int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, int32_t with_min, const int64_t *K, int64_t *head,
-                   int32_t *floor_out) {
+int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, const int64_t *K, int64_t *head, int32_t *floor_out,
+                   int64_t *rowmin_out) {
   clear_error();
-  const int nkeep = kp - 1 - (with_min ? 1 : 0);
-  if (nrows < 0 || k < 1 || k > 2048 || nkeep < 1 || nkeep > k || !K || !head || !floor_out)
-    return fail(ASL_ERR_INVALID, "keys_split: need 1 <= k <= 2048, 1 <= key slots <= k and non-null device arrays");
+  if (nrows < 0 || k < 1 || k > 2048 || kp < 2 || kp > k + 1 || !K || !head || !floor_out)
+    return fail(ASL_ERR_INVALID, "keys_split: need 1 <= k <= 2048, 2 <= kp <= k + 1 and non-null device arrays");
   ASL_TRY(ensure_device());
   return keys_split(reinterpret_cast<const u64 *>(K), nrows, k, kp, reinterpret_cast<u64 *>(head), floor_out,
-                    with_min ? 1 : 0);
+                    reinterpret_cast<u64 *>(rowmin_out));
 }
 
-int asl_keys_merge_heads(int32_t S, int32_t nq, int32_t kp, int32_t with_min, int32_t k, const int64_t *heads,
+int asl_keys_merge_heads(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
                          int64_t *out_keys, int64_t *bounds, int32_t *need) {
   clear_error();
-  if (S < 1 || nq < 0 || kp - (with_min ? 1 : 0) < 2 || k < 1 || k + 768 > 2048 || !heads || !out_keys || !bounds || !need)
-    return fail(ASL_ERR_INVALID, "keys_merge_heads: need S >= 1, at least one key slot, 1 <= k <= 1280 and non-null device arrays");
+  if (S < 1 || nq < 0 || kp < 2 || k < 1 || k + 768 > 2048 || !heads || !out_keys || !bounds || !need)
+    return fail(ASL_ERR_INVALID, "keys_merge_heads: need S >= 1, kp >= 2, 1 <= k <= 1280 and non-null device arrays");
   ASL_TRY(ensure_device());
   return keys_merge(reinterpret_cast<const u64 *>(heads), S, nq, kp, k, nullptr, 0, nullptr, need,
-                    reinterpret_cast<u64 *>(out_keys), reinterpret_cast<u64 *>(bounds), nullptr, nullptr, 0,
-                    with_min ? 1 : 0, nullptr, nullptr, nullptr, nullptr);
+                    reinterpret_cast<u64 *>(out_keys), reinterpret_cast<u64 *>(bounds), nullptr, nullptr, 0);
+}
+
+int asl_keys_rescan_list(int64_t nrows, const int64_t *bounds, const int64_t *rowmin, int32_t R, int64_t *rowlist,
+                         int32_t *rmap, int32_t *count, int32_t *overflow) {
+  clear_error();
+  if (nrows < 0 || R < 1 || !bounds || !rowmin || !rowlist || !rmap || !count || !overflow)
+    return fail(ASL_ERR_INVALID, "keys_rescan_list: bad argument");
+  ASL_TRY(ensure_device());
+  return rescan_list(reinterpret_cast<const u64 *>(bounds), reinterpret_cast<const u64 *>(rowmin), nrows, R, rowlist,
+                     rmap, count, overflow);
 }
 
 int asl_keys_extras(int32_t W, int32_t nq, int32_t k, const int64_t *K, const int32_t *floor_in,
-                    const int64_t *bounds, int64_t xcap, int64_t *xbuf, int32_t *cursor, int32_t *overflow) {
+                    const int64_t *bounds, int64_t xcap, int64_t *xbuf, int32_t *cursor, int32_t *overflow,
+                    const int32_t *rmap, const int64_t *K3, int32_t k3) {
   clear_error();
   if (W < 1 || nq < 0 || k < 1 || k > 2048 || xcap < 0 || xcap >= 0xFFFFFFFFLL || !K || !floor_in || !bounds || !xbuf ||
-      !cursor || !overflow)
+      !cursor || !overflow || (rmap && (!K3 || k3 < k || k3 > 2048)))
     return fail(ASL_ERR_INVALID, "keys_extras: bad argument");
   ASL_TRY(ensure_device());
   return keys_extras(reinterpret_cast<const u64 *>(K), floor_in, (int64_t)W * nq, k,
                      reinterpret_cast<const u64 *>(bounds), nq, xcap, reinterpret_cast<u64 *>(xbuf),
-                     reinterpret_cast<unsigned int *>(cursor), overflow);      // nothing waits here
+                     reinterpret_cast<unsigned int *>(cursor), overflow, rmap,
+                     reinterpret_cast<const u64 *>(K3), k3);      // nothing waits here
 }
 
-int asl_keys_merge_final(int32_t S, int32_t nq, int32_t kp, int32_t with_min, int32_t k, const int64_t *heads,
+int asl_keys_merge_final(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
                          const int64_t *xbuf, int64_t xcap, const int64_t *prev_keys, const int32_t *need,
-                         float *D, int64_t *I, int64_t *fin_keys, int64_t *req, int32_t *need3, int32_t *n3) {
+                         float *D, int64_t *I) {
   clear_error();
-  if (S < 1 || nq < 0 || kp - (with_min ? 1 : 0) < 2 || k < 1 || k + 768 > 2048 || !heads || !prev_keys || !I)
+  if (S < 1 || nq < 0 || kp < 2 || k < 1 || k + 768 > 2048 || !heads || !prev_keys || !I)
     return fail(ASL_ERR_INVALID, "keys_merge_final: bad argument");
-  if (with_min && (!fin_keys || !req || !need3 || !n3))
-    return fail(ASL_ERR_INVALID, "keys_merge_final: phase 3 needs fin_keys, req, need3 and n3");
   ASL_TRY(ensure_device());
   return keys_merge(reinterpret_cast<const u64 *>(heads), S, nq, kp, k, reinterpret_cast<const u64 *>(xbuf),
                     xbuf ? xcap : 0, reinterpret_cast<const u64 *>(prev_keys), const_cast<int32_t *>(need),
-                    nullptr, nullptr, I, D, 0, with_min ? 1 : 0, reinterpret_cast<u64 *>(fin_keys),
-                    reinterpret_cast<u64 *>(req), need3, reinterpret_cast<unsigned int *>(n3));
-}
-
-int asl_keys_rescan(int32_t W, int32_t nq, int32_t k, int64_t n3, const int64_t *K3, const int64_t *rowidx,
-                    const int64_t *req, int64_t xcap, int64_t *xbuf, int32_t *cursor, int32_t *overflow) {
-  clear_error();
-  if (W < 1 || nq < 0 || k < 1 || k > 2048 || n3 < 0 || xcap < 0 || xcap >= 0xFFFFFFFFLL || !req || !xbuf || !cursor ||
-      !overflow || (n3 > 0 && (!K3 || !rowidx)))
-    return fail(ASL_ERR_INVALID, "keys_rescan: bad argument");
-  ASL_TRY(ensure_device());
-  return keys_rescan(reinterpret_cast<const u64 *>(K3), n3, k, rowidx, reinterpret_cast<const u64 *>(req), nq, xcap,
-                     reinterpret_cast<u64 *>(xbuf), reinterpret_cast<unsigned int *>(cursor), overflow);
-}
-
-int asl_keys_merge3(int32_t W, int32_t nq, int32_t k, const int64_t *fin_keys, const int64_t *xbuf, int64_t xcap,
-                    const int32_t *need3, float *D, int64_t *I) {
-  clear_error();
-  if (W < 1 || nq < 0 || k < 1 || k + 768 > 2048 || !fin_keys || !xbuf || !need3 || !I)
-    return fail(ASL_ERR_INVALID, "keys_merge3: bad argument");
-  ASL_TRY(ensure_device());
-  return keys_merge3(reinterpret_cast<const u64 *>(fin_keys), W, nq, k, reinterpret_cast<const u64 *>(xbuf), xcap,
-                     need3, I, D, 0);
+                    nullptr, nullptr, I, D, 0);
 }
 
 }  // extern "C"

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
     const uint32_t *__restrict__ blk_base, const uint32_t *__restrict__ seg_tab,
     const char *__restrict__ seg_bytes, const int32_t *__restrict__ ids, int k,
     float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode,
-    const uint2 *__restrict__ ent, const int32_t *__restrict__ ent_cnt, int tab_stride) {
+    const uint2 *__restrict__ ent, const int32_t *__restrict__ ent_cnt, int tab_stride,
+    const int *__restrict__ gate) {
+  if (gate && (int)blockIdx.x >= *gate) return;      // device-side row count (see pq_scan_v3_kernel)
   constexpr float FX_SCALE = FX ? 1.0f / 4194304.0f : 1.0f;      // 2^-22, folded into the query values
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -474,7 +476,7 @@ static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse
                            const uint32_t *blk_base, const uint32_t *seg_tab,
                            const char *seg_bytes, const int32_t *ids, int k, float *D,
                            int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent,
-                           const int32_t *ent_cnt, int tab_stride) {
+                           const int32_t *ent_cnt, int tab_stride, const int *gate) {
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   const size_t lds = TopK::lds_bytes() + (size_t)FI_NW * FI_BLK * 4 + (size_t)((d + 3) & ~3) * 4 +
                      (size_t)FI_CHUNK * (sizeof(FiUnit) + 2) + 64 + (size_t)((d + 7) & ~7) * 2;
@@ -484,7 +486,7 @@ static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((flat_inv_scan_kernel<FI_CAP, FX>), dim3(nq), dim3(FI_NT), lds, stream(), xq, d,
                      coarse_I, nprobe, list_offsets, blk_offsets, blk_base, seg_tab, seg_bytes, ids,
-                     k, D, I64, I32, set_mode, ent, ent_cnt, tab_stride);
+                     k, D, I64, I32, set_mode, ent, ent_cnt, tab_stride, gate);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -496,13 +498,13 @@ int flat_inv_scan(int layout, const float *xq, int nq, int d, const int32_t *coa
                   const int32_t *list_offsets, const int32_t *blk_offsets,
                   const uint32_t *blk_base, const void *seg_tab, int tab_stride, const char *seg_bytes,
                   const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode,
-                  const uint2 *ent, const int32_t *ent_cnt) {
+                  const uint2 *ent, const int32_t *ent_cnt, const int *gate) {
   if (nq <= 0) return ASL_OK;
   const uint32_t *tab = reinterpret_cast<const uint32_t *>(seg_tab);
   const bool small = k + FI_NT + 256 <= 2048;
 #define FI_LAUNCH(CAP, FX)                                                                           \
   return launch_flat_inv<CAP, FX>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base, \
-                                  tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt, tab_stride)
+                                  tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt, tab_stride, gate)
   if (layout == 2) {
     if (small) FI_LAUNCH(2048, true);
     FI_LAUNCH(4096, true);

@@ -500,8 +500,11 @@ static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe,
 // Search with all-device arguments. Exactly one of I64 / I32 may be non-null (or both).
 int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
                         int64_t *I64, int32_t *I32, const float *pre_D = nullptr,
-                        const int32_t *pre_I = nullptr, bool set_mode = false) {
+                        const int32_t *pre_I = nullptr, bool set_mode = false, const int *gate = nullptr) {
   if (nq <= 0) return ASL_OK;
+  // gate: a device-side count -- only the first *gate rows are searched (layout-specific scans only)
+  if (gate && (!pre_I || ix->kind == ASL_INDEX_FLAT))
+    return fail(ASL_ERR_STATE, "gated search: needs the caller's probe lists and an IVF index");
   if (!ix->trained) return fail(ASL_ERR_STATE, "search: index is not trained");
   if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: k=%d outside 1..%d", k, TK_MAX_K);
   const int d = ix->d;
@@ -525,6 +528,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       const bool use_inv = ix->has_inv && ix->scan_variant == 0 && flat_inv_supported(d, k, nprobe);
       if (ix->unordered == 2 && !(use_inv && I64 && k + FLAT_KEYS_SLACK <= TK_MAX_K))
         return fail(ASL_ERR_STATE, "packed-key rows need the postings scan of IVF-Flat (sparse vectors, k <= 1280) and an int64 output");
+      if (gate && !use_inv) return fail(ASL_ERR_STATE, "gated search: needs the postings scan of IVF-Flat");
       if (use_inv) {
         ASL_TRY(ix->scan_ent.reserve((size_t)nq * 64));
         ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
@@ -537,9 +541,9 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
                                 ix->blk_offsets.p, ix->blk_base.p,
                                 fx ? (const void *)ix->inv_tab8.p : (const void *)ix->inv_tab.p,
                                 ix->tab_stride, ix->inv_data.p, ix->ids.p, k, D, I64, I32,
-                                ix->unordered ? ix->unordered : (set_mode ? 1 : 0), ix->scan_ent.p, ix->scan_cnt.p));
+                                ix->unordered ? ix->unordered : (set_mode ? 1 : 0), ix->scan_ent.p, ix->scan_cnt.p, gate));
         }
-        if (prof_counts()) {
+        if (prof_counts() && !gate) {
           // vectors scored by this launch, summed on the device (nothing waits inside a step)
           if (unsigned long long *acc = prof_scanned_dev())
             ASL_TRY(scanned_count(cI, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
@@ -580,6 +584,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   const int32_t *cI = pre_D ? pre_I : ix->coarse_I.p;
   // exact re-rank: the ADC scan returns k' > k candidates as a set, refine.hip keeps the k best
   const bool refine = ix->refine_k > k && ix->refine_rows && ix->unordered == 0;
+  if (gate && refine) return fail(ASL_ERR_STATE, "gated search: not with the exact re-rank");
   float *fin_D = D;
   int64_t *fin_I64 = I64;
   int32_t *fin_I32 = I32;
@@ -603,6 +608,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
                        pq_scan_tiled_supported(ix->pq_m, ix->ksub, k, nprobe);
     if (ix->unordered == 2 && !(tiled && I64))
       return fail(ASL_ERR_STATE, "packed-key rows need the tiled IVF-PQ scan (m = 32, 8 bits) and an int64 output");
+    if (gate && !tiled) return fail(ASL_ERR_STATE, "gated search: needs the tiled IVF-PQ scan");
     if (tiled) {
       if (!ix->cbt_ready) {
         const size_t ncb = (size_t)ix->pq_m * ix->ksub * ix->dsub;
@@ -628,7 +634,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks_t.p, ix->dsub, cD, cI,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
                          ix->ids_tiled.p, k, D, I64, I32, ix->unordered ? ix->unordered : (set_mode ? 1 : 0),
-                         ix->scan_ent.p, ix->scan_cnt.p));
+                         ix->scan_ent.p, ix->scan_cnt.p, gate));
     } else {
       ProfScope ps("scan");
       ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, cD,
@@ -636,7 +642,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
                       I64, I32));
     }
   }
-  if (prof_counts()) {
+  if (prof_counts() && !gate) {
     // vectors scored by this launch, summed on the device (nothing waits inside a step)
     if (unsigned long long *acc = prof_scanned_dev())
       ASL_TRY(scanned_count(cI, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
@@ -1281,6 +1287,25 @@ int asl_index_search_preassigned(asl_index_t *ix, int32_t nq, const float *xq, i
   ASL_TRY(dI.finish());
   if (dD.to_host() || dI.to_host() || dq.own.p || dcD.own.p || dcI.own.p) ASL_TRY(sync_stream());
   return ASL_OK;
+}
+
+// search_preassigned over a list whose length only the device knows: a launch for `cap` rows
+// of which the first *count (device memory) are searched; the other rows of D / I are left
+// untouched. Device pointers only; never waits.
+int asl_index_search_gated(asl_index_t *ix, int32_t cap, const float *xq, int32_t k, int32_t nprobe,
+                           const float *coarse_D, const int32_t *coarse_I, float *D, int64_t *I,
+                           const int32_t *count) {
+  clear_error();
+  if (!ix || ix->kind == ASL_INDEX_FLAT) return fail(ASL_ERR_INVALID, "search_gated: IVF index required");
+  if (cap <= 0) return ASL_OK;
+  if (!xq || !I || !coarse_D || !coarse_I || !count) return fail(ASL_ERR_INVALID, "search_gated: null argument");
+  if (nprobe < 1 || nprobe > ix->nlist) return fail(ASL_ERR_INVALID, "search_gated: nprobe outside 1..nlist");
+  ASL_TRY(ensure_device());
+  if (!is_device_ptr(xq) || !is_device_ptr(I) || !is_device_ptr(coarse_D) || !is_device_ptr(coarse_I) ||
+      !is_device_ptr(count) || (D && !is_device_ptr(D)))
+    return fail(ASL_ERR_INVALID, "search_gated: device pointers only");
+  return index_search_device(ix, cap, xq, k, nprobe, D, I, nullptr, coarse_D, coarse_I, false,
+                             reinterpret_cast<const int *>(count));
 }
 
 int asl_topk_merge(int32_t S, int32_t nq, int32_t k, const float *Ds, const int64_t *Is,

@@ -57,7 +57,8 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                const int32_t *list_offsets, const int32_t *tile_offsets,
                const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
                int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent = nullptr,
-               const int32_t *ent_cnt = nullptr);   // ent / ent_cnt: list_nonzeros (64 entries per query)
+               const int32_t *ent_cnt = nullptr,    // ent / ent_cnt: list_nonzeros (64 entries per query)
+               const int *gate = nullptr);          // device-side row count: workgroups past it return at once
 int tile_codes(const uint8_t *codes, const int32_t *ids, const int32_t *dst_slot, int64_t n,
                int64_t ntiles, uint8_t *codes_tiled, int32_t *ids_tiled);
 // dimension-major IVF-Flat (flat_scan.hip): blocks of FI_BLK vectors with per-dimension postings
@@ -70,7 +71,7 @@ int flat_inv_scan(int layout, const float *xq, int nq, int d, const int32_t *coa
                   const int32_t *list_offsets, const int32_t *blk_offsets,
                   const uint32_t *blk_base, const void *seg_tab, int tab_stride, const char *seg_bytes,
                   const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode,
-                  const uint2 *ent, const int32_t *ent_cnt);
+                  const uint2 *ent, const int32_t *ent_cnt, const int *gate = nullptr);
 int flat_inv_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *blk_offsets, const uint32_t *seg_tab, unsigned long long *out_dev);
 uint32_t inv_place_block(const uint32_t *cnt, int d, uint32_t *tab, bool *ok);
@@ -96,24 +97,18 @@ __host__ __device__ inline bool fx22_on_grid(float x) {
   return x > 0.0f && x < 1.0f && x * 4194304.0f == rintf(x * 4194304.0f);
 }
 int quantize_fx22(float *x, int64_t n);
-// the exact top-k exchange of a sharded search (exchange.hip): heads, bounds, held-back keys,
-// and (with_min) the third phase for shard-side k_s < k
+// the exact top-k exchange of a sharded search (exchange.hip)
 int keys_split(const unsigned long long *K, int64_t nrows, int k, int kp, unsigned long long *head,
-               int32_t *floor_out, int with_min = 0);
+               int32_t *floor_out, unsigned long long *rowmin_out = nullptr);
 int keys_merge(const unsigned long long *heads, int S, int nq, int kp, int k, const unsigned long long *xbuf,
                long long xcap, const unsigned long long *prev_keys, int32_t *need,
-               unsigned long long *out_keys, unsigned long long *bounds, int64_t *I, float *D, int sorted,
-               int with_min = 0, unsigned long long *fin_keys = nullptr, unsigned long long *req = nullptr,
-               int32_t *need3 = nullptr, unsigned int *n3 = nullptr);
-int keys_merge3(const unsigned long long *fin_keys, int W, int nq, int k, const unsigned long long *xbuf,
-                long long xcap, const int32_t *need3, int64_t *I, float *D, int sorted);
+               unsigned long long *out_keys, unsigned long long *bounds, int64_t *I, float *D, int sorted);
 int keys_extras(const unsigned long long *K, const int32_t *floor_in, int64_t nrows, int k,
                 const unsigned long long *bounds, int nq, long long xcap, unsigned long long *xbuf,
-                unsigned int *cursor, int32_t *overflow);
-int keys_rescan(const unsigned long long *K3, int64_t n3, int k, const int64_t *rowidx,
-                const unsigned long long *req, int nq, long long xcap, unsigned long long *xbuf,
-                unsigned int *cursor, int32_t *overflow);
-int req_rows(const unsigned long long *req, int64_t nrows, int64_t *rowidx, unsigned int *count);
+                unsigned int *cursor, int32_t *overflow, const int32_t *rmap = nullptr,
+                const unsigned long long *K3 = nullptr, int k3 = 0);
+int rescan_list(const unsigned long long *bounds, const unsigned long long *rowmin, int64_t nrows, int R,
+                int64_t *rowlist, int32_t *rmap, int *count, int32_t *overflow);
 int flat_fx_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                  const int32_t *blk_offsets, const uint8_t *tab8, int tab_stride,
                  const uint16_t *cnt16, unsigned long long *out_dev);

@@ -60,7 +60,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ tile_offsets,
     const uint8_t *__restrict__ codes_tiled, const int32_t *__restrict__ ids_tiled, int k,
     float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode,
-    const uint2 *__restrict__ ent, const int32_t *__restrict__ ent_cnt) {
+    const uint2 *__restrict__ ent, const int32_t *__restrict__ ent_cnt, const int *__restrict__ gate) {
+  // gate: a device-side row count -- workgroups past it leave at once (a launch of fixed size over
+  // a list whose length only the device knows: the shard-side rescans of exchange.hip)
+  if (gate && (int)blockIdx.x >= *gate) return;
   static_assert(DEPTH == 1, "one round of prefetch: at 24 waves per CU a second stage only costs registers");
   constexpr int NT = 64 * NW, ROUND_TILES = NW * T, ROUND_VECS = ROUND_TILES * 64;
   using TopK = HistTopK<CAP, ROUND_VECS, NT>;
@@ -177,7 +180,7 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                      const int32_t *list_offsets, const int32_t *tile_offsets,
                      const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
                      int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent,
-                     const int32_t *ent_cnt) {
+                     const int32_t *ent_cnt, const int *gate) {
   if ((size_t)d * 4 > (size_t)CAP * 8 || dsub > 64 ||
       (size_t)d * 2 + 8 > (size_t)V3_CHUNK * sizeof(TileEnt8) || d != PQT_M * dsub)
     return fail(ASL_ERR_CAPACITY, "pq scan: d=%d too large for the LDS staging", d);
@@ -189,7 +192,7 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((pq_scan_v3_kernel<CAP, T, NW, DEPTH>), dim3(nq), dim3(64 * NW), lds, stream(), xq, d,
                      codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets,
-                     codes_tiled, ids_tiled, k, D, I64, I32, set_mode, ent, ent_cnt);
+                     codes_tiled, ids_tiled, k, D, I64, I32, set_mode, ent, ent_cnt, gate);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -203,10 +206,11 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                const float *coarse_D, const int32_t *coarse_I, int nprobe,
                const int32_t *list_offsets, const int32_t *tile_offsets,
                const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
-               int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent, const int32_t *ent_cnt) {
+               int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent, const int32_t *ent_cnt,
+               const int *gate) {
   if (nq <= 0) return ASL_OK;
 #define V3_ARGS xq, nq, d, codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets, \
-                codes_tiled, ids_tiled, k, D, I64, I32, set_mode, ent, ent_cnt
+                codes_tiled, ids_tiled, k, D, I64, I32, set_mode, ent, ent_cnt, gate
   if (k + 256 + 512 <= 2048) return launch_v3<2048, 1, 8, 1>(V3_ARGS);
   return launch_v3<4096, 1, 8, 1>(V3_ARGS);
 #undef V3_ARGS

@@ -20,7 +20,7 @@ struct asl_index;
 namespace asl {
 int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
                         int64_t *I64, int32_t *I32, const float *pre_D, const int32_t *pre_I,
-                        bool set_mode);
+                        bool set_mode, const int *gate);
 int index_dim(const asl_index *ix);
 int index_nprobe(const asl_index *ix, int nprobe);
 int index_prepare(asl_index *ix);
@@ -166,17 +166,15 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
     static DevBuf<int64_t> &Kp = *new DevBuf<int64_t>(), &Hs = *new DevBuf<int64_t>(), &Hr = *new DevBuf<int64_t>(),
                            &Ko = *new DevBuf<int64_t>(), &Bs = *new DevBuf<int64_t>(),
                            &Br = *new DevBuf<int64_t>(), &Xs = *new DevBuf<int64_t>(), &Xr = *new DevBuf<int64_t>(),
-                           &Kf = *new DevBuf<int64_t>(), &Rs = *new DevBuf<int64_t>(), &Rr = *new DevBuf<int64_t>(),
-                           &rowidx = *new DevBuf<int64_t>(), &K3 = *new DevBuf<int64_t>(), &If = *new DevBuf<int64_t>();
+                           &Mn = *new DevBuf<int64_t>(), &rowlist = *new DevBuf<int64_t>(), &K3 = *new DevBuf<int64_t>();
     static DevBuf<int32_t> &need = *new DevBuf<int32_t>(), &flag = *new DevBuf<int32_t>(), &Fl = *new DevBuf<int32_t>(),
-                           &need3 = *new DevBuf<int32_t>(), &cI3 = *new DevBuf<int32_t>();
+                           &rmap = *new DevBuf<int32_t>(), &cI3 = *new DevBuf<int32_t>();
     static DevBuf<float> &x3 = *new DevBuf<float>(), &cD3 = *new DevBuf<float>();
     static DevBuf<unsigned int> &cursor = *new DevBuf<unsigned int>();
-    const int keys = std::min(k, (2 * k + world - 1) / world);
+    const int keys = std::min(k, (2 * k + world - 1) / world), kp = keys + 1;
     const bool second = keys < k;                          // heads hold something back
-    const int ks = second ? asl_shard_k(k, world) : k;     // the shards' own k
-    const bool third = ks < k;
-    const int kp = keys + 1 + (third ? 1 : 0);
+    const int ks = second ? asl_shard_k(k, world) : k;     // the shards' own k (exchange.hip)
+    const bool rescan = ks < k;
     const long long xcap = (long long)nq * std::max(8, k / 16);
     ASL_TRY(Kp.reserve(all * ks));
     ASL_TRY(Hs.reserve(all * kp));
@@ -186,15 +184,17 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
     ASL_TRY(Bs.reserve(all));
     ASL_TRY(Br.reserve(all));
     ASL_TRY(need.reserve((size_t)nq));
-    ASL_TRY(flag.reserve(2));          // [0] an answer buffer ran full, [1] third-phase requests of my queries
+    ASL_TRY(flag.reserve(2));          // [0] a buffer ran full, [1] rows this shard scans a second time
+    if (rescan) ASL_TRY(Mn.reserve(all));
     HIP_TRY(hipMemsetAsync(flag.p, 0, 2 * sizeof(int32_t), st));
     int prev = 0;
     ASL_TRY(index_swap_unordered(ix, 2, &prev));
-    const int rc = index_search_device(ix, (int)all, x_all.p, ks, np, nullptr, Kp.p, nullptr, cD_all.p, cI_all.p, true);
+    const int rc = index_search_device(ix, (int)all, x_all.p, ks, np, nullptr, Kp.p, nullptr, cD_all.p, cI_all.p, true,
+                                       nullptr);
     ASL_TRY(index_swap_unordered(ix, prev, nullptr));
     ASL_TRY(rc);
     ASL_TRY(keys_split(reinterpret_cast<const u64k *>(Kp.p), (int64_t)all, ks, kp, reinterpret_cast<u64k *>(Hs.p),
-                       Fl.p, third ? 1 : 0));
+                       Fl.p, rescan ? reinterpret_cast<u64k *>(Mn.p) : nullptr));
     auto all_to_all = [&](const int64_t *src, int64_t *dst, size_t per_rank) -> int {
       RCCL_TRY(R.GroupStart());
       for (int r = 0; r < world; ++r) {
@@ -206,8 +206,7 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
     };
     ASL_TRY(all_to_all(Hs.p, Hr.p, (size_t)nq * kp));
     ASL_TRY(keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, nullptr, 0, nullptr, need.p,
-                       reinterpret_cast<u64k *>(Ko.p), reinterpret_cast<u64k *>(Bs.p), nullptr, nullptr, 0,
-                       third ? 1 : 0));
+                       reinterpret_cast<u64k *>(Ko.p), reinterpret_cast<u64k *>(Bs.p), nullptr, nullptr, 0));
     bool overflow = false;
     const int64_t *xr = nullptr;
     if (second) {
@@ -216,85 +215,44 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
       ASL_TRY(cursor.reserve((size_t)world));
       ASL_TRY(all_to_all(Bs.p, Br.p, (size_t)nq));
       HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)world * sizeof(unsigned int), st));
+      const int32_t *rm = nullptr;
+      if (rescan) {
+        // rows whose bound lies below the smallest key of a full k_s-row are scanned again with the
+        // full k: a launch of `cap` workgroups gated by the device-side count (no host round trip)
+        const int cap = (int)std::max<size_t>(64, all / 16);
+        ASL_TRY(rowlist.reserve((size_t)cap));
+        ASL_TRY(rmap.reserve(all));
+        ASL_TRY(x3.reserve((size_t)cap * d));
+        ASL_TRY(cD3.reserve((size_t)cap * np));
+        ASL_TRY(cI3.reserve((size_t)cap * np));
+        ASL_TRY(K3.reserve((size_t)cap * k));
+        HIP_TRY(hipMemsetAsync(rowlist.p, 0, (size_t)cap * sizeof(int64_t), st));
+        ASL_TRY(rescan_list(reinterpret_cast<const u64k *>(Br.p), reinterpret_cast<const u64k *>(Mn.p), (int64_t)all, cap,
+                            rowlist.p, rmap.p, reinterpret_cast<int *>(flag.p + 1), flag.p));
+        ASL_TRY(gather_rows_f32(x_all.p, d, rowlist.p, cap, d, x3.p, d));
+        ASL_TRY(gather_rows_f32(cD_all.p, np, rowlist.p, cap, np, cD3.p, np));
+        ASL_TRY(gather_rows_f32(reinterpret_cast<const float *>(cI_all.p), np, rowlist.p, cap, np,
+                                reinterpret_cast<float *>(cI3.p), np));      // (4-byte words)
+        ASL_TRY(index_swap_unordered(ix, 2, &prev));
+        const int rc3 = index_search_device(ix, cap, x3.p, k, np, nullptr, K3.p, nullptr, cD3.p, cI3.p, true,
+                                            reinterpret_cast<const int *>(flag.p + 1));
+        ASL_TRY(index_swap_unordered(ix, prev, nullptr));
+        ASL_TRY(rc3);
+        rm = rmap.p;
+      }
       ASL_TRY(keys_extras(reinterpret_cast<const u64k *>(Kp.p), Fl.p, (int64_t)all, ks, reinterpret_cast<const u64k *>(Br.p),
-                          nq, xcap, reinterpret_cast<u64k *>(Xs.p), cursor.p, flag.p));
+                          nq, xcap, reinterpret_cast<u64k *>(Xs.p), cursor.p, flag.p, rm,
+                          reinterpret_cast<const u64k *>(K3.p), k));
       ASL_TRY(all_to_all(Xs.p, Xr.p, (size_t)nq + (size_t)xcap));
-      xr = Xr.p;
-    }
-    // the result of phases 1-2: final rows when the shards scanned with the full k, else the
-    // keys + the third-phase requests. (If a phase-2 buffer ran full somewhere the rows written
-    // here are discarded below.)
-    if (third) {
-      ASL_TRY(Kf.reserve((size_t)nq * k));
-      ASL_TRY(If.reserve((size_t)nq * k));
-      ASL_TRY(Rs.reserve(all * 2));
-      ASL_TRY(Rr.reserve(all * 2));
-      ASL_TRY(need3.reserve((size_t)nq));
-      ASL_TRY(keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, reinterpret_cast<const u64k *>(xr),
-                         xr ? xcap : 0, reinterpret_cast<const u64k *>(Ko.p), need.p, nullptr, nullptr, If.p, nullptr, 0,
-                         1, reinterpret_cast<u64k *>(Kf.p), reinterpret_cast<u64k *>(Rs.p), need3.p,
-                         reinterpret_cast<unsigned int *>(flag.p + 1)));
-    } else {
-      ASL_TRY(keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, reinterpret_cast<const u64k *>(xr),
-                         xr ? xcap : 0, reinterpret_cast<const u64k *>(Ko.p), need.p, nullptr, nullptr, I, D, 1));
-    }
-    if (second) {
-      // a full answer buffer ANYWHERE sends every rank down the full exchange, a third-phase
-      // request ANYWHERE sends every rank through the third phase: all ranks take the same branch
+      // a full buffer ANYWHERE sends every rank down the full exchange: all ranks take the same branch
       HIP_TRY(hipMemcpyAsync(mine.p, flag.p, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
       ASL_TRY(agree(h));
-      bool any3 = false;
-      for (int r = 0; r < world; ++r) {
-        overflow |= h[(size_t)r * 4] != 0;
-        any3 |= h[(size_t)r * 4 + 1] != 0;
-      }
-      if (!overflow && third) {
-        const long long xcap3 = xcap;
-        if (any3) {
-          // the requests travel; every shard lists the rows it was asked about, scans them again
-          // with the full k and answers with its keys strictly between B' and M
-          ASL_TRY(all_to_all(Rs.p, Rr.p, (size_t)nq * 2));
-          ASL_TRY(rowidx.reserve(all));
-          HIP_TRY(hipMemsetAsync(cursor.p, 0, sizeof(unsigned int), st));
-          ASL_TRY(req_rows(reinterpret_cast<const u64k *>(Rr.p), (int64_t)all, rowidx.p, cursor.p));
-          unsigned int n3 = 0;
-          ASL_TRY(cursor.download(&n3, 1));
-          ASL_TRY(sync_stream());
-          HIP_TRY(hipMemsetAsync(Xs.p, 0, (size_t)world * ((size_t)nq + (size_t)xcap3) * 8, st));
-          HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)world * sizeof(unsigned int), st));
-          HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int32_t), st));
-          if (n3 > 0) {
-            ASL_TRY(x3.reserve((size_t)n3 * d));
-            ASL_TRY(cD3.reserve((size_t)n3 * np));
-            ASL_TRY(cI3.reserve((size_t)n3 * np));
-            ASL_TRY(K3.reserve((size_t)n3 * k));
-            ASL_TRY(gather_rows_f32(x_all.p, d, rowidx.p, n3, d, x3.p, d));
-            ASL_TRY(gather_rows_f32(cD_all.p, np, rowidx.p, n3, np, cD3.p, np));
-            ASL_TRY(gather_rows_f32(reinterpret_cast<const float *>(cI_all.p), np, rowidx.p, n3, np,
-                                    reinterpret_cast<float *>(cI3.p), np));      // (4-byte words)
-            ASL_TRY(index_swap_unordered(ix, 2, &prev));
-            const int rc3 = index_search_device(ix, (int)n3, x3.p, k, np, nullptr, K3.p, nullptr, cD3.p, cI3.p, true);
-            ASL_TRY(index_swap_unordered(ix, prev, nullptr));
-            ASL_TRY(rc3);
-            ASL_TRY(keys_rescan(reinterpret_cast<const u64k *>(K3.p), n3, k, rowidx.p, reinterpret_cast<const u64k *>(Rr.p),
-                                nq, xcap3, reinterpret_cast<u64k *>(Xs.p), cursor.p, flag.p));
-          }
-          ASL_TRY(all_to_all(Xs.p, Xr.p, (size_t)nq + (size_t)xcap3));
-          HIP_TRY(hipMemcpyAsync(mine.p, flag.p, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-          ASL_TRY(agree(h));
-          for (int r = 0; r < world; ++r) overflow |= h[(size_t)r * 4] != 0;
-          if (!overflow)
-            return keys_merge3(reinterpret_cast<const u64k *>(Kf.p), world, nq, k, reinterpret_cast<const u64k *>(Xr.p),
-                               xcap3, need3.p, I, D, 1);
-        } else {
-          // nobody asked: the keys of phases 1-2 are the result; rows sorted as the unsharded index returns them
-          HIP_TRY(hipMemsetAsync(need3.p, 0, (size_t)nq * sizeof(int32_t), st));
-          return keys_merge3(reinterpret_cast<const u64k *>(Kf.p), world, nq, k, reinterpret_cast<const u64k *>(Xr.p),
-                             xcap3, need3.p, I, D, 1);
-        }
-      }
+      for (int r = 0; r < world; ++r) overflow |= h[(size_t)r * 4] != 0;
+      xr = Xr.p;
     }
-    if (!overflow) return ASL_OK;
+    if (!overflow)
+      return keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, reinterpret_cast<const u64k *>(xr),
+                        xr ? xcap : 0, reinterpret_cast<const u64k *>(Ko.p), need.p, nullptr, nullptr, I, D, 1);
   }
   // 2. the local lists, for all queries (rank-major rows), as exact top-k sets
   //    (unordered mode: un-refined ADC rows, see annsolo_mi.h at asl_index_set_refine)
@@ -304,7 +262,8 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
   ASL_TRY(Ir.reserve(all * k));
   int prev_unordered = 0;
   ASL_TRY(index_swap_unordered(ix, 1, &prev_unordered));
-  const int rc_scan = index_search_device(ix, (int)all, x_all.p, k, np, Dp.p, Ip.p, nullptr, cD_all.p, cI_all.p, true);
+  const int rc_scan = index_search_device(ix, (int)all, x_all.p, k, np, Dp.p, Ip.p, nullptr, cD_all.p, cI_all.p, true,
+                                          nullptr);
   ASL_TRY(index_swap_unordered(ix, prev_unordered, nullptr));
   ASL_TRY(rc_scan);
   // 3. rank r receives the `world` partial rows of its own queries

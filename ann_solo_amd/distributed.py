@@ -27,12 +27,13 @@ addition. Per batch and charge partition:
      once per batch) the batch is repeated with the full world * k exchange;
   5. (round 5) from four ranks on the shards scan with a shard-side k_s < k (``shard_k``: 512 of
      1024 at eight ranks -- a shard sees an eighth of a query's candidates, and the appends of a
-     k-deep row cost its scan ~1 ms per step). A head then also carries M, the smallest key of a
-     full row; after step 4 the owner knows B' = the k-th best key of its result, and only where
-     M_s > B' -- a fraction of a percent of the queries -- shard s may have dropped a key that
-     belongs there: the owner asks, the shard scans that query again with the full k and answers
-     with its keys between B' and M_s, the owner merges and rescores those queries again. One
-     host decision per batch (the flag of step 4 carries the number of requests).
+     k-deep row cost its scan 0.5-0.9 ms per step). A full k_s-row may have dropped keys, all of
+     them below its smallest key M. Nothing changes for the owners (a full row always holds keys
+     back, and M <= T: "ask iff T > B" covers dropped keys too); the SHARD completes its answer:
+     where the bound B it is sent lies below M (~1 % of its rows) it scans that query again with
+     the full k -- a launch of fixed size gated by a device-side count, no host round trip, no
+     extra collective -- and answers from that row. The result stays the exact top k of the
+     union of the shards' full rows.
 
 List ownership is the greedy heaviest-first balancing of ``asl_lpt_owner`` over the
 expected scan load of each list (size squared: populous lists are also probed more often);
@@ -168,85 +169,80 @@ class HipShardBackend:
         return faiss_compat.topk_merge_keys(Ks, unordered=True)   # rescoring consumes a set
 
     # ---- the two-phase exchange (csrc/exchange.hip); every tensor lives on the device
-    def keys_split(self, K: torch.Tensor, kp: int, with_min: bool = False):
+    def keys_split(self, K: torch.Tensor, kp: int, want_rowmin: bool = False):
         """-> head [rows, kp] and the rows' bucket floors [rows]: the keys held back are the keys of
-        ``K`` below its row's floor -- ``keys_extras`` reads them from ``K`` itself. ``with_min``:
-        the head also carries the smallest key of a full row (third phase)."""
+        ``K`` below its row's floor -- ``keys_extras`` reads them from ``K`` itself. ``want_rowmin``:
+        also M [rows], the smallest key of every FULL row (0 otherwise): shards that scan with
+        k_s < k."""
         rows, k = K.shape
         head = torch.empty((rows, kp), dtype=torch.int64, device=K.device)
         floor = torch.empty((rows,), dtype=torch.int32, device=K.device)
-        _lib.check(_lib.lib().asl_keys_split(rows, k, kp, int(with_min), _lib.ptr(K), _lib.ptr(head),
-                                             _lib.ptr(floor)))
-        return head, floor
+        rowmin = torch.empty((rows,), dtype=torch.int64, device=K.device) if want_rowmin else None
+        _lib.check(_lib.lib().asl_keys_split(rows, k, kp, _lib.ptr(K), _lib.ptr(head), _lib.ptr(floor),
+                                             _lib.ptr(rowmin)))
+        return (head, floor, rowmin) if want_rowmin else (head, floor)
 
-    def keys_merge_heads(self, heads: torch.Tensor, k: int, with_min: bool = False):
+    def keys_merge_heads(self, heads: torch.Tensor, k: int):
         S, n, kp = heads.shape
         dev = heads.device
         out = torch.empty((n, k), dtype=torch.int64, device=dev)
         bounds = torch.empty((S, n), dtype=torch.int64, device=dev)
         need = torch.empty((n,), dtype=torch.int32, device=dev)
-        _lib.check(_lib.lib().asl_keys_merge_heads(S, n, kp, int(with_min), k, _lib.ptr(heads), _lib.ptr(out),
+        _lib.check(_lib.lib().asl_keys_merge_heads(S, n, kp, k, _lib.ptr(heads), _lib.ptr(out),
                                                    _lib.ptr(bounds), _lib.ptr(need)))
         return out, bounds, need
 
+    rescan_capacity = None      # rows a piece may scan a second time (default max(64, rows / 16))
+
     def keys_extras(self, K: torch.Tensor, floor: torch.Tensor, bounds: torch.Tensor, world: int, xcap: int,
-                    overflow: torch.Tensor):
+                    overflow: torch.Tensor, rescan=None):
+        """``rescan`` = (rowmin, vectors, coarse_D, coarse_I, k) for shards that scanned with
+        k_s < k: the rows whose bound lies below the smallest key of a full row are listed on the
+        device, searched again with the full k by a launch of fixed size that the device-side count
+        gates, and answer from that row. Nothing here waits for the device."""
         rows, k = K.shape
         n = rows // world
-        xbuf = torch.empty((world, n + xcap), dtype=torch.int64, device=K.device)
+        dev = K.device
+        L = _lib.lib()
+        xbuf = torch.empty((world, n + xcap), dtype=torch.int64, device=dev)
         # the payload cursors are the caller's (a tensor on the stream): nothing waits in here, so
         # the collectives of this piece really travel under the next piece's scan
-        cursor = torch.zeros(world, dtype=torch.int32, device=K.device)
-        _lib.check(_lib.lib().asl_keys_extras(world, n, k, _lib.ptr(K), _lib.ptr(floor), _lib.ptr(bounds),
-                                              int(xcap), _lib.ptr(xbuf), _lib.ptr(cursor), _lib.ptr(overflow)))
+        cursor = torch.zeros(world, dtype=torch.int32, device=dev)
+        rmap = K3 = None
+        k3 = 0
+        if rescan is not None:
+            rowmin, xv, cD, cI, k3 = rescan
+            R = int(self.rescan_capacity or max(64, rows // 16))
+            rowlist = torch.zeros(R, dtype=torch.int64, device=dev)
+            rmap = torch.empty(rows, dtype=torch.int32, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(L.asl_keys_rescan_list(rows, _lib.ptr(bounds), _lib.ptr(rowmin), R, _lib.ptr(rowlist),
+                                              _lib.ptr(rmap), _lib.ptr(cnt), _lib.ptr(overflow)))
+            overflow[1:2] += cnt                              # (statistics: rows scanned a second time)
+            x3 = xv.index_select(0, rowlist)                  # slots past the count repeat row 0: never scanned
+            cD3, cI3 = cD.index_select(0, rowlist), cI.index_select(0, rowlist)
+            K3 = torch.empty((R, k3), dtype=torch.int64, device=dev)
+            self.index.set_unordered(2)
+            try:
+                _lib.check(L.asl_index_search_gated(self.index._h, R, _lib.ptr(x3), int(k3), int(cI3.shape[1]),
+                                                    _lib.ptr(cD3), _lib.ptr(cI3), None, _lib.ptr(K3), _lib.ptr(cnt)))
+            finally:
+                self.index.set_unordered(0)
+        _lib.check(L.asl_keys_extras(world, n, k, _lib.ptr(K), _lib.ptr(floor), _lib.ptr(bounds),
+                                     int(xcap), _lib.ptr(xbuf), _lib.ptr(cursor), _lib.ptr(overflow),
+                                     _lib.ptr(rmap), _lib.ptr(K3), int(k3)))
         return xbuf
 
-    def keys_merge_final(self, heads: torch.Tensor, xbuf: Optional[torch.Tensor], out_keys, need, k: int,
-                         flag: Optional[torch.Tensor] = None):
-        """``flag`` (the batch's [overflow, requests] pair) arms the third phase: -> (I, fin_keys
-        [n, k], req [S, n, 2], need3 [n]) and ``flag[1]`` += the number of requests."""
+    def keys_merge_final(self, heads: torch.Tensor, xbuf: Optional[torch.Tensor], out_keys, need, k: int):
         S, n, kp = heads.shape
-        dev = heads.device
-        I = torch.empty((n, k), dtype=torch.int64, device=dev)
+        I = torch.empty((n, k), dtype=torch.int64, device=heads.device)
         xcap = 0 if xbuf is None else xbuf.shape[1] - n
-        if flag is None:
-            _lib.check(_lib.lib().asl_keys_merge_final(S, n, kp, 0, k, _lib.ptr(heads), _lib.ptr(xbuf), int(xcap),
-                                                       _lib.ptr(out_keys), _lib.ptr(need), None, _lib.ptr(I),
-                                                       None, None, None, None))
-            return I
-        fin = torch.empty((n, k), dtype=torch.int64, device=dev)
-        req = torch.empty((S, n, 2), dtype=torch.int64, device=dev)
-        need3 = torch.empty((n,), dtype=torch.int32, device=dev)
-        _lib.check(_lib.lib().asl_keys_merge_final(S, n, kp, 1, k, _lib.ptr(heads), _lib.ptr(xbuf), int(xcap),
-                                                   _lib.ptr(out_keys), _lib.ptr(need), None, _lib.ptr(I),
-                                                   _lib.ptr(fin), _lib.ptr(req), _lib.ptr(need3),
-                                                   _lib.ptr(flag[1:])))
-        return I, fin, req, need3
-
-    def request_rows(self, req: torch.Tensor) -> torch.Tensor:
-        """req [rows, 2] -> the rows that carry a request (a host round trip: third phase only)."""
-        return torch.nonzero(req.reshape(-1, 2)[:, 0] != -1).reshape(-1)
-
-    def keys_rescan(self, K3: torch.Tensor, rowidx: torch.Tensor, req: torch.Tensor, world: int, n: int,
-                    xcap: int, flag: torch.Tensor):
-        k = K3.shape[1]
-        xbuf = torch.zeros((world, n + xcap), dtype=torch.int64, device=req.device)
-        cursor = torch.zeros(world, dtype=torch.int32, device=req.device)
-        n3 = int(rowidx.numel())
-        _lib.check(_lib.lib().asl_keys_rescan(world, n, k, n3, _lib.ptr(K3) if n3 else None,
-                                              _lib.ptr(rowidx) if n3 else None, _lib.ptr(req.contiguous()),
-                                              int(xcap), _lib.ptr(xbuf), _lib.ptr(cursor), _lib.ptr(flag)))
-        return xbuf
-
-    def keys_merge3(self, fin_keys: torch.Tensor, xbuf: torch.Tensor, need3: torch.Tensor, k: int):
-        n = fin_keys.shape[0]
-        I = torch.empty((n, k), dtype=torch.int64, device=fin_keys.device)
-        _lib.check(_lib.lib().asl_keys_merge3(xbuf.shape[0], n, k, _lib.ptr(fin_keys), _lib.ptr(xbuf),
-                                              int(xbuf.shape[1] - n), _lib.ptr(need3), None, _lib.ptr(I)))
+        _lib.check(_lib.lib().asl_keys_merge_final(S, n, kp, k, _lib.ptr(heads), _lib.ptr(xbuf), int(xcap),
+                                                   _lib.ptr(out_keys), _lib.ptr(need), None, _lib.ptr(I)))
         return I
 
     def new_flag(self):
-        """[0]: an answer buffer ran full somewhere; [1]: third-phase requests of my queries."""
+        """[0]: a buffer ran full somewhere; [1]: rows this shard scanned a second time."""
         return torch.zeros(2, dtype=torch.int32, device=self.device)
 
     def refine(self, vectors: torch.Tensor, knn: torch.Tensor):
@@ -530,33 +526,13 @@ def _agreed_keys(backend, world: int, group, k_scan: int) -> bool:
     return cache[key]
 
 
-def _patch_rows(res, sel, new):
-    """Overwrite the rows ``sel`` of a batch result (``BatchResult`` / dict of a test backend)
-    with ``new``, a result of len(sel) rows."""
-    names = ('best_row', 'best_score', 'n_candidates', 'pm_count', 'pm_pairs', 'knn')
-    for name in names:
-        dst = res.get(name) if isinstance(res, dict) else getattr(res, name, None)
-        src = new.get(name) if isinstance(new, dict) else getattr(new, name, None)
-        if dst is None or src is None:
-            continue
-        if torch.is_tensor(dst):
-            idx = sel.to(dst.device)
-            src = torch.as_tensor(src).to(dst.device)
-            if name == 'pm_pairs' and src.dtype != dst.dtype:
-                src = src.view(dst.dtype) if src.element_size() == dst.element_size() else src.to(dst.dtype)
-            dst[idx] = src.to(dst.dtype) if src.dtype != dst.dtype else src
-        else:
-            src = src.cpu().numpy() if torch.is_tensor(src) else np.asarray(src)
-            dst[sel.cpu().numpy()] = src.astype(dst.dtype, copy=False)
-
-
 def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, device_out=False,
                          chunks: Optional[int] = None, _force_exchange: bool = False,
                          pm_stride: Optional[int] = None, check_sizes: bool = False,
                          peak_width: Optional[int] = None, two_phase: Optional[bool] = None,
                          head_keys: Optional[int] = None, extras_per_query: Optional[int] = None,
                          comm: Optional['CommLog'] = None, stats: Optional[dict] = None,
-                         shard_keys: Optional[int] = None, answers_per_query: Optional[int] = None):
+                         shard_keys: Optional[int] = None):
     """One batch: ``queries_local`` is this rank's equally sized slice of the global
     batch. Returns the BatchResult of the local slice (library rows are global).
     ``peak_width``: a bound on the peaks per query that is IDENTICAL on every rank (e.g.
@@ -573,11 +549,11 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     ``ceil(2 k / world)``), ``extras_per_query`` the capacity of the phase-2 buffers (slots per
     query and pair of ranks, default ``max(8, k // 16)``). With heads as wide as the rows (two
     ranks) the rows travel whole. ``shard_keys``: the shards' own k (default ``shard_k(k,
-    world)``; a value below k arms the third phase, k switches it off), ``answers_per_query``
-    the capacity of its answer buffers. A full answer buffer of phase 2 or 3 repeats the
-    batch with the full exchange of k-deep rows (``stats['fallback']``). ``comm``: a ``CommLog``
-    that receives the bytes of every collective; ``stats`` also gets ``shard_k`` and
-    ``third_phase_queries`` (own queries that were merged and rescored again)."""
+    world)``; below k the shards scan again, with the full k, the rows whose bound asks for it).
+    A full answer buffer -- or more second scans than a piece has room for -- repeats the batch
+    with the full exchange of k-deep rows (``stats['fallback']``). ``comm``: a ``CommLog`` that
+    receives the bytes of every collective; ``stats`` also gets ``shard_k`` and
+    ``third_phase_queries`` (the (query, owner) rows this shard scanned a second time)."""
     world = dist.get_world_size(group)
     if queries_local.n == 0:
         # every rank must bring the same, non-zero number of queries (the collectives below are
@@ -626,17 +602,15 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     if two_phase is None:
         two_phase = use_keys and hasattr(backend, 'keys_split')
     two_phase = bool(two_phase and use_keys)
-    nkeep = head_width(k_scan, world, head_keys) - 1 if two_phase else 0
-    if two_phase and nkeep >= k_scan:        # (two ranks: a head of ceil(2k / 2) keys IS the row) the
-        two_phase, nkeep = False, 0          # rows travel whole: no split, no bound, one merge
-    # third phase: the shards scan with k_row < k_scan keys per row
+    kp = head_width(k_scan, world, head_keys) if two_phase else 0
+    if two_phase and kp - 1 >= k_scan:       # (two ranks: a head of ceil(2k / 2) keys IS the row) the
+        two_phase, kp = False, 0             # rows travel whole: no split, no bound, one merge
+    # the shards' own k: rows of k_row < k_scan keys, completed by second scans where a bound asks
     k_row = k_scan
-    if two_phase and hasattr(backend, 'keys_rescan'):
+    if two_phase:
         ks = int(shard_keys) if shard_keys is not None else shard_k(k_scan, world)
-        if nkeep < ks < k_scan:
+        if kp - 1 < ks < k_scan:
             k_row = ks
-    third = k_row < k_scan
-    kp = nkeep + 1 + int(third) if two_phase else 0
     second = two_phase                       # heads hold something back
     flag = backend.new_flag() if second else None
 
@@ -648,7 +622,7 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
         return backend.rescore_knn(sub, knn, device_out, **kw)
 
     def scan(lo, hi):
-        """shard scan of rows [lo, hi) of every rank's slice, rank-major"""
+        """shard scan of rows [lo, hi) of every rank's slice, rank-major -> (rows, its inputs)"""
         if chunks == 1:
             xv, pre = allvec, (cD, cI) if co is not None else None
         else:
@@ -657,11 +631,11 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
             pre = (cD.index_select(0, rows), cI.index_select(0, rows)) if co is not None else None
         if use_keys:
             pre_ = pre if pre is not None else (None, None)
-            if two_phase and third:
-                return backend.shard_search_keys(xv, *pre_, k=k_row)
-            return backend.shard_search_keys(xv, *pre_)
+            if two_phase and k_row < k_scan:
+                return backend.shard_search_keys(xv, *pre_, k=k_row), (xv,) + tuple(pre_)
+            return backend.shard_search_keys(xv, *pre_), None
         return (backend.shard_search_preassigned(xv, *pre) if pre is not None
-                else backend.shard_search(xv))
+                else backend.shard_search(xv)), None
 
     def wait(works):
         for w in works:
@@ -669,18 +643,8 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
 
     # every piece is a little state machine; `step` advances it by one stage and returns True
     # when its result has been appended
-    def piece(lo, hi, out):
+    def piece(lo, hi, out, inputs):
         st = {'stage': 0}
-
-        def final(xr):
-            if two_phase and third:
-                knn, fin, req, need3 = backend.keys_merge_final(st['heads'], xr, st['keys'], st['need'],
-                                                                k_scan, flag)
-                held3.append((lo, fin, req, need3))
-            else:
-                knn = backend.keys_merge_final(st['heads'], xr, st['keys'], st['need'], k_scan)
-            results.append((lo, rescore(lo, hi, knn)))
-            return True
 
         def step():
             n = hi - lo
@@ -695,7 +659,12 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
                         st['x'] = exchange_partials(out[0], out[1], world, group, async_op=True)
                     st['stage'] = 10
                     return False
-                head, floor = (backend.keys_split(out, kp, True) if third else backend.keys_split(out, kp))
+                if inputs is not None:        # rows of k_row < k keys: keep M and the scan's inputs
+                    head, floor, rowmin = backend.keys_split(out, kp, True)
+                    st['rescan'] = (rowmin,) + inputs + (k_scan,)
+                else:
+                    head, floor = backend.keys_split(out, kp)
+                    st['rescan'] = None
                 st['rest'] = (out, floor)          # the held-back keys stay in the scan's rows
                 st['x'] = _all_to_all(head, world, group, comm, 'heads_all_to_all')
                 st['stage'] = 1
@@ -712,19 +681,24 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
             if st['stage'] == 1:              # heads are here: merge, bound, questions to the shards
                 wait(st['x'][1])
                 st['heads'] = st['x'][0].contiguous()
-                st['keys'], bnd, st['need'] = (backend.keys_merge_heads(st['heads'], k_scan, True) if third
-                                               else backend.keys_merge_heads(st['heads'], k_scan))
+                st['keys'], bnd, st['need'] = backend.keys_merge_heads(st['heads'], k_scan)
                 if not second:
-                    return final(None)
+                    knn = backend.keys_merge_final(st['heads'], None, st['keys'], st['need'], k_scan)
+                    results.append((lo, rescore(lo, hi, knn)))
+                    return True
                 st['x'] = _all_to_all(bnd.reshape(world * n), world, group, comm, 'bounds_all_to_all')
                 st['stage'] = 2
                 return False
-            if st['stage'] == 2:              # the owners' bounds are here: what was held back above them
+            if st['stage'] == 2:              # the owners' bounds are here: what lies above them outside the heads
                 wait(st['x'][1])
                 xcap = n * (extras_per_query if extras_per_query is not None else max(8, k_scan // 16))
-                xbuf = backend.keys_extras(st['rest'][0], st['rest'][1],
-                                           st['x'][0].reshape(world * n).contiguous(), world, xcap, flag)
-                st['rest'] = None
+                bnd_in = st['x'][0].reshape(world * n).contiguous()
+                if st['rescan'] is not None:
+                    xbuf = backend.keys_extras(st['rest'][0], st['rest'][1], bnd_in, world, xcap, flag,
+                                               rescan=st['rescan'])
+                else:
+                    xbuf = backend.keys_extras(st['rest'][0], st['rest'][1], bnd_in, world, xcap, flag)
+                st['rest'] = st['rescan'] = None
                 st['x'] = _all_to_all(xbuf.reshape(world * (n + xcap)), world, group, comm,
                                       'held_back_keys_all_to_all')
                 st['xcap'] = xcap
@@ -732,7 +706,9 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
                 return False
             wait(st['x'][1])                  # stage 3: final merge, rescoring
             xr = st['x'][0].reshape(world, n + st['xcap']).contiguous()
-            return final(xr)
+            knn = backend.keys_merge_final(st['heads'], xr, st['keys'], st['need'], k_scan)
+            results.append((lo, rescore(lo, hi, knn)))
+            return True
         return step
 
     def run():
@@ -741,11 +717,11 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
             lo, hi = bounds[c], bounds[c + 1]
             if hi == lo:
                 continue
-            out = scan(lo, hi)
+            out, inputs = scan(lo, hi)
             for p_ in list(pending):          # older pieces: one stage each, behind this scan
                 if p_():
                     pending.remove(p_)
-            new = piece(lo, hi, out)
+            new = piece(lo, hi, out, inputs)
             new()                             # split + first collective, right behind its scan
             pending.append(new)
         while pending:
@@ -753,77 +729,32 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
                 if p_():
                     pending.remove(p_)
 
-    def agree_flag():
-        """[overflow anywhere, third-phase requests anywhere]: one host round trip"""
-        f = flag if dist.get_backend(group) == 'nccl' else flag.cpu()
-        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)
-        v = f.cpu().tolist()
-        return int(v[0]) != 0, int(v[1]) != 0
-
-    def third_phase(res):
-        """Queries of which a shard's k_row-deep row may hide a key of the result: the requests
-        (B', M) travel, the shards scan those queries again with the full k and answer with
-        their keys in between, the owner merges and rescores them again. Returns the overflow
-        flag of the answer buffers (all-reduced)."""
-        held3.sort(key=lambda t: t[0])
-        fin = torch.cat([t[1] for t in held3])
-        req = torch.cat([t[2] for t in held3], dim=1).contiguous()          # [world, n_local, 2]
-        need3 = torch.cat([t[3] for t in held3])
-        rq, works, _keep = _all_to_all(req.reshape(world * n_local, 2), world, group, comm,
-                                       'rescan_requests_all_to_all')
-        wait(works)
-        rq = rq.reshape(world * n_local, 2).contiguous()       # row = owner * n_local + query
-        rows = backend.request_rows(rq)
-        pre = (cD.index_select(0, rows.to(cD.device)), cI.index_select(0, rows.to(cI.device))) \
-            if co is not None else (None, None)
-        K3 = backend.shard_search_keys(allvec.index_select(0, rows.to(allvec.device)), *pre, k=k_scan)
-        xcap3 = n_local * (answers_per_query if answers_per_query is not None else max(8, k_scan // 16))
-        flag.zero_()
-        xbuf = backend.keys_rescan(K3, rows, rq, world, n_local, xcap3, flag)
-        xr, works, _keep2 = _all_to_all(xbuf.reshape(world * (n_local + xcap3)), world, group, comm,
-                                        'rescan_answers_all_to_all')
-        wait(works)
-        knn3 = backend.keys_merge3(fin, xr.reshape(world, n_local + xcap3).contiguous(), need3, k_scan)
-        sel = torch.nonzero(need3).reshape(-1)
-        if stats is not None:
-            stats['third_phase_queries'] = stats.get('third_phase_queries', 0) + int(sel.numel())
-            stats['third_phase_rescans'] = stats.get('third_phase_rescans', 0) + int(rows.numel())
-        if sel.numel():
-            knn = knn3.index_select(0, sel.to(knn3.device))
-            if hasattr(backend, 'refine'):
-                knn = backend.refine(vec.index_select(0, sel.to(vec.device)), knn)
-            sub = queries_local.select(sel.to(queries_local.device))
-            _patch_rows(res, sel, backend.rescore_knn(sub, knn, device_out, **kw))
-        return agree_flag()[0]
-
-    results, held3 = [], []
+    results = []
     run()
     fallback = False
-    res = None
+    rescans = 0
     if second:
-        # one pair of flags per batch: did any answer buffer of phase 2 run full anywhere, and
-        # does any owner have a third-phase request?
-        fallback, any3 = agree_flag()
-        if not fallback and third:
-            results.sort(key=lambda t: t[0])
-            res = _concat_results([r for _, r in results])
-            if any3:
-                fallback = third_phase(res)
-        if fallback:
+        # one pair of ints per batch: did any buffer run full anywhere (answers of phase 2, second
+        # scans of a piece), and how many rows did the shards scan a second time?
+        f = flag if dist.get_backend(group) == 'nccl' else flag.cpu()
+        rescans = int(f[1].item()) if k_row < k_scan else 0
+        f = f[:1].clone()
+        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)
+        if int(f.item()):
+            fallback = True
             if stats is not None:
                 stats['fallback'] = stats.get('fallback', 0) + 1
-            two_phase = second = third = False
-            results, held3, res = [], [], None
+            two_phase = second = False
+            results = []
             run()
     if stats is not None:
         stats['two_phase'] = bool(kp) and not fallback
-        stats['exchange_used'] = ('full rows (fallback)' if fallback else 'two-phase + third' if kp and k_row < k_scan
+        stats['exchange_used'] = ('full rows (fallback)' if fallback else
+                                  'two-phase, shard-side k + second scans' if kp and k_row < k_scan
                                   else 'two-phase' if kp else 'full rows')
         stats['head_width'] = kp
         stats['shard_k'] = k_row if kp else k_scan
-        stats.setdefault('third_phase_queries', 0)
-    if res is not None:
-        return res
+        stats['third_phase_queries'] = stats.get('third_phase_queries', 0) + rescans
     results.sort(key=lambda t: t[0])
     return _concat_results([r for _, r in results])
 

@@ -159,12 +159,32 @@ def make_library(n: int, seed: int = 20240807, device='cpu', charges=(2, 3, 4),
     return lib, aux
 
 
+# ``hard`` mode, calibrated on the bench library (2.1 M spectra, seed 20240807; scripts/tune_hard.py,
+# profiles/r05_hard_calibration.txt) against the reference's one behavioural anchor at this boundary:
+# with EXACT inner-product search the true match of a MODIFIED spectrum is inside the top 1024 for
+# 75.1 % of the iPRG2012 SSMs (notebooks/iprg2012_num_candidates.ipynb:282-288). The default queries
+# give 97.8 % -- far cleaner than real spectra of modified peptides.
+HARD_DEFAULT = 0.5
+
+
+def hard_levers(h: float) -> Dict[str, float]:
+    """The knobs of ``make_queries(hard=h)``, h in [0, 1] (0 = the default generator): dropped
+    peaks, intensity noise (rank changes), fragment m/z jitter (0.04-wide hash bins), noise peaks
+    and their level, and co-fragmentation (the peaks of a second, random library spectrum)."""
+    h = float(h)
+    return dict(drop=0.10 + 0.45 * h, int_sigma=0.3 + 0.9 * h, jitter=0.005 + 0.010 * h,
+                extra_noise=int(round(40 * h)), noise_level=0.15 + 0.45 * h, chimera=0.7 * h)
+
+
 def make_queries(lib: PackedSpectra, aux: Dict[str, torch.Tensor], nq: int, seed: int = 42,
                  mod_frac: float = 0.5, open_range: float = 500.0,
-                 charge: int = None) -> Tuple[PackedSpectra, Dict[str, torch.Tensor]]:
+                 charge: int = None, hard: float = 0.0) -> Tuple[PackedSpectra, Dict[str, torch.Tensor]]:
     """Query spectra re-drawn from library peptides: half unmodified (5 ppm precursor
     jitter), half with one PTM on a random residue; 0.005 Da fragment jitter, 10 % of
-    the peaks dropped, 10 noise peaks."""
+    the peaks dropped, 10 noise peaks. ``hard`` > 0 (``hard_levers``): noisier spectra --
+    more dropped peaks, stronger intensity noise, larger jitter, more and stronger noise
+    peaks, a co-fragmented second spectrum; ``hard`` = 0 draws exactly the default queries."""
+    lv = hard_levers(hard)
     dev = lib.device
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -201,15 +221,35 @@ def make_queries(lib: PackedSpectra, aux: Dict[str, torch.Tensor], nq: int, seed
         shifted = torch.where(it == 0, ii > ppos.unsqueeze(1), ii >= (plen - ppos).unsqueeze(1))
         mz = mz + torch.where(shifted, dm.unsqueeze(1) / fc.clamp_min(1).to(torch.float64),
                               torch.zeros((), dtype=torch.float64, device=dev))
-        mz = mz + 0.005 * torch.randn(mz.shape, generator=g, device=dev, dtype=torch.float64)
-        raw = raw * torch.exp(0.3 * torch.randn(raw.shape, generator=g, device=dev))
-        raw = torch.where(torch.rand(raw.shape, generator=g, device=dev) < 0.10,
+        mz = mz + lv['jitter'] * torch.randn(mz.shape, generator=g, device=dev, dtype=torch.float64)
+        raw = raw * torch.exp(lv['int_sigma'] * torch.randn(raw.shape, generator=g, device=dev))
+        raw = torch.where(torch.rand(raw.shape, generator=g, device=dev) < lv['drop'],
                           torch.zeros((), device=dev), raw)
         nmz = 100 + 1400 * torch.rand(mm, 10, generator=g, device=dev, dtype=torch.float64)
-        med = raw.max(1, keepdim=True).values * 0.15
+        med = raw.max(1, keepdim=True).values * lv['noise_level']
         nin = med * torch.exp(0.5 * torch.randn(mm, 10, generator=g, device=dev))
         mz = torch.cat([mz, nmz], 1)
         raw = torch.cat([raw, nin], 1)
+        hard_draws = hard > 0           # (extra draws come last in the chunk: hard = 0 is the default stream)
+        pmz = lib.precursor_mz[src] + dm / z
+        ppm = 5e-6 * torch.randn(mm, generator=g, device=dev, dtype=torch.float64)
+        pmz = pmz * (1 + ppm)
+        if hard_draws:
+            ne = lv['extra_noise']
+            if ne > 0:
+                emz = 100 + 1400 * torch.rand(mm, ne, generator=g, device=dev, dtype=torch.float64)
+                ein = med * torch.exp(0.5 * torch.randn(mm, ne, generator=g, device=dev))
+                mz, raw = torch.cat([mz, emz], 1), torch.cat([raw, ein], 1)
+            if lv['chimera'] > 0:       # co-fragmentation: a second precursor's fragments in the same scan
+                oth = pool[torch.randint(0, pool.numel(), (mm,), generator=g, device=dev)]
+                ocnt = off[oth + 1] - off[oth]
+                ohave = slot < ocnt.unsqueeze(1)
+                opos = (off[oth].unsqueeze(1) + slot).clamp_max(lib.mz.numel() - 1)
+                omz = torch.where(ohave, lib.mz[opos].to(torch.float64), torch.zeros((), dtype=torch.float64, device=dev))
+                oraw = torch.where(ohave, aux['raw_intensity'][opos], torch.zeros((), device=dev))
+                scale = lv['chimera'] * raw[:, :MAX_PEAKS].max(1, keepdim=True).values / oraw.max(1, keepdim=True).values.clamp_min(1e-30)
+                oraw = oraw * scale * torch.exp(0.5 * torch.randn(oraw.shape, generator=g, device=dev))
+                mz, raw = torch.cat([mz, omz], 1), torch.cat([raw, oraw], 1)
         ann = torch.zeros(mz.shape, dtype=torch.uint8, device=dev)
         cnt2, mz_s, in_s, ann_s, raw_s, valid = _process_padded(mz, raw, ann)
         keep = valid.clone()
@@ -220,9 +260,6 @@ def make_queries(lib: PackedSpectra, aux: Dict[str, torch.Tensor], nq: int, seed
         if int(keep.sum()) < m:
             raise RuntimeError('synthetic query generator: too many invalid draws')
         offsets, flat = _pack(cnt2, (mz_s, in_s, ann_s), keep)
-        pmz = lib.precursor_mz[src] + dm / z
-        ppm = 5e-6 * torch.randn(mm, generator=g, device=dev, dtype=torch.float64)
-        pmz = pmz * (1 + ppm)
         out_parts.append((offsets, flat, pmz[keep], lib.precursor_charge[src][keep]))
         truth_src.append(src[keep])
         truth_mod.append(is_mod[keep])

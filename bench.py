@@ -57,6 +57,9 @@ def main():
     ap.add_argument('--refine-k', type=int, default=0,
                     help="IVF-PQ: exact re-rank of the k' best ADC candidates (asl_index_set_refine); "
                          '0 = off (the default workload)')
+    ap.add_argument('--no-recall-hard', action='store_true',
+                    help='skip the `recall_hard` block (recall / hit@k / the fixed-recall operating point on the '
+                         'HARD synthetic queries, calibrated to the reference\'s exact-search hit@1024 of 75 %)')
     ap.add_argument('--no-fixed-recall', action='store_true',
                     help='skip the IVF-Flat measurement at the fixed-recall operating point '
                          '(default run, N = 1, IVF-PQ: same library, same coarse quantiser)')
@@ -88,17 +91,21 @@ def main():
                          '(default max(8, k / 16); diagnostic: 0 forces the fallback to the full exchange)')
     ap.add_argument('--shard-keys', type=int, default=None,
                     help='N > 1: the shards\' own k (default asl_shard_k(k, N): k / 2 from 8 ranks on, 5 k / 8 '
-                         'from 4, k below); a value below k arms the third exchange phase (the owner asks a '
-                         'shard for a second scan with the full k where its row may hide a key of the result)')
-    ap.add_argument('--answers-per-query', type=int, default=None,
-                    help='N > 1, third phase: answer-buffer slots per query and pair of ranks (default '
-                         'max(8, k / 16); diagnostic: 0 forces the fallback to the full exchange)')
+                         'from 4, k below); below k a shard scans again, with the full k, the rows whose bound '
+                         'lies under the smallest key of a full row (csrc/exchange.hip; exact)')
     ap.add_argument('--preflight-seconds', type=float, default=120.0,
                     help='N > 1: every collective of the sharded path is first run at a tiny size '
                          'under a watchdog that ends the process (exit code 17, a diagnostic line on '
                          'stderr) if it has not finished within this many seconds; 0 = skip')
+    ap.add_argument('--no-reference-geometry', action='store_true',
+                    help='skip the two legs at the reference\'s own defaults (JSON field `reference_geometry`: '
+                         'configs[1] = a 9 k-spectrum library, and the 2.1 M library, both IVF-Flat nlist 256 / '
+                         'nprobe 128, src/ann_solo/config.py:188-211)')
     ap.add_argument('--no-cascade', action='store_true',
                     help='skip the configs[4] cascade pass of the default N = 1 run (JSON field `cascade`)')
+    ap.add_argument('--ring', type=int, default=4,
+                    help='distinct query batches the timed loop cycles through (step i searches batch '
+                         'i mod ring; every leg that is not `value` uses batch 0)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0,
                     help='target core-seconds of the CPU baseline sample (0 = skip)')
     args = ap.parse_args()
@@ -163,16 +170,36 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- queries: world * batch, identical on every rank, each rank owns one slice
+    # ---- queries: ring x world x batch, identical on every rank; ring element j = queries
+    # [j * world * batch, (j + 1) * world * batch), of which each rank owns one slice. Element 0 is
+    # the batch of every earlier round (same seed, same draws: the generator works in chunks of 65 536
+    # whose first world * batch queries do not depend on how many follow... they do when world * batch
+    # * ring crosses a chunk, so element 0 is drawn on its own and the rest from another seed)
+    ring = max(1, args.ring)
     q_all, truth = synthetic.make_queries(lib, aux, world * args.batch, seed=42,
                                           open_range=args.open_da, charge=charge)
     sl_rows = torch.arange(rank * args.batch, (rank + 1) * args.batch, device=dev)
     q = q_all.select(sl_rows).contiguous()
     src_local = truth['source_row'][sl_rows]
     mod_local = truth['is_modified'][sl_rows]
+    q_ring = [q]
+    if ring > 1:
+        q_more, _ = synthetic.make_queries(lib, aux, (ring - 1) * world * args.batch, seed=4242,
+                                           open_range=args.open_da, charge=charge)
+        for j in range(ring - 1):
+            rows_j = torch.arange((j * world + rank) * args.batch, (j * world + rank + 1) * args.batch, device=dev)
+            q_ring.append(q_more.select(rows_j).contiguous())
+        del q_more
+    ring_pos = [0]
+
+    def next_batch():
+        b = q_ring[ring_pos[0] % ring]
+        ring_pos[0] += 1
+        return b
 
     # ---- recall@k vs exact inner product (outside the timed region; unsharded index)
     recall = None
+    recall_hard, hard_ctx = None, None
     recall_ctx = None
     if rank == 0 and args.recall_queries > 0:
         nr = min(args.recall_queries, q.n)
@@ -183,6 +210,15 @@ def main():
         flat.add(vec)
         del vec
         _, Ie = flat.search(sl._encode(qs), args.k)
+        # the same on HARD queries (synthetic.make_queries(hard=HARD_DEFAULT): calibrated so that exact
+        # search finds the source of ~75 % of the modified queries, the reference's iPRG2012 figure)
+        hard_ctx = None
+        if not args.no_recall_hard:
+            qh, truth_h = synthetic.make_queries(lib, aux, 2 * args.batch, seed=43, open_range=args.open_da,
+                                                 charge=charge, hard=synthetic.HARD_DEFAULT)
+            qhs = qh.select(torch.arange(nr, device=dev))
+            _, Ie_h = flat.search(sl._encode(qhs), args.k)
+            hard_ctx = (qh, qhs, Ie_h, truth_h['source_row'][:nr], truth_h['is_modified'][:nr])
         del flat
         knn = r.knn
 
@@ -221,6 +257,7 @@ def main():
             del vec
             fl.nprobe = args.nprobe
             _, If = fl.search(sl._encode(qs), args.k)
+            If_h = fl.search(sl._encode(hard_ctx[1]), args.k)[1] if hard_ctx else None
             del fl
             rf = overlap(If) / float(nr * args.k)
             recall.update({'ivfflat_same_geometry_recall_at_k': rf,
@@ -231,6 +268,32 @@ def main():
                                                      '(SURVEY.md 8d)',
                            'meets_criterion': bool(rf > 0 and rec / rf >= 0.95)})
         recall_ctx = (qs, Ie, nr) if args.index == 'ivfpq' else None
+        if hard_ctx:
+            qh, qhs, Ie_h, src_h, mod_h = hard_ctx
+            rh = sl._search_batch(qhs, charge, 'open', want_knn=True, device_out=True)
+
+            def ov_h(A):
+                return sum(int(torch.isin(A[i][A[i] >= 0], Ie_h[i]).sum()) for i in range(nr)) / float(nr * args.k)
+
+            def hits(A):
+                h_ = (A == src_h.unsqueeze(1)).any(1)
+                return {'hit_at_k_source_spectrum': float(h_.float().mean()),
+                        'hit_at_k_modified_only': float(h_[mod_h].float().mean()) if mod_h.any() else None}
+            recall_hard = {
+                'data': f'synthetic.make_queries(hard={synthetic.HARD_DEFAULT}): ' + json.dumps(synthetic.hard_levers(synthetic.HARD_DEFAULT)),
+                'calibration': 'exact inner-product hit@1024 of MODIFIED queries tuned to the reference\'s 75.1 % on '
+                               'iPRG2012 (notebooks/iprg2012_num_candidates.ipynb:282-288); scripts/tune_hard.py, '
+                               'profiles/r05_hard_calibration.txt',
+                'queries': nr, 'k': args.k,
+                'exact': dict(hits(Ie_h), reference_exact_hit_at_1024_modified_iprg2012=0.751),
+                args.index: dict(hits(rh.knn), recall_at_k_vs_exact_ip=ov_h(rh.knn), nprobe=args.nprobe,
+                                 top1_is_source_spectrum=float((rh.best_row.to(torch.int64) == src_h).float().mean())),
+            }
+            if args.index == 'ivfpq' and If_h is not None:
+                rfh = ov_h(If_h)
+                recall_hard['ivfflat_same_geometry'] = dict(hits(If_h), recall_at_k_vs_exact_ip=rfh, nprobe=args.nprobe)
+                recall_hard[args.index]['ratio_to_ivfflat'] = recall_hard[args.index]['recall_at_k_vs_exact_ip'] / rfh if rfh > 0 else None
+            del rh
         torch.cuda.empty_cache()
 
     def barrier():
@@ -255,7 +318,7 @@ def main():
         return el, out
 
     def unsharded_step():
-        return sl._search_batch(q, charge, 'open', device_out=True)
+        return sl._search_batch(next_batch(), charge, 'open', device_out=True)
 
     # ---- shard for N > 1
     shard_check, alt = None, None
@@ -290,14 +353,15 @@ def main():
             comm_log, xstats = CommLog(), {}
 
             def step():
-                return sharded_search_batch(shard_backend, q, group=group, device_out=True,
+                return sharded_search_batch(shard_backend, next_batch(), group=group, device_out=True,
                                             peak_width=peak_width, comm=comm_log, stats=xstats,
                                             two_phase=None if args.exchange == 'two-phase' else False,
                                             head_keys=args.head_keys, extras_per_query=args.extras_per_query,
-                                            shard_keys=args.shard_keys, answers_per_query=args.answers_per_query)
+                                            shard_keys=args.shard_keys)
         else:
             step = unsharded_step
-        got = step()
+        ring_pos[0] = 0
+        got = step()                     # (ring element 0 = q)
         same = bool(torch.equal(got.best_row[:ns], ref.best_row) and
                     torch.equal(got.best_score[:ns], ref.best_score))
         flag = torch.tensor([int(same)], device=dev if backend == 'nccl' else 'cpu')
@@ -315,6 +379,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sl.synchronize()
+    ring_pos[0] = 0
     if world > 1 and degree > 1:
         comm_log.calls.clear()
         xstats.clear()
@@ -334,13 +399,13 @@ def main():
         comm['head_width'] = xstats.get('head_width')
         comm['shard_k'] = xstats.get('shard_k')
         comm['fallbacks_to_full_exchange'] = xstats.get('fallback', 0)
-        # third phase: own queries merged and rescored again / rows this shard scanned again, per
-        # step, summed over the ranks of the job
-        t3 = torch.tensor([xstats.get('third_phase_queries', 0), xstats.get('third_phase_rescans', 0)],
-                          dtype=torch.int64, device=dev if backend == 'nccl' else 'cpu')
+        # (query, owner) rows the shards scanned a second time with the full k, per step, summed
+        # over the ranks of the job (the "third phase" of VERDICT r4, done on the shard inside phase 2)
+        t3 = torch.tensor([xstats.get('third_phase_queries', 0)], dtype=torch.int64,
+                          device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t3, op=dist.ReduceOp.SUM)
-        comm['third_phase_queries'] = round(int(t3[0]) / max(args.steps, 1), 2)
-        comm['third_phase_rescans'] = round(int(t3[1]) / max(args.steps, 1), 2)
+        comm['third_phase_queries'] = round(int(t3[0]) / max(args.steps + args.warmup * 0, 1), 2)
+        comm['third_phase_share_of_rows'] = round(int(t3[0]) / max(args.steps, 1) / (degree * degree * args.batch), 6)
         comm['collective_ms_alone'] = time_collectives(comm_log, group, degree, dev, backend, args.steps)
     L.asl_profile_enable(0)
     scan_timed = {}
@@ -351,11 +416,18 @@ def main():
     # the device (not part of `value`; the count is a property of the batch, the same in both passes)
     L.asl_profile_reset()
     L.asl_profile_enable(1)
+    ring_pos[0] = 0                      # the same batches as the timed pass
     timed(step, args.steps)
     sl.synchronize()
     L.asl_profile_enable(0)
     scanned = L.asl_profile_scanned_vectors()
     sl.set_pipeline(False)
+    # batch 0 once more, synchronously: the result the parity / post-path legs below refer to
+    q_keep, q_ring[:] = q_ring[:], [q]
+    ring_pos[0] = 0
+    res = step()
+    sl.synchronize()
+    q_ring[:] = q_keep
 
     stages = {}
     for name in ('encode', 'coarse_gemm', 'coarse_select', 'scan', 'refine', 'filter', 'rescore',
@@ -372,7 +444,8 @@ def main():
     if pipelined and world == 1:
         L.asl_profile_reset()
         L.asl_profile_enable(1)
-        for _ in range(3):
+        ring_pos[0] = 0
+        for _ in range(ring if args.steps % ring == 0 else 3):       # the same mix of batches as the timed pass
             step()
         sl.synchronize()
         L.asl_profile_enable(0)
@@ -408,11 +481,12 @@ def main():
         sl_f._num_probe = best
 
         def flat_step():
-            return sl_f._search_batch(q, charge, 'open', device_out=True)
+            return sl_f._search_batch(next_batch(), charge, 'open', device_out=True)
         sl_f.set_pipeline(pipelined)
         for _ in range(args.warmup):
             flat_step()
         sl_f.synchronize()
+        ring_pos[0] = 0
         L.asl_profile_enable(2)
         L.asl_profile_reset()
         el_f, _ = timed(flat_step, args.steps)
@@ -421,13 +495,14 @@ def main():
         sl_f.set_pipeline(False)
         ms_f, n_f = C.c_double(), C.c_int64()
         L.asl_profile_get(b'scan', C.byref(ms_f), C.byref(n_f))
-        res_f = flat_step()
+        res_f = sl_f._search_batch(q, charge, 'open', device_out=True)     # batch 0: what the parity leg checks
         sl_f.synchronize()
         alone_f = None
         if pipelined:           # the scan kernel on its own, as for the headline kernel below
             L.asl_profile_reset()
             L.asl_profile_enable(1)
-            for _ in range(3):
+            ring_pos[0] = 0
+            for _ in range(ring if args.steps % ring == 0 else 3):
                 flat_step()
             sl_f.synchronize()
             L.asl_profile_enable(0)
@@ -462,7 +537,54 @@ def main():
             cb = cpu_baseline(a_f, sl_f, sl_f.partitions[charge], idx_f, q, res_f, charge, cfg, faiss_leg=False)
             fixed_recall['parity_vs_gpu'] = cb['parity_vs_gpu']
             fixed_recall['cpu_baseline'] = {k_: cb[k_] for k_ in ('value', 'unit', 'cores', 'kind', 'sample',
-                                                                     'single_core_value', 'dense_definition_check')}
+                                                                     'single_core_value', 'parallel_efficiency',
+                                                                     'dense_definition_check')}
+        if hard_ctx and recall_hard is not None:
+            # the same question on the HARD queries: the smallest nprobe (steps of 8) that keeps
+            # recall@k >= 0.95 x IVF-Flat(nprobe) there, and the whole hot path timed at that point
+            qh, qhs, Ie_h, src_h, mod_h = hard_ctx
+            vqh = sl_f._encode(qhs)
+
+            def recall_h(nprobe):
+                idx_f.nprobe = nprobe
+                _, A = idx_f.search(vqh, args.k)
+                return sum(int(torch.isin(A[i][A[i] >= 0], Ie_h[i]).sum()) for i in range(nr)) / float(nr * args.k), A
+            ref_h, _ = recall_h(args.nprobe)
+            best_h, best_rec_h, A_best = args.nprobe, ref_h, None
+            for nprobe in range(args.nprobe - 8, args.nprobe // 2, -8):
+                r_, A_ = recall_h(nprobe)
+                if r_ < 0.95 * ref_h:
+                    break
+                best_h, best_rec_h, A_best = nprobe, r_, A_
+            if A_best is None:
+                _, A_best = recall_h(best_h)
+            hb = [qh.select(torch.arange(j * args.batch, (j + 1) * args.batch, device=dev)).contiguous() for j in range(2)]
+            hp = [0]
+            sl_f._num_probe = best_h
+
+            def hard_step():
+                b_ = hb[hp[0] % 2]
+                hp[0] += 1
+                return sl_f._search_batch(b_, charge, 'open', device_out=True)
+            sl_f.set_pipeline(pipelined)
+            for _ in range(args.warmup):
+                hard_step()
+            sl_f.synchronize()
+            hp[0] = 0
+            n_h = max(2, min(args.steps, 10))
+            el_h, _ = timed(hard_step, n_h)
+            sl_f.synchronize()
+            sl_f.set_pipeline(False)
+            hb_hit = (A_best == src_h.unsqueeze(1)).any(1)
+            recall_hard['fixed_recall'] = {
+                'index': 'ivfflat', 'storage': idx_f.storage, 'nlist': args.nlist, 'nprobe': best_h,
+                'recall_at_k_vs_exact_ip': best_rec_h,
+                'criterion': f'>= 0.95 x {ref_h:.4f} (IVF-Flat, nprobe {args.nprobe}, hard queries)',
+                'hit_at_k_source_spectrum': float(hb_hit.float().mean()),
+                'hit_at_k_modified_only': float(hb_hit[mod_h].float().mean()) if mod_h.any() else None,
+                'value': round(args.batch * n_h / el_h, 2), 'unit': 'query spectra/s',
+                'ms_per_step': round(el_h / n_h * 1e3, 3), 'steps': n_h, 'distinct_batches': 2}
+            del vqh, hb
         sl_f.shutdown()
         del sl_f, idx_f
         torch.cuda.empty_cache()
@@ -473,18 +595,21 @@ def main():
         sl_x._num_probe = best
 
         def fx_step():
-            return sl_x._search_batch(q, charge, 'open', device_out=True)
+            return sl_x._search_batch(next_batch(), charge, 'open', device_out=True)
         sl_x.set_pipeline(pipelined)
         for _ in range(args.warmup):
             fx_step()
         sl_x.synchronize()
+        ring_pos[0] = 0
         L.asl_profile_enable(2)
         L.asl_profile_reset()
         n_x = max(2, min(args.steps, 10))
-        el_x, res_x = timed(fx_step, n_x)
+        el_x, _ = timed(fx_step, n_x)
         sl_x.synchronize()
         L.asl_profile_enable(0)
         sl_x.set_pipeline(False)
+        res_x = sl_x._search_batch(q, charge, 'open', device_out=True)
+        sl_x.synchronize()
         ms_x, c_x = C.c_double(), C.c_int64()
         L.asl_profile_get(b'scan', C.byref(ms_x), C.byref(c_x))
         fixed_recall['alt_storage'] = {
@@ -500,6 +625,73 @@ def main():
         del sl_x, idx_x
         torch.cuda.empty_cache()
 
+
+    # ---- the reference's own default geometry (config.py:202-211: num_list 256, num_probe 128, IVF-Flat,
+    # k 1024, batch 16 384): configs[1] (an iPRG2012-sized library, ~9 k spectra) and the 2.1 M library
+    ref_geometry = None
+    if world == 1 and rank == 0 and not args.no_reference_geometry and args.index == 'ivfpq' and not args.refine_k:
+        from argparse import Namespace
+        from dataclasses import replace
+        ref_geometry = {}
+
+        def leg(name, lib_x, aux_x, open_da, steps, cpu_s, what):
+            cfg_x = replace(cfg, index='ivfflat', num_list=256, num_probe=128, num_candidates=1024, refine_k=None,
+                            precursor_tolerance_mass_open=open_da)
+            t0 = time.time()
+            sl_x = SpectralLibrary(lib_x, config=cfg_x, device=dev)
+            idx_x = sl_x._get_ann_index(charge)
+            t_build = time.time() - t0
+            nb = max(2, min(ring, 4))
+            qx, _ = synthetic.make_queries(lib_x, aux_x, nb * args.batch, seed=42, open_range=open_da, charge=charge)
+            bx = [qx.select(torch.arange(j * args.batch, (j + 1) * args.batch, device=dev)).contiguous() for j in range(nb)]
+            pos = [0]
+
+            def step_x():
+                b_ = bx[pos[0] % nb]
+                pos[0] += 1
+                return sl_x._search_batch(b_, charge, 'open', device_out=True)
+            sl_x.set_pipeline(pipelined)
+            for _ in range(2):
+                step_x()
+            sl_x.synchronize()
+            pos[0] = 0
+            L.asl_profile_enable(2)
+            L.asl_profile_reset()
+            el_x, _ = timed(step_x, steps)
+            sl_x.synchronize()
+            L.asl_profile_enable(0)
+            sl_x.set_pipeline(False)
+            ms_x, c_x = C.c_double(), C.c_int64()
+            L.asl_profile_get(b'scan', C.byref(ms_x), C.byref(c_x))
+            res_x = sl_x._search_batch(bx[0], charge, 'open', device_out=True)
+            sl_x.synchronize()
+            out_x = {'workload': what, 'library_size': int(lib_x.n), 'index': 'ivfflat', 'storage': idx_x.storage,
+                     'nlist': 256, 'nprobe': 128, 'k': 1024, 'open_da': open_da, 'batch': args.batch,
+                     'value': round(args.batch * steps / el_x, 2), 'unit': 'query spectra/s',
+                     'ms_per_step': round(el_x / steps * 1e3, 3), 'steps': steps, 'distinct_batches': nb,
+                     'scan_ms_per_step': round(ms_x.value / max(c_x.value, 1), 3),
+                     'index_build_s': round(t_build, 2),
+                     'identified': int((res_x.best_row >= 0).sum())}
+            if cpu_s > 0:
+                a_x = Namespace(**{**vars(args), 'nprobe': 128, 'k': 1024, 'nlist': 256, 'open_da': open_da,
+                                   'cpu_seconds': cpu_s})
+                cb = cpu_baseline(a_x, sl_x, sl_x.partitions[charge], idx_x, bx[0], res_x, charge, cfg_x, faiss_leg=False)
+                out_x['parity_vs_gpu'] = cb['parity_vs_gpu']
+                out_x['cpu_baseline'] = {k_: cb[k_] for k_ in ('value', 'unit', 'cores', 'kind', 'sample',
+                                                               'single_core_value', 'parallel_efficiency')}
+            sl_x.shutdown()
+            del sl_x, idx_x, qx, bx
+            torch.cuda.empty_cache()
+            ref_geometry[name] = out_x
+        lib9, aux9 = synthetic.make_library(9000, seed=20120701, device=dev, charges=(charge,), charge_p=(1.0,))
+        leg('configs_1_iprg2012_sized', lib9, aux9, 300.0, max(4, min(args.steps, 20)), min(args.cpu_seconds, 4.0),
+            'configs[1]: an iPRG2012-sized synthetic library (9 000 spectra), IVF-Flat at the reference defaults '
+            '(nlist 256, nprobe 128, k 1024), open +-300 Da (the notebooks\' window), shifted dot')
+        del lib9, aux9
+        leg('massivekb_sized_reference_defaults', lib, aux, args.open_da, max(2, min(args.steps, 5)),
+            min(args.cpu_seconds, 6.0),
+            f'the {args.library_size}-spectrum library at the reference defaults (IVF-Flat nlist 256, nprobe 128: a '
+            f'query scans half of the library), open +-{args.open_da:g} Da, shifted dot')
 
     if rank == 0:
         total_queries = world * args.batch * args.steps
@@ -580,6 +772,7 @@ def main():
                                    f'k={args.k}{f" (exact re-rank of {args.refine_k})" if args.refine_k else ""}, open +-{args.open_da:g} Da, shifted dot, '
                                    f'fragment tol 0.02 Da',
                        'library_size': args.library_size, 'batch_per_gpu': args.batch,
+                       'distinct_batches_in_the_timed_loop': ring,
                        'global_batch': world * args.batch, 'index': args.index,
                        'nlist': args.nlist, 'nprobe': args.nprobe, 'k': args.k,
                        'refine_k': args.refine_k or None,
@@ -595,6 +788,7 @@ def main():
                                          'with events around every stage (not part of value; its scan: '
                                          f"{stages_pass_scan['ms_total'] / max(stages_pass_scan['launches'], 1):.3f} ms)"},
             'recall': recall,
+            'recall_hard': recall_hard,
             # which number answers "query spectra/sec at fixed recall@k" (north star / SURVEY 8d)
             'metric_note': (None if args.index != 'ivfpq' or recall is None else
                             'value is configs[2] as BASELINE.json names it (IVF-PQ m=32): its recall@k is '
@@ -602,8 +796,13 @@ def main():
                             + ('which meets' if recall.get('meets_criterion') else 'which does NOT meet')
                             + ' the fixed-recall criterion (>= 0.95); the throughput AT FIXED RECALL is '
                             'fixed_recall.value (IVF-Flat over the same quantiser, measured in this run '
-                            'with its own roofline and oracle parity)'),
+                            'with its own roofline and oracle parity). Data sets: `value`, `recall`, `fixed_recall`, '
+                            '`cascade`, `reference_geometry` use the DEFAULT synthetic queries (clean: exact search '
+                            'finds the source of 98 % of the modified ones); `recall_hard` (and its '
+                            '`fixed_recall`) uses the HARD queries calibrated to the reference\'s 75 % '
+                            '(iPRG2012, exact search, k = 1024)'),
             'fixed_recall': fixed_recall,
+            'reference_geometry': ref_geometry,
             'cascade': cascade,
             'shard_check': shard_check,
             'comm': comm,
@@ -1137,6 +1336,50 @@ def faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_queries, knn_gpu=None
         return f'importable, leg failed: {type(e).__name__}: {e}'
 
 
+def host_cores():
+    """How many host cores this process may really use: the affinity mask, cut down to the cgroup
+    CPU quota when there is one (a container that sees 128 CPUs but is throttled to a quota of a
+    few runs 128 OpenMP threads at a fraction of their speed -- round 4's "11x on 128 threads")."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:                      # cgroup v2: "<quota|max> <period>"
+            a, b = f.read().split()
+            if a != 'max':
+                quota = float(a) / float(b)
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f1, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f2:
+                qv, pv = float(f1.read()), float(f2.read())
+                if qv > 0:
+                    quota = qv / pv
+        except (OSError, ValueError):
+            pass
+    physical = None
+    try:
+        seen = set()
+        with open('/proc/cpuinfo') as f:
+            phys = core = None
+            for line in f:
+                if line.startswith('physical id'):
+                    phys = line.split(':')[1].strip()
+                elif line.startswith('core id'):
+                    core = line.split(':')[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        physical = len(seen) or None
+    except OSError:
+        pass
+    usable = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return {'affinity_cpus': aff, 'cgroup_cpu_quota': quota, 'physical_cores_in_cpuinfo': physical,
+            'usable': usable}
+
+
 def cpu_baseline(args, sl, part, idx, q, res, charge, cfg, faiss_leg=True, ctx=None):
     """The oracle (plain-C port of the reference path, oracle/) on the host cores of this
     box, on a bounded sample of the SAME batch against the SAME index; doubles as a
@@ -1149,11 +1392,8 @@ def cpu_baseline(args, sl, part, idx, q, res, charge, cfg, faiss_leg=True, ctx=N
     t0 = time.time()
     ctx = ctx or oracle_context(sl, part, idx)
     O, Lh, ivf = ctx['O'], ctx['Lh'], ctx['ivf']
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, O.max_threads()))
+    host = host_cores()
+    cores = max(1, min(host['usable'], O.max_threads()))
 
     def run(n, threads):
         qs = q.select(torch.arange(n, device=q.device)).to('cpu')
@@ -1194,7 +1434,11 @@ def cpu_baseline(args, sl, part, idx, q, res, charge, cfg, faiss_leg=True, ctx=N
     faiss_note = faiss_cpu_leg(args, sl, part, idx, q, charge, cores, n_all, g.knn) if faiss_leg else None
     log(f'[bench] cpu baseline: {n_all} queries on {cores} threads in {t_all:.2f}s, '
         f'single core {per_q * 1e3:.2f} ms/query (setup {time.time() - t0:.1f}s)')
+    eff = (n_all / t_all) / (cores / per_q) if per_q > 0 else None
     return {'value': round(n_all / t_all, 2), 'unit': 'query spectra/s', 'cores': cores,
+            'host': host,
+            # value / (cores x the single-thread rate of the same build on the same box)
+            'parallel_efficiency': round(eff, 3) if eff else None,
             'kind': 'port', 'faiss': faiss_note,
             'sample': f'{n_all} queries of the same batch, same index, all {cores} host threads '
                       f'(OpenMP over queries)' + ('; IVF-Flat lists as sparse rows (CSR), same fmaf chain'

@@ -207,51 +207,54 @@ int asl_index_supports_keys(asl_index_t *idx, int32_t k, int32_t nprobe);
 /* The exact top-k exchange of a sharded search (csrc/exchange.hip; device pointers only; what
  * ann_solo_amd/distributed.py and asl_index_search_sharded run between their collectives; no
  * reference counterpart: spectral_library.py:494 uses device 0 only). Rows of packed keys as
- * asl_index_set_unordered mode 2 emits them (0 = empty, any order). with_min != 0 arms the third
- * phase: the shards scan with a shard-side k_s < k and a head carries M, the smallest key of a
- * FULL row (0 otherwise), in front of T; head layout [keys x (kp - 1 - with_min)][M][T].
- *   asl_keys_split: K [nrows, k_s] -> head [nrows, kp] (the row's best keys, all those at or
- *     above a score-bucket floor that admits at most the head's key slots; M; T = the best key
- *     held back, 0 if none) and floor [nrows] (that bucket floor: the keys held back are the
- *     keys of K below it, which stay where they are).
+ * asl_index_set_unordered mode 2 emits them (0 = empty, any order).
+ *   asl_keys_split: K [nrows, k_s] -> head [nrows, kp] (slots 0 .. kp-2: the row's best keys, all
+ *     those at or above a score-bucket floor that admits at most kp - 1; slot kp-1: T, the best
+ *     key held back, 0 if none), floor [nrows] (that bucket floor: the keys held back are the
+ *     keys of K below it, which stay where they are) and -- rowmin != NULL, for shards that scan
+ *     with k_s < k -- rowmin [nrows]: the row's smallest key if the row is FULL (the scan may have
+ *     dropped keys, all below it), else 0.
  *   asl_keys_merge_heads: heads [S, nq, kp] of the S shards -> out_keys [nq, k] (the best k keys
  *     seen, a set), bounds [S, nq] (B = the k-th best key seen if shard s must send what it holds
  *     above B -- its T beats B --, else ~0: send nothing), need [nq] (some shard was asked).
+ *   asl_keys_rescan_list: on the shard (k_s < k), after the bounds arrived: the rows whose bound
+ *     lies below rowmin -- a dropped key may be above the bound -- -> rowlist [R] (int64, ZEROED BY
+ *     THE CALLER; the first *count slots), rmap [nrows] (slot or -1), *count += their number
+ *     (device memory: the gate of asl_index_search_gated, which scans exactly those rows again
+ *     with the full k); more than R rows: *overflow = 1.
  *   asl_keys_extras: on the shard, rows destination-major (row = dst * nq + q): K [W * nq, k_s]
  *     and floor [W * nq] as asl_keys_split saw / wrote them, bounds [W * nq] -> xbuf
- *     [W, nq + xcap]: per destination nq header words (count << 32 | start) then the payload;
- *     cursor [W] int32, ZEROED BY THE CALLER (the payload cursors; the call returns without
- *     waiting); *overflow = 1 when a destination's xcap slots do not suffice (the caller must
- *     then repeat the batch with the full exchange). *overflow is never cleared here.
+ *     [W, nq + xcap]: per destination nq header words (count << 32 | start) then the payload =
+ *     the row's keys outside the head above the bound; rmap != NULL: a row with rmap[row] >= 0
+ *     answers from K3 [rmap[row], k3], its second scan. cursor [W] int32, ZEROED BY THE CALLER
+ *     (the payload cursors; the call returns without waiting); *overflow = 1 when a
+ *     destination's xcap slots do not suffice (the caller must then repeat the batch with the
+ *     full exchange of k-deep rows). *overflow is never cleared here.
  *   asl_keys_merge_final: heads + the xbuf [S, nq + xcap] received (NULL: none) + out_keys/need of
  *     asl_keys_merge_heads -> I [nq, k] ids (a set, -1 padded) and D (may be NULL): the exact
- *     top-k of the union of the shards' rows. k <= 1280. With with_min also fin_keys [nq, k] (the
- *     keys behind I), req [S, nq, 2] = (B', M_s) for every shard that may have dropped a key of
- *     the result (M_s > B' = the k-th best key of the result, 0 if fewer than k) else (~0, 0),
- *     need3 [nq] (some shard is asked) and *n3 += the number of requests (never cleared here).
- *   asl_keys_rescan: on the shard, after the requests travelled (req [W * nq, 2], destination-
- *     major): K3 [n3, k] = the rows of a scan with the FULL k of the n3 requested (query, owner)
- *     rows rowidx [n3] (= dst * nq + q, any order) -> xbuf [W, nq + xcap] (ZEROED BY THE CALLER):
- *     the keys strictly between B' and M; cursor / overflow as above.
- *   asl_keys_merge3: fin_keys + the answers xbuf [W, nq + xcap] + need3 -> I / D [nq, k]: the
- *     exact top-k of the union of the shards' FULL rows. */
-int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, int32_t with_min, const int64_t *K, int64_t *head,
-                   int32_t *floor);
-int asl_keys_merge_heads(int32_t S, int32_t nq, int32_t kp, int32_t with_min, int32_t k, const int64_t *heads,
+ *     top-k of the union of the shards' FULL rows. k <= 1280. */
+int asl_keys_split(int64_t nrows, int32_t k, int32_t kp, const int64_t *K, int64_t *head, int32_t *floor,
+                   int64_t *rowmin);
+int asl_keys_merge_heads(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
                          int64_t *out_keys, int64_t *bounds, int32_t *need);
+int asl_keys_rescan_list(int64_t nrows, const int64_t *bounds, const int64_t *rowmin, int32_t R, int64_t *rowlist,
+                         int32_t *rmap, int32_t *count, int32_t *overflow);
 int asl_keys_extras(int32_t W, int32_t nq, int32_t k, const int64_t *K, const int32_t *floor,
-                    const int64_t *bounds, int64_t xcap, int64_t *xbuf, int32_t *cursor, int32_t *overflow);
-int asl_keys_merge_final(int32_t S, int32_t nq, int32_t kp, int32_t with_min, int32_t k, const int64_t *heads,
+                    const int64_t *bounds, int64_t xcap, int64_t *xbuf, int32_t *cursor, int32_t *overflow,
+                    const int32_t *rmap, const int64_t *K3, int32_t k3);
+int asl_keys_merge_final(int32_t S, int32_t nq, int32_t kp, int32_t k, const int64_t *heads,
                          const int64_t *xbuf, int64_t xcap, const int64_t *prev_keys, const int32_t *need,
-                         float *D, int64_t *I, int64_t *fin_keys, int64_t *req, int32_t *need3, int32_t *n3);
-int asl_keys_rescan(int32_t W, int32_t nq, int32_t k, int64_t n3, const int64_t *K3, const int64_t *rowidx,
-                    const int64_t *req, int64_t xcap, int64_t *xbuf, int32_t *cursor, int32_t *overflow);
-int asl_keys_merge3(int32_t W, int32_t nq, int32_t k, const int64_t *fin_keys, const int64_t *xbuf, int64_t xcap,
-                    const int32_t *need3, float *D, int64_t *I);
-/* The shard-side k of the third phase for a final k at `world` ranks: k / 2 from 8 ranks on,
- * 5 k / 8 from 4 (rounded up to 64); k itself below 4 ranks or when that is not more than the
- * head's ceil(2 k / world) key slots (pure host integer code). */
+                         float *D, int64_t *I);
+/* The shards' own k for a final k at `world` ranks: k / 2 from 8 ranks on, 5 k / 8 from 4
+ * (rounded up to 64); k itself below 4 ranks or when that is not more than the head's
+ * ceil(2 k / world) key slots (pure host integer code). */
 int32_t asl_shard_k(int32_t k, int32_t world);
+/* asl_index_search_preassigned for a list whose length only the device knows (device pointers
+ * only, never waits): a launch for `cap` rows of which the first *count are searched; the other
+ * rows of D / I stay untouched. Layout-specific scans only (what asl_index_supports_keys says). */
+int asl_index_search_gated(asl_index_t *idx, int32_t cap, const float *xq, int32_t k, int32_t nprobe,
+                           const float *coarse_D, const int32_t *coarse_I, float *D, int64_t *I,
+                           const int32_t *count);
 /* list -> owner rank map of the balancing above, for inspection. */
 int asl_index_shard_map(const asl_index_t *idx, int32_t world, int32_t *owner /* [nlist] */);
 

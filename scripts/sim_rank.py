@@ -28,32 +28,40 @@ idx.set_scan_variant(variant)
 q_all, _ = synthetic.make_queries(lib, aux, W * batch, seed=42, open_range=500.0, charge=2)
 q = q_all.select(torch.arange(batch, device=dev)).contiguous()
 be = HipShardBackend(sl, 2, 'open')
+from ann_solo_amd import _lib
 from ann_solo_amd.distributed import head_width, shard_k
 k = be.k_scan
-# the shards' own k: asl_shard_k by default (k / 2 at 8 ranks, 5 k / 8 at 4: the third phase keeps the
-# result exact); argv[6] overrides it (k itself: the round-4 protocol)
+# the shards' own k: asl_shard_k by default (k / 2 at 8 ranks, 5 k / 8 at 4; second scans on the shard
+# keep the result exact); argv[6] overrides it (k itself: the round-4 protocol)
 k_row = int(sys.argv[6]) if len(sys.argv) > 6 else shard_k(k, W)
-nkeep = head_width(k, W) - 1
-if not (nkeep < k_row < k):
+kp = head_width(k, W)
+if not (kp - 1 < k_row < k):
     k_row = k
-third = k_row < k
+shard_side = k_row < k
+two_phase = kp - 1 < k_row
 allvec = be.encode(q_all)
 cD, cI = be.coarse(allvec)
-# the W shards of the index, side by side on this GPU (copies through a file): the rows every shard
-# holds for this rank's own `batch` queries are what the exchange statistics need -- the k_row-deep
-# rows that travel and the FULL rows a third-phase rescan would see
+nall = W * batch
+# the W shards of the index, side by side on this GPU (copies through a file). Every shard scans ALL
+# W x batch queries (that is its work per step); kept: the heads of all its rows (what the owners
+# receive), and for this rank's own `batch` queries its rows, floors, smallest keys and FULL rows
 import tempfile
 from ann_solo_amd import faiss_compat as faiss
 tmp = os.path.join(tempfile.mkdtemp(), 'sim.idxmi')
 faiss.write_index(idx, tmp)
-own_rows, own_full = [], []
+heads_all, own = [None] * W, [None] * W
 for s_ in range(1, W):
     other = faiss.read_index(tmp)
     other.shard(s_, W)
-    own_full.append(other.search_preassigned_keys(allvec[:batch], k, cD[:batch], cI[:batch]))
-    own_rows.append(other.search_preassigned_keys(allvec[:batch], k_row, cD[:batch], cI[:batch]) if third
-                    else own_full[-1])
-    del other
+    rows_s = other.search_preassigned_keys(allvec, k_row, cD, cI)
+    if two_phase:
+        h_, f_, m_ = be.keys_split(rows_s, kp, True)
+        heads_all[s_] = h_
+        own[s_] = (rows_s[:batch].contiguous(), f_[:batch].contiguous(), m_[:batch].contiguous(),
+                   other.search_preassigned_keys(allvec[:batch], k, cD[:batch], cI[:batch]) if shard_side else None)
+    else:
+        own[s_] = (rows_s[:batch].contiguous(), None, None, None)
+    del other, rows_s
 os.remove(tmp)
 idx.shard(0, W)
 
@@ -71,93 +79,86 @@ def timed(fn, reps=3):
 t_enc, _ = timed(lambda: be.encode(q_all))      # every rank hashes ALL queries (peaks travel)
 vec = be.encode(q)
 t_coarse, _ = timed(lambda: be.coarse(vec))     # ... and quantises its own slice
-# the exchange's compute on this rank: split of the W x batch local rows, merge of the heads this
-# rank would own (here: the heads of its own rows for the first `batch` queries of every "shard" --
-# the same work), the held-back keys above the bounds, the final merge, and the third phase
 t_scan, K = timed(lambda: be.shard_search_keys(allvec, cD, cI, k=k_row))
 t_scan_k = None
-if third:
+if shard_side:
     t_scan_k, _ = timed(lambda: be.shard_search_keys(allvec, cD, cI, k=k))
 full0 = be.shard_search_keys(allvec[:batch], cD[:batch], cI[:batch], k=k)
-kp = nkeep + 1 + int(third)
-t_split, (head, floor) = timed(lambda: be.keys_split(K, kp, third))
-# what this rank receives: the heads of its own queries' rows from every shard
-heads = torch.stack([head[:batch]] + [be.keys_split(r_, kp, third)[0] for r_ in own_rows]).contiguous()
-rows_own = [K[:batch].contiguous()] + own_rows          # every shard's rows for this rank's own queries ...
-rows_full = [full0] + own_full
-floors = [floor[:batch].contiguous()] + [be.keys_split(r_, kp, third)[1] for r_ in own_rows]     # ... and their floors
-t_m1, (okeys, bnd, need) = timed(lambda: be.keys_merge_heads(heads, k, third))
-t_x = t_m2 = t_3 = 0.0
-n3 = q3 = 0
-if nkeep < k_row:
-    flag = be.new_flag()
+t_split = t_m1 = t_x = t_m2 = 0.0
+rescans, asked, held, overflow, exact = 0, 0.0, 0.0, 0, True
+if two_phase:
+    t_split, (head, floor, rowmin) = timed(lambda: be.keys_split(K, kp, True) if shard_side else be.keys_split(K, kp) + (None,))
+    heads_all[0] = head
+    own[0] = (K[:batch].contiguous(), floor[:batch].contiguous(), None if rowmin is None else rowmin[:batch].contiguous(), full0)
+    # owner side: this rank merges the heads of its own `batch` queries (timed); the bounds of ALL
+    # queries (what the W owners send to shard 0) come from the same merge over everything
+    heads_own = torch.stack([h_[:batch] for h_ in heads_all]).contiguous()
+    t_m1, (okeys, bnd, need) = timed(lambda: be.keys_merge_heads(heads_own, k))
+    bnd_all = torch.cat([be.keys_merge_heads(torch.stack([h_[o_ * batch:(o_ + 1) * batch] for h_ in heads_all]).contiguous(), k)[1][0]
+                         for o_ in range(W)])                     # [W * batch]: the bounds shard 0 is sent
+    del heads_all
     xcap = batch * max(8, k // 16)
-    # shard side: this rank answers W x batch rows (timed on its own rows against the bounds its
-    # own queries got -- the same amount of work); owner side: the real answers of the W shards
-    t_x, _ = timed(lambda: be.keys_extras(K, floor, bnd.reshape(-1).contiguous(), W, xcap, be.new_flag()))
-    xbuf = torch.stack([be.keys_extras(rows_own[s_], floors[s_], bnd[s_].contiguous(), 1, xcap, flag)[0]
-                        for s_ in range(W)])
-    if third:
-        t_m2, (knn, fin, req, need3) = timed(lambda: be.keys_merge_final(heads, xbuf, okeys, need, k, be.new_flag()))
-        # third phase. Shard side: the requests the W owners address to ONE shard are as many as one
-        # owner addresses to the W shards -- timed as a scan with the full k of exactly those (query,
-        # shard) rows on this shard. Owner side: the real answers from every shard's FULL rows.
-        sels = [be.request_rows(req[s_].contiguous()) for s_ in range(W)]
-        allsel = torch.cat(sels)
-        n3 = int(allsel.numel())
-        xcap3 = batch * max(8, k // 16)
-        f3 = be.new_flag()
-
-        def shard_side():
-            K3 = be.shard_search_keys(allvec.index_select(0, allsel), cD.index_select(0, allsel),
-                                      cI.index_select(0, allsel), k=k)
-            return be.keys_rescan(K3, allsel, req.reshape(-1, 2)[:batch].contiguous(), 1, batch, xcap3 * W, be.new_flag())
-        t_rescan, _ = timed(shard_side) if n3 else (0.0, None)
-        ans = torch.stack([be.keys_rescan(rows_full[s_].index_select(0, sels[s_]), sels[s_], req[s_].contiguous(),
-                                          1, batch, xcap3, f3)[0] for s_ in range(W)])
-        t_m3, knn3 = timed(lambda: be.keys_merge3(fin, ans, need3, k))
-        sel3 = torch.nonzero(need3).reshape(-1)
-        q3 = int(sel3.numel())
-        t_r3 = 0.0
-        if q3:
-            sub = q.select(sel3)
-            kn = knn3.index_select(0, sel3).contiguous()
-            t_r3, _ = timed(lambda: be.rescore_knn(sub, kn, True))
-        t_3 = t_rescan + t_m3 + t_r3
-        knn = knn3
-        flag[0] = max(int(flag[0]), int(f3[0]))
-    else:
-        t_m2, knn = timed(lambda: be.keys_merge_final(heads, xbuf, okeys, need, k))
-    want = be.merge_keys(torch.stack(rows_full).contiguous())[1]
+    # shard side, exactly this rank's work: the answers to all W owners, with the second scans
+    def shard_side_step():
+        f_ = be.new_flag()
+        x_ = be.keys_extras(K, floor, bnd_all, W, xcap, f_, rescan=(rowmin, allvec, cD, cI, k) if shard_side else None)
+        return x_, f_
+    t_x, (xbuf0, f0) = timed(shard_side_step)
+    rescans, overflow = int(f0[1].item()), int(f0[0].item())
+    # owner side: the real answers of the W shards for the own queries (shard 0's from the step
+    # above; the other shards' second scans answered from their full rows)
+    xbufs = [xbuf0[0].contiguous()]
+    flag = be.new_flag()
+    L = _lib.lib()
+    for s_ in range(1, W):
+        rows_s, f_s, m_s, full_s = own[s_]
+        b_ = bnd[s_].contiguous()
+        if shard_side:
+            R = batch
+            rowlist = torch.zeros(R, dtype=torch.int64, device=dev)
+            rmap = torch.empty(batch, dtype=torch.int32, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(L.asl_keys_rescan_list(batch, _lib.ptr(b_), _lib.ptr(m_s), R, _lib.ptr(rowlist), _lib.ptr(rmap),
+                                              _lib.ptr(cnt), _lib.ptr(flag)))
+            K3 = full_s.index_select(0, rowlist)
+            x_ = torch.empty((1, batch + xcap), dtype=torch.int64, device=dev)
+            cur = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(L.asl_keys_extras(1, batch, k_row, _lib.ptr(rows_s), _lib.ptr(f_s), _lib.ptr(b_), xcap, _lib.ptr(x_),
+                                         _lib.ptr(cur), _lib.ptr(flag), _lib.ptr(rmap), _lib.ptr(K3), k))
+            xbufs.append(x_[0])
+        else:
+            xbufs.append(be.keys_extras(rows_s, f_s, b_, 1, xcap, flag)[0])
+    xbuf = torch.stack(xbufs)
+    overflow |= int(flag[0].item())
+    t_m2, knn = timed(lambda: be.keys_merge_final(heads_own, xbuf, okeys, need, k))
+    want = be.merge_keys(torch.stack([o_[3] if shard_side else o_[0] for o_ in own]).contiguous())[1]
     exact = bool(torch.equal(torch.sort(knn, 1).values, torch.sort(want, 1).values))
     held = float(((xbuf[:, :batch] >> 32).sum()).item()) / batch
     asked = float(need.float().mean())
 else:
-    t_m2, knn = timed(lambda: be.keys_merge_final(heads, None, okeys, need, k))
-    flag, asked, exact, held = None, 0.0, True, 0.0
+    own[0] = (K[:batch].contiguous(), None, None, None)
+    t_m2, (_, knn) = timed(lambda: be.merge_keys(torch.stack([o_[0] for o_ in own]).contiguous()))
 t_old, _ = timed(lambda: be.merge_keys(K.view(W, batch, -1).contiguous()))
 t_resc, _ = timed(lambda: be.rescore_knn(q, knn, True))
 t_merge = t_split + t_m1 + t_x + t_m2
-tot = t_enc + t_coarse + t_scan + t_merge + t_3 + t_resc
-print(f'{index} W={W} batch/rank={batch} variant={variant} shard k {k_row} of {k}: encode (all {W * batch}) {t_enc:.2f} coarse {t_coarse:.2f} '
-      f'shard scan ({W * batch} queries) {t_scan:.2f}' + (f' (with the full k: {t_scan_k:.2f})' if t_scan_k else '') +
+tot = t_enc + t_coarse + t_scan + t_merge + t_resc
+print(f'{index} W={W} batch/rank={batch} variant={variant} shard k {k_row} of {k}: encode (all {nall}) {t_enc:.2f} coarse {t_coarse:.2f} '
+      f'shard scan ({nall} queries) {t_scan:.2f}' + (f' (with the full k: {t_scan_k:.2f})' if t_scan_k else '') +
       f' exchange compute {t_merge:.2f} (split {t_split:.2f} + heads {t_m1:.2f} + '
-      f'held-back {t_x:.2f} + final {t_m2:.2f}; head width {kp}, queries asking {asked:.3f}, held-back keys per query {held:.1f}) '
-      f'third phase {t_3:.2f}' + (f' (rescan of {n3} (query, shard) rows {t_rescan:.2f} + merge {t_m3:.2f} + rescoring of {q3} queries again {t_r3:.2f}; '
-                                   f'third_phase_queries {q3 / batch:.5f} of the batch)' if third and nkeep < k_row else '') +
-      f'; equals the merge of the full rows: {exact}, overflow '
-      f'{int(flag[0].item()) if flag is not None else 0}; the full-row merge it replaces {t_old:.2f}; rescore {t_resc:.2f} '
-      f'| compute per step {tot:.2f} ms (collectives excluded)')
+      f'answers incl. second scans {t_x:.2f} + final {t_m2:.2f}; head width {kp}, queries asking {asked:.3f}, '
+      f'answer keys per query {held:.1f}, rows this shard scanned a second time {rescans} = {rescans / nall:.5f} of its rows); '
+      f'equals the merge of the full rows: {exact}, overflow {overflow}; the full-row merge it replaces {t_old:.2f}; '
+      f'rescore {t_resc:.2f} | compute per step {tot:.2f} ms (collectives excluded)')
 
 # how the final top-k spreads over the shards: per query the largest number of its k best hits
 # that ONE shard holds (what a shard-side k smaller than k has to cover)
-rows = torch.stack(rows_full)                                   # [W, batch, k] packed keys
-flip = torch.tensor(-2 ** 63, dtype=torch.int64, device=dev)   # unsigned order as signed order
-allk = (rows ^ flip).permute(1, 0, 2).reshape(batch, -1)
-kth = torch.topk(allk, k, dim=1).values[:, -1:]                 # the k-th best key of the union
-share = ((rows ^ flip) >= kth.unsqueeze(0)).sum(2)              # [W, batch]
-mx = share.max(0).values.float()
-qs = torch.quantile(mx, torch.tensor([0.5, 0.9, 0.99, 0.999, 1.0], device=dev)).tolist()
-print(f'largest share of a query\'s top {k} in one shard: median {qs[0]:.0f}, 90 % {qs[1]:.0f}, 99 % {qs[2]:.0f}, '
-      f'99.9 % {qs[3]:.0f}, max {qs[4]:.0f}; queries with a shard holding more than 512: {(mx > 512).float().mean():.5f}, '
-      f'more than 384: {(mx > 384).float().mean():.5f}, more than 640: {(mx > 640).float().mean():.5f}')
+if shard_side:
+    rows = torch.stack([o_[3] for o_ in own])                       # [W, batch, k] packed keys
+    flip = torch.tensor(-2 ** 63, dtype=torch.int64, device=dev)   # unsigned order as signed order
+    allk = (rows ^ flip).permute(1, 0, 2).reshape(batch, -1)
+    kth = torch.topk(allk, k, dim=1).values[:, -1:]                 # the k-th best key of the union
+    share = ((rows ^ flip) >= kth.unsqueeze(0)).sum(2)              # [W, batch]
+    mx = share.max(0).values.float()
+    qs = torch.quantile(mx, torch.tensor([0.5, 0.9, 0.99, 0.999, 1.0], device=dev)).tolist()
+    print(f'largest share of a query\'s top {k} in one shard: median {qs[0]:.0f}, 90 % {qs[1]:.0f}, 99 % {qs[2]:.0f}, '
+          f'99.9 % {qs[3]:.0f}, max {qs[4]:.0f}; queries with a shard holding more than {k_row}: {(mx > k_row).float().mean():.5f}')

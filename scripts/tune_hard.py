@@ -1,0 +1,50 @@
+"""Calibration of the ``hard`` query mode (ann_solo_amd/synthetic.py) against the reference's one
+behavioural anchor: EXACT inner-product search, k = 1024, finds the true match of 75.1 % of the
+MODIFIED SSMs of iPRG2012 (/root/reference/notebooks/iprg2012_num_candidates.ipynb:282-288).
+Bisection over the hardness h on the bench library (2.1 M spectra, seed 20240807): prints
+hit@1024 of the source spectrum (modified only / all) per h and the h that gives 0.75.
+
+  python scripts/tune_hard.py [library_size] [queries] [target]"""
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+import torch
+from ann_solo_amd import synthetic, faiss_compat as faiss
+from ann_solo_amd.spectral_library import Config, SpectralLibrary
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_100_000
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+target = float(sys.argv[3]) if len(sys.argv) > 3 else 0.75
+dev = torch.device('cuda', 0)
+lib, aux = synthetic.make_library(n, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
+sl = SpectralLibrary(lib, config=Config(mode='bf'), device=dev)
+flat = faiss.IndexFlatIP(800)
+flat.add(sl._encode(sl.partitions[2].spectra))
+
+
+def hit(h, seed=43):
+    q, truth = synthetic.make_queries(lib, aux, nq, seed=seed, open_range=500.0, charge=2, hard=h)
+    _, I = flat.search(sl._encode(q), 1024)
+    ok = (I == truth['source_row'].unsqueeze(1)).any(1)
+    mod = truth['is_modified']
+    return float(ok[mod].float().mean()), float(ok.float().mean()), float(ok[~mod].float().mean())
+
+
+print(f'library {n}, {nq} queries per point, target exact hit@1024 (modified) {target}')
+for h in (0.0, 0.25, 0.5, 0.75, 1.0):
+    m, a, u = hit(h)
+    print(f'h = {h:.3f}: modified {m:.4f}  all {a:.4f}  unmodified {u:.4f}  levers {synthetic.hard_levers(h)}', flush=True)
+lo, hi = 0.0, 1.0
+for _ in range(7):
+    mid = 0.5 * (lo + hi)
+    m, a, u = hit(mid)
+    print(f'h = {mid:.4f}: modified {m:.4f}  all {a:.4f}  unmodified {u:.4f}', flush=True)
+    if m > target:
+        lo = mid
+    else:
+        hi = mid
+best = round(0.5 * (lo + hi), 3)
+for seed in (43, 44, 45):
+    m, a, u = hit(best, seed)
+    print(f'h = {best} seed {seed}: modified {m:.4f}  all {a:.4f}  unmodified {u:.4f}', flush=True)
+print(f'HARD_DEFAULT = {best}')

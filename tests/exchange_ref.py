@@ -47,7 +47,7 @@ def score_bucket(s):
 
 
 def shard_k(k, world):
-    """asl_shard_k (csrc/index.hip): the shards' own k of the third phase."""
+    """asl_shard_k (csrc/index.hip): the shards' own k."""
     if k < 1 or world < 4:
         return k
     raw = (k + 1) // 2 if world >= 8 else (5 * k + 7) // 8
@@ -56,27 +56,29 @@ def shard_k(k, world):
     return ks if ks > head else k
 
 
-def keys_split(K, kp, with_min=False):
-    """K [rows, k] -> head [rows, kp] (kept keys, then 0; last slot = best held-back key; with_min:
-    the slot before it = the row's smallest key when the row is full, else 0), floor [rows] (int32).
-    Kept = every key whose bucket is at or above the lowest bucket floor that admits at most
-    kp - 1 - with_min keys; the held-back keys are the keys of K below the floor (``held_back``)."""
+def row_min(K):
+    """M of every row: its smallest key if the row is FULL (no empty slot), else 0."""
+    K = np.asarray(K).view(np.uint64)
+    return np.where((K != 0).all(1), K.min(1), np.uint64(0)).astype(np.uint64).view(np.int64)
+
+
+def keys_split(K, kp):
+    """K [rows, k] -> head [rows, kp] (kept keys, then 0; last slot = best held-back key), floor
+    [rows] (int32). Kept = every key whose bucket is at or above the lowest bucket floor that admits
+    at most kp - 1 keys; the held-back keys are the keys of K below the floor (``held_back``)."""
     K = np.asarray(K).view(np.uint64)
     rows, k = K.shape
-    nkeep = kp - 1 - int(bool(with_min))
     head = np.zeros((rows, kp), np.uint64)
     floors = np.zeros(rows, np.int32)
     for r in range(rows):
         keys = K[r][K[r] != 0]
         b = score_bucket(key_score(keys))
         cum = np.cumsum(np.bincount(b, minlength=HT_NB)[::-1])[::-1]      # keys in buckets >= j
-        ok = np.nonzero(cum <= nkeep)[0]
+        ok = np.nonzero(cum <= kp - 1)[0]
         floor = int(ok[0]) if len(ok) else HT_NB
         a, h = keys[b >= floor], keys[b < floor]
         head[r, :len(a)] = a
         head[r, kp - 1] = h.max() if len(h) else 0
-        if with_min:
-            head[r, kp - 2] = keys.min() if len(keys) >= k else 0
         floors[r] = floor
     return head.view(np.int64), floors
 
@@ -98,17 +100,16 @@ def _topk_set(cands, k):
     return cands[::-1][:k]
 
 
-def keys_merge_heads(heads, k, with_min=False):
+def keys_merge_heads(heads, k):
     """heads [S, n, kp] -> out_keys [n, k] (best k keys seen, descending here; the device emits a
     set), bounds [S, n] (B or NONE), need [n]."""
     heads = np.asarray(heads).view(np.uint64)
     S, n, kp = heads.shape
-    nkeep = kp - 1 - int(bool(with_min))
     out = np.zeros((n, k), np.uint64)
     bounds = np.full((S, n), NONE, np.uint64)
     need = np.zeros(n, np.int32)
     for q in range(n):
-        best = _topk_set(heads[:, q, :nkeep].reshape(-1), k)
+        best = _topk_set(heads[:, q, :kp - 1].reshape(-1), k)
         out[q, :len(best)] = best
         B = best[-1] if len(best) >= k else np.uint64(0)
         ask = heads[:, q, kp - 1] > B
@@ -117,12 +118,38 @@ def keys_merge_heads(heads, k, with_min=False):
     return out.view(np.int64), bounds.view(np.int64), need
 
 
-def keys_extras(K, floors, bounds, world, xcap):
+def rescan_list(bounds, rowmin, R):
+    """Rows whose bound lies below the smallest key of a full row (a dropped key may be above the
+    bound): -> rowlist [R] (the first count slots, ascending here; the device's order is whatever
+    its atomics gave), rmap [rows] (slot or -1), count, overflow (more than R rows)."""
+    bounds = np.asarray(bounds).view(np.uint64).reshape(-1)
+    rowmin = np.asarray(rowmin).view(np.uint64).reshape(-1)
+    need = np.nonzero((bounds != NONE) & (rowmin != 0) & (rowmin > bounds))[0]
+    rowlist = np.zeros(R, np.int64)
+    rmap = np.full(len(bounds), -1, np.int32)
+    take = need[:R]
+    rowlist[:len(take)] = take
+    rmap[take] = np.arange(len(take), dtype=np.int32)
+    return rowlist, rmap, len(need), int(len(need) > R)
+
+
+def keys_extras(K, floors, bounds, world, xcap, rmap=None, K3=None):
     """K [world * n, k] (destination-major rows) and the floors of ``keys_split``, bounds [world * n] -> xbuf [world, n + xcap]
     (n header words count << 32 | start, then the payload) and the overflow flag. Payload order
     inside a destination is the row order here (the device's is whatever its atomics gave: the
-    headers say where each row's keys are)."""
+    headers say where each row's keys are). ``rmap`` / ``K3``: rows with rmap[row] >= 0 answer from
+    K3[rmap[row]] (their second scan with the full k: every key below the floor counts)."""
     rest = held_back(K, floors).view(np.uint64)
+    if rmap is not None:
+        K3u = np.asarray(K3).view(np.uint64)
+        wide = np.zeros((len(rest), max(rest.shape[1], K3u.shape[1])), np.uint64)
+        wide[:, :rest.shape[1]] = rest
+        for r in np.nonzero(np.asarray(rmap) >= 0)[0]:
+            row3 = K3u[rmap[r]]
+            keep = row3[(row3 != 0) & (score_bucket(key_score(row3)) < floors[r])]
+            wide[r] = 0
+            wide[r, :len(keep)] = keep
+        rest = wide
     bounds = np.asarray(bounds).view(np.uint64)
     rows, k = rest.shape
     n = rows // world
@@ -146,86 +173,22 @@ def keys_extras(K, floors, bounds, world, xcap):
     return xbuf.view(np.int64), overflow
 
 
-def keys_merge_final(heads, xbuf, out_keys, need, k, with_min=False):
-    """-> I [n, k] ids of the exact top-k of everything received (descending here), -1 padded.
-    with_min: -> (I, fin_keys [n, k], req [S, n, 2], need3 [n], n3): the keys behind I and, per
-    shard, (B', M_s) where the shard's full row may hide a key of the result (M_s > B' = the k-th
-    best key of the result, 0 if it holds fewer than k), else (NONE, 0)."""
+def keys_merge_final(heads, xbuf, out_keys, need, k):
+    """-> I [n, k] ids of the exact top-k of everything received (descending here), -1 padded."""
     heads = np.asarray(heads).view(np.uint64)
     S, n, kp = heads.shape
-    nkeep = kp - 1 - int(bool(with_min))
     I = np.full((n, k), -1, np.int64)
-    fin = np.zeros((n, k), np.uint64)
-    req = np.zeros((S, n, 2), np.uint64)
-    req[:, :, 0] = NONE
-    need3 = np.zeros(n, np.int32)
     xb = None if xbuf is None else np.asarray(xbuf).view(np.uint64)
     for q in range(n):
         if xb is None or not need[q]:
             keys = np.asarray(out_keys).view(np.uint64)[q]
             keys = keys[keys != 0]
         else:
-            parts = [heads[:, q, :nkeep].reshape(-1)]
+            parts = [heads[:, q, :kp - 1].reshape(-1)]
             for s_ in range(S):
                 h = xb[s_, q]
                 cnt, st = int(h >> np.uint64(32)), int(h & np.uint64(0xFFFFFFFF))
                 parts.append(xb[s_, n + st:n + st + cnt])
             keys = _topk_set(np.concatenate(parts), k)
-        I[q, :len(keys)] = key_id(keys)
-        if with_min:
-            fin[q, :len(keys)] = keys
-            B = keys.min() if len(keys) >= k else np.uint64(0)
-            M = heads[:, q, kp - 2]
-            ask = (M != 0) & (M > B)
-            req[ask, q, 0] = B
-            req[ask, q, 1] = M[ask]
-            need3[q] = int(ask.any())
-    if with_min:
-        return I, fin.view(np.int64), req.view(np.int64), need3, int((req[:, :, 0] != NONE).sum())
-    return I
-
-
-def request_rows(req):
-    """req [rows, 2] -> the rows that carry a request (ascending)."""
-    return np.nonzero(np.asarray(req).view(np.uint64).reshape(-1, 2)[:, 0] != NONE)[0].astype(np.int64)
-
-
-def keys_rescan(K3, rowidx, req, world, n, xcap):
-    """Phase 3 on the shard. K3 [n3, k]: full-k rows of the requested (destination-major) rows
-    ``rowidx``; req [world * n, 2] = (B', M). -> xbuf [world, n + xcap] (headers count << 32 |
-    start, payload = the keys strictly between B' and M) and the overflow flag."""
-    K3 = np.asarray(K3).view(np.uint64).reshape(len(rowidx), -1)
-    req = np.asarray(req).view(np.uint64).reshape(-1, 2)
-    xbuf = np.zeros((world, n + xcap), np.uint64)
-    cur = [0] * world
-    overflow = 0
-    for r, row in enumerate(rowidx):
-        d, q = int(row) // n, int(row) % n
-        B, M = req[row]
-        e = K3[r][(K3[r] != 0) & (K3[r] > B) & (K3[r] < M)]
-        if cur[d] + len(e) > xcap:
-            overflow = 1
-            cur[d] += len(e)
-            continue
-        xbuf[d, q] = (np.uint64(len(e)) << np.uint64(32)) | np.uint64(cur[d])
-        xbuf[d, n + cur[d]:n + cur[d] + len(e)] = e
-        cur[d] += len(e)
-    return xbuf.view(np.int64), overflow
-
-
-def keys_merge3(fin_keys, xbuf, need3, k):
-    """Phase 3 on the owner: fin_keys [n, k] + answers xbuf [W, n + xcap] -> I [n, k]."""
-    fin = np.asarray(fin_keys).view(np.uint64)
-    xb = np.asarray(xbuf).view(np.uint64)
-    n = len(fin)
-    I = np.full((n, k), -1, np.int64)
-    for q in range(n):
-        parts = [fin[q]]
-        if need3[q]:
-            for s_ in range(xb.shape[0]):
-                h = xb[s_, q]
-                cnt, st = int(h >> np.uint64(32)), int(h & np.uint64(0xFFFFFFFF))
-                parts.append(xb[s_, n + st:n + st + cnt])
-        keys = _topk_set(np.concatenate(parts), k)
         I[q, :len(keys)] = key_id(keys)
     return I

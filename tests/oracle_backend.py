@@ -71,41 +71,43 @@ class OracleShardBackend:
             I[q, :len(best)] = X.key_id(best)
         return None, torch.from_numpy(I)
 
-    def keys_split(self, K, kp, with_min=False):
-        head, floors = X.keys_split(K.numpy(), kp, with_min)
+    def keys_split(self, K, kp, want_rowmin=False):
+        head, floors = X.keys_split(K.numpy(), kp)
+        if want_rowmin:
+            return torch.from_numpy(head), torch.from_numpy(floors), torch.from_numpy(X.row_min(K.numpy()))
         return torch.from_numpy(head), torch.from_numpy(floors)
 
-    def keys_merge_heads(self, heads, k, with_min=False):
-        out, bounds, need = X.keys_merge_heads(heads.numpy(), k, with_min)
+    def keys_merge_heads(self, heads, k):
+        out, bounds, need = X.keys_merge_heads(heads.numpy(), k)
         return torch.from_numpy(out), torch.from_numpy(bounds), torch.from_numpy(need)
 
-    def keys_extras(self, K, floors, bounds, world, xcap, overflow):
-        xbuf, ov = X.keys_extras(K.numpy(), floors.numpy(), bounds.numpy(), world, xcap)
+    rescan_capacity = None          # tests: a tiny capacity forces the overflow fallback
+
+    def keys_extras(self, K, floors, bounds, world, xcap, overflow, rescan=None):
+        """``rescan`` = (rowmin, vectors, coarse_D, coarse_I, k): rows whose bound lies below the
+        smallest key of a full row are searched again with the full k and answer from that row."""
+        rmap = K3 = None
+        if rescan is not None:
+            rowmin, xv, cD, cI, k_full = rescan
+            R = self.rescan_capacity or max(64, K.shape[0] // 16)
+            rowlist, rmap, cnt, ov = X.rescan_list(bounds.numpy(), rowmin.numpy(), R)
+            overflow[0] = max(int(overflow[0]), ov)
+            overflow[1] += cnt
+            n3 = min(cnt, R)
+            K3 = np.zeros((R, k_full), np.int64)
+            if n3:
+                sel = torch.from_numpy(rowlist[:n3])
+                K3[:n3] = self.shard_search_keys(xv.index_select(0, sel), None, None, k=k_full).numpy()
+        xbuf, ov = X.keys_extras(K.numpy(), floors.numpy(), bounds.numpy(), world, xcap, rmap, K3)
         overflow[0] = max(int(overflow[0]), ov)
         return torch.from_numpy(xbuf)
 
-    def keys_merge_final(self, heads, xbuf, out_keys, need, k, flag=None):
-        """``flag`` (the batch's [overflow, requests] pair) arms the third phase."""
-        r = X.keys_merge_final(heads.numpy(), None if xbuf is None else xbuf.numpy(),
-                               out_keys.numpy(), need.numpy(), k, with_min=flag is not None)
-        if flag is None:
-            return torch.from_numpy(r)
-        I, fin, req, need3, n3 = r
-        flag[1] += n3
-        return torch.from_numpy(I), torch.from_numpy(fin), torch.from_numpy(req), torch.from_numpy(need3)
-
-    def request_rows(self, req):
-        return torch.from_numpy(X.request_rows(req.numpy()))
-
-    def keys_rescan(self, K3, rowidx, req, world, n, xcap, flag):
-        xbuf, ov = X.keys_rescan(K3.numpy(), rowidx.numpy(), req.numpy(), world, n, xcap)
-        flag[0] = max(int(flag[0]), ov)
-        return torch.from_numpy(xbuf)
-
-    def keys_merge3(self, fin_keys, xbuf, need3, k):
-        return torch.from_numpy(X.keys_merge3(fin_keys.numpy(), xbuf.numpy(), need3.numpy(), k))
+    def keys_merge_final(self, heads, xbuf, out_keys, need, k):
+        return torch.from_numpy(X.keys_merge_final(heads.numpy(), None if xbuf is None else xbuf.numpy(),
+                                                   out_keys.numpy(), need.numpy(), k))
 
     def new_flag(self):
+        """[0]: a buffer ran full somewhere; [1]: rows this shard searched a second time."""
         return torch.zeros(2, dtype=torch.int32)
 
     def _window_ok(self, q_pmz, tol, mode):

@@ -96,22 +96,23 @@ def _worker(rank, world, port, kind, out_dir):
     # heads (40 of k = 64 keys per shard: the bound / held-back-keys round runs; 1 key per shard:
     # the owner sees fewer than k keys and asks for everything), with phase-2 buffers too small (the
     # flag repeats the batch with the full exchange), the full packed-key rows, the (D, I) rows
-    # Round 5, the third phase: the shards keep rows of shard_keys < k keys; a full row may hide a
-    # key of the result, the owner asks (B', M), the shard scans again with the full k. 'third':
-    # rows of 16 keys from 2-4 shards cannot even fill k = 64 -- B' = 0, every full row is asked
-    # about (a forced third phase); 'third_mid': some queries ask; 'third_overflow': answer buffers
-    # of zero slots send the batch down the full exchange. 'disagree': ONE rank's shard cannot
-    # emit packed keys (an empty / dense IVF-Flat shard): all ranks must take the (D, I) rows.
+    # Round 5, shard-side k: the shards keep rows of shard_keys < k keys; a full row may have dropped
+    # keys, and where the bound a shard is sent lies below the row's smallest key it searches that
+    # query again with the full k and answers from that row. 'third': rows of 16 keys from 2-4
+    # shards cannot even fill k = 64 -- B = 0, every full row is searched again; 'third_mid': some
+    # rows are; 'third_overflow': room for ONE second search per piece sends the batch down the
+    # full exchange. 'disagree': ONE rank's shard cannot emit packed keys (an empty / dense
+    # IVF-Flat shard): all ranks must take the (D, I) rows.
     ok, seen = True, {}
     for name, kw in (('two_phase', {}), ('small_heads', dict(head_keys=40, extras_per_query=32)),
                      ('tiny_heads', dict(head_keys=1, extras_per_query=64)),
                      ('overflow', dict(head_keys=9, extras_per_query=0)),
-                     ('third', dict(head_keys=8, shard_keys=16, extras_per_query=64, answers_per_query=64)),
+                     ('third', dict(head_keys=8, shard_keys=16, extras_per_query=64)),
                      ('third_mid', dict(head_keys=20, shard_keys=44, extras_per_query=64)),
-                     ('third_overflow', dict(head_keys=8, shard_keys=16, extras_per_query=64,
-                                             answers_per_query=0)),
+                     ('third_overflow', dict(head_keys=8, shard_keys=16, extras_per_query=64)),
                      ('full_keys', dict(two_phase=False)), ('disagree', {}), ('rows', None)):
         be.keys = kw is not None and (name != 'disagree' or rank == 0)
+        be.rescan_capacity = 1 if name == 'third_overflow' else None
         be.index_epoch = getattr(be, 'index_epoch', 0) + 1     # the agreed exchange format is cached per epoch
         stats, comm = {}, CommLog()
         res = sharded_search_batch(be, q, stats=stats, comm=comm, **(kw or {}))
@@ -121,13 +122,14 @@ def _worker(rank, world, port, kind, out_dir):
         ok = ok and same
         seen[name] = (same, stats.get('fallback', 0), sorted(comm.calls), stats.get('third_phase_queries', 0),
                       stats.get('shard_k'), stats.get('exchange_used'))
-    be.keys = True
+    be.keys, be.rescan_capacity = True, None
     ok = (ok and seen['overflow'][1] == 1 and seen['small_heads'][1] == 0 and
           'held_back_keys_all_to_all' in seen['small_heads'][2] and
           ('heads_all_to_all' in seen['two_phase'][2]) == (world > 2) and    # two ranks: the rows travel whole
-          seen['third'][3] == nloc and seen['third'][4] == 16 and seen['third'][1] == 0 and
-          'rescan_answers_all_to_all' in seen['third'][2] and
-          seen['third_mid'][4] == 44 and seen['third_mid'][1] == 0 and
+          seen['third'][3] > nloc and seen['third'][4] == 16 and seen['third'][1] == 0 and
+          seen['third'][5] == 'two-phase, shard-side k + second scans' and
+          seen['third_mid'][4] == 44 and seen['third_mid'][1] == 0 and seen['third_mid'][3] > 0 and
+          seen['small_heads'][3] == 0 and
           seen['third_overflow'][1] == 1 and seen['third_overflow'][5] == 'full rows (fallback)' and
           seen['disagree'][2].count('topk_rows_all_to_all') == 1 and seen['disagree'][5] == 'full rows' and
           'heads_all_to_all' not in seen['disagree'][2] and

@@ -1,7 +1,7 @@
 """The device kernels of the exact top-k exchange (ann_solo_amd/csrc/exchange.hip) against their
 numpy restatement (tests/exchange_ref.py) and against the definition: the ids the owner ends up
-with are the top-k of the union of all shards' rows, whatever the head width -- and, with the
-third phase, whatever the shards' own k."""
+with are the top-k of the union of all shards' rows, whatever the head width -- and, with second
+scans on the shards, whatever the shards' own k."""
 import numpy as np
 import pytest
 
@@ -31,34 +31,34 @@ def _sets(a):
     return [set(r[r != 0].tolist()) for r in a]
 
 
-@pytest.mark.parametrize('with_min', [False, True])
-@pytest.mark.parametrize('k,kp', [(1024, 257), (1024, 513), (64, 17), (100, 101), (1280, 3), (256, 33), (512, 258)])
-def test_keys_split_equals_the_restatement(k, kp, with_min):
+@pytest.mark.parametrize('k,kp', [(1024, 257), (1024, 513), (64, 17), (100, 101), (1280, 2), (256, 33)])
+def test_keys_split_equals_the_restatement(k, kp):
     import torch
     from ann_solo_amd.distributed import HipShardBackend
     be = HipShardBackend.__new__(HipShardBackend)
     rng = np.random.default_rng(k + kp)
     K = np.concatenate([_rows(rng, 40, k, fill=0.5), _rows(rng, 24, k, grid=50),
                         np.zeros((2, k), np.int64)])
-    head, floors = be.keys_split(torch.from_numpy(K).cuda(), kp, with_min)
+    head, floors, rowmin = be.keys_split(torch.from_numpy(K).cuda(), kp, True)
+    h1, f1 = be.keys_split(torch.from_numpy(K).cuda(), kp)
+    assert torch.equal(h1.sort(1).values, head.sort(1).values) and torch.equal(f1, floors)
     head, floors = head.cpu().numpy(), floors.cpu().numpy()
-    h0, f0 = X.keys_split(K, kp, with_min)
-    nkeep = kp - 1 - int(with_min)
-    assert np.array_equal(head[:, nkeep:], h0[:, nkeep:])                     # (M,) best held-back key
-    if with_min:                                                              # M: the smallest key of a FULL row
-        Ku = K.view(np.uint64)
-        full = (Ku != 0).all(1)
-        assert full.any() and (~full).any()
-        assert np.array_equal(head[:, kp - 2].view(np.uint64), np.where(full, Ku.min(1), 0))
+    h0, f0 = X.keys_split(K, kp)
+    Ku = K.view(np.uint64)                                                    # M: the smallest key of a FULL row
+    full = (Ku != 0).all(1)
+    assert full.any() and (~full).any()
+    assert np.array_equal(rowmin.cpu().numpy().view(np.uint64), np.where(full, Ku.min(1), 0))
+    assert np.array_equal(rowmin.cpu().numpy(), X.row_min(K))
+    assert np.array_equal(head[:, kp - 1], h0[:, kp - 1])                     # best held-back key
     assert np.array_equal(floors, f0)                                         # the bucket floor of every row
-    assert _sets(head[:, :nkeep]) == _sets(h0[:, :nkeep])
+    assert _sets(head[:, :kp - 1]) == _sets(h0[:, :kp - 1])
     rest = X.held_back(K, floors)                                             # what stays behind in K
     for r in range(len(K)):                                                   # zero padding is at the end
-        nz = np.nonzero(head[r, :nkeep])[0]
+        nz = np.nonzero(head[r, :kp - 1])[0]
         assert len(nz) == 0 or nz[-1] == len(nz) - 1
-        a, h = _sets(head[r:r + 1, :nkeep])[0], _sets(rest[r:r + 1])[0]
+        a, h = _sets(head[r:r + 1, :kp - 1])[0], _sets(rest[r:r + 1])[0]
         assert not h or not a or max(h) < min(a)                              # kept keys beat held-back ones
-        assert len(a) <= nkeep and a | h == _sets(K[r:r + 1])[0]
+        assert len(a) <= kp - 1 and a | h == _sets(K[r:r + 1])[0]
 
 
 @pytest.mark.parametrize('S,k,head_keys,xper,grid', [(8, 1024, 256, 64, None), (4, 256, 40, 256, None),
@@ -128,17 +128,83 @@ def test_two_phase_exchange_is_the_top_k_of_the_union(S, k, head_keys, xper, gri
         assert (I[q][len(got):] == -1).all()
 
 
-@pytest.mark.parametrize('S,k,ks,head_keys,xper,grid,skew', [
-    (8, 1024, 512, 256, 64, None, 0.45), (8, 1024, 512, 256, 1024, None, 0.9), (4, 1024, 640, 512, 1024, None, 0.6),
-    (8, 1024, 128, 64, 1024, None, 0.2),        # 8 x 128 = k: nearly every full row is asked about
-    (3, 256, 64, 16, 256, 30, 0.5), (8, 512, 192, 128, 512, 8, 0.5), (2, 64, 16, 8, 64, None, 0.3),
-    (8, 1024, 512, 256, 2, None, 0.9)])         # answer buffers of 2 slots per query: overflow
-def test_third_phase_is_the_top_k_of_the_union_of_the_full_rows(S, k, ks, head_keys, xper, grid, skew):
-    """The shards hold FULL rows of k keys but send the exchange only their k_s best (what a scan
-    with a shard-side k_s keeps). Heads with M -> bounds -> held-back keys -> final merge + requests
-    (B', M) -> rescan answers (the keys of the full row between the two) -> last merge: every step
-    equals the restatement, the result is the top k of the union of the FULL rows."""
+@pytest.mark.parametrize('index', ['ivfpq', 'ivfflat'])
+def test_gated_search_scans_exactly_the_counted_rows(index):
+    """asl_index_search_gated: a launch for `cap` rows of which a DEVICE-side count says how many are
+    real -- those rows equal search_preassigned's packed-key rows, the others stay untouched; and
+    HipShardBackend.keys_extras(rescan=...) through a real (sharded) index equals the restatement."""
     import torch
+    from ann_solo_amd import _lib, synthetic
+    from ann_solo_amd.distributed import HipShardBackend
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    lib, aux = synthetic.make_library(20000, seed=5, device='cpu', charges=(2,), charge_p=(1.0,))
+    q, _ = synthetic.make_queries(lib, aux, 300, seed=6, charge=2)
+    sl = SpectralLibrary(lib, config=Config(num_list=32, num_probe=12, num_candidates=256, index=index, kmeans_niter=3))
+    be = HipShardBackend(sl, 2, 'open')
+    idx = be.index
+    vec = be.encode(q)
+    cD, cI = be.coarse(vec)
+    k = 256
+    want = idx.search_preassigned_keys(vec, k, cD, cI)
+    for count in (0, 1, 77, 300):
+        K = torch.full((300, k), -7, dtype=torch.int64, device=vec.device)
+        cnt = torch.tensor([count], dtype=torch.int32, device=vec.device)
+        idx.set_unordered(2)
+        try:
+            _lib.check(_lib.lib().asl_index_search_gated(idx._h, 300, _lib.ptr(vec), k, 12, _lib.ptr(cD), _lib.ptr(cI),
+                                                         None, _lib.ptr(K), _lib.ptr(cnt)))
+        finally:
+            idx.set_unordered(0)
+        assert torch.equal(K[:count].sort(1).values, want[:count].sort(1).values)
+        assert bool((K[count:] == -7).all())
+    # the whole shard-side step on a real shard: rows of 64 keys, bounds that ask about a third of them
+    idx.shard(0, 2)
+    ks = 64
+    Ks = idx.search_preassigned_keys(vec, ks, cD, cI)
+    Kf = idx.search_preassigned_keys(vec, k, cD, cI)
+    head, floor, rowmin = be.keys_split(Ks, 17, True)
+    Kn = Ks.cpu().numpy().view(np.uint64)
+    rng = np.random.default_rng(3)
+    b = np.full(300, X.NONE, np.uint64)
+    for r in range(300):
+        row = np.sort(Kn[r][Kn[r] != 0])
+        u = rng.random()
+        if len(row) and u < 0.3:
+            b[r] = row[0] - np.uint64(1 + rng.integers(0, 1 << 30))      # below the smallest key: second scan if full
+        elif len(row) and u < 0.6:
+            b[r] = row[len(row) // 2]                                        # inside the row: held-back keys only
+    bounds = torch.from_numpy(b.view(np.int64)).cuda()
+    flag = be.new_flag()
+    xcap = 300 * k
+    be.rescan_capacity = 300
+    xbuf = be.keys_extras(Ks, floor, bounds, 1, xcap, flag, rescan=(rowmin, vec, cD, cI, k))
+    assert int(flag[0].item()) == 0 and int(flag[1].item()) > 10
+    rl0, rm0, c0, _ = X.rescan_list(b, rowmin.cpu().numpy(), 300)
+    assert int(flag[1].item()) == c0
+    K3 = np.zeros((300, k), np.int64)
+    K3[:c0] = Kf.cpu().numpy()[rl0[:c0]]
+    x0, ov = X.keys_extras(Ks.cpu().numpy(), floor.cpu().numpy(), b, 1, xcap, rm0, K3)
+    got, exp = xbuf[0].cpu().numpy().view(np.uint64), x0[0].view(np.uint64)
+    for r in range(300):
+        c, st = int(got[r] >> np.uint64(32)), int(got[r] & np.uint64(0xFFFFFFFF))
+        c1, st1 = int(exp[r] >> np.uint64(32)), int(exp[r] & np.uint64(0xFFFFFFFF))
+        assert c == c1 and set(got[300 + st:300 + st + c].tolist()) == set(exp[300 + st1:300 + st1 + c1].tolist()), r
+    sl.shutdown()
+
+
+@pytest.mark.parametrize('S,k,ks,head_keys,xper,grid,skew,cap', [
+    (8, 1024, 512, 256, 1024, None, 0.45, None), (8, 1024, 512, 256, 1024, None, 0.9, None),
+    (4, 1024, 640, 512, 1024, None, 0.6, None),
+    (8, 1024, 128, 64, 1024, None, 0.2, None),        # 8 x 128 = k: nearly every full row is scanned again
+    (3, 256, 64, 16, 256, 30, 0.5, None), (8, 512, 192, 128, 512, 8, 0.5, None), (2, 64, 16, 8, 64, None, 0.3, None),
+    (8, 1024, 128, 64, 1024, None, 0.2, 3)])          # room for 3 second scans: overflow
+def test_shard_side_k_with_second_scans_is_the_top_k_of_the_union_of_the_full_rows(S, k, ks, head_keys, xper, grid, skew, cap):
+    """The shards hold FULL rows of k keys but run the exchange on their k_s best (what a scan with
+    a shard-side k_s keeps). Heads -> bounds -> rescan list (bound below the smallest key of a full
+    row) -> answers from the full row for those, from the k_s-row for the others -> final merge:
+    every step equals the restatement, the result is the top k of the union of the FULL rows."""
+    import torch
+    from ann_solo_amd import _lib
     from ann_solo_amd.distributed import HipShardBackend
     be = HipShardBackend.__new__(HipShardBackend)
     rng = np.random.default_rng(S * k + ks)
@@ -151,57 +217,61 @@ def test_third_phase_is_the_top_k_of_the_union_of_the_full_rows(S, k, ks, head_k
             rng.shuffle(r)
         return Ku.view(np.int64)
     rows = [top(f, ks) for f in full]
-    kp = head_keys + 2
+    kp = head_keys + 1
     dev_rows = [torch.from_numpy(r).cuda() for r in rows]
     split = [be.keys_split(r, kp, True) for r in dev_rows]
-    heads = torch.stack([h for h, _ in split])
-    out, bounds, need = be.keys_merge_heads(heads, k, True)
-    o0, b0, n0 = X.keys_merge_heads(heads.cpu().numpy(), k, True)
-    assert _sets(out.cpu().numpy()) == _sets(o0)
+    heads = torch.stack([h for h, _, _ in split])
+    out, bounds, need = be.keys_merge_heads(heads, k)
+    o0, b0, n0 = X.keys_merge_heads(heads.cpu().numpy(), k)
     assert np.array_equal(bounds.cpu().numpy(), b0) and np.array_equal(need.cpu().numpy(), n0)
     flag = torch.zeros(2, dtype=torch.int32, device='cuda')
-    xcap = n * max(64, ks)
-    xb = torch.stack([be.keys_extras(dev_rows[s], split[s][1], bounds[s].contiguous(), 1, xcap, flag)[0]
-                      for s in range(S)])
-    assert int(flag[0].item()) == 0
-    I, fin, req, need3 = be.keys_merge_final(heads, xb, out, need, k, flag)
-    I0, fin0, req0, need30, n30 = X.keys_merge_final(heads.cpu().numpy(), xb.cpu().numpy(), o0, n0, k, with_min=True)
-    assert _sets(fin.cpu().numpy()) == _sets(fin0)
-    assert [set(r[r >= 0].tolist()) for r in I.cpu().numpy()] == [set(r[r >= 0].tolist()) for r in I0]
-    assert np.array_equal(req.cpu().numpy(), req0) and np.array_equal(need3.cpu().numpy(), need30)
-    assert int(flag[1].item()) == n30
-    # the union of the k_s-rows is what phases 1-2 must have produced
-    u12 = np.concatenate(rows, axis=1).view(np.uint64)
-    assert _sets(fin.cpu().numpy()) == [set(np.sort(u[u != 0])[::-1][:k].tolist()) for u in u12]
-    # phase 3: every shard answers the one owner (world = 1 on the shard side)
-    flag.zero_()
-    xcap3 = n * xper
-    answers, over_ref = [], 0
+    xcap = n * xper
+    R = cap or max(64, n // 16)
+    L = _lib.lib()
+    xbufs, rescans, over_ref = [], 0, 0
     for s in range(S):
-        rq = req[s].contiguous()                                 # [n, 2]
-        sel = be.request_rows(rq)
-        assert np.array_equal(sel.cpu().numpy(), X.request_rows(req0[s]))
-        K3 = torch.from_numpy(full[s]).cuda().index_select(0, sel)
-        answers.append(be.keys_rescan(K3, sel, rq, 1, n, xcap3, flag)[0])
-        x0, ov = X.keys_rescan(full[s][sel.cpu().numpy()], sel.cpu().numpy(), req0[s], 1, n, xcap3)
-        over_ref |= ov
-        if not ov:
-            got, exp = answers[-1].cpu().numpy().view(np.uint64), x0[0].view(np.uint64)
-            for q in range(n):
-                c, st = int(got[q] >> np.uint64(32)), int(got[q] & np.uint64(0xFFFFFFFF))
-                c0, st0 = int(exp[q] >> np.uint64(32)), int(exp[q] & np.uint64(0xFFFFFFFF))
-                assert c == c0 and set(got[n + st:n + st + c].tolist()) == set(exp[n + st0:n + st0 + c0].tolist())
+        # the device steps of keys_extras(rescan=...) one by one, the second scan answered from the full rows
+        bnd = bounds[s].contiguous()
+        rowlist = torch.zeros(R, dtype=torch.int64, device='cuda')
+        rmap = torch.empty(n, dtype=torch.int32, device='cuda')
+        cnt = torch.zeros(1, dtype=torch.int32, device='cuda')
+        _lib.check(L.asl_keys_rescan_list(n, _lib.ptr(bnd), _lib.ptr(split[s][2]), R, _lib.ptr(rowlist), _lib.ptr(rmap),
+                                          _lib.ptr(cnt), _lib.ptr(flag)))
+        rl0, rm0, c0, ov0 = X.rescan_list(b0[s], split[s][2].cpu().numpy(), R)
+        over_ref |= ov0
+        assert int(cnt.item()) == c0
+        got_rows = set(rowlist[:min(c0, R)].cpu().tolist())
+        assert got_rows <= set(np.nonzero((b0[s].view(np.uint64) != X.NONE))[0].tolist()) and len(got_rows) == min(c0, R)
+        if not ov0:
+            assert got_rows == set(rl0[:c0].tolist())
+            assert np.array_equal(rmap.cpu().numpy() >= 0, rm0 >= 0)
+        rescans += min(c0, R)
+        K3 = torch.from_numpy(full[s]).cuda().index_select(0, rowlist)
+        xbuf = torch.empty((1, n + xcap), dtype=torch.int64, device='cuda')
+        cursor = torch.zeros(1, dtype=torch.int32, device='cuda')
+        _lib.check(L.asl_keys_extras(1, n, ks, _lib.ptr(dev_rows[s]), _lib.ptr(split[s][1]), _lib.ptr(bnd), xcap,
+                                     _lib.ptr(xbuf), _lib.ptr(cursor), _lib.ptr(flag), _lib.ptr(rmap), _lib.ptr(K3), k))
+        xbufs.append(xbuf[0])
+        if not ov0:
+            rm_dev = rmap.cpu().numpy()
+            x0, ov = X.keys_extras(rows[s], split[s][1].cpu().numpy(), b0[s], 1, xcap, rm_dev,
+                                   K3.cpu().numpy())
+            over_ref |= ov
+            if not ov:
+                got, exp = xbuf[0].cpu().numpy().view(np.uint64), x0[0].view(np.uint64)
+                for q in range(n):
+                    c, st = int(got[q] >> np.uint64(32)), int(got[q] & np.uint64(0xFFFFFFFF))
+                    c1, st1 = int(exp[q] >> np.uint64(32)), int(exp[q] & np.uint64(0xFFFFFFFF))
+                    assert c == c1 and set(got[n + st:n + st + c].tolist()) == set(exp[n + st1:n + st1 + c1].tolist())
     assert int(flag[0].item()) == over_ref
     if over_ref:
-        assert xper < k
+        assert cap is not None or xper < k
         return
-    I3 = be.keys_merge3(fin, torch.stack(answers), need3, k).cpu().numpy()
+    assert rescans > 0 or ks * S > k
+    I = be.keys_merge_final(heads, torch.stack(xbufs), out, need, k).cpu().numpy()
     union = np.concatenate(full, axis=1).view(np.uint64)
     want = [set(X.key_id(np.sort(u[u != 0])[::-1][:k]).tolist()) for u in union]
-    asked = 0
     for q in range(n):
-        got = I3[q][I3[q] >= 0]
+        got = I[q][I[q] >= 0]
         assert len(got) == len(set(got.tolist())) == len(want[q]) and set(got.tolist()) == want[q], q
-        assert (I3[q][len(got):] == -1).all()
-        asked += int(need30[q])
-    assert asked > 0 or ks * S > k               # rows that cannot fill k between them: everybody asks
+        assert (I[q][len(got):] == -1).all()
