@@ -232,6 +232,38 @@ asl_library_t *asl_library_create(const asl_peaks_t *p, const float *lib_pmz_f32
   return L;
 }
 
+// Physical order of the packed peak records (what the rescoring kernel gathers, ~270 B per
+// candidate): order[i] = the library row whose record is stored i-th. Rows keep their numbers
+// (row r <-> spec_info id[r]); only the placement inside the record array changes -- e.g. the
+// inverted-list order of the partition's ANN index, so that the candidates of a query (members
+// of its <= nprobe probed lists) come from a few contiguous regions instead of the whole array.
+int asl_library_set_record_order(asl_library_t *L, const int32_t *order) {
+  clear_error();
+  if (!L || !order) return fail(ASL_ERR_INVALID, "set_record_order: null argument");
+  const size_t n = (size_t)L->n;
+  if (n == 0) return ASL_OK;
+  ASL_TRY(ensure_device());
+  std::vector<int32_t> h_order(n);
+  HIP_TRY(hipMemcpy(h_order.data(), order, n * 4, hipMemcpyDefault));
+  std::vector<RowMeta> hm(n);
+  ASL_TRY(L->meta.download(hm.data(), n));
+  ASL_TRY(sync_stream());
+  std::vector<uint8_t> seen(n, 0);
+  uint64_t rec_bytes = 0;
+  for (size_t i = 0; i < n; i++) {
+    const int32_t r = h_order[i];
+    if (r < 0 || (size_t)r >= n || seen[(size_t)r])
+      return fail(ASL_ERR_INVALID, "set_record_order: order is not a permutation of the rows");
+    seen[(size_t)r] = 1;
+    hm[(size_t)r].rec4 = (uint32_t)(rec_bytes >> 2);
+    rec_bytes += (asl::rec_bytes((uint64_t)hm[(size_t)r].cn) + 15) & ~15ull;
+  }
+  ASL_TRY(L->meta.upload(hm.data(), n));
+  ASL_TRY(pack_peak_records(L->offsets.p, L->mz.p, L->intensity.p, L->charge.p, L->meta.p, (int64_t)n,
+                            L->records.p));
+  return sync_stream();
+}
+
 void asl_library_free(asl_library_t *L) { delete L; }
 int64_t asl_library_size(const asl_library_t *L) { return L ? L->n : 0; }
 

@@ -164,7 +164,7 @@ def make_library(n: int, seed: int = 20240807, device='cpu', charges=(2, 3, 4),
 # with EXACT inner-product search the true match of a MODIFIED spectrum is inside the top 1024 for
 # 75.1 % of the iPRG2012 SSMs (notebooks/iprg2012_num_candidates.ipynb:282-288). The default queries
 # give 97.8 % -- far cleaner than real spectra of modified peptides.
-HARD_DEFAULT = 0.5
+HARD_DEFAULT = 0.21
 
 
 def hard_levers(h: float) -> Dict[str, float]:

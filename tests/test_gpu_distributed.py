@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (0, 'ivfflat', ['--head-keys', '600', '--extras-per-query', '0']),   # ... and overflows: fallback
     (0, 'ivfpq', ['--head-keys', '200', '--shard-keys', '448', '--extras-per-query', '1024']),   # 2 x 448 < k: B = 0,
                                                                       # every full row is scanned a second time
-    (0, 'ivfflat', ['--head-keys', '300', '--shard-keys', '640', '--extras-per-query', '512']),   # some rows are
+    (0, 'ivfflat', ['--head-keys', '600', '--shard-keys', '768', '--extras-per-query', '512']),   # a few rows are
     (0, 'ivfpq', ['--exchange', 'full'])])
 def test_two_rank_sharded_bench_path(degree, index, extra):
     """degree 0 = lists sharded over both ranks; degree 1 = two replicas (no exchange). The
