@@ -249,10 +249,6 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
         if constexpr (FX) {
           const uint8_t *trow = reinterpret_cast<const uint8_t *>(seg_tab) + (size_t)blk * tab_stride;
           if (lane * 16 < tab_stride) tb = *reinterpret_cast<const uint4 *>(trow + lane * 16);
-          tb.x &= 0x7f7f7f7fu;      // (bit 7 of a table byte: the half-line flag of flat_scan_q.hip)
-          tb.y &= 0x7f7f7f7fu;
-          tb.z &= 0x7f7f7f7fu;
-          tb.w &= 0x7f7f7f7fu;
           const uint32_t mine = __builtin_amdgcn_sad_u8(tb.x, 0u, 0u) + __builtin_amdgcn_sad_u8(tb.y, 0u, 0u) +
                                 __builtin_amdgcn_sad_u8(tb.z, 0u, 0u) + __builtin_amdgcn_sad_u8(tb.w, 0u, 0u);
           tpre = wave_incl_scan(mine) - mine;
@@ -510,16 +506,6 @@ int flat_inv_scan(int layout, const float *xq, int nq, int d, const int32_t *coa
   return launch_flat_inv<CAP, FX>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base, \
                                   tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt, tab_stride, gate)
   if (layout == 2) {
-    // four block streams per wave (flat_scan_q.hip): measured 2.3 x SLOWER (profiles/r05_flat_scan_notes.txt),
-    // so only ASL_FLAT_Q=1 (or 2: with phase timers) selects it
-    static const bool quarter_waves = [] {
-      const char *e = getenv("ASL_FLAT_Q");
-      return e && (e[0] == '1' || e[0] == '2');
-    }();
-    if (quarter_waves && flat_q_supported(d, k, nprobe))
-      return flat_q_scan(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base,
-                         reinterpret_cast<const uint8_t *>(seg_tab), tab_stride, seg_bytes, ids, k, D, I64, I32,
-                         set_mode, ent, ent_cnt, gate);
     if (small) FI_LAUNCH(2048, true);
     FI_LAUNCH(4096, true);
   }
@@ -778,7 +764,7 @@ __global__ __launch_bounds__(256) void flat_fx_work_kernel(
     for (int b = blk_offsets[l]; b < blk_offsets[l + 1]; ++b) {
       for (int t = tid; t < K; t += 256) {
         bytes += 1ull + 4ull * cnt16[(size_t)b * d + s_dim[t]];
-        lines += tab8[(size_t)b * tab_stride + s_dim[t]] & 0x7f;
+        lines += tab8[(size_t)b * tab_stride + s_dim[t]];
       }
       if (tid == 0) lines += (unsigned long long)((d + 127) / 128);
     }

@@ -388,9 +388,7 @@ static int build_lists(asl_index *ix) {
             const uint32_t c = h_cnt[b * (size_t)ix->d + j];       // <= FI_BLK: at most 26 lines
             h_line[b * (size_t)ix->d + j] = (uint32_t)run;
             h_c16[b * (size_t)ix->d + j] = (uint16_t)c;
-            // lines of the cell; bit 7: the second half of its last line holds repeats only (1..16
-            // postings there): the quarter-wave scan (flat_scan_q.hip) skips that half
-            h_tab8[b * (size_t)stride + j] = (uint8_t)(((c + 31) / 32) | (((c & 31u) >= 1u && (c & 31u) <= 16u) ? 0x80u : 0u));
+            h_tab8[b * (size_t)stride + j] = (uint8_t)((c + 31) / 32);
             run += (c + 31) / 32;
           }
         }

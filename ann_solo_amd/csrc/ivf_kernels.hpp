@@ -72,13 +72,6 @@ int flat_inv_scan(int layout, const float *xq, int nq, int d, const int32_t *coa
                   const uint32_t *blk_base, const void *seg_tab, int tab_stride, const char *seg_bytes,
                   const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode,
                   const uint2 *ent, const int32_t *ent_cnt, const int *gate = nullptr);
-// the same scan with four block streams per wave (flat_scan_q.hip; fixed-point layout)
-bool flat_q_supported(int d, int k, int nprobe);
-int flat_q_scan(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
-                const int32_t *list_offsets, const int32_t *blk_offsets, const uint32_t *blk_base,
-                const uint8_t *tab8, int tab_stride, const char *seg_bytes, const int32_t *ids, int k,
-                float *D, int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent,
-                const int32_t *ent_cnt, const int *gate);
 int flat_inv_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *blk_offsets, const uint32_t *seg_tab, unsigned long long *out_dev);
 uint32_t inv_place_block(const uint32_t *cnt, int d, uint32_t *tab, bool *ok);

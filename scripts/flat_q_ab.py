@@ -1,7 +1,8 @@
-"""Same-box timing of the IVF-Flat postings scan (fixed-point storage) with one block per wave
-(ASL_FLAT_Q=0, flat_scan.hip) against four block streams per wave (default, flat_scan_q.hip): scan
-stage time of synchronous steps at the fixed-recall operating point, and whether ids and score
-bits are identical to the other kernel's.   python scripts/flat_q_ab.py [nprobe] [storage] [steps]"""
+"""Same-box timing of the IVF-Flat postings scan with one block per wave (ASL_FLAT_Q=0, flat_scan.hip)
+against four block streams per wave (ASL_FLAT_Q=1; 2 = with phase timers): the round-5 experiment of
+profiles/r05_flat_scan_notes.txt. The second kernel lives in commit eb62a9e only (csrc/flat_scan_q.hip;
+measured 2.3 x slower and removed), so on the current tree all three runs time the same kernel.
+python scripts/flat_q_ab.py [nprobe] [storage] [steps]"""
 import ctypes as C
 import os
 import subprocess
@@ -48,7 +49,7 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
         print(f'ASL_FLAT_Q={os.environ.get("ASL_FLAT_Q", "(default: 1)")} storage {storage} layout {idx.flat_layout} nprobe {nprobe} '
               f'{"pipelined" if pipelined else "serial   "}: step {el:.3f} ms, scan {ms.value / max(n.value, 1):.4f} ms', flush=True)
     sl.set_pipeline(False)
-    if os.environ.get('ASL_FLAT_Q') == '2':       # the measurement build's phase timers
+    if os.environ.get('ASL_FLAT_Q') == '2' and hasattr(L, 'asl_debug_flat_q_prof'):       # the measurement build's phase timers
         import numpy as np
         buf = np.zeros(16, np.uint64)
         L.asl_debug_flat_q_prof(buf.ctypes.data_as(C.c_void_p))        # (clear)
