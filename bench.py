@@ -1201,8 +1201,8 @@ def _lib_handle():
     return _lib.lib()
 
 
-PMC_TRAFFIC_FILE = 'profiles/r04_pmc_traffic.json'
-PMC_TRAFFIC_FILE_FLAT = 'profiles/r04_ivfflat_np112_pmc_traffic.json'     # IVF-Flat (fixed-point postings), nprobe 112
+PMC_TRAFFIC_FILE = 'profiles/r05_pmc_traffic.json'
+PMC_TRAFFIC_FILE_FLAT = 'profiles/r05_ivfflat_np112_pmc_traffic.json'     # IVF-Flat (float32 postings, the default storage), nprobe 112
 
 
 def pmc_traffic(args, world):
@@ -1255,7 +1255,7 @@ def postings_roofline(sl, idx, q, nprobe, avg_ms, args=None):
     move). HBM-bound: every (query, block) pair touches its own lines."""
     b, l = idx.postings_work(sl._encode(q), nprobe)
     layout = idx.flat_layout
-    traffic, src = flat_pmc_traffic(args, nprobe) if args is not None and layout == 2 else (None, None)
+    traffic, src = flat_pmc_traffic(args, nprobe) if args is not None and layout == 1 else (None, None)
     achieved = b / (avg_ms * 1e-3) / 1e9
     by_line = l * 128 / (avg_ms * 1e-3) / 1e9
     return {'bound': 'hbm', 'kernel': 'flat_inv_scan_kernel', 'achieved': round(achieved, 2),

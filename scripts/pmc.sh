@@ -8,7 +8,7 @@ mkdir -p gpurun_out/$tag
 run() {  # name, counters...
   name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "pq_scan|flat_inv|rescore_|gemm_nt|row_topk|row_select|coarse_sparse" \
-     --output-format csv -d /tmp/pmc_$name -o x -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --recall-queries 0 --no-cascade "${BENCH_ARGS[@]}" > /tmp/pmc_$name.log 2>&1
+     --output-format csv -d /tmp/pmc_$name -o x -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --recall-queries 0 --no-cascade --no-reference-geometry --no-recall-hard "${BENCH_ARGS[@]}" > /tmp/pmc_$name.log 2>&1
   python3 - "$name" <<'PY' >> gpurun_out/$TAG/summary.txt
 import csv, sys, collections, glob
 name = sys.argv[1]

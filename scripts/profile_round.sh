@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 tag=$1; shift
 mkdir -p gpurun_out/$tag
 python3 bench.py "$@" > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o x -- python3 bench.py --cpu-seconds 0 "$@" > gpurun_out/$tag/bench_under_rocprof.json 2> /tmp/prof_$tag.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o x -- python3 bench.py --cpu-seconds 0 --no-reference-geometry "$@" > gpurun_out/$tag/bench_under_rocprof.json 2> /tmp/prof_$tag.err
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/$tag/kernel_stats.csv
 # the default run launches the scan at several sizes (recall sample, cascade tail): the per-dispatch
