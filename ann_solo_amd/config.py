@@ -3,16 +3,16 @@
 ``Config`` carries the reference's flags under the reference's names
 (/root/reference/src/ann_solo/config.py:62-216) plus the ADDITIVE flags of this implementation
 (``index``, ``pq_m``, ``pq_bits``, ``refine_k``, ``kmeans_niter``, ``ann_seed``, ``num_gpus``,
-``flat_storage``). Defaults are the reference's, with these DELIBERATE deviations, all of them
-options the reference's parser makes the user state (so a parsed reference configuration never
-meets them; they only matter to ``Config()`` built by hand, as the tests and ``bench.py`` do):
-``precursor_tolerance_mass`` / ``precursor_tolerance_mode`` / ``fragment_mz_tolerance`` are
-REQUIRED there (config.py:137-150) and default here to 20 ppm / 0.02 Da (the values of the
-reference's notebooks); ``precursor_tolerance_mass_open`` / ``_mode_open`` default to ``None``
-there (cascade off, config.py:151-156) and to 300 Da here; ``allow_peak_shifts`` is a
-``store_true`` flag there (default False, config.py:157) and True here. ``tests/ref_config.py``
-holds the reference's own defaults; ``Config.from_reference`` takes every value from the parsed
-reference object, so none of these defaults survives an integration.
+``flat_storage``). Defaults are the reference's: ``precursor_tolerance_mass_open`` /
+``_mode_open`` are ``None`` (cascade off, config.py:151-156) and ``allow_peak_shifts`` is False
+(a ``store_true`` flag, config.py:157), as a parsed reference configuration without those flags
+has them. The one deviation: ``precursor_tolerance_mass`` / ``precursor_tolerance_mode`` /
+``fragment_mz_tolerance`` are REQUIRED by the reference's parser (config.py:137-150) and default
+here to 20 ppm / 0.02 Da, the values of the reference's notebooks. ``Config.open_search(**kw)``
+is the hand-built configuration the tests and ``bench.py`` use: the notebooks' open search
+(+-300 Da second cascade level, notebooks/iprg2012_ann_hyperparameters.ipynb:100-101) with peak
+shifts on. ``tests/ref_config.py`` holds the reference's own defaults; ``Config.from_reference``
+takes every value from the parsed reference object.
 
 Capacity limits of the device kernels are checked at construction (``ValueError``), not deep
 inside a search: ``max_peaks_used`` / ``max_peaks_used_library`` <= 256 (the reference has no
@@ -56,10 +56,10 @@ class Config:
     mode: str = 'ann'                       # 'ann' | 'bf'
     precursor_tolerance_mass: float = 20.0
     precursor_tolerance_mode: str = 'ppm'   # 'Da' | 'ppm'
-    precursor_tolerance_mass_open: Optional[float] = 300.0
-    precursor_tolerance_mode_open: Optional[str] = 'Da'
+    precursor_tolerance_mass_open: Optional[float] = None
+    precursor_tolerance_mode_open: Optional[str] = None
     fragment_mz_tolerance: float = 0.02
-    allow_peak_shifts: bool = True
+    allow_peak_shifts: bool = False
     no_gpu: bool = False
     # SSM scoring (config.py:158-164): carried for the caller's scorer. The engine itself has no
     # FDR model (out of scope): ``score_ssms=`` is injected; without one every SSM is
@@ -99,6 +99,15 @@ class Config:
     @property
     def ann_seed(self) -> int:              # the flag's name on the command line
         return self.seed
+
+    @classmethod
+    def open_search(cls, **kw) -> 'Config':
+        """A hand-built configuration with the open-modification search switched on the way the
+        reference's notebooks run it: second cascade level +-300 Da, shifted dot product."""
+        base = dict(precursor_tolerance_mass_open=300.0, precursor_tolerance_mode_open='Da',
+                    allow_peak_shifts=True)
+        base.update(kw)
+        return cls(**base)
 
     @classmethod
     def from_reference(cls, obj, **overrides) -> 'Config':

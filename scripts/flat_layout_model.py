@@ -33,7 +33,7 @@ def main():
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     dev = torch.device('cuda', 0)
     lib, aux = synthetic.make_library(N, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
-    cfg = Config(num_list=NLIST, num_probe=NPROBE, num_candidates=1024, index='ivfpq', pq_m=32,
+    cfg = Config.open_search(num_list=NLIST, num_probe=NPROBE, num_candidates=1024, index='ivfpq', pq_m=32,
                  kmeans_niter=25, mode='ann', precursor_tolerance_mass_open=500.0,
                  precursor_tolerance_mode_open='Da', batch_size=16384, seed=1234)
     sl = SpectralLibrary(lib, config=cfg, device=dev)
@@ -147,7 +147,7 @@ def pairing_model():
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     dev = torch.device('cuda', 0)
     lib, aux = synthetic.make_library(N, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
-    cfg = Config(num_list=NLIST, num_probe=NPROBE, num_candidates=1024, index='ivfpq', pq_m=32,
+    cfg = Config.open_search(num_list=NLIST, num_probe=NPROBE, num_candidates=1024, index='ivfpq', pq_m=32,
                  kmeans_niter=25, mode='ann', precursor_tolerance_mass_open=500.0,
                  precursor_tolerance_mode_open='Da', batch_size=16384, seed=1234)
     sl = SpectralLibrary(lib, config=cfg, device=dev)

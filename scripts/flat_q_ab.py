@@ -17,7 +17,7 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
     nprobe, storage, steps, out = int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
     dev = torch.device('cuda', 0)
     lib, aux = synthetic.make_library(2_100_000, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
-    cfg = Config(num_list=4096, num_probe=nprobe, num_candidates=1024, index='ivfflat', kmeans_niter=25, mode='ann',
+    cfg = Config.open_search(num_list=4096, num_probe=nprobe, num_candidates=1024, index='ivfflat', kmeans_niter=25, mode='ann',
                  precursor_tolerance_mass_open=500.0, precursor_tolerance_mode_open='Da', batch_size=16384,
                  seed=1234, flat_storage=storage)
     sl = SpectralLibrary(lib, config=cfg, device=dev)

@@ -15,7 +15,7 @@ nprobe = int(sys.argv[1]) if len(sys.argv) > 1 else 112
 n, batch = 2_100_000, 16384
 dev = torch.device('cuda', 0)
 lib, aux = synthetic.make_library(n, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
-cfg = Config(num_list=4096, num_probe=nprobe, num_candidates=1024, index='ivfflat', kmeans_niter=25, mode='ann',
+cfg = Config.open_search(num_list=4096, num_probe=nprobe, num_candidates=1024, index='ivfflat', kmeans_niter=25, mode='ann',
              precursor_tolerance_mass_open=500.0, precursor_tolerance_mode_open='Da', batch_size=batch, seed=1234)
 sl = SpectralLibrary(lib, config=cfg, device=dev)
 idx = sl._get_ann_index(2)

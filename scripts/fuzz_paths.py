@@ -47,7 +47,7 @@ while time.time() < t_end and trials < int(os.environ.get('FUZZ_MAX', 10 ** 9)):
         continue
     if os.environ.get('FUZZ_PIPE') is not None:
         pipe = bool(int(os.environ['FUZZ_PIPE']))
-    cfg = Config(num_list=nlist, num_probe=nprobe, num_candidates=k, index=index, pq_m=pq_m,
+    cfg = Config.open_search(num_list=nlist, num_probe=nprobe, num_candidates=k, index=index, pq_m=pq_m,
                  pq_bits=pq_bits, kmeans_niter=n_iter, seed=s_train,
                  precursor_tolerance_mass_open=tol, precursor_tolerance_mode_open=tol_mode,
                  fragment_mz_tolerance=frag, allow_peak_shifts=shifts, refine_k=refine or None)

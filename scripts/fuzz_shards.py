@@ -34,7 +34,7 @@ while time.time() < t_end:
     lib, aux = synthetic.make_library(n, seed=int(rng.integers(1, 1 << 30)), device='cpu', charges=(2,),
                                       charge_p=(1.0,))
     q, _ = synthetic.make_queries(lib, aux, nq, seed=int(rng.integers(1, 1 << 30)), charge=2)
-    sl = SpectralLibrary(lib, config=Config(num_list=nlist, num_probe=nprobe, num_candidates=k, index=index,
+    sl = SpectralLibrary(lib, config=Config.open_search(num_list=nlist, num_probe=nprobe, num_candidates=k, index=index,
                                             pq_m=pq_m, kmeans_niter=2), device=dev)
     idx = sl._get_ann_index(2)
     idx.nprobe = nprobe

@@ -10,7 +10,7 @@ from ann_solo_amd.spectral_library import Config, SpectralLibrary
 
 dev = torch.device('cuda', 0)
 lib, aux = synthetic.make_library(2_100_000, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
-cfg = Config(num_list=4096, num_probe=128, num_candidates=1024, index='ivfpq', pq_m=32,
+cfg = Config.open_search(num_list=4096, num_probe=128, num_candidates=1024, index='ivfpq', pq_m=32,
              kmeans_niter=25, mode='ann', batch_size=16384, seed=1234)
 sl = SpectralLibrary(lib, config=cfg, device=dev)
 idx = sl._get_ann_index(2)

@@ -34,7 +34,7 @@ def main():
     dev = torch.device('cuda', 0)
     lib, aux = synthetic.make_library(args.library_size, seed=20240807, device=dev, charges=(2,),
                                       charge_p=(1.0,))
-    cfg = Config(num_list=args.nlist, num_probe=128, num_candidates=args.k, index='ivfpq',
+    cfg = Config.open_search(num_list=args.nlist, num_probe=128, num_candidates=args.k, index='ivfpq',
                  kmeans_niter=args.niter, precursor_tolerance_mass_open=500.0,
                  precursor_tolerance_mode_open='Da')
     sl = SpectralLibrary(lib, config=cfg, device=dev)

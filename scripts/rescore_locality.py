@@ -26,7 +26,7 @@ nprobe = int(sys.argv[3]) if len(sys.argv) > 3 else 112
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 dev = torch.device('cuda', 0)
 lib, aux = synthetic.make_library(2_100_000, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
-cfg = Config(num_list=4096, num_probe=nprobe, num_candidates=1024, index=index, pq_m=32, kmeans_niter=25,
+cfg = Config.open_search(num_list=4096, num_probe=nprobe, num_candidates=1024, index=index, pq_m=32, kmeans_niter=25,
              mode='ann', precursor_tolerance_mass_open=500.0, precursor_tolerance_mode_open='Da',
              batch_size=16384, seed=1234)
 sl = SpectralLibrary(lib, config=cfg, device=dev)

@@ -19,7 +19,7 @@ variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 index = sys.argv[5] if len(sys.argv) > 5 else 'ivfpq'
 dev = torch.device('cuda', 0)
 lib, aux = synthetic.make_library(n, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
-cfg = Config(num_list=4096, num_probe=128, num_candidates=1024, index=index, pq_m=32,
+cfg = Config.open_search(num_list=4096, num_probe=128, num_candidates=1024, index=index, pq_m=32,
              kmeans_niter=25, mode='ann', precursor_tolerance_mass_open=500.0,
              precursor_tolerance_mode_open='Da', batch_size=batch, seed=1234)
 sl = SpectralLibrary(lib, config=cfg, device=dev)

@@ -17,7 +17,7 @@ nq = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 target = float(sys.argv[3]) if len(sys.argv) > 3 else 0.75
 dev = torch.device('cuda', 0)
 lib, aux = synthetic.make_library(n, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
-sl = SpectralLibrary(lib, config=Config(mode='bf'), device=dev)
+sl = SpectralLibrary(lib, config=Config.open_search(mode='bf'), device=dev)
 flat = faiss.IndexFlatIP(800)
 flat.add(sl._encode(sl.partitions[2].spectra))
 

@@ -200,7 +200,7 @@ def test_search_cascade_control_flow(monkeypatch):
                                    pm_count=np.ones(n, np.int32), pm_pairs=np.zeros((n, 1, 2), np.uint32),
                                    peak_matches=lambda i: np.zeros((1, 2), np.int64))
     sl = Stub.__new__(Stub)
-    sl.config = Config(batch_size=4)
+    sl.config = Config.open_search(batch_size=4)
     sl.device = torch.device('cpu')
     sl.partitions = {2: SimpleNamespace(spectra=lib), 3: SimpleNamespace(spectra=lib)}
     monkeypatch.setattr(spectrum_similarity, 'ssm_cosine',

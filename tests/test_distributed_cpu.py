@@ -240,7 +240,7 @@ def _cascade_worker(rank, world, port, out_dir):
     spectrum_similarity.ssm_cosine = oracle_cosines
     lib, aux = synthetic.make_library(1400, seed=95, device='cpu', charges=(2, 3),
                                       charge_p=(0.8, 0.2))
-    cfg = Config(batch_size=16, precursor_tolerance_mass_open=300.0,
+    cfg = Config.open_search(batch_size=16, precursor_tolerance_mass_open=300.0,
                  precursor_tolerance_mode_open='Da', fdr=0.01)
     parts, qs, qmeta, lmeta = {}, {}, {}, {}
     pz = lib.precursor_charge.numpy()

@@ -32,7 +32,7 @@ def test_config0_bruteforce_cosine_plumbing(O, iprg):
     from ann_solo_amd import synthetic
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     lib, aux = iprg
-    sl = SpectralLibrary(lib, config=Config(mode='bf'))
+    sl = SpectralLibrary(lib, config=Config.open_search(mode='bf'))
     for z in (2, 3):
         q, truth = synthetic.make_queries(lib, aux, 150, seed=100 + z, charge=z)
         part = sl.partitions[z]
@@ -70,7 +70,7 @@ def test_config1_ivfflat_default_parameters(O, iprg):
     from ann_solo_amd import synthetic
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     lib, aux = iprg
-    cfg = Config(index='ivfflat', kmeans_niter=10)       # num_list 256, num_probe 128, k 1024
+    cfg = Config.open_search(index='ivfflat', kmeans_niter=10)       # num_list 256, num_probe 128, k 1024
     sl = SpectralLibrary(lib, config=cfg)
     assert sorted(sl._ann_filenames) == [2, 3, 4]
     for z in (2, 3, 4):

@@ -104,12 +104,12 @@ def test_sharded_exchange_falls_back_without_packed_keys():
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     lib, aux = synthetic.make_library(5000, seed=79, device='cpu', charges=(2,), charge_p=(1.0,))
     for kw, want in ((dict(pq_m=32), True), (dict(pq_m=16), False), (dict(pq_m=32, pq_bits=6), False)):
-        sl = SpectralLibrary(lib, config=Config(num_list=32, num_probe=8, num_candidates=200,
+        sl = SpectralLibrary(lib, config=Config.open_search(num_list=32, num_probe=8, num_candidates=200,
                                                 index='ivfpq', kmeans_niter=3, **kw))
         be = HipShardBackend(sl, 2, 'open')
         assert be.supports_keys is want, kw
         sl.shutdown()
-    sl = SpectralLibrary(lib, config=Config(num_list=32, num_probe=8, num_candidates=1500,
+    sl = SpectralLibrary(lib, config=Config.open_search(num_list=32, num_probe=8, num_candidates=1500,
                                             index='ivfpq', kmeans_niter=3))
     assert HipShardBackend(sl, 2, 'open').supports_keys is False      # k + 768 > 2048
 
@@ -139,7 +139,7 @@ g, w = _all_gather_rows(D, 1, async_op=True); w.wait()
 assert torch.equal(g, D)
 # the whole chunked pipeline over RCCL at world 1 == the unsharded search
 lib, aux = synthetic.make_library(20000, seed=5, device=dev, charges=(2,), charge_p=(1.0,))
-cfg = Config(num_list=64, num_probe=16, num_candidates=256, index=sys.argv[3], pq_m=32,
+cfg = Config.open_search(num_list=64, num_probe=16, num_candidates=256, index=sys.argv[3], pq_m=32,
              kmeans_niter=4, mode='ann', batch_size=512)
 sl = SpectralLibrary(lib, config=cfg, device=dev)
 q, _ = synthetic.make_queries(lib, aux, 512, seed=6, open_range=300.0, charge=2)
@@ -149,7 +149,7 @@ be = HipShardBackend(sl, 2, 'open')
 got = sharded_search_batch(be, q, device_out=True, _force_exchange=True, check_sizes=True)
 assert torch.equal(got.best_row, ref.best_row) and torch.equal(got.best_score, ref.best_score)
 if sys.argv[3] == 'ivfpq':      # a PQ shape without packed keys takes the (D, I) exchange
-    cfg16 = Config(num_list=64, num_probe=16, num_candidates=256, index='ivfpq', pq_m=16,
+    cfg16 = Config.open_search(num_list=64, num_probe=16, num_candidates=256, index='ivfpq', pq_m=16,
                    kmeans_niter=4, mode='ann', batch_size=512)
     s16 = SpectralLibrary(lib, config=cfg16, device=dev)
     ref16 = s16._search_batch(q, 2, 'open', device_out=True)
@@ -206,7 +206,7 @@ lib, aux = synthetic.make_library(20000, seed=5, device=dev, charges=(2,), charg
 q, _ = synthetic.make_queries(lib, aux, 300, seed=6, open_range=300.0, charge=2)
 L = _lib.lib()
 for index in ('ivfpq', 'ivfflat'):
-    sl = SpectralLibrary(lib, config=Config(num_list=64, num_probe=16, num_candidates=256, index=index,
+    sl = SpectralLibrary(lib, config=Config.open_search(num_list=64, num_probe=16, num_candidates=256, index=index,
                                             kmeans_niter=4), device=dev)
     idx = sl._get_ann_index(2)
     vec = sl._encode(q)
@@ -247,7 +247,7 @@ def test_search_preassigned_equals_search():
     from ann_solo_amd import synthetic
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     lib, aux = synthetic.make_library(5000, seed=77, device='cpu', charges=(2,), charge_p=(1.0,))
-    sl = SpectralLibrary(lib, config=Config(num_list=32, num_probe=8, num_candidates=200,
+    sl = SpectralLibrary(lib, config=Config.open_search(num_list=32, num_probe=8, num_candidates=200,
                                             index='ivfpq', kmeans_niter=4))
     q, _ = synthetic.make_queries(lib, aux, 100, seed=78, charge=2)
     idx = sl._get_ann_index(2)
@@ -264,7 +264,7 @@ def test_search_preassigned_equals_search():
     D3, I3 = idx.search_preassigned(vec, 200, cD, cI3)
     assert torch.equal(I3, I4)
     # the same contract for IVF-Flat (both scan formulations)
-    sf = SpectralLibrary(lib, config=Config(num_list=32, num_probe=8, num_candidates=200,
+    sf = SpectralLibrary(lib, config=Config.open_search(num_list=32, num_probe=8, num_candidates=200,
                                             index='ivfflat', kmeans_niter=4))
     fidx = sf._get_ann_index(2)
     for variant in (0, 1):

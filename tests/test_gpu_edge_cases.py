@@ -135,7 +135,7 @@ def test_degenerate_queries_through_the_fused_search(O):
                                  np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
                                  np.concatenate([p[2] for p in parts]), qpmz, qpz)
     for index in ('ivfpq', 'ivfflat'):
-        cfg = Config(num_list=16, num_probe=16, num_candidates=2048, index=index, kmeans_niter=4,
+        cfg = Config.open_search(num_list=16, num_probe=16, num_candidates=2048, index=index, kmeans_niter=4,
                      precursor_tolerance_mass_open=300, precursor_tolerance_mode_open='Da')
         sl = SpectralLibrary(lib, config=cfg)
         res = sl._search_batch(q, 2, 'open', want_knn=True)

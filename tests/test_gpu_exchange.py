@@ -139,7 +139,7 @@ def test_gated_search_scans_exactly_the_counted_rows(index):
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     lib, aux = synthetic.make_library(20000, seed=5, device='cpu', charges=(2,), charge_p=(1.0,))
     q, _ = synthetic.make_queries(lib, aux, 300, seed=6, charge=2)
-    sl = SpectralLibrary(lib, config=Config(num_list=32, num_probe=12, num_candidates=256, index=index, kmeans_niter=3))
+    sl = SpectralLibrary(lib, config=Config.open_search(num_list=32, num_probe=12, num_candidates=256, index=index, kmeans_niter=3))
     be = HipShardBackend(sl, 2, 'open')
     idx = be.index
     vec = be.encode(q)

@@ -124,11 +124,11 @@ def test_engine_imports_an_existing_reference_cache(tmp_path):
     from ann_solo_amd.spectral_library import Config, SpectralLibrary, INDEX_EXT
     lib, aux = synthetic.make_library(6000, seed=61, device='cpu', charges=(2,), charge_p=(1.0,))
     q, _ = synthetic.make_queries(lib, aux, 200, seed=62, charge=2, open_range=300.0)
-    cfg = Config(num_list=32, num_probe=8, num_candidates=256, index='ivfflat', kmeans_niter=7, seed=99)
+    cfg = Config.open_search(num_list=32, num_probe=8, num_candidates=256, index='ivfflat', kmeans_niter=7, seed=99)
     first = SpectralLibrary(lib, config=cfg)                       # "FAISS": some trainer, some seed
     want = first._search_batch(q, 2, 'open', want_knn=True)
     cen = first._get_ann_index(2).centroids()
-    ref_cfg = Config(num_list=32, num_probe=8, num_candidates=256, index='ivfflat')
+    ref_cfg = Config.open_search(num_list=32, num_probe=8, num_candidates=256, index='ivfflat')
     probe = SpectralLibrary.__new__(SpectralLibrary)
     probe.config = ref_cfg
     name = f'lib_{probe._get_hyperparameter_hash()[:7]}_2.idxann'

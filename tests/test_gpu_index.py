@@ -472,7 +472,7 @@ def test_ivfflat_postings_scan_many_small_lists():
     from ann_solo_amd import synthetic
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     lib, aux = synthetic.make_library(9000, seed=20240807, device='cpu')
-    sl = SpectralLibrary(lib, config=Config(index='ivfflat', kmeans_niter=10))
+    sl = SpectralLibrary(lib, config=Config.open_search(index='ivfflat', kmeans_niter=10))
     for z in (2, 3, 4):
         q, _ = synthetic.make_queries(lib, aux, 200, seed=110 + z, charge=z)
         idx = sl._get_ann_index(z)

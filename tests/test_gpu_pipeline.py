@@ -17,7 +17,7 @@ def world():
     lib, aux = synthetic.make_library(60000, seed=11, device=dev, charges=(2,), charge_p=(1.0,))
     out = {}
     for index in ('ivfpq', 'ivfflat'):
-        cfg = Config(num_list=256, num_probe=32, num_candidates=512, index=index, kmeans_niter=4,
+        cfg = Config.open_search(num_list=256, num_probe=32, num_candidates=512, index=index, kmeans_niter=4,
                      precursor_tolerance_mass_open=500.0, precursor_tolerance_mode_open='Da')
         out[index] = SpectralLibrary(lib, config=cfg, device=dev)
     batches = [synthetic.make_queries(lib, aux, n, seed=20 + i, open_range=500.0, charge=2)[0].contiguous()

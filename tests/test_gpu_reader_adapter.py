@@ -52,7 +52,7 @@ def test_filename_constructor_search_and_caches(setup, tmp_path, monkeypatch):
         r.config_hash = config_hash
         made.append(r)
         return r
-    cfg = Config(num_list=32, num_probe=16, num_candidates=512, index='ivfpq', kmeans_niter=4,
+    cfg = Config.open_search(num_list=32, num_probe=16, num_candidates=512, index='ivfpq', kmeans_niter=4,
                  batch_size=128, query_filename=str(tmp_path / 'q.mgf'), spectral_library_filename=fn)
     q_objs = _objects(q, chg_as_annotation=False, ids=[f'scan={i}' for i in range(q.n)])
     for i in range(0, q.n, 10):
@@ -151,22 +151,22 @@ def test_stale_or_foreign_index_cache_is_rebuilt(setup, tmp_path):
     from ann_solo_amd import synthetic
     lib, aux, q, _ = setup
     base = dict(num_list=32, num_probe=16, num_candidates=256, kmeans_niter=4)
-    a = SpectralLibrary(lib, config=Config(index='ivfpq', **base), index_dir=str(tmp_path), basename='lib')
-    b = SpectralLibrary(lib, config=Config(index='ivfflat', **base), index_dir=str(tmp_path), basename='lib')
-    c = SpectralLibrary(lib, config=Config(index='ivfpq', pq_m=16, **base), index_dir=str(tmp_path), basename='lib')
+    a = SpectralLibrary(lib, config=Config.open_search(index='ivfpq', **base), index_dir=str(tmp_path), basename='lib')
+    b = SpectralLibrary(lib, config=Config.open_search(index='ivfflat', **base), index_dir=str(tmp_path), basename='lib')
+    c = SpectralLibrary(lib, config=Config.open_search(index='ivfpq', pq_m=16, **base), index_dir=str(tmp_path), basename='lib')
     names = {os.path.basename(x._ann_filenames[2]) for x in (a, b, c)}
     assert len(names) == 3                                            # no sharing across options
     # reference configuration keeps the reference's five-key hash in the name
-    d = SpectralLibrary(lib, config=Config(index='ivfflat', num_list=32, num_probe=16), basename='lib')
+    d = SpectralLibrary(lib, config=Config.open_search(index='ivfflat', num_list=32, num_probe=16), basename='lib')
     assert d._get_index_hash() == d._get_hyperparameter_hash()
     # another library under the same base name: ntotal differs -> rebuilt, results are its own
     small, aux2 = synthetic.make_library(3000, seed=33, device='cpu', charges=(2,), charge_p=(1.0,))
-    e = SpectralLibrary(small, config=Config(index='ivfpq', **base), index_dir=str(tmp_path), basename='lib')
+    e = SpectralLibrary(small, config=Config.open_search(index='ivfpq', **base), index_dir=str(tmp_path), basename='lib')
     for p in e.partitions.values():
         p.index = None
     q2, _ = synthetic.make_queries(small, aux2, 64, seed=34, charge=2)
     r = e._search_batch(q2, 2, 'open')
-    fresh = SpectralLibrary(small, config=Config(index='ivfpq', **base))
+    fresh = SpectralLibrary(small, config=Config.open_search(index='ivfpq', **base))
     r0 = fresh._search_batch(q2, 2, 'open')
     assert np.array_equal(r.best_row, r0.best_row) and e._get_ann_index(2).ntotal == small.n
     # garbage and truncated files

@@ -14,7 +14,7 @@ def world(O):
     from ann_solo_amd import synthetic
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     lib, aux = synthetic.make_library(60000, seed=51, device='cpu', charges=(2,), charge_p=(1.0,))
-    cfg = Config(num_list=256, num_probe=32, num_candidates=256, index='ivfpq', kmeans_niter=4,
+    cfg = Config.open_search(num_list=256, num_probe=32, num_candidates=256, index='ivfpq', kmeans_niter=4,
                  refine_k=1024, precursor_tolerance_mass_open=500.0, precursor_tolerance_mode_open='Da')
     sl = SpectralLibrary(lib, config=cfg)
     q, _ = synthetic.make_queries(lib, aux, 400, seed=52, open_range=500.0, charge=2)

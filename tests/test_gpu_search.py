@@ -13,7 +13,7 @@ def world(O):
     from ann_solo_amd import synthetic
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     lib, aux = synthetic.make_library(6000, seed=41, device='cpu')
-    cfg = Config(num_list=16, num_probe=6, num_candidates=256, index='ivfpq', kmeans_niter=5,
+    cfg = Config.open_search(num_list=16, num_probe=6, num_candidates=256, index='ivfpq', kmeans_niter=5,
                  precursor_tolerance_mass=20, precursor_tolerance_mode='ppm',
                  precursor_tolerance_mass_open=300, precursor_tolerance_mode_open='Da')
     sl = SpectralLibrary(lib, config=cfg)
@@ -41,7 +41,7 @@ def test_open_search_batch_matches_oracle(O, world, index):
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     lib, aux, sl = world
     if index == 'ivfflat':
-        cfg = Config(**{**sl.config.__dict__, 'index': 'ivfflat'})
+        cfg = Config.open_search(**{**sl.config.__dict__, 'index': 'ivfflat'})
         sl = SpectralLibrary(lib, config=cfg)
     for z in (2, 3):
         q, truth = synthetic.make_queries(lib, aux, 300, seed=50 + z, charge=z)
@@ -76,7 +76,7 @@ def test_std_and_bruteforce_modes_match_oracle(O, world):
     q, truth = synthetic.make_queries(lib, aux, 200, seed=60, charge=z)
     L, pmz32, _ = _oracle_partition(O, sl, z)
     Q = O.Spectra(*q.numpy())
-    bf = SpectralLibrary(lib, config=Config(**{**sl.config.__dict__, 'mode': 'bf'}))
+    bf = SpectralLibrary(lib, config=Config.open_search(**{**sl.config.__dict__, 'mode': 'bf'}))
     for engine, mode, tol, tmode in ((sl, 'std', 20, 'ppm'), (bf, 'open', 300, 'Da')):
         res = engine._search_batch(q, z, mode)
         lists = engine._get_library_candidates(q, z, mode)
@@ -106,7 +106,7 @@ def test_device_resident_io_and_small_charge_fallback(O, world):
     torch.cuda.synchronize()
     assert np.array_equal(a.best_row, b.best_row.cpu().numpy())
     assert np.array_equal(a.best_score, b.best_score.cpu().numpy())
-    small = SpectralLibrary(lib, config=Config(**{**sl.config.__dict__, 'num_list': 1000}))
+    small = SpectralLibrary(lib, config=Config.open_search(**{**sl.config.__dict__, 'num_list': 1000}))
     assert 4 not in small._ann_filenames and 2 in small._ann_filenames
     q4, _ = synthetic.make_queries(lib, aux, 32, seed=71, charge=4)
     r4 = small._search_batch(q4, 4, 'open')
@@ -114,11 +114,39 @@ def test_device_resident_io_and_small_charge_fallback(O, world):
     assert small._search_batch(q4, 7, 'open') is None      # charge absent from the library
 
 
+def test_record_order_changes_placement_only(world):
+    """asl_library_set_record_order: the packed peak records of a partition in inverted-list order,
+    in a random order and back in row order -- ids, winners, scores and peak matches never change
+    (rows keep their numbers); an order that is not a permutation is refused."""
+    from ann_solo_amd import _lib, synthetic
+    lib, aux, sl = world
+    q, _ = synthetic.make_queries(lib, aux, 200, seed=77, charge=2)
+    part = sl.partitions[2]
+    ref = sl._search_batch(q, 2, 'open', want_knn=True)
+    std = sl._search_batch(q, 2, 'std')
+    n = len(part.ids)
+    L = _lib.lib()
+    _, ids, _ = part.index.lists()
+    for order in (np.ascontiguousarray(ids, np.int32), np.random.default_rng(5).permutation(n).astype(np.int32),
+                  np.arange(n, dtype=np.int32)):
+        _lib.check(L.asl_library_set_record_order(part.handle, _lib.ptr(order)))
+        got = sl._search_batch(q, 2, 'open', want_knn=True)
+        assert np.array_equal(got.knn, ref.knn) and np.array_equal(got.best_row, ref.best_row)
+        assert np.array_equal(got.best_score, ref.best_score) and np.array_equal(got.pm_count, ref.pm_count)
+        assert np.array_equal(got.pm_pairs, ref.pm_pairs)
+        got_std = sl._search_batch(q, 2, 'std')
+        assert np.array_equal(got_std.best_row, std.best_row) and np.array_equal(got_std.best_score, std.best_score)
+    bad = np.zeros(n, np.int32)
+    assert L.asl_library_set_record_order(part.handle, _lib.ptr(bad)) != 0
+    got = sl._search_batch(q, 2, 'open')            # a refused order leaves the handle as it was
+    assert np.array_equal(got.best_row, ref.best_row)
+
+
 def test_index_cache_files(tmp_path, world):
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     import os
     lib, aux, sl = world
-    cfg = Config(**sl.config.__dict__)
+    cfg = Config.open_search(**sl.config.__dict__)
     a = SpectralLibrary(lib, config=cfg, index_dir=str(tmp_path), basename='lib')
     h7 = a._get_index_hash()[:7]        # (== the reference's five-key hash for its own IVF-Flat setup)
     assert (cfg.index == 'ivfflat') == (a._get_index_hash() == a._get_hyperparameter_hash())
@@ -143,7 +171,7 @@ def test_search_driver_end_to_end_to_mztab(tmp_path, monkeypatch):
     import mztab_check as M
     lib, aux = synthetic.make_library(4000, seed=71, device='cpu', charges=(2,), charge_p=(1.0,))
     q, truth = synthetic.make_queries(lib, aux, 300, seed=72, charge=2, open_range=300.0)
-    cfg = Config(num_list=32, num_probe=32, num_candidates=1024, index='ivfpq', kmeans_niter=5,
+    cfg = Config.open_search(num_list=32, num_probe=32, num_candidates=1024, index='ivfpq', kmeans_niter=5,
                  batch_size=128, query_filename='/data/q.mgf', spectral_library_filename='/data/l.splib')
     sl = SpectralLibrary(lib, config=cfg)
     qmeta = {2: [dict(identifier=f'scan={i}', index=i, retention_time=0.5 * i, precursor_charge=2,
@@ -198,7 +226,7 @@ def test_cascade_with_the_cosine_tdc_gate():
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     lib, aux = synthetic.make_library(6000, seed=81, device='cpu', charges=(2,), charge_p=(1.0,))
     q, truth = synthetic.make_queries(lib, aux, 900, seed=82, charge=2, open_range=300.0)
-    cfg = Config(num_list=32, num_probe=32, num_candidates=1024, index='ivfpq', kmeans_niter=5,
+    cfg = Config.open_search(num_list=32, num_probe=32, num_candidates=1024, index='ivfpq', kmeans_niter=5,
                  batch_size=256, model='none', fdr=0.05, fdr_min_group_size=10)
     sl = SpectralLibrary(lib, config=cfg, score_ssms=fdr.CosineTDC(cfg.fdr_min_group_size))
     rng = np.random.default_rng(7)

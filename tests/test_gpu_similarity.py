@@ -133,7 +133,7 @@ def test_features_of_a_searched_batch(O):
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     from ann_solo_amd.spectrum_similarity import compute_ssm_features, FEATURE_NAMES
     lib, aux = synthetic.make_library(3000, seed=31, device='cpu', charges=(2,), charge_p=(1.0,))
-    cfg = Config(mode='bf', precursor_tolerance_mass_open=300, precursor_tolerance_mode_open='Da')
+    cfg = Config.open_search(mode='bf', precursor_tolerance_mass_open=300, precursor_tolerance_mode_open='Da')
     sl = SpectralLibrary(lib, config=cfg)
     q, _ = synthetic.make_queries(lib, aux, 200, seed=32, charge=2)
     res = sl._search_batch(q, 2, 'open')

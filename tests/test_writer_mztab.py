@@ -44,7 +44,7 @@ def test_config_dataclass_prints_like_the_reference(golden):
     of the reference's file."""
     from ann_solo_amd.spectral_library import Config
     c = golden['cases']['ann_defaults']
-    cfg = Config(spectral_library_filename='/data/lib/massivekb.splib',
+    cfg = Config.open_search(spectral_library_filename='/data/lib/massivekb.splib',
                  query_filename='/data/run/queries.mgf')
     for k, v in c['config'].items():
         if k != 'out_filename':
