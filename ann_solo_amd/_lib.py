@@ -73,7 +73,7 @@ EXPORTS = [
     'asl_ssm_features_batch', 'asl_ssm_cosine_batch', 'asl_index_set_unordered', 'asl_topk_merge_keys',
     'asl_index_set_flat_storage', 'asl_index_get_flat_storage', 'asl_index_flat_layout',
     'asl_keys_split', 'asl_keys_merge_heads', 'asl_keys_extras', 'asl_keys_merge_final',
-    'asl_keys_rescan_list', 'asl_shard_k', 'asl_index_search_gated', 'asl_library_set_record_order',
+    'asl_keys_rescan_list', 'asl_shard_k', 'asl_index_search_gated',
 ]
 
 
@@ -206,7 +206,6 @@ def lib():
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         L.asl_library_create.restype = C.c_void_p
         L.asl_library_create.argtypes = [C.POINTER(AslPeaks), C.c_void_p, C.c_void_p]
-        L.asl_library_set_record_order.argtypes = [C.c_void_p, C.c_void_p]
         L.asl_library_free.argtypes = [C.c_void_p]
         L.asl_library_free.restype = None
         L.asl_library_size.argtypes = [C.c_void_p]

@@ -753,11 +753,12 @@ __global__ __launch_bounds__(64 * RS_WAVES, RS_OCC) void rescore_score_v2_kernel
       if (okr) {
         const long long row = cv.row(sb + slot);
         if (cv.flt.meta) {     // one 32-byte sector per candidate
-          const uint4 a = *reinterpret_cast<const uint4 *>(&cv.flt.meta[row]);
+          const RowMeta *mr = meta_row(cv.flt, row);
+          const uint4 a = *reinterpret_cast<const uint4 *>(mr);
           m_co = (int)a.x;
           m_cn = (int)a.y;
           m_chg = (int)a.z;
-          m_pmz = cv.flt.meta[row].pmz64;
+          m_pmz = mr->pmz64;
         } else {
           m_co = L.offsets[row];
           m_cn = L.offsets[row + 1] - m_co;
@@ -969,12 +970,13 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
       if (okr) {
         const long long row = cv.row(sb + slot);
         if (cv.flt.meta) {     // one 32-byte sector per candidate
-          const uint4 a = *reinterpret_cast<const uint4 *>(&cv.flt.meta[row]);
+          const RowMeta *mr = meta_row(cv.flt, row);
+          const uint4 a = *reinterpret_cast<const uint4 *>(mr);
           m_co = (int)a.x;
           m_cn = (int)a.y;
           m_chg = (int)a.z;
-          m_pmz = cv.flt.meta[row].pmz64;
-          if (L.records) m_co = (int)cv.flt.meta[row].rec4;     // base of the peak record, 4-byte units
+          m_pmz = mr->pmz64;
+          if (L.records) m_co = (int)mr->rec4;     // base of the peak record, 4-byte units
         } else {
           m_co = L.offsets[row];
           m_cn = L.offsets[row + 1] - m_co;

@@ -8,7 +8,8 @@ namespace asl {
 // kernel's compaction stage (spectral_library.py:417-429 AND :441-446): a candidate row
 // passes if it is valid and within the window of the query's precursor m/z.
 // lib_pmz == nullptr switches the filter off.
-// Everything the rescoring kernel needs to know about a library row, in one 32-byte sector:
+// Everything the rescoring kernel needs to know about a library row, in one 32-byte sector
+// (asl_library: the head of the row's slot, see PrecFilter::meta_stride):
 // the candidate filter and the per-candidate metadata cost one random gather each instead of
 // one per field (offsets x2, charge, precursor m/z, window column, validity).
 struct __attribute__((aligned(32))) RowMeta {
@@ -28,6 +29,10 @@ struct PrecFilter {
   int mode = ASL_TOL_DA;
   int charge = 0;
   const RowMeta *meta = nullptr;    // packed rows (asl_library): replaces lib_pmz / valid
+  // bytes from one row's record to the next: sizeof(RowMeta) for a plain array; the library keeps
+  // every row record at the head of its row's fixed-size SLOT, right in front of the packed peaks
+  // (one gather brings the record AND the first peaks; the peaks' address needs no second hop)
+  uint32_t meta_stride = sizeof(RowMeta);
   // the window column alone, NaN for invalid spectra (4 bytes per row: the flat kernel filters
   // 16.7 M slots per batch on it and touches the 32-byte records of the survivors only)
   const float *wcol = nullptr;
@@ -35,6 +40,10 @@ struct PrecFilter {
   // rows (one gather per candidate, one peak record) and nothing is filtered
   bool pass_all = false;
 };
+
+__device__ __forceinline__ const RowMeta *meta_row(const PrecFilter &f, long long row) {
+  return reinterpret_cast<const RowMeta *>(reinterpret_cast<const char *>(f.meta) + (size_t)row * f.meta_stride);
+}
 
 // spectral_library.py:421-427 (numexpr evaluates in float64)
 __device__ __forceinline__ bool precursor_ok(double q, float lib, int charge, double tol,
@@ -47,7 +56,7 @@ __device__ __forceinline__ bool precursor_ok(double q, float lib, int charge, do
 __device__ __forceinline__ bool filter_pass(const PrecFilter &f, double q_pmz, long long row) {
   if (f.pass_all) return true;
   if (f.wcol) return precursor_ok(q_pmz, f.wcol[row], f.charge, f.tol, f.mode);
-  if (f.meta) return precursor_ok(q_pmz, f.meta[row].pmz32, f.charge, f.tol, f.mode);
+  if (f.meta) return precursor_ok(q_pmz, meta_row(f, row)->pmz32, f.charge, f.tol, f.mode);
   if (!f.lib_pmz) return true;
   if (f.valid && !f.valid[row]) return false;
   return precursor_ok(q_pmz, f.lib_pmz[row], f.charge, f.tol, f.mode);

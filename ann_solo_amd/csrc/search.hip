@@ -78,9 +78,14 @@ struct asl_library {
   DevBuf<float> mz, intensity, pmz32;
   DevBuf<uint8_t> charge, valid;
   DevBuf<double> pmz;
-  DevBuf<RowMeta> meta;   // packed per-row record for the rescoring kernel
+  // One fixed-size SLOT per row: [RowMeta 32 B][mz x n][charge x n][intensity x n]. The rescoring
+  // kernels gather the row record and find the row's first ~24 m/z values in the SAME 128-byte line;
+  // the address of a row's peaks is row * slot + 32, not a second, dependent look-up (round 5; until
+  // then a 32-byte record array and a separately packed record per row: 4.1 lines and two hops per
+  // candidate instead of 3 lines and one).
+  DevBuf<uint8_t> records;   // n * slot bytes (DevPeaks::records)
+  uint32_t slot = 0;         // bytes per row (a multiple of 128)
   DevBuf<float> wcol;     // window column alone, NaN for invalid spectra
-  DevBuf<uint8_t> records;   // packed peak records (DevPeaks::records)
   bool has_valid = false;
   DevPeaks dev;
   // precursor-sorted view (window search)
@@ -97,16 +102,18 @@ struct asl_library {
   DevBuf<int> status;
 };
 
-// one wave per spectrum: its peaks from the three arrays into one record
+// one wave per spectrum: its row record and its peaks from the three arrays into its slot
 __global__ void pack_records_kernel(const int32_t *__restrict__ offsets, const float *__restrict__ mz,
                                     const float *__restrict__ inten, const uint8_t *__restrict__ chg,
-                                    const RowMeta *__restrict__ meta, int64_t n,
+                                    const RowMeta *__restrict__ meta, int64_t n, uint32_t slot,
                                     uint8_t *__restrict__ rec) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (r >= n) return;
   const int co = offsets[r], cn = offsets[r + 1] - co;
-  uint8_t *b = rec + (size_t)meta[r].rec4 * 4;
+  uint8_t *s0 = rec + (size_t)r * slot;
+  if (lane < 8) reinterpret_cast<uint32_t *>(s0)[lane] = reinterpret_cast<const uint32_t *>(meta + r)[lane];
+  uint8_t *b = rec + (size_t)meta[r].rec4 * 4;      // = s0 + 32
   float *f = reinterpret_cast<float *>(b);
   for (int j = lane; j < cn; j += 64) {
     f[j] = mz[co + j];
@@ -116,12 +123,19 @@ __global__ void pack_records_kernel(const int32_t *__restrict__ offsets, const f
 }
 
 static int pack_peak_records(const int32_t *offsets, const float *mz, const float *inten,
-                             const uint8_t *chg, const RowMeta *meta, int64_t n, uint8_t *rec) {
+                             const uint8_t *chg, const RowMeta *meta, int64_t n, uint32_t slot, uint8_t *rec) {
   if (n <= 0) return ASL_OK;
   hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), offsets,
-                     mz, inten, chg, meta, n, rec);
+                     mz, inten, chg, meta, n, slot, rec);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
+}
+
+// the precursor filter / row records of a library handle
+static void library_filter(const asl_library *L, PrecFilter &flt) {
+  flt.meta = reinterpret_cast<const RowMeta *>(L->records.p);
+  flt.meta_stride = L->slot;
+  flt.wcol = L->wcol.p;
 }
 
 extern "C" {
@@ -180,28 +194,34 @@ asl_library_t *asl_library_create(const asl_peaks_t *p, const float *lib_pmz_f32
     if (ok && valid) ok = hipMemcpy(h_valid.data(), valid, n, hipMemcpyDefault) == hipSuccess;
     std::vector<RowMeta> hm(n);
     std::vector<float> h_wcol(n);
-    uint64_t rec_bytes = 0;
+    int max_cn = 0;
+    for (size_t i = 0; i < n; i++) max_cn = std::max(max_cn, h_off[i + 1] - h_off[i]);
+    // slot = row record + the largest packed peak record, rounded up to whole 128-byte lines
+    const uint64_t slot = (sizeof(RowMeta) + asl::rec_bytes((uint64_t)max_cn) + 127) & ~127ull;
     for (size_t i = 0; ok && i < n; i++) {
       hm[i].off = h_off[i];
       hm[i].cn = h_off[i + 1] - h_off[i];
       hm[i].charge = h_chg[i];
       hm[i].pmz32 = h_valid[i] ? h_pmz32[i] : __builtin_nanf("");
       hm[i].pmz64 = h_pmz[i];
-      hm[i].rec4 = (uint32_t)(rec_bytes >> 2);
+      hm[i].rec4 = (uint32_t)(((uint64_t)i * slot + sizeof(RowMeta)) >> 2);
       hm[i].pad = 0u;
       h_wcol[i] = hm[i].pmz32;
-      rec_bytes += (asl::rec_bytes((uint64_t)hm[i].cn) + 15) & ~15ull;
     }
-    if (rec_bytes >= (1ull << 34)) {     // rec4 is 32 bits of 4-byte units
+    if ((uint64_t)n * slot >= (1ull << 34)) {     // rec4 is 32 bits of 4-byte units
       ok = false;
-      fail(ASL_ERR_CAPACITY, "library_create: more than 16 GiB of peak records in one partition");
+      fail(ASL_ERR_CAPACITY, "library_create: more than 16 GiB of row slots (%llu rows x %llu bytes) in one partition",
+           (unsigned long long)n, (unsigned long long)slot);
     }
-    up(L->meta, hm.data(), n);
+    L->slot = (uint32_t)slot;
     up(L->wcol, h_wcol.data(), n);
-    if (ok && np) {
-      ok = L->records.reserve((size_t)rec_bytes + 16) == ASL_OK &&
-           pack_peak_records(L->offsets.p, L->mz.p, L->intensity.p, L->charge.p, L->meta.p, (int64_t)n,
-                             L->records.p) == ASL_OK;
+    if (ok) {
+      DevBuf<RowMeta> meta_tmp;
+      ok = meta_tmp.upload(hm.data(), n) == ASL_OK && L->records.reserve((size_t)n * slot + 16) == ASL_OK &&
+           hipMemsetAsync(L->records.p, 0, (size_t)n * slot + 16, stream()) == hipSuccess &&
+           pack_peak_records(L->offsets.p, L->mz.p, L->intensity.p, L->charge.p, meta_tmp.p, (int64_t)n,
+                             L->slot, L->records.p) == ASL_OK &&
+           sync_stream() == ASL_OK;
     }
   }
   if (ok && n) {
@@ -230,38 +250,6 @@ asl_library_t *asl_library_create(const asl_peaks_t *p, const float *lib_pmz_f32
   L->dev.precursor_charge = L->pcharge.p;
   L->dev.records = L->records.p;
   return L;
-}
-
-// Physical order of the packed peak records (what the rescoring kernel gathers, ~270 B per
-// candidate): order[i] = the library row whose record is stored i-th. Rows keep their numbers
-// (row r <-> spec_info id[r]); only the placement inside the record array changes -- e.g. the
-// inverted-list order of the partition's ANN index, so that the candidates of a query (members
-// of its <= nprobe probed lists) come from a few contiguous regions instead of the whole array.
-int asl_library_set_record_order(asl_library_t *L, const int32_t *order) {
-  clear_error();
-  if (!L || !order) return fail(ASL_ERR_INVALID, "set_record_order: null argument");
-  const size_t n = (size_t)L->n;
-  if (n == 0) return ASL_OK;
-  ASL_TRY(ensure_device());
-  std::vector<int32_t> h_order(n);
-  HIP_TRY(hipMemcpy(h_order.data(), order, n * 4, hipMemcpyDefault));
-  std::vector<RowMeta> hm(n);
-  ASL_TRY(L->meta.download(hm.data(), n));
-  ASL_TRY(sync_stream());
-  std::vector<uint8_t> seen(n, 0);
-  uint64_t rec_bytes = 0;
-  for (size_t i = 0; i < n; i++) {
-    const int32_t r = h_order[i];
-    if (r < 0 || (size_t)r >= n || seen[(size_t)r])
-      return fail(ASL_ERR_INVALID, "set_record_order: order is not a permutation of the rows");
-    seen[(size_t)r] = 1;
-    hm[(size_t)r].rec4 = (uint32_t)(rec_bytes >> 2);
-    rec_bytes += (asl::rec_bytes((uint64_t)hm[(size_t)r].cn) + 15) & ~15ull;
-  }
-  ASL_TRY(L->meta.upload(hm.data(), n));
-  ASL_TRY(pack_peak_records(L->offsets.p, L->mz.p, L->intensity.p, L->charge.p, L->meta.p, (int64_t)n,
-                            L->records.p));
-  return sync_stream();
 }
 
 void asl_library_free(asl_library_t *L) { delete L; }
@@ -359,8 +347,7 @@ int asl_rescore_knn(asl_library_t *L, const asl_peaks_t *queries, const asl_sear
   PrecFilter flt;
   flt.lib_pmz = L->pmz32.p;
   flt.valid = L->has_valid ? L->valid.p : nullptr;
-  flt.meta = L->meta.p;
-  flt.wcol = L->wcol.p;
+  library_filter(L, flt);
   flt.tol = P->precursor_tol;
   flt.mode = P->precursor_mode;
   flt.charge = P->charge;
@@ -449,8 +436,7 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
     PrecFilter flt;
     flt.lib_pmz = L->pmz32.p;
     flt.valid = L->has_valid ? L->valid.p : nullptr;
-    flt.meta = L->meta.p;
-  flt.wcol = L->wcol.p;
+    library_filter(L, flt);
     flt.tol = P->precursor_tol;
     flt.mode = P->precursor_mode;
     flt.charge = P->charge;
@@ -524,8 +510,7 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
     PrecFilter flt;
     flt.lib_pmz = L->pmz32.p;
     flt.valid = L->has_valid ? L->valid.p : nullptr;
-    flt.meta = L->meta.p;
-  flt.wcol = L->wcol.p;
+    library_filter(L, flt);
     flt.tol = P->precursor_tol;
     flt.mode = P->precursor_mode;
     flt.charge = P->charge;
@@ -542,7 +527,8 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
     }
     ASL_TRY(L->pair_score.reserve((size_t)std::max<int64_t>(total, 1)));
     PrecFilter rows_only;       // packed row records for the kernels, no second filtering
-    rows_only.meta = L->meta.p;
+    library_filter(L, rows_only);
+    rows_only.wcol = nullptr;
     rows_only.pass_all = true;
     ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->cand.p, L->woff.p, 0, total,
                            P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,

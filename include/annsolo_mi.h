@@ -394,12 +394,6 @@ typedef struct asl_library asl_library_t;
  * NULL (then (float)precursor_mz). valid: per-spectrum is_valid flag or NULL. */
 asl_library_t *asl_library_create(const asl_peaks_t *library, const float *lib_pmz_f32,
                                   const uint8_t *valid);
-/* Placement of the packed peak records inside the handle (no reference counterpart: the
- * reference reads candidates one by one from HDF5, reader.py:239-245): order[n] = the library row
- * stored i-th. Row numbers, results and every other array are unchanged -- only where a
- * candidate's ~270-byte record lies, e.g. in the inverted-list order of the partition's index so
- * that a query's candidates come from its probed lists' contiguous regions. */
-int asl_library_set_record_order(asl_library_t *lib, const int32_t *order);
 void asl_library_free(asl_library_t *lib);
 int64_t asl_library_size(const asl_library_t *lib);
 

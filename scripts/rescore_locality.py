@@ -8,7 +8,9 @@ lies in spec_info (= row) order, i.e. scattered over the whole array. Modes (arg
   both        list-order records AND probe-sorted queries
   random      records in a random order (control: is row order already 'local'?)
 
-Prints the stage times (HIP events around the stages of a synchronous step, asl_profile) of
+(The modes that move records need ``asl_library_set_record_order``, which existed only for this
+experiment -- commits 0b5a6c3..eb62a9e -- and went when the records became fixed-size row slots;
+on the current tree only ``base`` and ``query`` run.) Prints the stage times (HIP events around the stages of a synchronous step, asl_profile) of
 steps over ONE batch; run the same command under `rocprofv3 --pmc FETCH_SIZE` for the traffic of
 rescore_flat_kernel.   python scripts/rescore_locality.py MODE [ivfflat|ivfpq] [nprobe] [steps]"""
 import ctypes as C
@@ -35,6 +37,8 @@ idx = sl._get_ann_index(2)
 q, _ = synthetic.make_queries(lib, aux, 16384, seed=42, open_range=500.0, charge=2)
 L = _lib.lib()
 ref = sl._search_batch(q, 2, 'open', device_out=True)
+if mode in ('store', 'both', 'random') and not hasattr(L, 'asl_library_set_record_order'):
+    sys.exit('this build has no asl_library_set_record_order (see the module docstring)')
 if mode in ('store', 'both'):
     _, ids, _ = idx.lists()                      # library rows in inverted-list order
     order = np.ascontiguousarray(ids, np.int32)

@@ -114,34 +114,6 @@ def test_device_resident_io_and_small_charge_fallback(O, world):
     assert small._search_batch(q4, 7, 'open') is None      # charge absent from the library
 
 
-def test_record_order_changes_placement_only(world):
-    """asl_library_set_record_order: the packed peak records of a partition in inverted-list order,
-    in a random order and back in row order -- ids, winners, scores and peak matches never change
-    (rows keep their numbers); an order that is not a permutation is refused."""
-    from ann_solo_amd import _lib, synthetic
-    lib, aux, sl = world
-    q, _ = synthetic.make_queries(lib, aux, 200, seed=77, charge=2)
-    part = sl.partitions[2]
-    ref = sl._search_batch(q, 2, 'open', want_knn=True)
-    std = sl._search_batch(q, 2, 'std')
-    n = len(part.ids)
-    L = _lib.lib()
-    _, ids, _ = part.index.lists()
-    for order in (np.ascontiguousarray(ids, np.int32), np.random.default_rng(5).permutation(n).astype(np.int32),
-                  np.arange(n, dtype=np.int32)):
-        _lib.check(L.asl_library_set_record_order(part.handle, _lib.ptr(order)))
-        got = sl._search_batch(q, 2, 'open', want_knn=True)
-        assert np.array_equal(got.knn, ref.knn) and np.array_equal(got.best_row, ref.best_row)
-        assert np.array_equal(got.best_score, ref.best_score) and np.array_equal(got.pm_count, ref.pm_count)
-        assert np.array_equal(got.pm_pairs, ref.pm_pairs)
-        got_std = sl._search_batch(q, 2, 'std')
-        assert np.array_equal(got_std.best_row, std.best_row) and np.array_equal(got_std.best_score, std.best_score)
-    bad = np.zeros(n, np.int32)
-    assert L.asl_library_set_record_order(part.handle, _lib.ptr(bad)) != 0
-    got = sl._search_batch(q, 2, 'open')            # a refused order leaves the handle as it was
-    assert np.array_equal(got.best_row, ref.best_row)
-
-
 def test_index_cache_files(tmp_path, world):
     from ann_solo_amd.spectral_library import Config, SpectralLibrary
     import os
