@@ -463,6 +463,57 @@ def test_flat_storage_survives_save_and_load(vecs, trained, tmp_path):
         assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
 
 
+def test_version_1_files_say_what_they_hold(vecs, trained, tmp_path):
+    """a version-1 cache with storage field 0 is either a fixed-point file (round 4) or
+    an unrounded float32 file written before the storage modes existed (the field was padding).
+    The loader decides by the components: off-grid data loads as 'fp32' (so an engine configured
+    for 'fx22' rebuilds instead of silently serving float postings), on-grid data as 'fx22'.
+    Files are written with version 2 now."""
+    import struct
+    from ann_solo_amd import faiss_compat as faiss
+    xb, _ = vecs
+    cen, _ = trained
+    for storage, want in (('fp32', 'fp32'), ('fx22', 'fx22')):
+        idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16, storage=storage)
+        idx.set_trained(cen)
+        idx.add(xb[:800])
+        path = str(tmp_path / f'v1_{storage}.idxmi')
+        faiss.write_index(idx, path)
+        raw = bytearray(open(path, 'rb').read())
+        # header: magic[8], then int32 version, d, nlist, kind, pq_m, pq_bits, niter, trained; int64 ntotal,
+        # n_store; int32 shard_rank, shard_world, has_vids, pad
+        assert struct.unpack_from('<i', raw, 8)[0] == 2
+        pad_at = 8 + 8 * 4 + 2 * 8 + 3 * 4
+        assert struct.unpack_from('<i', raw, pad_at)[0] == (0 if storage == 'fx22' else 1)
+        struct.pack_into('<i', raw, 8, 1)            # an old file: version 1 ...
+        struct.pack_into('<i', raw, pad_at, 0)       # ... whose storage field reads 0 either way
+        open(path, 'wb').write(bytes(raw))
+        back = faiss.read_index(path)
+        assert back.storage == want, (storage, back.storage)
+
+
+def test_supports_keys_depends_on_what_a_shard_holds(vecs, trained):
+    """for IVF-Flat the packed-key scan exists only where a shard stores sparse vectors
+    -- an empty shard and a dense one answer 0 -- so a sharded driver must agree on the exchange
+    format across ranks (distributed._agreed_keys, asl_index_search_sharded)."""
+    from ann_solo_amd import _lib, faiss_compat as faiss
+    xb, _ = vecs
+    cen, _ = trained
+    L = _lib.lib()
+    sparse = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    sparse.set_trained(cen)
+    sparse.add(xb[:500])
+    empty = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    empty.set_trained(cen)
+    dense = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+    dense.set_trained(cen)
+    dense.add(np.abs(np.random.default_rng(2).standard_normal((300, 800))).astype(np.float32))
+    assert L.asl_index_supports_keys(sparse._h, 256, 8) == 1
+    assert L.asl_index_supports_keys(empty._h, 256, 8) == 0
+    assert L.asl_index_supports_keys(dense._h, 256, 8) == 0
+    assert L.asl_index_supports_keys(sparse._h, 1500, 8) == 0      # k + 768 > 2048
+
+
 def test_ivfflat_postings_scan_many_small_lists():
     """The postings scan where the candidate set only just exceeds the key buffer and the
     threshold bucket is crowded (small scores, k = 1024): bulk offers have to fall back to
