@@ -737,10 +737,11 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
         # one pair of ints per batch: did any buffer run full anywhere (answers of phase 2, second
         # scans of a piece), and how many rows did the shards scan a second time?
         f = flag if dist.get_backend(group) == 'nccl' else flag.cpu()
-        rescans = int(f[1].item()) if k_row < k_scan else 0
-        f = f[:1].clone()
-        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)
-        if int(f.item()):
+        full = f[:1].clone()
+        dist.all_reduce(full, op=dist.ReduceOp.MAX, group=group)
+        full, mine = torch.cat([full, f[1:2]]).tolist()         # the batch's one host round trip
+        rescans = int(mine) if k_row < k_scan else 0
+        if int(full):
             fallback = True
             if stats is not None:
                 stats['fallback'] = stats.get('fallback', 0) + 1
