@@ -6,8 +6,8 @@
 //
 // One 64-lane wavefront per SSM, both spectra and every derived list in LDS. The O(n^2)
 // parts (top-5 membership, Kendall pair counts, average ranks) and the reductions are
-// lane-parallel; the short serial pieces (exact Kendall p-value recurrence, <= 33 x 265
-// steps) run on lane 0. Arithmetic is fp64 on the fp32 peaks; the reference sums float32
+// lane-parallel, the exact Kendall p-value recurrence (<= 33 rows of <= 265 counts) too since
+// round 5 (five counts per lane, a wave scan per row). Arithmetic is fp64 on the fp32 peaks; the reference sums float32
 // arrays, so agreement with it is ~1e-6 (tolerance 1e-5), with the oracle ~1e-12.
 #include "common.hpp"
 
@@ -197,27 +197,48 @@ __device__ double kendall_neglogp(int lane, const float *x, const float *y, int 
       p = 2.0 / tgamma((double)n);
     else if (4 * c == (long long)n * (n - 1))
       p = 1.0;
-    else {   // counts of permutations with <= c inversions (Kendall's recurrence), lane 0
-      double s = 0.0;
-      if (lane == 0) {
-        double *cur = kc0, *nxt = kc1;
-        for (int i = 0; i <= (int)c; i++) cur[i] = 0.0;
-        cur[0] = cur[1] = 1.0;
-        for (int j = 3; j <= n; j++) {
-          double acc = 0.0;
-          for (int i = 0; i <= (int)c; i++) {
-            acc += cur[i];
-            nxt[i] = acc;
-          }
-          if (j <= c)
-            for (int i = (int)c; i >= j; i--) nxt[i] -= nxt[i - j];
-          double *t = cur;
-          cur = nxt;
-          nxt = t;
+    else {
+      // counts of permutations of j items with <= i inversions, j = 3 .. n (Kendall's recurrence:
+      // new[i] = P[i] - P[i - j], P = prefix sums of the old row), i <= c <= 264. All 64 lanes:
+      // lane L holds entries 5 L .. 5 L + 4, a row step is a prefix sum inside the lane, a scan of
+      // the lanes' totals and one exchange through LDS for P[i - j]. (On lane 0 alone -- 31 x 265
+      // dependent LDS round trips per SSM -- this recurrence was most of the kernel's time.)
+      constexpr int PER = 5;
+      static_assert(PER * 64 >= SIM_KC, "");
+      double v[PER];
+#pragma unroll
+      for (int u = 0; u < PER; u++) v[u] = lane * PER + u <= 1 ? 1.0 : 0.0;
+      for (int j = 3; j <= n; j++) {
+#pragma unroll
+        for (int u = 1; u < PER; u++) v[u] += v[u - 1];
+        double incl = v[PER - 1];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const double t = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += t;
         }
-        for (int i = 0; i <= (int)c; i++) s += cur[i];
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 0.0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) v[u] += excl;
+        if (j <= c) {          // wave-uniform
+          sim_sync();
+#pragma unroll
+          for (int u = 0; u < PER; u++)
+            if (lane * PER + u <= (int)c) kc0[lane * PER + u] = v[u];
+          sim_sync();
+#pragma unroll
+          for (int u = 0; u < PER; u++) {
+            const int i = lane * PER + u;
+            if (i >= j && i <= (int)c) v[u] -= kc0[i - j];
+          }
+        }
       }
-      s = __shfl(s, 0, 64);
+      double s = 0.0;
+#pragma unroll
+      for (int u = 0; u < PER; u++)
+        if (lane * PER + u <= (int)c) s += v[u];
+      s = wsum(s);
       p = 2.0 * s / tgamma(n + 1.0);
     }
     p = fmax(0.0, fmin(1.0, p));
