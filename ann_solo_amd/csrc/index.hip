@@ -110,6 +110,9 @@ struct asl_index {
   int scan_variant = 0;  // 0 = the layout-specific scan when the shape allows; 1 = the generic kernels
   int unordered = 0;  // 1: search rows = exact top-k as a set, unspecified order (no final sort); 2: rows of packed keys
   bool lists_dirty = true;
+  // asl_index_search_sharded: did every rank's shard answer asl_index_supports_keys with 1 for this
+  // (k, nprobe, world)? -1 = not agreed yet (reset whenever the lists are rebuilt)
+  int agreed_k = -1, agreed_np = -1, agreed_world = -1, agreed_val = -1;
   // exact re-rank of the IVF-PQ short-list (refine.hip): sparse copies of the added vectors,
   // add order = global id; kept whole on every shard
   int refine_k = 0;            // 0 = off; else the short-list size k' (> k) that is re-ranked
@@ -285,6 +288,7 @@ static int pq_train_device(asl_index *ix, const float *x, int64_t n, uint64_t se
 // list-ordered copy of the PQ codes (the scan layout) from the add-order master
 static int build_lists(asl_index *ix) {
   if (!ix->lists_dirty) return ASL_OK;
+  ix->agreed_val = -1;
   const int64_t n = ix->n_store;
   std::vector<int32_t> h_vlist((size_t)n), h_order((size_t)n), h_ids;
   ix->h_list_offsets.assign((size_t)ix->nlist + 1, 0);
@@ -671,6 +675,15 @@ int index_prepare(asl_index *ix) {   // everything that may allocate or synchron
 int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, float *out_D,
                         int32_t *out_I) {
   return coarse_search(ix, xq, nq, nprobe, out_D, out_I);
+}
+int index_agreed_keys(const asl_index *ix, int k, int np, int world) {
+  return (ix->agreed_val >= 0 && ix->agreed_k == k && ix->agreed_np == np && ix->agreed_world == world) ? ix->agreed_val : -1;
+}
+void index_set_agreed_keys(asl_index *ix, int k, int np, int world, int v) {
+  ix->agreed_k = k;
+  ix->agreed_np = np;
+  ix->agreed_world = world;
+  ix->agreed_val = v;
 }
 int index_shard_world(const asl_index *ix, int *rank) {
   if (rank) *rank = ix->shard_rank;

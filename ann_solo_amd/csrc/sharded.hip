@@ -27,6 +27,8 @@ int index_prepare(asl_index *ix);
 int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, float *out_D,
                         int32_t *out_I);
 int index_shard_world(const asl_index *ix, int *rank);
+int index_agreed_keys(const asl_index *ix, int k, int np, int world);
+void index_set_agreed_keys(asl_index *ix, int k, int np, int world, int v);
 int index_refine_k(const asl_index *ix);
 int index_swap_unordered(asl_index *ix, int mode, int *prev);
 int index_refine_device(asl_index *ix, int nq, const float *xq, int kp, const int64_t *I_in, int k,
@@ -154,12 +156,20 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
   //     remain the path for everything else and the fallback when an answer buffer runs full
   bool keys_everywhere = false;
   if (!refine) {
+    // (asl_index_supports_keys first: it rebuilds a stale scan layout, which forgets the agreement)
     const int32_t local = asl_index_supports_keys(ix, k, np) ? 1 : 0;
-    int32_t hm[4] = {local, 0, 0, 0};
-    ASL_TRY(mine.upload(hm, 4));
-    ASL_TRY(agree(h));
-    keys_everywhere = true;
-    for (int r = 0; r < world; ++r) keys_everywhere = keys_everywhere && h[(size_t)r * 4] != 0;
+    int known = index_agreed_keys(ix, k, np, world);
+    // every rank must take the same branch HERE too: the agreement is made on the first call after
+    // any change of the index (all ranks change it together: add / shard are collective by contract)
+    if (known < 0) {
+      int32_t hm[4] = {local, 0, 0, 0};
+      ASL_TRY(mine.upload(hm, 4));
+      ASL_TRY(agree(h));
+      known = 1;
+      for (int r = 0; r < world; ++r) known = known && h[(size_t)r * 4] != 0;
+      index_set_agreed_keys(ix, k, np, world, known);
+    }
+    keys_everywhere = known != 0;
   }
   if (keys_everywhere) {
     typedef unsigned long long u64k;
