@@ -787,8 +787,8 @@ int asl_index_supports_keys(asl_index_t *ix, int32_t k, int32_t nprobe) {
          k + 768 <= TK_MAX_K;
 }
 
-// shard-side k of the third exchange phase (exchange.hip; measured in profiles/r04_shard_scan_probe.txt:
-// k / 2 at 8 ranks takes ~1 ms off the shard scan, 0.06-0.8 % of the queries need the third phase)
+// the shards' own k (exchange.hip "shard-side k_s < k"; profiles/r05_sim_rank.txt: k / 2 at 8 ranks takes
+// 0.3 (IVF-PQ) / 0.9 ms (IVF-Flat) off the shard scan, 0.25 % / 0.04 % of a shard's rows are scanned a second time)
 int32_t asl_shard_k(int32_t k, int32_t world) {
   if (k < 1 || world < 4) return k;
   const int raw = world >= 8 ? (k + 1) / 2 : (5 * k + 7) / 8;

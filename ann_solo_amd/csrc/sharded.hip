@@ -152,7 +152,7 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
   // 2'. the exact key exchange (exchange.hip) whenever EVERY shard's scan can emit packed keys (for
   //     IVF-Flat that depends on the vectors a shard holds: agreed across the ranks, once per state
   //     of the index): heads of ~2k / world keys, the owners' bounds, the held-back keys above
-  //     them, and -- the shards scanning with k_s < k -- the third phase; the full rows below
+  //     them (the shards scanning with k_s < k and a second, full-k scan where a bound asks); the full rows below
   //     remain the path for everything else and the fallback when an answer buffer runs full
   bool keys_everywhere = false;
   if (!refine) {

@@ -496,13 +496,13 @@ def _concat_results(parts):
 
 def head_width(k: int, world: int, head_keys: Optional[int] = None) -> int:
     """Row width kp of the phase-1 exchange: ``min(k, ceil(2 k / world))`` key slots (or
-    ``head_keys``) + the slot of the best held-back key (the third phase adds one more)."""
+    ``head_keys``) + the slot of the best held-back key."""
     keys = head_keys if head_keys is not None else -(-2 * k // max(world, 1))
     return max(1, min(int(keys), k)) + 1
 
 
 def shard_k(k: int, world: int) -> int:
-    """The shards' own k of the third phase (``asl_shard_k``): k / 2 from 8 ranks on, 5 k / 8 from
+    """The shards' own k (``asl_shard_k``; completed by second scans on the shard, module docstring 5): k / 2 from 8 ranks on, 5 k / 8 from
     4, rounded up to 64; k below 4 ranks or when that is not more than a head's key slots."""
     return int(_lib.lib().asl_shard_k(int(k), int(world)))
 

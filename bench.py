@@ -404,7 +404,7 @@ def main():
         t3 = torch.tensor([xstats.get('third_phase_queries', 0)], dtype=torch.int64,
                           device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t3, op=dist.ReduceOp.SUM)
-        comm['third_phase_queries'] = round(int(t3[0]) / max(args.steps + args.warmup * 0, 1), 2)
+        comm['third_phase_queries'] = round(int(t3[0]) / max(args.steps, 1), 2)
         comm['third_phase_share_of_rows'] = round(int(t3[0]) / max(args.steps, 1) / (degree * degree * args.batch), 6)
         comm['collective_ms_alone'] = time_collectives(comm_log, group, degree, dev, backend, args.steps)
     L.asl_profile_enable(0)

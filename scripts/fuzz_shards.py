@@ -46,7 +46,7 @@ while time.time() < t_end:
     owner = idx.shard_map(W)
     parts, keys, keys_s, nloc = [], [], [], 0
     use_keys = bool(_lib.lib().asl_index_supports_keys(idx._h, k, nprobe))
-    # third phase: a random head and a random shard-side k between the head and k
+    # a random head and a random shard-side k between the head and k (second scans answered from the full rows)
     hk = int(rng.integers(1, k + 1)) if rng.random() < 0.7 else min(k, -(-2 * k // W))
     ks = int(rng.integers(hk + 1, k)) if hk + 1 < k and rng.random() < 0.6 else k
     for r in range(W):
