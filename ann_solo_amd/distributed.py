@@ -291,6 +291,26 @@ class HipShardBackend:
         return BatchResult(best_row, best_score, n_cand, pm_count, pm_pairs, knn)
 
 
+# The collectives below have two forms: on RCCL the tensors travel as they are (all_to_all_single /
+# all_gather_into_tensor on device memory, asynchronous handles); on gloo (CPU tests, two ranks
+# sharing one GPU) host copies are all-gathered and sliced. gloo implements the direct forms for
+# HOST tensors too, so the CPU tests can run the RCCL branches -- shapes, views, handles, the
+# four-piece pipeline -- by setting this flag (tests/test_distributed_cpu.py, kinds '*_direct').
+FORCE_DIRECT_COLLECTIVES = False
+
+
+def _direct(group=None) -> bool:
+    return FORCE_DIRECT_COLLECTIVES or dist.get_backend(group) == 'nccl'
+
+
+def _comm_tensor(x: torch.Tensor, group=None) -> torch.Tensor:
+    """RCCL moves device memory only: a host tensor handed to a collective (results a caller
+    produced with numpy, a query batch read from a file) goes to this process's GPU first."""
+    if x.device.type == 'cpu' and dist.get_backend(group) == 'nccl':
+        return x.cuda()
+    return x
+
+
 def exchange_partials(D: torch.Tensor, I: torch.Tensor, world: int, group=None,
                       async_op: bool = False):
     """[world*n, k] per-shard results for n queries of every rank (rank-major) ->
@@ -303,8 +323,7 @@ def exchange_partials(D: torch.Tensor, I: torch.Tensor, world: int, group=None,
     nq_all, k = D.shape
     n = nq_all // world
     rank = dist.get_rank(group)
-    backend = dist.get_backend(group)
-    if backend == 'nccl':
+    if _direct(group):
         Do, Io = torch.empty_like(D), torch.empty_like(I)
         w1 = dist.all_to_all_single(Do, D, group=group, async_op=async_op)
         w2 = dist.all_to_all_single(Io, I, group=group, async_op=async_op)
@@ -356,8 +375,8 @@ def _all_to_all(x: torch.Tensor, world: int, group=None, comm: Optional[CommLog]
     rank = dist.get_rank(group)
     if comm is not None:
         comm.add(name, x, world, 'all_to_all')
-    if dist.get_backend(group) == 'nccl':
-        x = x.contiguous()
+    if _direct(group):
+        x = _comm_tensor(x, group).contiguous()
         out = torch.empty_like(x)
         w = dist.all_to_all_single(out, x, group=group, async_op=True)
         return out.view((world, m) + tuple(x.shape[1:])), [w], x
@@ -374,7 +393,7 @@ def exchange_keys(K: torch.Tensor, world: int, group=None):
     nq_all, k = K.shape
     n = nq_all // world
     rank = dist.get_rank(group)
-    if dist.get_backend(group) == 'nccl':
+    if _direct(group):
         Ko = torch.empty_like(K)
         w = dist.all_to_all_single(Ko, K, group=group, async_op=True)
         return Ko.view(world, n, k), [w], K
@@ -389,10 +408,10 @@ def exchange_keys(K: torch.Tensor, world: int, group=None):
 def _all_gather_rows(x: torch.Tensor, world: int, group=None, async_op: bool = False):
     """Concatenate every rank's [n, ...] tensor along dim 0 (rank order). With ``async_op``
     returns (tensor, work-or-None); ``work.wait()`` before the tensor is read."""
-    if dist.get_backend(group) == 'nccl':
+    if _direct(group):
+        x = _comm_tensor(x, group).contiguous()
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype,
                           device=x.device)
-        x = x.contiguous()
         w = dist.all_gather_into_tensor(out, x, group=group, async_op=async_op)
         return (out, w) if async_op else out
     parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(world)]
@@ -421,8 +440,8 @@ def _peak_row_width(queries: PackedSpectra, world: int, group=None,
         m = int(agreed)
     elif world > 1:
         t = torch.tensor([local], dtype=torch.int64)
-        if dist.get_backend(group) == 'nccl':
-            t = t.to(queries.device)
+        if _direct(group):
+            t = _comm_tensor(t, group)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         m = int(t[0])
     else:
@@ -519,8 +538,8 @@ def _agreed_keys(backend, world: int, group, k_scan: int) -> bool:
     key = (id(group), world, k_scan, getattr(backend, 'index_epoch', 0))
     if key not in cache:
         t = torch.tensor([int(local)], dtype=torch.int32)
-        if dist.get_backend(group) == 'nccl':
-            t = t.to(backend.device)
+        if _direct(group):
+            t = _comm_tensor(t, group)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
         cache[key] = bool(int(t.item()))
     return cache[key]
@@ -559,10 +578,12 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
         # every rank must bring the same, non-zero number of queries (the collectives below are
         # fixed-shape); callers with ragged batches pad -- see sharded_cascade_batch
         raise ValueError('sharded_search_batch: empty local slice (pad ragged batches)')
+    if getattr(backend, 'device', None) is not None:
+        queries_local = queries_local.to(backend.device)     # (the peaks travel from device memory)
     if check_sizes and world > 1:
         t = torch.tensor([queries_local.n, -queries_local.n], dtype=torch.int64)
-        if dist.get_backend(group) == 'nccl':
-            t = t.to(queries_local.device)
+        if _direct(group):
+            t = _comm_tensor(t, group)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         if int(t[0]) != -int(t[1]):
             raise ValueError('sharded_search_batch: ranks hold slices of different sizes')
@@ -590,7 +611,7 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     rank = dist.get_rank(group)
     allvec[rank * n_local:(rank + 1) * n_local] = vec      # (same bits; skips nothing, documents intent)
     if chunks is None:
-        chunks = 4 if dist.get_backend(group) == 'nccl' else 2
+        chunks = 4 if _direct(group) else 2
     chunks = max(1, min(chunks, n_local))
     bounds = [(n_local * c) // chunks for c in range(chunks + 1)]
     rank_base = torch.arange(world, device=allvec.device).unsqueeze(1) * n_local
@@ -736,7 +757,7 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
     if second:
         # one pair of ints per batch: did any buffer run full anywhere (answers of phase 2, second
         # scans of a piece), and how many rows did the shards scan a second time?
-        f = flag if dist.get_backend(group) == 'nccl' else flag.cpu()
+        f = flag if _direct(group) else flag.cpu()
         full = f[:1].clone()
         dist.all_reduce(full, op=dist.ReduceOp.MAX, group=group)
         full, mine = torch.cat([full, f[1:2]]).tolist()         # the batch's one host round trip

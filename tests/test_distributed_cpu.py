@@ -51,7 +51,14 @@ def _worker(rank, world, port, kind, out_dir):
     from oracle import oracle_py as O
     from oracle_backend import OracleShardBackend
     from ann_solo_amd import synthetic
+    from ann_solo_amd import distributed
     from ann_solo_amd.distributed import lpt_owner, sharded_search_batch
+    if kind.endswith('_direct'):
+        # the RCCL forms of the collectives (all_to_all_single / all_gather_into_tensor on the tensors
+        # as they are, asynchronous handles, four pieces per batch) over gloo: no multi-GPU node runs
+        # them before the driver's scaling bench does
+        distributed.FORCE_DIRECT_COLLECTIVES = True
+        kind = kind[:-len('_direct')]
     lib, aux = synthetic.make_library(1500, seed=91, device='cpu', charges=(2,), charge_p=(1.0,))
     q_all, _ = synthetic.make_queries(lib, aux, 2 * 24, seed=92, charge=2)
     lib_np = lib.numpy()
@@ -76,10 +83,14 @@ def _worker(rank, world, port, kind, out_dir):
         from ann_solo_amd.distributed import _all_gather_peaks, _unpack_peaks
         assert q.max_peaks() == (70 if rank == 0 else 90)
         rows, w = _all_gather_peaks(q, world)
+        if w is not None:
+            w.wait()
         assert rows.shape == (q_all.n, 2 * 96 + 1)
         back = _unpack_peaks(rows, q)
         assert torch.equal(back.mz, q_all.mz) and torch.equal(back.offsets, q_all.offsets.to(torch.int32))
-        rows2, _ = _all_gather_peaks(q, world, agreed=100)     # a caller-guaranteed common bound
+        rows2, w2 = _all_gather_peaks(q, world, agreed=100)     # a caller-guaranteed common bound
+        if w2 is not None:
+            w2.wait()
         assert rows2.shape == (q_all.n, 2 * 112 + 1)
         try:
             _all_gather_peaks(q, world, agreed=64)
@@ -143,10 +154,11 @@ def _worker(rank, world, port, kind, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind', ['pq', 'flat', 'flat_wide', 'pq4'])
+@pytest.mark.parametrize('kind', ['pq', 'flat', 'flat_wide', 'pq4', 'pq_direct', 'flat_wide_direct', 'pq4_direct'])
 def test_two_rank_sharded_search_equals_unsharded(tmp_path, kind):
-    """(kind 'pq4': the same through FOUR ranks -- heads really hold keys back by default)"""
-    world = 4 if kind == 'pq4' else 2
+    """(kind 'pq4': the same through FOUR ranks -- heads really hold keys back by default;
+    '*_direct': the collectives in their RCCL form)"""
+    world = 4 if kind.startswith('pq4') else 2
     port = _free_port()
     mp.spawn(_worker, args=(world, port, kind, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
@@ -225,7 +237,7 @@ def test_lpt_owner_rule():
 
 
 # ------------------------------------------------------------------ configs[4]: the cascade
-def _cascade_worker(rank, world, port, out_dir):
+def _cascade_worker(rank, world, port, out_dir, direct=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -235,8 +247,9 @@ def _cascade_worker(rank, world, port, out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from oracle import oracle_py as O
     from oracle_backend import OracleSpectralLibrary, oracle_cosines
-    from ann_solo_amd import synthetic, spectrum_similarity
+    from ann_solo_amd import distributed, synthetic, spectrum_similarity
     from ann_solo_amd.spectral_library import Config
+    distributed.FORCE_DIRECT_COLLECTIVES = bool(direct)     # the collectives in their RCCL form
     spectrum_similarity.ssm_cosine = oracle_cosines
     lib, aux = synthetic.make_library(1400, seed=95, device='cpu', charges=(2, 3),
                                       charge_p=(0.8, 0.2))
@@ -285,13 +298,14 @@ def _cascade_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_cascade_equals_unsharded(tmp_path):
+@pytest.mark.parametrize('direct', [False, True])
+def test_two_rank_sharded_cascade_equals_unsharded(tmp_path, direct):
     """configs[4] on CPU: standard search (data-parallel window search) -> FDR gate -> open search
     of the remainder over the list-sharded index, ragged batches, a charge without an index and
     a duplicated identifier -- identical identifications on every rank and to one process
     (reference: spectral_library.py:237-259, 301-317)."""
     world = 2
-    mp.spawn(_cascade_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_cascade_worker, args=(world, _free_port(), str(tmp_path), direct), nprocs=world, join=True)
     seen = []
     for r in range(world):
         same, n, n_std, owners = open(os.path.join(tmp_path, f'rank{r}.txt')).read().split()
