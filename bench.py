@@ -143,6 +143,12 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
+            if os.environ.get('ASL_DIRECT_COLLECTIVES') == '1':
+                # the collectives in their RCCL form (all_to_all_single / all_gather_into_tensor on the
+                # device tensors as they are, asynchronous handles, four pieces per batch) over gloo:
+                # what tests/test_gpu_distributed.py can run of the multi-GPU path on a 1-GPU box
+                from ann_solo_amd import distributed as _dist_mod
+                _dist_mod.FORCE_DIRECT_COLLECTIVES = True
         if args.preflight_seconds > 0:
             preflight(args, world, rank, dev, backend)
 

@@ -70,14 +70,46 @@ def test_two_rank_sharded_bench_path(degree, index, extra):
         assert d['config']['parallelism'] == 'replicas x2' and d['alt_layouts'] is None
 
 
-@pytest.mark.parametrize('index', ['ivfpq', 'ivfflat'])
+@pytest.mark.parametrize('index,extra', [
+    ('ivfpq', []), ('ivfflat', ['--head-keys', '600', '--shard-keys', '768', '--extras-per-query', '512']),
+    ('ivfpq', ['--head-keys', '700'])])
+def test_two_rank_sharded_bench_path_rccl_form_of_the_collectives(index, extra):
+    """The same two ranks on GPU 0, but the collectives in the form the RCCL runs use: all_to_all_single
+    / all_gather_into_tensor on the DEVICE tensors as they are, asynchronous handles, four pieces per
+    batch (gloo carries device tensors for these; RCCL itself refuses two ranks on one GPU:
+    scripts/probe_collectives.py)."""
+    env = dict(os.environ, ASL_BENCH_BACKEND='gloo', ASL_DIRECT_COLLECTIVES='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(29611 + len(extra) + (3 if index == 'ivfflat' else 0)),
+           os.path.join(ROOT, 'bench.py'),
+           '--gpus', '2', '--steps', '2', '--warmup', '1', '--library-size', '60000', '--nlist',
+           '256', '--niter', '4', '--batch', '1024', '--recall-queries', '64', '--index', index] + extra
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert line, out.stderr[-2000:]
+    d = json.loads(line[-1])
+    assert d['n_gpus'] == 2 and d['shard_check']['sharded_equals_unsharded'] is True
+    c = d['comm']
+    assert c['fallbacks_to_full_exchange'] == 0 and c['total_bytes_out_per_rank_per_step'] > 0
+    if '--shard-keys' in extra:
+        assert c['exchange'] == 'two-phase, shard-side k + second scans'
+    elif extra:
+        assert c['exchange'].startswith('two-phase') and 'held_back_keys_all_to_all' in c
+
+
+@pytest.mark.parametrize('index', ['ivfpq', 'ivfflat', 'ivfpq+rccl-form'])
 def test_two_rank_sharded_cascade(index):
     """configs[4] through the real engine on two ranks sharing GPU 0 (host-side collectives):
     standard search data-parallel over the queries, open search over the list-sharded index;
     the identifications must equal the one-GPU cascade's (bench.py --workload cascade)."""
     env = dict(os.environ, ASL_BENCH_BACKEND='gloo')
+    if index.endswith('+rccl-form'):       # the collectives as the RCCL runs issue them (see above)
+        env['ASL_DIRECT_COLLECTIVES'] = '1'
+        index = 'ivfpq'
+        env['MASTER_PORT_SHIFT'] = '1'
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29541' if index == 'ivfpq' else '29542',
+           '--master-addr', '127.0.0.1', '--master-port',
+           str((29541 if index == 'ivfpq' else 29542) + 2 * int(env.get('MASTER_PORT_SHIFT', 0))),
            os.path.join(ROOT, 'bench.py'), '--workload', 'cascade',
            '--gpus', '2', '--steps', '1', '--warmup', '1', '--library-size', '60000', '--nlist',
            '256', '--niter', '4', '--batch', '1024', '--cascade-batches', '2', '--index', index]
