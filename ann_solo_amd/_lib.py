@@ -73,7 +73,8 @@ EXPORTS = [
     'asl_ssm_features_batch', 'asl_ssm_cosine_batch', 'asl_index_set_unordered', 'asl_topk_merge_keys',
     'asl_index_set_flat_storage', 'asl_index_get_flat_storage', 'asl_index_flat_layout',
     'asl_keys_split', 'asl_keys_merge_heads', 'asl_keys_extras', 'asl_keys_merge_final',
-    'asl_keys_rescan_list', 'asl_shard_k', 'asl_index_search_gated',
+    'asl_keys_rescan_list', 'asl_shard_k', 'asl_index_search_gated', 'asl_index_search_entries',
+    'asl_encode_entries_batch',
 ]
 
 
@@ -183,6 +184,11 @@ def lib():
         L.asl_index_supports_keys.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.asl_index_search_gated.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.asl_index_search_entries.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.asl_encode_entries_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                               C.c_double, C.c_double, C.c_int32, C.c_uint32, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]
         L.asl_index_postings_work.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, c_i64p, c_i64p]
         L.asl_index_get_refine.argtypes = [C.c_void_p]
         L.asl_index_get_refine.restype = C.c_int32

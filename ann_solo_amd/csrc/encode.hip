@@ -4,10 +4,11 @@
 // One 64-lane wavefront per spectrum, four spectra per workgroup. Lanes hash
 // their peaks in parallel (float64 NumPy floor-division of the float32 m/z,
 // MurmurHash3_x86_32 of the decimal string of the bin index, seed 42); the fp32
-// scatter-add into the LDS-resident vector is applied by lane 0 in ascending
-// peak order so that colliding bins round exactly like the reference's
-// `vector[bin] += intensity` loop. The L2 norm is the canonical ascending-index
-// fmaf chain. Output rows are written coalesced.
+// scatter-add into the LDS-resident vector is applied per bin in ascending
+// peak order (rounds by a peak's rank within its bin), so that colliding bins
+// round exactly like the reference's `vector[bin] += intensity` loop. The L2
+// norm is the canonical ascending-index fmaf chain. Output rows are written
+// coalesced, or as the entry lists the scans read (non-zero components only).
 #include "common.hpp"
 
 namespace asl {
@@ -16,8 +17,70 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) {
   return (x << r) | (x >> (32 - r));
 }
 
+__device__ __forceinline__ uint32_t murmur3_round(uint32_t h1, uint32_t k1) {
+  k1 *= 0xcc9e2d51u;
+  k1 = rotl32(k1, 15);
+  k1 *= 0x1b873593u;
+  h1 ^= k1;
+  h1 = rotl32(h1, 13);
+  return h1 * 5 + 0xe6546b64u;
+}
+
+// MurmurHash3_x86_32 over the ASCII decimal representation of v (with '-'), |v| < 10^9 (every
+// bin of a real spectrum: m/z / bin size): at most 10 characters, kept in three 32-bit words --
+// 32-bit digit arithmetic and no byte arrays (the general form below runs three data-dependent
+// loops over 64-bit divisions and register-resident arrays: ~3 000 instructions per peak, which
+// made the encoder VALU-bound). Same bytes, same hash.
+__device__ __forceinline__ uint32_t murmur3_decimal_small(int v, uint32_t seed) {
+  const bool neg = v < 0;
+  uint32_t u = neg ? (uint32_t)(-(long long)v) : (uint32_t)v;
+  int nd = 1;
+  nd += u >= 10u;
+  nd += u >= 100u;
+  nd += u >= 1000u;
+  nd += u >= 10000u;
+  nd += u >= 100000u;
+  nd += u >= 1000000u;
+  nd += u >= 10000000u;
+  nd += u >= 100000000u;
+  const int len = nd + (neg ? 1 : 0);
+  uint32_t w0 = neg ? (uint32_t)'-' : 0u, w1 = 0u, w2 = 0u;      // byte p of the string = byte p & 3 of word p >> 2
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {          // digit j from the right goes to position len - 1 - j
+    if (j < nd) {
+      const uint32_t qd = u / 10u;
+      const uint32_t ch = (uint32_t)'0' + (u - qd * 10u);
+      u = qd;
+      const int pos = len - 1 - j;
+      const uint32_t sh = ch << ((pos & 3) * 8);
+      w0 |= (pos >> 2) == 0 ? sh : 0u;
+      w1 |= (pos >> 2) == 1 ? sh : 0u;
+      w2 |= (pos >> 2) == 2 ? sh : 0u;
+    }
+  }
+  uint32_t h1 = seed;
+  if (len >= 4) h1 = murmur3_round(h1, w0);
+  if (len >= 8) h1 = murmur3_round(h1, w1);
+  const uint32_t tail = len >= 8 ? w2 : (len >= 4 ? w1 : w0);    // the len & 3 bytes behind the full blocks
+  if (len & 3) {
+    uint32_t k1 = tail & (0xFFFFFFFFu >> (32 - 8 * (len & 3)));
+    k1 *= 0xcc9e2d51u;
+    k1 = rotl32(k1, 15);
+    k1 *= 0x1b873593u;
+    h1 ^= k1;
+  }
+  h1 ^= (uint32_t)len;
+  h1 ^= h1 >> 16;
+  h1 *= 0x85ebca6bu;
+  h1 ^= h1 >> 13;
+  h1 *= 0xc2b2ae35u;
+  h1 ^= h1 >> 16;
+  return h1;
+}
+
 // MurmurHash3_x86_32 over the ASCII decimal representation of v (with '-').
 __device__ uint32_t murmur3_decimal(long long v, uint32_t seed) {
+  if (v > -1000000000ll && v < 1000000000ll) return murmur3_decimal_small((int)v, seed);
   unsigned char buf[24];
   int len = 0;
   unsigned long long u = v < 0 ? (unsigned long long)(-(v + 1)) + 1ull : (unsigned long long)v;
@@ -65,6 +128,18 @@ __device__ uint32_t murmur3_decimal(long long v, uint32_t seed) {
 
 // NumPy npy_floor_divide on doubles, then math.floor (spectrum.py:207).
 __device__ long long np_floor_div_bin(double a, double b) {
+  // NumPy's route (exact remainder by fmod, quotient of the difference, the corrections below) yields
+  // the EXACT floor of a / b for quotients far inside the double range; so does this one, without
+  // the fmod loop: the correctly rounded quotient can only have been rounded UP across an integer
+  // (an integer n <= a / b is representable, rounding is monotone), and the sign of the fused
+  // a - q b is the sign of the exact remainder. b > 0 (checked by the callers); everything else --
+  // huge quotients, infinities, NaN -- takes NumPy's route.
+  const double q0 = a / b;
+  if (b > 0.0 && fabs(q0) < 2147483648.0) {
+    double q = floor(q0);
+    if (fma(-q, b, a) < 0.0) q -= 1.0;
+    return (long long)q;
+  }
   double mod = fmod(a, b);
   double div = (a - mod) / b;
   if (mod != 0.0 && ((b < 0) != (mod < 0))) div -= 1.0;
@@ -79,36 +154,53 @@ __device__ long long np_floor_div_bin(double a, double b) {
 }
 
 constexpr int ENC_WAVES = 4;
+constexpr int QE_CAP = 64;         // entries of a query's entry list (coarse_sparse.hip: CS_CAP)
+constexpr int QE_DIM_SHIFT = 7;    // an entry holds dimension * 128: the byte offset of its tile row (CS_TL * 4)
 
+// ENTRIES = false: out[spec][hash_len], the dense vector. ENTRIES = true: the vector leaves as its
+// ENTRY LIST -- the non-zero components, ascending, as (dimension * 128, value bits), 64 per query,
+// cnt = their number or -1 - count beyond 64 -- exactly what list_nonzeros_kernel
+// (coarse_sparse.hip) makes of the dense row; the scans take their queries in this form, and a
+// sharded search encodes the other ranks' queries straight into it (no 3.2 KB row per query
+// written and read again).
+template <bool ENTRIES>
 __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
     const float *__restrict__ mz, const float *__restrict__ inten,
     const int32_t *__restrict__ offsets, int32_t n, double min_bound, double bin_size,
-    int32_t hash_len, uint32_t seed, int norm, float *__restrict__ out) {
+    int32_t hash_len, uint32_t seed, int norm, float *__restrict__ out, uint2 *__restrict__ ent,
+    int32_t *__restrict__ ent_cnt, int *__restrict__ n_over) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int spec = blockIdx.x * ENC_WAVES + wave;
-  // per-wave LDS: vec[hash_len] | hidx[64] | hval[64]
-  const int per_wave = hash_len + 128;
-  float *vec = reinterpret_cast<float *>(smem) + (size_t)wave * per_wave;
-  int *hidx = reinterpret_cast<int *>(vec + hash_len);
-  float *hval = vec + hash_len + 64;
+  float *vec = reinterpret_cast<float *>(smem) + (size_t)wave * hash_len;   // per-wave LDS: vec[hash_len]
   if (spec >= n) return;  // whole wave exits together (no block barriers are used)
 
   for (int i = lane; i < hash_len; i += 64) vec[i] = 0.0f;
   const int p0 = offsets[spec], p1 = offsets[spec + 1];
   for (int base = p0; base < p1; base += 64) {
     const int p = base + lane;
-    if (p < p1) {
+    const int cnt = min(64, p1 - base);
+    const bool live = lane < cnt;
+    int idx = -1 - lane;        // (a dead lane matches nobody)
+    float val = 0.0f;
+    if (live) {
       long long b = np_floor_div_bin((double)mz[p] - min_bound, bin_size);
-      hidx[lane] = (int)(murmur3_decimal(b, seed) % (uint32_t)hash_len);
-      hval[lane] = inten[p];
+      idx = (int)(murmur3_decimal(b, seed) % (uint32_t)hash_len);
+      val = inten[p];
     }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-      const int cnt = min(64, p1 - base);
-      for (int t = 0; t < cnt; ++t) vec[hidx[t]] += hval[t];
+    // `vector[bin] += intensity` in ascending peak order: peaks of different bins do not interact, so
+    // a lane's turn is its RANK among the peaks of its own bin (the earlier lanes holding the same
+    // bin) -- round r applies all peaks of rank r at once, one read-modify-write per bin and round.
+    // Two or three rounds instead of 50 dependent LDS round trips of one lane.
+    int rank = 0;
+    for (int j = 0; j < cnt; ++j) {                 // wave-uniform trip count
+      const int o = __builtin_amdgcn_readlane(idx, j);
+      rank += (o == idx && j < lane) ? 1 : 0;
     }
-    __builtin_amdgcn_wave_barrier();
+    for (int r = 0; __ballot(live && rank >= r) != 0ull; ++r) {
+      if (live && rank == r) vec[idx] += val;
+      __builtin_amdgcn_wave_barrier();              // (a wave's LDS accesses execute in program order)
+    }
   }
   float nrm = 1.0f;
   if (norm) {
@@ -130,8 +222,48 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
     }
     nrm = __builtin_sqrtf(acc);
   }
-  float *row = out + (size_t)spec * hash_len;
-  for (int i = lane; i < hash_len; i += 64) row[i] = norm ? vec[i] / nrm : vec[i];
+  if (!ENTRIES) {
+    float *row = out + (size_t)spec * hash_len;
+    for (int i = lane; i < hash_len; i += 64) row[i] = norm ? vec[i] / nrm : vec[i];
+    return;
+  }
+  // the entry list of the row the dense form would hold (the test is on the STORED value, as
+  // list_nonzeros applies it: a component that underflows to zero in the division is no entry)
+  uint2 *row = ent + (size_t)spec * QE_CAP;
+  int have = 0;
+  for (int i0 = 0; i0 < hash_len; i0 += 64) {
+    const int i = i0 + lane;
+    float x = i < hash_len ? vec[i] : 0.0f;
+    if (norm) x = x / nrm;
+    if (!(i < hash_len)) x = 0.0f;
+    const unsigned long long m = __ballot(x != 0.0f);
+    if (x != 0.0f) {
+      const int t = have + __popcll(m & ((1ull << lane) - 1ull));
+      if (t < QE_CAP) row[t] = make_uint2((uint32_t)i << QE_DIM_SHIFT, __float_as_uint(x));
+    }
+    have += __popcll(m);
+  }
+  for (int t = have + lane; t < QE_CAP; t += 64) row[t] = make_uint2(0u, 0u);     // (dim 0, +0.0)
+  if (lane == 0) {
+    ent_cnt[spec] = have <= QE_CAP ? have : -1 - have;
+    if (have > QE_CAP && n_over) atomicAdd(n_over, 1);
+  }
+}
+
+template <bool ENTRIES>
+static int encode_launch(const float *mz, const float *inten, const int32_t *offsets, int32_t n,
+                         double min_bound, double bin_size, int32_t hash_len, uint32_t seed, int norm,
+                         float *out, uint2 *ent, int32_t *ent_cnt, int *n_over) {
+  size_t lds = (size_t)ENC_WAVES * hash_len * sizeof(float);
+  if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "encode: hash_len %d too large for LDS", hash_len);
+  dim3 grid((unsigned)cdiv(n, ENC_WAVES));
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void *)encode_kernel<ENTRIES>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(encode_kernel<ENTRIES>, grid, dim3(64 * ENC_WAVES), lds, stream(), mz, inten,
+                     offsets, n, min_bound, bin_size, hash_len, seed, norm, out, ent, ent_cnt, n_over);
+  ASL_CHECK_LAUNCH();
+  return ASL_OK;
 }
 
 int encode_device(const float *mz, const float *inten, const int32_t *offsets, int32_t n,
@@ -139,16 +271,19 @@ int encode_device(const float *mz, const float *inten, const int32_t *offsets, i
                   int norm, float *out) {
   if (n == 0) return ASL_OK;
   ProfScope ps("encode");
-  size_t lds = (size_t)ENC_WAVES * (hash_len + 128) * sizeof(float);
-  if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "encode: hash_len %d too large for LDS", hash_len);
-  dim3 grid((unsigned)cdiv(n, ENC_WAVES));
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)encode_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(encode_kernel, grid, dim3(64 * ENC_WAVES), lds, stream(), mz, inten,
-                     offsets, n, min_bound, bin_size, hash_len, seed, norm, out);
-  ASL_CHECK_LAUNCH();
-  return ASL_OK;
+  return encode_launch<false>(mz, inten, offsets, n, min_bound, bin_size, hash_len, seed, norm, out,
+                              nullptr, nullptr, nullptr);
+}
+
+// the same vectors as entry lists: ent [n][64] (dimension * 128, value bits), cnt [n], n_over: one
+// device int that counts the rows with more than 64 non-zeros (may be null)
+int encode_entries_device(const float *mz, const float *inten, const int32_t *offsets, int32_t n,
+                          double min_bound, double bin_size, int32_t hash_len, uint32_t seed, int norm,
+                          uint2 *ent, int32_t *cnt, int *n_over) {
+  if (n == 0) return ASL_OK;
+  ProfScope ps("encode");
+  return encode_launch<true>(mz, inten, offsets, n, min_bound, bin_size, hash_len, seed, norm, nullptr,
+                             ent, cnt, n_over);
 }
 
 }  // namespace asl
@@ -245,6 +380,45 @@ int asl_encode_batch(const float *mz, const float *intensity, const int32_t *off
                         dout.d));
   ASL_TRY(dout.finish());
   if (dout.to_host() || dmz.own.p || din.own.p || doff.own.p) ASL_TRY(sync_stream());
+  return ASL_OK;
+}
+
+// The same vectors as ENTRY LISTS, the form the IVF scans read their queries in
+// (asl_index_search_entries): entries [n][64] pairs of 32-bit words (dimension * 128, the bits of
+// the fp32 value), ascending dimension, unused pairs zero; counts [n] = the number of non-zero
+// components, or -1 - count when a vector has more than 64 (such a query needs the dense form);
+// n_over (may be null): a device int this call ADDS the number of such rows to. entries / counts
+// are device memory; n_peaks = offsets[n] when the caller knows it (>= 0: nothing is read back).
+int asl_encode_entries_batch(const float *mz, const float *intensity, const int32_t *offsets,
+                             int32_t n, int32_t n_peaks, double min_bound, double bin_size,
+                             int32_t hash_len, uint32_t seed, int norm, uint32_t *entries,
+                             int32_t *counts, int32_t *n_over) {
+  clear_error();
+  if (n < 0 || hash_len <= 0 || !(bin_size > 0))
+    return fail(ASL_ERR_INVALID, "encode_entries_batch: bad n/hash_len/bin_size");
+  if (n == 0) return ASL_OK;
+  if (!offsets || !entries || !counts) return fail(ASL_ERR_INVALID, "encode_entries_batch: null offsets/entries/counts");
+  ASL_TRY(ensure_device());
+  if (!is_device_ptr(entries) || !is_device_ptr(counts) || (n_over && !is_device_ptr(n_over)))
+    return fail(ASL_ERR_INVALID, "encode_entries_batch: entries / counts / n_over must be device memory");
+  int32_t last = n_peaks;
+  if (last < 0) {
+    if (is_device_ptr(offsets)) {
+      HIP_TRY(hipMemcpyAsync(&last, offsets + n, sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
+      ASL_TRY(sync_stream());
+    } else {
+      last = offsets[n];
+    }
+  }
+  if (last > 0 && (!mz || !intensity)) return fail(ASL_ERR_INVALID, "encode_entries_batch: null peaks");
+  In<float> dmz, din;
+  In<int32_t> doff;
+  ASL_TRY(dmz.init(mz, (size_t)last));
+  ASL_TRY(din.init(intensity, (size_t)last));
+  ASL_TRY(doff.init(offsets, (size_t)n + 1));
+  ASL_TRY(encode_entries_device(dmz.d, din.d, doff.d, n, min_bound, bin_size, hash_len, seed, norm,
+                                reinterpret_cast<uint2 *>(entries), counts, n_over));
+  if (dmz.own.p || din.own.p || doff.own.p) ASL_TRY(sync_stream());
   return ASL_OK;
 }
 

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   // the query's non-zero components, ascending: from the ready entry list (list_nonzeros: 512
   // bytes) or listed here from the dense row (staged through the accumulator area)
   float *s_q = s_acc;
-  const int ecnt = ent ? ent_cnt[q] : -1;          // block-uniform; < 0: more than 64 non-zeros
+  int ecnt = ent ? ent_cnt[q] : -1;                // block-uniform; < 0: more than 64 non-zeros
+  if (!xq && ecnt < 0) ecnt = 0;                   // (entry lists only: such a row is searched as all-zero)
   const bool fast = ecnt >= 0;
   if (!fast)
     for (int i = tid; i < d; i += FI_NT) s_q[i] = xq[(size_t)q * d + i];

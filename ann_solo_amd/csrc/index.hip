@@ -504,8 +504,16 @@ static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe,
 // Search with all-device arguments. Exactly one of I64 / I32 may be non-null (or both).
 int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
                         int64_t *I64, int32_t *I32, const float *pre_D = nullptr,
-                        const int32_t *pre_I = nullptr, bool set_mode = false, const int *gate = nullptr) {
+                        const int32_t *pre_I = nullptr, bool set_mode = false, const int *gate = nullptr,
+                        const uint2 *pre_ent = nullptr, const int32_t *pre_cnt = nullptr) {
   if (nq <= 0) return ASL_OK;
+  // pre_ent / pre_cnt: the queries as ENTRY LISTS (list_nonzeros / encode_entries_device); xq may
+  // then be null -- only the layout-specific scans read their queries in that form, and a row
+  // whose count is negative (more than 64 non-zeros) is searched as an all-zero query: the
+  // caller watches the producer's n_over
+  if (pre_ent && (!pre_cnt || !pre_I || ix->kind == ASL_INDEX_FLAT))
+    return fail(ASL_ERR_STATE, "entry-list search: needs the counts, the caller's probe lists and an IVF index");
+  if (!xq && !pre_ent) return fail(ASL_ERR_INVALID, "search: null queries");
   // gate: a device-side count -- only the first *gate rows are searched (layout-specific scans only)
   if (gate && (!pre_I || ix->kind == ASL_INDEX_FLAT))
     return fail(ASL_ERR_STATE, "gated search: needs the caller's probe lists and an IVF index");
@@ -533,11 +541,18 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       if (ix->unordered == 2 && !(use_inv && I64 && k + FLAT_KEYS_SLACK <= TK_MAX_K))
         return fail(ASL_ERR_STATE, "packed-key rows need the postings scan of IVF-Flat (sparse vectors, k <= 1280) and an int64 output");
       if (gate && !use_inv) return fail(ASL_ERR_STATE, "gated search: needs the postings scan of IVF-Flat");
+      if (pre_ent && !use_inv) return fail(ASL_ERR_STATE, "entry-list search: needs the postings scan of IVF-Flat");
       if (use_inv) {
-        ASL_TRY(ix->scan_ent.reserve((size_t)nq * 64));
-        ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
-        ASL_TRY(ix->scan_over.reserve(1));
-        ASL_TRY(list_nonzeros(xq, nq, d, d, ix->scan_ent.p, ix->scan_cnt.p, ix->scan_over.p));
+        const uint2 *q_ent = pre_ent;
+        const int32_t *q_cnt = pre_cnt;
+        if (!pre_ent) {
+          ASL_TRY(ix->scan_ent.reserve((size_t)nq * 64));
+          ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
+          ASL_TRY(ix->scan_over.reserve(1));
+          ASL_TRY(list_nonzeros(xq, nq, d, d, ix->scan_ent.p, ix->scan_cnt.p, ix->scan_over.p));
+          q_ent = ix->scan_ent.p;
+          q_cnt = ix->scan_cnt.p;
+        }
         {
           ProfScope ps("scan");     // the scan kernel itself
           const bool fx = ix->inv_layout == 2;
@@ -545,7 +560,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
                                 ix->blk_offsets.p, ix->blk_base.p,
                                 fx ? (const void *)ix->inv_tab8.p : (const void *)ix->inv_tab.p,
                                 ix->tab_stride, ix->inv_data.p, ix->ids.p, k, D, I64, I32,
-                                ix->unordered ? ix->unordered : (set_mode ? 1 : 0), ix->scan_ent.p, ix->scan_cnt.p, gate));
+                                ix->unordered ? ix->unordered : (set_mode ? 1 : 0), q_ent, q_cnt, gate));
         }
         if (prof_counts() && !gate) {
           // vectors scored by this launch, summed on the device (nothing waits inside a step)
@@ -589,6 +604,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   // exact re-rank: the ADC scan returns k' > k candidates as a set, refine.hip keeps the k best
   const bool refine = ix->refine_k > k && ix->refine_rows && ix->unordered == 0;
   if (gate && refine) return fail(ASL_ERR_STATE, "gated search: not with the exact re-rank");
+  if (pre_ent && refine) return fail(ASL_ERR_STATE, "entry-list search: not with the exact re-rank (it reads the dense queries)");
   float *fin_D = D;
   int64_t *fin_I64 = I64;
   int32_t *fin_I32 = I32;
@@ -613,6 +629,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
     if (ix->unordered == 2 && !(tiled && I64))
       return fail(ASL_ERR_STATE, "packed-key rows need the tiled IVF-PQ scan (m = 32, 8 bits) and an int64 output");
     if (gate && !tiled) return fail(ASL_ERR_STATE, "gated search: needs the tiled IVF-PQ scan");
+    if (pre_ent && !tiled) return fail(ASL_ERR_STATE, "entry-list search: needs the tiled IVF-PQ scan (m = 32, 8 bits)");
     if (tiled) {
       if (!ix->cbt_ready) {
         const size_t ncb = (size_t)ix->pq_m * ix->ksub * ix->dsub;
@@ -630,15 +647,21 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       // the queries' non-zero components as ready lists: the table build of every workgroup
       // starts from 512 bytes instead of listing a 3.2 KB row (17 us per 16 384 queries here,
       // ~4 us saved per (query, shard) workgroup)
-      ASL_TRY(ix->scan_ent.reserve((size_t)nq * 64));
-      ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
-      ASL_TRY(ix->scan_over.reserve(1));
-      ASL_TRY(list_nonzeros(xq, nq, d, d, ix->scan_ent.p, ix->scan_cnt.p, ix->scan_over.p));
+      const uint2 *q_ent = pre_ent;
+      const int32_t *q_cnt = pre_cnt;
+      if (!pre_ent) {
+        ASL_TRY(ix->scan_ent.reserve((size_t)nq * 64));
+        ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
+        ASL_TRY(ix->scan_over.reserve(1));
+        ASL_TRY(list_nonzeros(xq, nq, d, d, ix->scan_ent.p, ix->scan_cnt.p, ix->scan_over.p));
+        q_ent = ix->scan_ent.p;
+        q_cnt = ix->scan_cnt.p;
+      }
       ProfScope ps("scan");     // the scan kernel itself
       ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks_t.p, ix->dsub, cD, cI,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
                          ix->ids_tiled.p, k, D, I64, I32, ix->unordered ? ix->unordered : (set_mode ? 1 : 0),
-                         ix->scan_ent.p, ix->scan_cnt.p, gate));
+                         q_ent, q_cnt, gate));
     } else {
       ProfScope ps("scan");
       ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, cD,
@@ -1319,6 +1342,29 @@ int asl_index_search_gated(asl_index_t *ix, int32_t cap, const float *xq, int32_
     return fail(ASL_ERR_INVALID, "search_gated: device pointers only");
   return index_search_device(ix, cap, xq, k, nprobe, D, I, nullptr, coarse_D, coarse_I, false,
                              reinterpret_cast<const int *>(count));
+}
+
+// search_preassigned with the queries as ENTRY LISTS (asl_encode_entries_batch: entries [nq][64]
+// word pairs, counts [nq]) instead of dense rows: what the layout-specific scans read anyway -- 512
+// bytes per query instead of 3.2 KB, and no listing pass. Results are those of
+// asl_index_search_preassigned on the dense rows, bit for bit. A row whose count is negative (more
+// than 64 non-zeros) is searched as an all-zero query: check the n_over the encoder reported. `count`
+// (may be null): a device int -- only the first *count rows are searched, the launch covers nq
+// (asl_index_search_gated). Device pointers only; never waits.
+int asl_index_search_entries(asl_index_t *ix, int32_t nq, const uint32_t *entries, const int32_t *counts,
+                             int32_t k, int32_t nprobe, const float *coarse_D, const int32_t *coarse_I,
+                             float *D, int64_t *I, const int32_t *count) {
+  clear_error();
+  if (!ix || ix->kind == ASL_INDEX_FLAT) return fail(ASL_ERR_INVALID, "search_entries: IVF index required");
+  if (nq <= 0) return ASL_OK;
+  if (!entries || !counts || !I || !coarse_D || !coarse_I) return fail(ASL_ERR_INVALID, "search_entries: null argument");
+  if (nprobe < 1 || nprobe > ix->nlist) return fail(ASL_ERR_INVALID, "search_entries: nprobe outside 1..nlist");
+  ASL_TRY(ensure_device());
+  if (!is_device_ptr(entries) || !is_device_ptr(counts) || !is_device_ptr(I) || !is_device_ptr(coarse_D) ||
+      !is_device_ptr(coarse_I) || (count && !is_device_ptr(count)) || (D && !is_device_ptr(D)))
+    return fail(ASL_ERR_INVALID, "search_entries: device pointers only");
+  return index_search_device(ix, nq, nullptr, k, nprobe, D, I, nullptr, coarse_D, coarse_I, false,
+                             reinterpret_cast<const int *>(count), reinterpret_cast<const uint2 *>(entries), counts);
 }
 
 int asl_topk_merge(int32_t S, int32_t nq, int32_t k, const float *Ds, const int64_t *Is,

@@ -88,7 +88,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
   }
   build_lut_cbt<NT>(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, reinterpret_cast<uint8_t *>(table),
                     tid, ent ? ent + (size_t)q * 64 : nullptr,
-                    ent ? ent_cnt[q] : -1);  // codebooks = cbT[m][t][c]; the tile table is not live yet
+                    ent ? (xq ? ent_cnt[q] : max(ent_cnt[q], 0)) : -1);  // codebooks = cbT[m][t][c]; the tile table is
+                                                                        // not live yet; entry lists only: a row with
+                                                                        // more than 64 non-zeros is searched as all-zero
 
   // ---- exclusive scan of the probes' tile counts
   int total;

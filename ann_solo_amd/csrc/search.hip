@@ -22,7 +22,8 @@ int encode_device(const float *mz, const float *inten, const int32_t *offsets, i
                   int norm, float *out);
 int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
                         int64_t *I64, int32_t *I32, const float *pre_D, const int32_t *pre_I,
-                        bool set_mode, const int *gate = nullptr);
+                        bool set_mode, const int *gate = nullptr, const uint2 *pre_ent = nullptr,
+                        const int32_t *pre_cnt = nullptr);
 int index_dim(const asl_index *ix);
 int index_nprobe(const asl_index *ix, int nprobe);
 int index_prepare(asl_index *ix);

@@ -20,7 +20,8 @@ struct asl_index;
 namespace asl {
 int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
                         int64_t *I64, int32_t *I32, const float *pre_D, const int32_t *pre_I,
-                        bool set_mode, const int *gate);
+                        bool set_mode, const int *gate, const uint2 *pre_ent = nullptr,
+                        const int32_t *pre_cnt = nullptr);
 int index_dim(const asl_index *ix);
 int index_nprobe(const asl_index *ix, int nprobe);
 int index_prepare(asl_index *ix);

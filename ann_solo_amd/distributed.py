@@ -104,6 +104,28 @@ def make_shard_groups(degree: int):
     return mine, rank % degree, rank // degree
 
 
+class EntryQueries:
+    """A batch of hashed queries as ENTRY LISTS -- the non-zero components only (entries [n, 64, 2]
+    int32 = (dimension * 128, value bits), counts [n] int32; ``asl_encode_entries_batch``): what the
+    shard scans read, 512 bytes per query instead of a 3.2 KB dense row. Behaves like the dense
+    tensor where the driver touches it (rows, device, ``index_select``)."""
+
+    def __init__(self, entries: torch.Tensor, counts: torch.Tensor):
+        self.entries, self.counts = entries, counts
+
+    @property
+    def shape(self):
+        return (self.counts.shape[0],)
+
+    @property
+    def device(self):
+        return self.counts.device
+
+    def index_select(self, dim: int, rows: torch.Tensor) -> 'EntryQueries':
+        assert dim == 0
+        return EntryQueries(self.entries.index_select(0, rows), self.counts.index_select(0, rows))
+
+
 class HipShardBackend:
     """Product backend: one charge partition of a ``SpectralLibrary`` whose ANN index has
     been sharded with ``index.shard(rank, world)``."""
@@ -127,6 +149,25 @@ class HipShardBackend:
 
     def encode(self, queries: PackedSpectra) -> torch.Tensor:
         return self.sl._encode(queries.to(self.device))
+
+    MAX_ENTRIES = 64      # non-zero components an entry list holds (csrc/encode.hip: QE_CAP)
+
+    def encode_entries(self, queries: PackedSpectra) -> EntryQueries:
+        """The hashed vectors of ``queries`` as entry lists (same values as ``encode``, bit for bit);
+        only for spectra of at most ``MAX_ENTRIES`` peaks -- a vector has no more non-zeros than
+        its spectrum has peaks -- which the driver checks on the agreed peak-row width."""
+        from .spectrum import get_dim, HASH_SEED
+        cfg = self.sl.config
+        q = queries.to(self.device)
+        n = q.n
+        ent = torch.empty((n, self.MAX_ENTRIES, 2), dtype=torch.int32, device=self.device)
+        cnt = torch.empty((n,), dtype=torch.int32, device=self.device)
+        _, start_dim, _ = get_dim(cfg.min_mz, cfg.max_mz, cfg.bin_size)
+        _lib.check(_lib.lib().asl_encode_entries_batch(
+            _lib.ptr(q.mz), _lib.ptr(q.intensity), _lib.ptr(q.offsets.to(torch.int32)), n, int(q.mz.numel()),
+            float(start_dim), float(cfg.bin_size), int(cfg.hash_len), int(HASH_SEED), 1,
+            _lib.ptr(ent), _lib.ptr(cnt), None))
+        return EntryQueries(ent, cnt)
 
     def shard_search(self, vectors: torch.Tensor):
         self.index.nprobe = self.sl._num_probe
@@ -162,6 +203,8 @@ class HipShardBackend:
         k = int(k or self.k_scan)
         if vectors.shape[0] == 0:
             return torch.zeros((0, k), dtype=torch.int64, device=vectors.device)
+        if isinstance(vectors, EntryQueries):
+            return self.index.search_entries_keys(vectors.entries, vectors.counts, k, coarse_D, coarse_I)
         return self.index.search_preassigned_keys(vectors, k, coarse_D, coarse_I)
 
     def merge_keys(self, Ks: torch.Tensor):
@@ -221,13 +264,17 @@ class HipShardBackend:
             overflow[1:2] += cnt                              # (statistics: rows scanned a second time)
             x3 = xv.index_select(0, rowlist)                  # slots past the count repeat row 0: never scanned
             cD3, cI3 = cD.index_select(0, rowlist), cI.index_select(0, rowlist)
-            K3 = torch.empty((R, k3), dtype=torch.int64, device=dev)
-            self.index.set_unordered(2)
-            try:
-                _lib.check(L.asl_index_search_gated(self.index._h, R, _lib.ptr(x3), int(k3), int(cI3.shape[1]),
-                                                    _lib.ptr(cD3), _lib.ptr(cI3), None, _lib.ptr(K3), _lib.ptr(cnt)))
-            finally:
-                self.index.set_unordered(0)
+            if isinstance(x3, EntryQueries):
+                K3 = self.index.search_entries_keys(x3.entries, x3.counts, int(k3), cD3, cI3, gate=cnt)
+            else:
+                K3 = torch.empty((R, k3), dtype=torch.int64, device=dev)
+                self.index.set_unordered(2)
+                try:
+                    _lib.check(L.asl_index_search_gated(self.index._h, R, _lib.ptr(x3), int(k3), int(cI3.shape[1]),
+                                                        _lib.ptr(cD3), _lib.ptr(cI3), None, _lib.ptr(K3),
+                                                        _lib.ptr(cnt)))
+                finally:
+                    self.index.set_unordered(0)
         _lib.check(L.asl_keys_extras(world, n, k, _lib.ptr(K), _lib.ptr(floor), _lib.ptr(bounds),
                                      int(xcap), _lib.ptr(xbuf), _lib.ptr(cursor), _lib.ptr(overflow),
                                      _lib.ptr(rmap), _lib.ptr(K3), int(k3)))
@@ -551,9 +598,11 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
                          peak_width: Optional[int] = None, two_phase: Optional[bool] = None,
                          head_keys: Optional[int] = None, extras_per_query: Optional[int] = None,
                          comm: Optional['CommLog'] = None, stats: Optional[dict] = None,
-                         shard_keys: Optional[int] = None):
+                         shard_keys: Optional[int] = None, entry_lists: Optional[bool] = None):
     """One batch: ``queries_local`` is this rank's equally sized slice of the global
     batch. Returns the BatchResult of the local slice (library rows are global).
+    ``entry_lists=False`` keeps the other ranks' queries as dense rows (default: entry lists
+    whenever the packed-key scans run and no spectrum has more than 64 peaks).
     ``peak_width``: a bound on the peaks per query that is IDENTICAL on every rank (e.g.
     ``config.max_peaks_used`` for processed queries); without it the ranks agree on the row
     width of the peak exchange by an all-reduce.
@@ -605,21 +654,32 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
             comm.add('probe_lists_all_gather', co[0], world, 'all_gather')
             comm.add('probe_lists_all_gather', co[1], world, 'all_gather')
         cD, cI = _all_gather_rows(co[0], world, group), _all_gather_rows(co[1], world, group)
-    if w_vec is not None:
-        w_vec.wait()
-    allvec = backend.encode(_unpack_peaks(packed, queries_local))
-    rank = dist.get_rank(group)
-    allvec[rank * n_local:(rank + 1) * n_local] = vec      # (same bits; skips nothing, documents intent)
-    if chunks is None:
-        chunks = 4 if _direct(group) else 2
-    chunks = max(1, min(chunks, n_local))
-    bounds = [(n_local * c) // chunks for c in range(chunks + 1)]
-    rank_base = torch.arange(world, device=allvec.device).unsqueeze(1) * n_local
-
     k_scan = int(getattr(backend, 'k_scan', getattr(backend, 'k', 0)))
     # the exchange format is a COLLECTIVE choice (see _agreed_keys)
     use_keys = _agreed_keys(backend, world, group, k_scan) and \
         (co is not None or not getattr(backend, 'supports_preassigned', False))
+    if w_vec is not None:
+        w_vec.wait()
+    rank = dist.get_rank(group)
+    # The packed-key scans read their queries as ENTRY LISTS (the non-zero components), so the other
+    # ranks' queries are hashed straight into that form -- no 3.2 KB dense row per query written,
+    # listed and gathered per piece. A vector has no more non-zeros than its spectrum has peaks: the
+    # (agreed) row width of the peak exchange decides, identically on every rank.
+    use_entries = (entry_lists is not False and use_keys and hasattr(backend, 'encode_entries')
+                   and (packed.shape[1] - 1) // 2 <= getattr(backend, 'MAX_ENTRIES', 0)
+                   and k_scan == int(getattr(backend, 'k', k_scan)))
+    if use_entries:
+        allvec = backend.encode_entries(_unpack_peaks(packed, queries_local))
+    else:
+        allvec = backend.encode(_unpack_peaks(packed, queries_local))
+        allvec[rank * n_local:(rank + 1) * n_local] = vec      # (same bits; skips nothing, documents intent)
+    if stats is not None:
+        stats['query_form'] = 'entry lists' if use_entries else 'dense rows'
+    if chunks is None:
+        chunks = 4 if _direct(group) else 2
+    chunks = max(1, min(chunks, n_local))
+    bounds = [(n_local * c) // chunks for c in range(chunks + 1)]
+    rank_base = torch.arange(world, device=vec.device).unsqueeze(1) * n_local
     if two_phase is None:
         two_phase = use_keys and hasattr(backend, 'keys_split')
     two_phase = bool(two_phase and use_keys)
@@ -647,7 +707,7 @@ def sharded_search_batch(backend, queries_local: PackedSpectra, group=None, devi
         if chunks == 1:
             xv, pre = allvec, (cD, cI) if co is not None else None
         else:
-            rows = (rank_base + torch.arange(lo, hi, device=allvec.device).unsqueeze(0)).reshape(-1)
+            rows = (rank_base + torch.arange(lo, hi, device=vec.device).unsqueeze(0)).reshape(-1)
             xv = allvec.index_select(0, rows)
             pre = (cD.index_select(0, rows), cI.index_select(0, rows)) if co is not None else None
         if use_keys:

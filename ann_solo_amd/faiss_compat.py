@@ -261,6 +261,23 @@ class Index:
             self.set_unordered(0)
         return K
 
+    def search_entries_keys(self, entries, counts, k, coarse_D, coarse_I, gate=None):
+        """``search_preassigned_keys`` with the queries as ENTRY LISTS (``encode_entries``: entries
+        [nq, 64, 2] int32 = (dimension * 128, value bits), counts [nq] int32) instead of dense rows
+        -- device tensors only; the rows equal the dense call's bit for bit. ``gate``: a device int,
+        only the first ``gate[0]`` rows are searched (the others are left as they are)."""
+        import torch
+        nq, nprobe = coarse_I.shape
+        K = torch.empty((nq, k), dtype=torch.int64, device=entries.device)
+        self.set_unordered(2)
+        try:
+            _lib.check(_lib.lib().asl_index_search_entries(
+                self._h, nq, _lib.ptr(entries), _lib.ptr(counts), int(k), int(nprobe), _lib.ptr(coarse_D),
+                _lib.ptr(coarse_I), None, _lib.ptr(K), _lib.ptr(gate)))
+        finally:
+            self.set_unordered(0)
+        return K
+
     def shard(self, rank: int, world: int):
         _lib.check(_lib.lib().asl_index_shard(self._h, int(rank), int(world)))
 

@@ -77,6 +77,18 @@ int32_t asl_hash_idx(int64_t bin_idx, int32_t hash_len, uint32_t seed);
 int asl_encode_batch(const float *mz, const float *intensity, const int32_t *offsets,
                      int32_t n, double min_bound, double bin_size, int32_t hash_len,
                      uint32_t seed, int norm, float *out);
+/* The same vectors as ENTRY LISTS -- the non-zero components only, the form the IVF scans read
+ * their queries in (asl_index_search_entries; a hashed spectrum has <= ~50 non-zeros of 800):
+ * entries [n][64] pairs of 32-bit words (dimension * 128, the bits of the fp32 value), ascending
+ * dimension, unused pairs zero; counts [n] = the number of non-zero components, or -1 - count
+ * when a vector has more than 64 (that query needs the dense form); n_over (may be null): a
+ * device int the call ADDS the number of such rows to. The values are those asl_encode_batch
+ * stores, bit for bit. entries / counts / n_over: device memory; n_peaks = offsets[n] when the
+ * caller knows it (>= 0: nothing is read back, the call never waits), else -1. */
+int asl_encode_entries_batch(const float *mz, const float *intensity, const int32_t *offsets,
+                             int32_t n, int32_t n_peaks, double min_bound, double bin_size,
+                             int32_t hash_len, uint32_t seed, int norm, uint32_t *entries,
+                             int32_t *counts, int32_t *n_over);
 
 /* ------------------------------------------------------------------ ANN index
  * Replaces the FAISS objects used at spectral_library.py:73-87,167-181,191,
@@ -255,6 +267,15 @@ int32_t asl_shard_k(int32_t k, int32_t world);
 int asl_index_search_gated(asl_index_t *idx, int32_t cap, const float *xq, int32_t k, int32_t nprobe,
                            const float *coarse_D, const int32_t *coarse_I, float *D, int64_t *I,
                            const int32_t *count);
+/* asl_index_search_preassigned with the queries as entry lists (asl_encode_entries_batch) instead
+ * of dense rows: 512 bytes per query instead of 3.2 KB and no listing pass -- a sharded search
+ * encodes the other ranks' queries straight into this form. Results equal the dense call's, bit
+ * for bit. A row with a negative count is searched as an all-zero query (watch the encoder's
+ * n_over). count (may be null): as in asl_index_search_gated. Device pointers only, never waits;
+ * layout-specific scans only (what asl_index_supports_keys says), not with the exact re-rank. */
+int asl_index_search_entries(asl_index_t *idx, int32_t nq, const uint32_t *entries, const int32_t *counts,
+                             int32_t k, int32_t nprobe, const float *coarse_D, const int32_t *coarse_I,
+                             float *D, int64_t *I, const int32_t *count);
 /* list -> owner rank map of the balancing above, for inspection. */
 int asl_index_shard_map(const asl_index_t *idx, int32_t world, int32_t *owner /* [nlist] */);
 

@@ -1,7 +1,8 @@
 """Measurement helper: the compute one rank of a W-GPU sharded search performs per step,
 emulated on ONE GPU (shard 0 of W, W x batch queries). Collectives are not included.
 
-  python scripts/sim_rank.py W [library_size] [batch] [scan_variant] [ivfpq|ivfflat] [shard_k (default asl_shard_k(k, W); k = the round-4 protocol)]
+  python scripts/sim_rank.py W [library_size] [batch] [scan_variant] [ivfpq|ivfflat] [shard_k (default asl_shard_k(k, W); k = the round-4 protocol)] [dense]
+(`dense`: the other ranks' queries as dense rows, as before the entry lists)
 """
 import os
 import sys
@@ -33,7 +34,8 @@ from ann_solo_amd.distributed import head_width, shard_k
 k = be.k_scan
 # the shards' own k: asl_shard_k by default (k / 2 at 8 ranks, 5 k / 8 at 4; second scans on the shard
 # keep the result exact); argv[6] overrides it (k itself: the round-4 protocol)
-k_row = int(sys.argv[6]) if len(sys.argv) > 6 else shard_k(k, W)
+k_row = int(sys.argv[6]) if len(sys.argv) > 6 and int(sys.argv[6]) > 0 else shard_k(k, W)
+entries = not (len(sys.argv) > 7 and sys.argv[7] == 'dense')
 kp = head_width(k, W)
 if not (kp - 1 < k_row < k):
     k_row = k
@@ -76,13 +78,20 @@ def timed(fn, reps=3):
     return (time.perf_counter() - t0) / reps * 1e3, out
 
 
-t_enc, _ = timed(lambda: be.encode(q_all))      # every rank hashes ALL queries (peaks travel)
+# every rank hashes ALL queries (peaks travel): into entry lists -- what the scans read -- or dense rows
 vec = be.encode(q)
+if entries:
+    def enc_all():
+        be.encode(q)                            # the own slice as dense rows (the coarse quantiser's input)
+        return be.encode_entries(q_all)
+    t_enc, allq = timed(enc_all)
+else:
+    t_enc, allq = timed(lambda: be.encode(q_all))
 t_coarse, _ = timed(lambda: be.coarse(vec))     # ... and quantises its own slice
-t_scan, K = timed(lambda: be.shard_search_keys(allvec, cD, cI, k=k_row))
+t_scan, K = timed(lambda: be.shard_search_keys(allq, cD, cI, k=k_row))
 t_scan_k = None
 if shard_side:
-    t_scan_k, _ = timed(lambda: be.shard_search_keys(allvec, cD, cI, k=k))
+    t_scan_k, _ = timed(lambda: be.shard_search_keys(allq, cD, cI, k=k))
 full0 = be.shard_search_keys(allvec[:batch], cD[:batch], cI[:batch], k=k)
 t_split = t_m1 = t_x = t_m2 = 0.0
 rescans, asked, held, overflow, exact = 0, 0.0, 0.0, 0, True
@@ -101,7 +110,7 @@ if two_phase:
     # shard side, exactly this rank's work: the answers to all W owners, with the second scans
     def shard_side_step():
         f_ = be.new_flag()
-        x_ = be.keys_extras(K, floor, bnd_all, W, xcap, f_, rescan=(rowmin, allvec, cD, cI, k) if shard_side else None)
+        x_ = be.keys_extras(K, floor, bnd_all, W, xcap, f_, rescan=(rowmin, allq, cD, cI, k) if shard_side else None)
         return x_, f_
     t_x, (xbuf0, f0) = timed(shard_side_step)
     rescans, overflow = int(f0[1].item()), int(f0[0].item())
@@ -142,7 +151,7 @@ t_old, _ = timed(lambda: be.merge_keys(K.view(W, batch, -1).contiguous()))
 t_resc, _ = timed(lambda: be.rescore_knn(q, knn, True))
 t_merge = t_split + t_m1 + t_x + t_m2
 tot = t_enc + t_coarse + t_scan + t_merge + t_resc
-print(f'{index} W={W} batch/rank={batch} variant={variant} shard k {k_row} of {k}: encode (all {nall}) {t_enc:.2f} coarse {t_coarse:.2f} '
+print(f'{index} W={W} batch/rank={batch} variant={variant} shard k {k_row} of {k}, queries as {"entry lists" if entries else "dense rows"}: encode (all {nall}) {t_enc:.2f} coarse {t_coarse:.2f} '
       f'shard scan ({nall} queries) {t_scan:.2f}' + (f' (with the full k: {t_scan_k:.2f})' if t_scan_k else '') +
       f' exchange compute {t_merge:.2f} (split {t_split:.2f} + heads {t_m1:.2f} + '
       f'answers incl. second scans {t_x:.2f} + final {t_m2:.2f}; head width {kp}, queries asking {asked:.3f}, '

@@ -40,6 +40,35 @@ class OracleShardBackend:
         o, mz, inten, *_ = queries.numpy()
         return torch.from_numpy(O.encode_batch(mz, inten, o, 10.96, 0.04, self.ivf.d))
 
+    # ---- the queries as entry lists (csrc/encode.hip: the non-zero components, ascending, as
+    # (dimension * 128, value bits), 64 per query), restated with numpy
+    MAX_ENTRIES = 64
+
+    def encode_entries(self, queries):
+        from ann_solo_amd.distributed import EntryQueries
+        v = self.encode(queries).numpy()
+        n = v.shape[0]
+        ent = np.zeros((n, self.MAX_ENTRIES, 2), np.int32)
+        cnt = np.zeros(n, np.int32)
+        for q in range(n):
+            nz = np.nonzero(v[q])[0]
+            cnt[q] = len(nz) if len(nz) <= self.MAX_ENTRIES else -1 - len(nz)
+            nz = nz[:self.MAX_ENTRIES]
+            ent[q, :len(nz), 0] = nz * 128
+            ent[q, :len(nz), 1] = v[q, nz].view(np.int32)
+        return EntryQueries(torch.from_numpy(ent), torch.from_numpy(cnt))
+
+    def _dense(self, vectors):
+        from ann_solo_amd.distributed import EntryQueries
+        if not isinstance(vectors, EntryQueries):
+            return vectors.numpy()
+        ent, cnt = vectors.entries.numpy(), vectors.counts.numpy()
+        v = np.zeros((len(cnt), self.ivf.d), np.float32)
+        for q in range(len(cnt)):
+            assert cnt[q] >= 0
+            v[q, ent[q, :cnt[q], 0] // 128] = ent[q, :cnt[q], 1].view(np.float32)
+        return v
+
     def shard_search(self, vectors):
         D, I = self.ivf.search(vectors.numpy(), self.k, self.nprobe)
         return torch.from_numpy(D), torch.from_numpy(I)
@@ -59,7 +88,7 @@ class OracleShardBackend:
     def shard_search_keys(self, vectors, coarse_D=None, coarse_I=None, k=None):
         if vectors.shape[0] == 0:
             return torch.zeros((0, k or self.k), dtype=torch.int64)
-        D, I = self.ivf.search(vectors.numpy(), k or self.k, self.nprobe)
+        D, I = self.ivf.search(self._dense(vectors), k or self.k, self.nprobe)
         return torch.from_numpy(X.pack_keys(D, I))
 
     def merge_keys(self, Ks):

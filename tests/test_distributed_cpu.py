@@ -74,6 +74,7 @@ def _worker(rank, world, port, kind, out_dir):
     be = OracleShardBackend(lib_np, pmz32, cen, a, payload, cb, rank, world, 2, 64, 4, 300, 'Da',
                             0.02, True, lpt_owner)
     nloc = q_all.n // world
+    wide = kind == 'flat_wide'
     if kind == 'flat_wide':
         # slices whose widest spectra differ (rank 0: <= 70 peaks -> 80-wide rows,
         # rank 1: <= 90 -> 96) must still agree on ONE row width for the peak all-gather
@@ -121,7 +122,8 @@ def _worker(rank, world, port, kind, out_dir):
                      ('third', dict(head_keys=8, shard_keys=16, extras_per_query=64)),
                      ('third_mid', dict(head_keys=20, shard_keys=44, extras_per_query=64)),
                      ('third_overflow', dict(head_keys=8, shard_keys=16, extras_per_query=64)),
-                     ('full_keys', dict(two_phase=False)), ('disagree', {}), ('rows', None)):
+                     ('full_keys', dict(two_phase=False)), ('dense_queries', dict(entry_lists=False)),
+                     ('disagree', {}), ('rows', None)):
         be.keys = kw is not None and (name != 'disagree' or rank == 0)
         be.rescan_capacity = 1 if name == 'third_overflow' else None
         be.index_epoch = getattr(be, 'index_epoch', 0) + 1     # the agreed exchange format is cached per epoch
@@ -132,7 +134,7 @@ def _worker(rank, world, port, kind, out_dir):
                 and np.array_equal(res['best_score'], ref['best_score']))
         ok = ok and same
         seen[name] = (same, stats.get('fallback', 0), sorted(comm.calls), stats.get('third_phase_queries', 0),
-                      stats.get('shard_k'), stats.get('exchange_used'))
+                      stats.get('shard_k'), stats.get('exchange_used'), stats.get('query_form'))
     be.keys, be.rescan_capacity = True, None
     ok = (ok and seen['overflow'][1] == 1 and seen['small_heads'][1] == 0 and
           'held_back_keys_all_to_all' in seen['small_heads'][2] and
@@ -144,7 +146,12 @@ def _worker(rank, world, port, kind, out_dir):
           seen['third_overflow'][1] == 1 and seen['third_overflow'][5] == 'full rows (fallback)' and
           seen['disagree'][2].count('topk_rows_all_to_all') == 1 and seen['disagree'][5] == 'full rows' and
           'heads_all_to_all' not in seen['disagree'][2] and
-          seen['rows'][2].count('topk_rows_all_to_all') == 1)
+          seen['rows'][2].count('topk_rows_all_to_all') == 1 and
+          # the other ranks' queries travel as peaks and are hashed straight into entry lists whenever the
+          # packed-key scans run (flat_wide: spectra of up to 90 peaks -> dense rows)
+          seen['two_phase'][6] == ('dense rows' if wide else 'entry lists') and
+          seen['third_mid'][6] == seen['two_phase'][6] and seen['dense_queries'][6] == 'dense rows' and
+          seen['disagree'][6] == 'dense rows' and seen['rows'][6] == 'dense rows')
     if not ok:
         print('exchange modes:', seen, flush=True)
     owner_ok = set(be.owner.tolist()) == set(range(world))

@@ -65,6 +65,60 @@ def test_encoder_device_pointers_and_empty(O, data):
                                        800).shape == (0, 800)
 
 
+def test_encoder_colliding_bins_and_entry_lists(O):
+    """Peaks that share a hash bin are added in peak order (the kernel applies them in rounds by
+    their rank within the bin): spectra built to collide -- runs of equal m/z, up to 200 peaks, ties
+    across the 64-peak chunks -- equal the oracle's serial loop bit for bit; and
+    asl_encode_entries_batch emits exactly the non-zero components of those rows, ascending, as
+    (dimension * 128, value bits), the count negative beyond 64 entries."""
+    import torch
+    from ann_solo_amd import _lib, spectrum
+    rng = np.random.default_rng(12)
+    mzs, ins, off = [], [], [0]
+    for npk in [0, 1, 2, 50, 63, 64, 65, 70, 128, 129, 200] + list(rng.integers(1, 90, 60)):
+        # ~3 peaks per distinct m/z (collisions); the long ones mostly distinct (more than 64 non-zeros)
+        base = rng.uniform(100, 1900, max(1, npk if npk > 100 else npk // 3 + 1)).astype(np.float32)
+        m = base[rng.integers(0, len(base), npk)]
+        # intensities of very different magnitude: the order of the additions shows in the last bit
+        i = (rng.random(npk) * 10.0 ** rng.integers(-6, 4, npk)).astype(np.float32)
+        mzs.append(m)
+        ins.append(i)
+        off.append(off[-1] + npk)
+    mz, inten, off = np.concatenate(mzs).astype(np.float32), np.concatenate(ins).astype(np.float32), np.asarray(off, np.int32)
+    n = len(off) - 1
+    for norm in (True, False):
+        want = O.encode_batch(mz, inten, off, 10.96, 0.04, 800, 42, norm)
+        got = spectrum.spectra_to_vectors(mz, inten, off, 11, 2010, 0.04, 800, norm)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        ent = torch.full((n, 64, 2), -1, dtype=torch.int32, device='cuda')
+        cnt = torch.full((n,), -99, dtype=torch.int32, device='cuda')
+        over = torch.zeros(1, dtype=torch.int32, device='cuda')
+        dm, di, do = (torch.from_numpy(a).cuda() for a in (mz, inten, off))
+        _lib.check(_lib.lib().asl_encode_entries_batch(_lib.ptr(dm), _lib.ptr(di), _lib.ptr(do), n, len(mz), 10.96,
+                                                       0.04, 800, 42, int(norm), _lib.ptr(ent), _lib.ptr(cnt),
+                                                       _lib.ptr(over)))
+        ent, cnt = ent.cpu().numpy(), cnt.cpu().numpy()
+        n_over = 0
+        for q in range(n):
+            nz = np.nonzero(want[q])[0]
+            if len(nz) > 64:
+                assert cnt[q] == -1 - len(nz)
+                n_over += 1
+                nz = nz[:64]
+            else:
+                assert cnt[q] == len(nz)
+            assert np.array_equal(ent[q, :len(nz), 0], nz * 128)
+            assert np.array_equal(ent[q, :len(nz), 1], want[q, nz].view(np.int32))
+            assert not ent[q, len(nz):].any()
+        assert n_over >= 2 and int(over.item()) == n_over
+        # host pointers for the peaks, the peak count read back by the library
+        ent2 = torch.empty((n, 64, 2), dtype=torch.int32, device='cuda')
+        cnt2 = torch.empty((n,), dtype=torch.int32, device='cuda')
+        _lib.check(_lib.lib().asl_encode_entries_batch(_lib.ptr(mz), _lib.ptr(inten), _lib.ptr(off), n, -1, 10.96,
+                                                       0.04, 800, 42, int(norm), _lib.ptr(ent2), _lib.ptr(cnt2), None))
+        assert np.array_equal(ent2.cpu().numpy(), ent) and np.array_equal(cnt2.cpu().numpy(), cnt)
+
+
 def _check_rescoring(O, Q, L, cand, off, tol, shift, res):
     best, score, count, pairs = res
     for qi in range(Q.n):

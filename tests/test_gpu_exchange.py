@@ -192,6 +192,83 @@ def test_gated_search_scans_exactly_the_counted_rows(index):
     sl.shutdown()
 
 
+@pytest.mark.parametrize('index,storage', [('ivfpq', None), ('ivfflat', 'fp32'), ('ivfflat', 'fx22')])
+def test_entry_list_search_equals_the_dense_search(index, storage):
+    """asl_index_search_entries (queries as the entry lists of asl_encode_entries_batch) returns the
+    packed-key rows of asl_index_search_preassigned on the dense rows, bit for bit -- whole batch,
+    gated by a device-side count, on a sharded index -- and HipShardBackend.keys_extras answers the
+    same from second scans of entry-list queries as from dense ones."""
+    import torch
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.distributed import EntryQueries, HipShardBackend
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    lib, aux = synthetic.make_library(20000, seed=15, device='cpu', charges=(2,), charge_p=(1.0,))
+    q, _ = synthetic.make_queries(lib, aux, 300, seed=16, charge=2)
+    kw = dict(flat_storage=storage) if storage else {}
+    sl = SpectralLibrary(lib, config=Config.open_search(num_list=32, num_probe=12, num_candidates=256, index=index,
+                                                        kmeans_niter=3, **kw))
+    be = HipShardBackend(sl, 2, 'open')
+    idx = be.index
+    vec = be.encode(q)
+    eq = be.encode_entries(q)
+    assert isinstance(eq, EntryQueries) and eq.shape == (300,) and int(eq.counts.min()) > 0
+    # the entry lists ARE the rows' non-zeros
+    v = vec.cpu().numpy()
+    e, c = eq.entries.cpu().numpy(), eq.counts.cpu().numpy()
+    for r in (0, 17, 299):
+        nz = np.nonzero(v[r])[0]
+        assert c[r] == len(nz) and np.array_equal(e[r, :len(nz), 0], nz * 128)
+        assert np.array_equal(e[r, :len(nz), 1], v[r, nz].view(np.int32))
+    cD, cI = be.coarse(vec)
+    for shard in (None, (1, 3)):
+        if shard:
+            idx.shard(*shard)
+        for k in (256, 64):
+            want = idx.search_preassigned_keys(vec, k, cD, cI)
+            got = be.shard_search_keys(eq, cD, cI, k=k)
+            assert torch.equal(got.sort(1).values, want.sort(1).values)
+        sub = torch.arange(299, -1, -3, device=vec.device)            # a selection of rows, as a piece takes them
+        got = be.shard_search_keys(eq.index_select(0, sub), cD[sub].contiguous(), cI[sub].contiguous(), k=256)
+        assert torch.equal(got.sort(1).values, idx.search_preassigned_keys(vec, 256, cD, cI)[sub].sort(1).values)
+        want = idx.search_preassigned_keys(vec, 256, cD, cI)
+        for count in (0, 5, 300):
+            cnt = torch.tensor([count], dtype=torch.int32, device=vec.device)
+            K = idx.search_entries_keys(eq.entries, eq.counts, 256, cD, cI, gate=cnt)
+            assert torch.equal(K[:count].sort(1).values, want[:count].sort(1).values)
+    # second scans inside keys_extras: entry-list inputs give the dense inputs' answer buffer
+    ks, k = 64, 256
+    Ks = idx.search_preassigned_keys(vec, ks, cD, cI)
+    head, floor, rowmin = be.keys_split(Ks, 17, True)
+    Kn = Ks.cpu().numpy().view(np.uint64)
+    rng = np.random.default_rng(4)
+    b = np.full(300, X.NONE, np.uint64)
+    for r in range(300):
+        row = np.sort(Kn[r][Kn[r] != 0])
+        if len(row) and rng.random() < 0.4:
+            b[r] = row[0] - np.uint64(1 + rng.integers(0, 1 << 30))
+    bounds = torch.from_numpy(b.view(np.int64)).cuda()
+    be.rescan_capacity = 300
+    out = []
+    for xv in (vec, eq):
+        flag = be.new_flag()
+        xbuf = be.keys_extras(Ks, floor, bounds, 1, 300 * k, flag, rescan=(rowmin, xv, cD, cI, k))
+        assert int(flag[0].item()) == 0
+        out.append((xbuf[0].cpu().numpy().view(np.uint64), int(flag[1].item())))
+    (a, na), (bb, nb) = out
+    assert na == nb and na > 10
+    for r in range(300):
+        ca, sa = int(a[r] >> np.uint64(32)), int(a[r] & np.uint64(0xFFFFFFFF))
+        cb, sb = int(bb[r] >> np.uint64(32)), int(bb[r] & np.uint64(0xFFFFFFFF))
+        assert ca == cb and set(a[300 + sa:300 + sa + ca].tolist()) == set(bb[300 + sb:300 + sb + cb].tolist()), r
+    # a row with more than 64 non-zeros and no dense form is searched as an all-zero query, never read
+    cnt_bad = eq.counts.clone()
+    cnt_bad[3] = -70
+    K = idx.search_entries_keys(eq.entries, cnt_bad, 64, cD, cI)
+    torch.cuda.synchronize()
+    assert torch.equal(K[4:].sort(1).values, idx.search_preassigned_keys(vec, 64, cD, cI)[4:].sort(1).values)
+    sl.shutdown()
+
+
 @pytest.mark.parametrize('S,k,ks,head_keys,xper,grid,skew,cap', [
     (8, 1024, 512, 256, 1024, None, 0.45, None), (8, 1024, 512, 256, 1024, None, 0.9, None),
     (4, 1024, 640, 512, 1024, None, 0.6, None),
