@@ -84,6 +84,15 @@ def test_encoder_colliding_bins_and_entry_lists(O):
         mzs.append(m)
         ins.append(i)
         off.append(off[-1] + npk)
+    # bins around and beyond the limits of the encoder's short routes (decimal strings of up to nine
+    # digits in 32-bit words; quotients below 2^31 by division + fused remainder): 10^9 - 1 | 10^9,
+    # 2^31 - 1 | 2^31, far beyond, below the first bin (negative indices), exactly on bin edges
+    edge = np.array([10.96 + 0.04 * 999999999.0, 10.96 + 0.04 * 1000000000.0, 10.96 + 0.04 * 2147483647.0,
+                     10.96 + 0.04 * 2147483648.0, 5e7, 1e8, 1e12, 1e15, 0.0, 5.0, 10.96, 10.959999, 11.0,
+                     10.96 + 0.04 * 7, 10.96 + 0.04 * 12345], np.float64).astype(np.float32)
+    mzs.append(edge)
+    ins.append(np.arange(1, len(edge) + 1, dtype=np.float32))
+    off.append(off[-1] + len(edge))
     mz, inten, off = np.concatenate(mzs).astype(np.float32), np.concatenate(ins).astype(np.float32), np.asarray(off, np.int32)
     n = len(off) - 1
     for norm in (True, False):
