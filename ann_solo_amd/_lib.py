@@ -74,7 +74,7 @@ EXPORTS = [
     'asl_index_set_flat_storage', 'asl_index_get_flat_storage', 'asl_index_flat_layout',
     'asl_keys_split', 'asl_keys_merge_heads', 'asl_keys_extras', 'asl_keys_merge_final',
     'asl_keys_rescan_list', 'asl_shard_k', 'asl_index_search_gated', 'asl_index_search_entries',
-    'asl_encode_entries_batch',
+    'asl_encode_entries_batch', 'asl_index_search_sharded_ex',
 ]
 
 
@@ -155,6 +155,9 @@ def lib():
                                            C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.asl_index_search_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                                C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.asl_index_search_sharded_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                                  C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                                  C.c_int32, C.c_int32, C.c_int64]
         L.asl_index_set_refine.argtypes = [C.c_void_p, C.c_int32]
         L.asl_index_refine.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                        C.c_int32, C.c_void_p, C.c_void_p]

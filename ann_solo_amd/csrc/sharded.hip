@@ -97,9 +97,15 @@ using namespace asl;
 // hits, the merge yields the k' best of the whole index -- the unsharded short-list -- and the
 // owner of the query re-ranks that against the exact rows (replicated on every rank).
 // D / I [nq, k]: identical to what the unsharded index returns for these queries.
-extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_t nq,
-                                        const float *xq, int32_t k, int32_t nprobe, float *D,
-                                        int64_t *I) {
+// head_keys / shard_keys / extras_per_query: the exchange's three sizes (keys a head carries, the
+// shards' own k, answer slots per query and destination); <= 0 / <= 0 / < 0 = the defaults
+// (ceil(2k / world), asl_shard_k(k, world), max(8, k / 16)). Results do not depend on them; tests
+// set them to run the bound / held-back-key / second-scan steps and the overflow fallback on a
+// communicator of any size (at world 1 the default head is the whole row).
+extern "C" int asl_index_search_sharded_ex(asl_index_t *ix, void *rccl_comm, int32_t nq,
+                                           const float *xq, int32_t k, int32_t nprobe, float *D,
+                                           int64_t *I, int32_t head_keys, int32_t shard_keys,
+                                           int64_t extras_per_query) {
   clear_error();
   if (!ix || !rccl_comm || !xq || !I) return fail(ASL_ERR_INVALID, "search_sharded: null argument");
   if (nq <= 0) return fail(ASL_ERR_INVALID, "search_sharded: every rank must bring nq > 0 queries");
@@ -182,11 +188,12 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
                            &rmap = *new DevBuf<int32_t>(), &cI3 = *new DevBuf<int32_t>();
     static DevBuf<float> &x3 = *new DevBuf<float>(), &cD3 = *new DevBuf<float>();
     static DevBuf<unsigned int> &cursor = *new DevBuf<unsigned int>();
-    const int keys = std::min(k, (2 * k + world - 1) / world), kp = keys + 1;
+    const int keys = std::min(k, head_keys > 0 ? (int)head_keys : (2 * k + world - 1) / world), kp = keys + 1;
     const bool second = keys < k;                          // heads hold something back
-    const int ks = second ? asl_shard_k(k, world) : k;     // the shards' own k (exchange.hip)
+    int ks = second ? (shard_keys > 0 ? (int)shard_keys : asl_shard_k(k, world)) : k;   // the shards' own k (exchange.hip)
+    if (!(keys < ks && ks < k)) ks = k;
     const bool rescan = ks < k;
-    const long long xcap = (long long)nq * std::max(8, k / 16);
+    const long long xcap = (long long)nq * (extras_per_query >= 0 ? (long long)extras_per_query : std::max(8, k / 16));
     ASL_TRY(Kp.reserve(all * ks));
     ASL_TRY(Hs.reserve(all * kp));
     ASL_TRY(Hr.reserve(all * kp));
@@ -303,4 +310,10 @@ extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_
     Df = Dfin.p;
   }
   return index_refine_device(ix, nq, xq, k, Im.p, k_out, Df, I);
+}
+
+extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_t nq,
+                                        const float *xq, int32_t k, int32_t nprobe, float *D,
+                                        int64_t *I) {
+  return asl_index_search_sharded_ex(ix, rccl_comm, nq, xq, k, nprobe, D, I, 0, 0, -1);
 }

@@ -207,6 +207,14 @@ int asl_index_shard(asl_index_t *idx, int32_t rank, int32_t world);
  * process at first use (never linked). */
 int asl_index_search_sharded(asl_index_t *idx, void *rccl_comm, int32_t nq, const float *xq,
                              int32_t k, int32_t nprobe, float *D, int64_t *I);
+/* The same with the exchange's three sizes given: keys a head carries (<= 0: ceil(2k / world)), the
+ * shards' own k (<= 0: asl_shard_k(k, world)), answer slots per query and destination (< 0:
+ * max(8, k / 16)). The result does not depend on them (a buffer that runs full sends the batch
+ * down the full-row exchange); tests set them to run every step of the exchange on a communicator
+ * of any size -- at world 1 the default head is the whole row. */
+int asl_index_search_sharded_ex(asl_index_t *idx, void *rccl_comm, int32_t nq, const float *xq,
+                                int32_t k, int32_t nprobe, float *D, int64_t *I, int32_t head_keys,
+                                int32_t shard_keys, int64_t extras_per_query);
 /* 1 if asl_index_search_preassigned can emit packed keys (unordered mode 2) for this index at
  * (k, nprobe) -- IVF-PQ: the tiled scan (m = 32, 8-bit codes, automatic scan variant, nprobe
  * within the tiled kernel's limit, k + 768 <= 2048); IVF-Flat: the postings scan (sparse stored

@@ -252,6 +252,22 @@ for index in ('ivfpq', 'ivfflat'):
     assert rc == 0, L.asl_last_error()
     torch.cuda.synchronize()
     assert torch.equal(I, I0) and torch.equal(D, D0), index
+    # every step of the exact exchange inside the library (at world 1 the default head is the whole
+    # row: the sizes are given): heads of 100 keys + bound + held-back keys; shards with their own
+    # k = 160 and a second, full-k scan of the rows the bound asks about (few queries: all fit);
+    # no room for the answers / for the second scans: the batch falls back to the full rows
+    for nq_, head, sk, xper in ((q.n, 100, 0, -1), (q.n, 100, 0, 256), (40, 100, 160, 256), (q.n, 100, 160, 256),
+                                (q.n, 100, 0, 0), (q.n, 255, 0, -1), (40, 8, 64, 256)):
+        D.fill_(-5.0)
+        I.fill_(-5)
+        rc = L.asl_index_search_sharded_ex(idx._h, comm, nq_, _lib.ptr(vec), 256, 16, _lib.ptr(D), _lib.ptr(I),
+                                           head, sk, xper)
+        assert rc == 0, (L.asl_last_error(), head, sk, xper)
+        torch.cuda.synchronize()
+        # (the exchange returns sets: rows ordered only by the final merge -- compare as sorted rows)
+        assert torch.equal(I[:nq_].sort(1).values, I0[:nq_].sort(1).values), (index, nq_, head, sk, xper)
+        assert torch.equal(D[:nq_].sort(1).values, D0[:nq_].sort(1).values), (index, nq_, head, sk, xper)
+        assert torch.equal(I[:nq_], I0[:nq_]), (index, nq_, head, sk, xper)
     # host pointers and missing communicators are errors, not crashes
     assert L.asl_index_search_sharded(idx._h, None, q.n, _lib.ptr(vec), 256, 16, _lib.ptr(D), _lib.ptr(I)) < 0
     host = np.zeros((q.n, 256), np.int64)
