@@ -87,7 +87,9 @@ using namespace asl;
 
 // Every rank calls this with ITS nq queries (the same nq on every rank, device pointers) after
 // asl_index_shard(idx, rank, world) on an index holding the same vectors everywhere:
-//   all-gather of the hashed queries -> coarse quantiser on the own slice, probe lists
+//   all-gather of the hashed queries (as entry lists -- their <= 64 non-zero components, 516 bytes
+//   instead of 3.2 KB per query -- whenever the packed-key scans run, which read them in that
+//   form) -> coarse quantiser on the own slice, probe lists
 //   all-gathered -> scan of the local inverted lists for all world x nq queries (exact top-k
 //   sets) -> the two-phase exact exchange of exchange.hip (heads of ~2k / world packed keys,
 //   the owners' bounds, the held-back keys above them; grouped send/recv = direct peer copies
@@ -132,19 +134,16 @@ extern "C" int asl_index_search_sharded_ex(asl_index_t *ix, void *rccl_comm, int
                        &Dr = *new DevBuf<float>(), &Dtmp = *new DevBuf<float>();
   static DevBuf<int32_t> &cI = *new DevBuf<int32_t>(), &cI_all = *new DevBuf<int32_t>();
   static DevBuf<int64_t> &Ip = *new DevBuf<int64_t>(), &Ir = *new DevBuf<int64_t>();
-  ASL_TRY(x_all.reserve(all * d));
+  // the queries as entry lists (coarse_sparse.hip: list_nonzeros): own, everybody's, second scans
+  static DevBuf<uint2> &e_loc = *new DevBuf<uint2>(), &e_all = *new DevBuf<uint2>(), &e3 = *new DevBuf<uint2>();
+  static DevBuf<int32_t> &c_loc = *new DevBuf<int32_t>(), &c_all = *new DevBuf<int32_t>(), &c3 = *new DevBuf<int32_t>(),
+                         &over = *new DevBuf<int32_t>();
   ASL_TRY(cD.reserve((size_t)nq * np));
   ASL_TRY(cI.reserve((size_t)nq * np));
   ASL_TRY(cD_all.reserve(all * np));
   ASL_TRY(cI_all.reserve(all * np));
   hipStream_t st = stream();
   nccl_comm_t comm = rccl_comm;
-  // 1. everybody's queries; the coarse quantiser runs on the own slice meanwhile (same stream:
-  //    RCCL orders itself after it; a second stream would overlap the two)
-  RCCL_TRY(R.AllGather(xq, x_all.p, (size_t)nq * d, NCCL_FLOAT32, comm, st));
-  ASL_TRY(index_coarse_device(ix, nq, xq, np, cD.p, cI.p));
-  RCCL_TRY(R.AllGather(cD.p, cD_all.p, (size_t)nq * np, NCCL_FLOAT32, comm, st));
-  RCCL_TRY(R.AllGather(cI.p, cI_all.p, (size_t)nq * np, NCCL_INT32, comm, st));
   // a few ints every rank must see the same way: gathered, downloaded (one stream synchronisation)
   static DevBuf<int32_t> &mine = *new DevBuf<int32_t>(), &everyone = *new DevBuf<int32_t>();
   ASL_TRY(mine.reserve(4));
@@ -156,11 +155,11 @@ extern "C" int asl_index_search_sharded_ex(asl_index_t *ix, void *rccl_comm, int
     return sync_stream();
   };
   std::vector<int32_t> h;
-  // 2'. the exact key exchange (exchange.hip) whenever EVERY shard's scan can emit packed keys (for
-  //     IVF-Flat that depends on the vectors a shard holds: agreed across the ranks, once per state
-  //     of the index): heads of ~2k / world keys, the owners' bounds, the held-back keys above
-  //     them (the shards scanning with k_s < k and a second, full-k scan where a bound asks); the full rows below
-  //     remain the path for everything else and the fallback when an answer buffer runs full
+  // The exact key exchange (exchange.hip) whenever EVERY shard's scan can emit packed keys (for
+  // IVF-Flat that depends on the vectors a shard holds: agreed across the ranks, once per state
+  // of the index): heads of ~2k / world keys, the owners' bounds, the held-back keys above
+  // them (the shards scanning with k_s < k and a second, full-k scan where a bound asks); the full
+  // rows remain the path for everything else and the fallback when an answer buffer runs full
   bool keys_everywhere = false;
   if (!refine) {
     // (asl_index_supports_keys first: it rebuilds a stale scan layout, which forgets the agreement)
@@ -178,138 +177,195 @@ extern "C" int asl_index_search_sharded_ex(asl_index_t *ix, void *rccl_comm, int
     }
     keys_everywhere = known != 0;
   }
-  if (keys_everywhere) {
-    typedef unsigned long long u64k;
-    static DevBuf<int64_t> &Kp = *new DevBuf<int64_t>(), &Hs = *new DevBuf<int64_t>(), &Hr = *new DevBuf<int64_t>(),
-                           &Ko = *new DevBuf<int64_t>(), &Bs = *new DevBuf<int64_t>(),
-                           &Br = *new DevBuf<int64_t>(), &Xs = *new DevBuf<int64_t>(), &Xr = *new DevBuf<int64_t>(),
-                           &Mn = *new DevBuf<int64_t>(), &rowlist = *new DevBuf<int64_t>(), &K3 = *new DevBuf<int64_t>();
-    static DevBuf<int32_t> &need = *new DevBuf<int32_t>(), &flag = *new DevBuf<int32_t>(), &Fl = *new DevBuf<int32_t>(),
-                           &rmap = *new DevBuf<int32_t>(), &cI3 = *new DevBuf<int32_t>();
-    static DevBuf<float> &x3 = *new DevBuf<float>(), &cD3 = *new DevBuf<float>();
-    static DevBuf<unsigned int> &cursor = *new DevBuf<unsigned int>();
-    const int keys = std::min(k, head_keys > 0 ? (int)head_keys : (2 * k + world - 1) / world), kp = keys + 1;
-    const bool second = keys < k;                          // heads hold something back
-    int ks = second ? (shard_keys > 0 ? (int)shard_keys : asl_shard_k(k, world)) : k;   // the shards' own k (exchange.hip)
-    if (!(keys < ks && ks < k)) ks = k;
-    const bool rescan = ks < k;
-    const long long xcap = (long long)nq * (extras_per_query >= 0 ? (long long)extras_per_query : std::max(8, k / 16));
-    ASL_TRY(Kp.reserve(all * ks));
-    ASL_TRY(Hs.reserve(all * kp));
-    ASL_TRY(Hr.reserve(all * kp));
-    ASL_TRY(Fl.reserve(all));
-    ASL_TRY(Ko.reserve((size_t)nq * k));
-    ASL_TRY(Bs.reserve(all));
-    ASL_TRY(Br.reserve(all));
-    ASL_TRY(need.reserve((size_t)nq));
-    ASL_TRY(flag.reserve(2));          // [0] a buffer ran full, [1] rows this shard scans a second time
-    if (rescan) ASL_TRY(Mn.reserve(all));
-    HIP_TRY(hipMemsetAsync(flag.p, 0, 2 * sizeof(int32_t), st));
-    int prev = 0;
-    ASL_TRY(index_swap_unordered(ix, 2, &prev));
-    const int rc = index_search_device(ix, (int)all, x_all.p, ks, np, nullptr, Kp.p, nullptr, cD_all.p, cI_all.p, true,
-                                       nullptr);
-    ASL_TRY(index_swap_unordered(ix, prev, nullptr));
-    ASL_TRY(rc);
-    ASL_TRY(keys_split(reinterpret_cast<const u64k *>(Kp.p), (int64_t)all, ks, kp, reinterpret_cast<u64k *>(Hs.p),
-                       Fl.p, rescan ? reinterpret_cast<u64k *>(Mn.p) : nullptr));
-    auto all_to_all = [&](const int64_t *src, int64_t *dst, size_t per_rank) -> int {
-      RCCL_TRY(R.GroupStart());
-      for (int r = 0; r < world; ++r) {
-        RCCL_TRY(R.Send(src + (size_t)r * per_rank, per_rank, NCCL_INT64, r, comm, st));
-        RCCL_TRY(R.Recv(dst + (size_t)r * per_rank, per_rank, NCCL_INT64, r, comm, st));
-      }
-      RCCL_TRY(R.GroupEnd());
-      return ASL_OK;
-    };
-    ASL_TRY(all_to_all(Hs.p, Hr.p, (size_t)nq * kp));
-    ASL_TRY(keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, nullptr, 0, nullptr, need.p,
-                       reinterpret_cast<u64k *>(Ko.p), reinterpret_cast<u64k *>(Bs.p), nullptr, nullptr, 0));
-    bool overflow = false;
-    const int64_t *xr = nullptr;
-    if (second) {
-      ASL_TRY(Xs.reserve((size_t)world * ((size_t)nq + (size_t)xcap)));
-      ASL_TRY(Xr.reserve((size_t)world * ((size_t)nq + (size_t)xcap)));
-      ASL_TRY(cursor.reserve((size_t)world));
-      ASL_TRY(all_to_all(Bs.p, Br.p, (size_t)nq));
-      HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)world * sizeof(unsigned int), st));
-      const int32_t *rm = nullptr;
-      if (rescan) {
-        // rows whose bound lies below the smallest key of a full k_s-row are scanned again with the
-        // full k: a launch of `cap` workgroups gated by the device-side count (no host round trip)
-        const int cap = (int)std::max<size_t>(64, all / 16);
-        ASL_TRY(rowlist.reserve((size_t)cap));
-        ASL_TRY(rmap.reserve(all));
-        ASL_TRY(x3.reserve((size_t)cap * d));
-        ASL_TRY(cD3.reserve((size_t)cap * np));
-        ASL_TRY(cI3.reserve((size_t)cap * np));
-        ASL_TRY(K3.reserve((size_t)cap * k));
-        HIP_TRY(hipMemsetAsync(rowlist.p, 0, (size_t)cap * sizeof(int64_t), st));
-        ASL_TRY(rescan_list(reinterpret_cast<const u64k *>(Br.p), reinterpret_cast<const u64k *>(Mn.p), (int64_t)all, cap,
-                            rowlist.p, rmap.p, reinterpret_cast<int *>(flag.p + 1), flag.p));
-        ASL_TRY(gather_rows_f32(x_all.p, d, rowlist.p, cap, d, x3.p, d));
-        ASL_TRY(gather_rows_f32(cD_all.p, np, rowlist.p, cap, np, cD3.p, np));
-        ASL_TRY(gather_rows_f32(reinterpret_cast<const float *>(cI_all.p), np, rowlist.p, cap, np,
-                                reinterpret_cast<float *>(cI3.p), np));      // (4-byte words)
-        ASL_TRY(index_swap_unordered(ix, 2, &prev));
-        const int rc3 = index_search_device(ix, cap, x3.p, k, np, nullptr, K3.p, nullptr, cD3.p, cI3.p, true,
-                                            reinterpret_cast<const int *>(flag.p + 1));
-        ASL_TRY(index_swap_unordered(ix, prev, nullptr));
-        ASL_TRY(rc3);
-        rm = rmap.p;
-      }
-      ASL_TRY(keys_extras(reinterpret_cast<const u64k *>(Kp.p), Fl.p, (int64_t)all, ks, reinterpret_cast<const u64k *>(Br.p),
-                          nq, xcap, reinterpret_cast<u64k *>(Xs.p), cursor.p, flag.p, rm,
-                          reinterpret_cast<const u64k *>(K3.p), k));
-      ASL_TRY(all_to_all(Xs.p, Xr.p, (size_t)nq + (size_t)xcap));
-      // a full buffer ANYWHERE sends every rank down the full exchange: all ranks take the same branch
-      HIP_TRY(hipMemcpyAsync(mine.p, flag.p, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-      ASL_TRY(agree(h));
-      for (int r = 0; r < world; ++r) overflow |= h[(size_t)r * 4] != 0;
-      xr = Xr.p;
+  // The packed-key scans read their queries as ENTRY LISTS -- the non-zero components, at most 64
+  // (dimension * 128, value bits) -- so that is the form the queries travel in: 516 bytes per
+  // query on the wire instead of 3.2 KB, no dense row per (rank, query) in memory. A query with
+  // more non-zeros has no such form: any rank that meets one says so in the step's agreement and
+  // the batch is repeated with dense rows (`entries` = false).
+  bool redo_dense = false;
+  auto run = [&](const bool entries) -> int {
+    // 1. everybody's queries; the coarse quantiser runs on the own slice meanwhile (same stream:
+    //    RCCL orders itself after it; a second stream would overlap the two)
+    if (entries) {
+      ASL_TRY(e_loc.reserve((size_t)nq * 64));
+      ASL_TRY(c_loc.reserve((size_t)nq));
+      ASL_TRY(e_all.reserve(all * 64));
+      ASL_TRY(c_all.reserve(all));
+      ASL_TRY(over.reserve(1));
+      HIP_TRY(hipMemsetAsync(over.p, 0, sizeof(int32_t), st));
+      ASL_TRY(list_nonzeros(xq, nq, d, d, e_loc.p, c_loc.p, over.p));
+      RCCL_TRY(R.AllGather(e_loc.p, e_all.p, (size_t)nq * 128, NCCL_INT32, comm, st));
+      RCCL_TRY(R.AllGather(c_loc.p, c_all.p, (size_t)nq, NCCL_INT32, comm, st));
+    } else {
+      ASL_TRY(x_all.reserve(all * d));
+      RCCL_TRY(R.AllGather(xq, x_all.p, (size_t)nq * d, NCCL_FLOAT32, comm, st));
     }
-    if (!overflow)
-      return keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, reinterpret_cast<const u64k *>(xr),
-                        xr ? xcap : 0, reinterpret_cast<const u64k *>(Ko.p), need.p, nullptr, nullptr, I, D, 1);
+    const float *xs = entries ? nullptr : x_all.p;
+    const uint2 *es = entries ? e_all.p : nullptr;
+    const int32_t *cs = entries ? c_all.p : nullptr;
+    ASL_TRY(index_coarse_device(ix, nq, xq, np, cD.p, cI.p));
+    RCCL_TRY(R.AllGather(cD.p, cD_all.p, (size_t)nq * np, NCCL_FLOAT32, comm, st));
+    RCCL_TRY(R.AllGather(cI.p, cI_all.p, (size_t)nq * np, NCCL_INT32, comm, st));
+    if (keys_everywhere) {
+      typedef unsigned long long u64k;
+      static DevBuf<int64_t> &Kp = *new DevBuf<int64_t>(), &Hs = *new DevBuf<int64_t>(), &Hr = *new DevBuf<int64_t>(),
+                             &Ko = *new DevBuf<int64_t>(), &Bs = *new DevBuf<int64_t>(),
+                             &Br = *new DevBuf<int64_t>(), &Xs = *new DevBuf<int64_t>(), &Xr = *new DevBuf<int64_t>(),
+                             &Mn = *new DevBuf<int64_t>(), &rowlist = *new DevBuf<int64_t>(), &K3 = *new DevBuf<int64_t>();
+      static DevBuf<int32_t> &need = *new DevBuf<int32_t>(), &flag = *new DevBuf<int32_t>(), &Fl = *new DevBuf<int32_t>(),
+                             &rmap = *new DevBuf<int32_t>(), &cI3 = *new DevBuf<int32_t>();
+      static DevBuf<float> &x3 = *new DevBuf<float>(), &cD3 = *new DevBuf<float>();
+      static DevBuf<unsigned int> &cursor = *new DevBuf<unsigned int>();
+      const int keys = std::min(k, head_keys > 0 ? (int)head_keys : (2 * k + world - 1) / world), kp = keys + 1;
+      const bool second = keys < k;                          // heads hold something back
+      int ks = second ? (shard_keys > 0 ? (int)shard_keys : asl_shard_k(k, world)) : k;   // the shards' own k (exchange.hip)
+      if (!(keys < ks && ks < k)) ks = k;
+      const bool rescan = ks < k;
+      const long long xcap = (long long)nq * (extras_per_query >= 0 ? (long long)extras_per_query : std::max(8, k / 16));
+      ASL_TRY(Kp.reserve(all * ks));
+      ASL_TRY(Hs.reserve(all * kp));
+      ASL_TRY(Hr.reserve(all * kp));
+      ASL_TRY(Fl.reserve(all));
+      ASL_TRY(Ko.reserve((size_t)nq * k));
+      ASL_TRY(Bs.reserve(all));
+      ASL_TRY(Br.reserve(all));
+      ASL_TRY(need.reserve((size_t)nq));
+      ASL_TRY(flag.reserve(2));          // [0] a buffer ran full, [1] rows this shard scans a second time
+      if (rescan) ASL_TRY(Mn.reserve(all));
+      HIP_TRY(hipMemsetAsync(flag.p, 0, 2 * sizeof(int32_t), st));
+      int prev = 0;
+      ASL_TRY(index_swap_unordered(ix, 2, &prev));
+      const int rc = index_search_device(ix, (int)all, xs, ks, np, nullptr, Kp.p, nullptr, cD_all.p, cI_all.p, true,
+                                         nullptr, es, cs);
+      ASL_TRY(index_swap_unordered(ix, prev, nullptr));
+      ASL_TRY(rc);
+      ASL_TRY(keys_split(reinterpret_cast<const u64k *>(Kp.p), (int64_t)all, ks, kp, reinterpret_cast<u64k *>(Hs.p),
+                         Fl.p, rescan ? reinterpret_cast<u64k *>(Mn.p) : nullptr));
+      auto all_to_all = [&](const int64_t *src, int64_t *dst, size_t per_rank) -> int {
+        RCCL_TRY(R.GroupStart());
+        for (int r = 0; r < world; ++r) {
+          RCCL_TRY(R.Send(src + (size_t)r * per_rank, per_rank, NCCL_INT64, r, comm, st));
+          RCCL_TRY(R.Recv(dst + (size_t)r * per_rank, per_rank, NCCL_INT64, r, comm, st));
+        }
+        RCCL_TRY(R.GroupEnd());
+        return ASL_OK;
+      };
+      ASL_TRY(all_to_all(Hs.p, Hr.p, (size_t)nq * kp));
+      ASL_TRY(keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, nullptr, 0, nullptr, need.p,
+                         reinterpret_cast<u64k *>(Ko.p), reinterpret_cast<u64k *>(Bs.p), nullptr, nullptr, 0));
+      bool overflow = false;
+      const int64_t *xr = nullptr;
+      if (second) {
+        ASL_TRY(Xs.reserve((size_t)world * ((size_t)nq + (size_t)xcap)));
+        ASL_TRY(Xr.reserve((size_t)world * ((size_t)nq + (size_t)xcap)));
+        ASL_TRY(cursor.reserve((size_t)world));
+        ASL_TRY(all_to_all(Bs.p, Br.p, (size_t)nq));
+        HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)world * sizeof(unsigned int), st));
+        const int32_t *rm = nullptr;
+        if (rescan) {
+          // rows whose bound lies below the smallest key of a full k_s-row are scanned again with the
+          // full k: a launch of `cap` workgroups gated by the device-side count (no host round trip)
+          const int cap = (int)std::max<size_t>(64, all / 16);
+          ASL_TRY(rowlist.reserve((size_t)cap));
+          ASL_TRY(rmap.reserve(all));
+          ASL_TRY(cD3.reserve((size_t)cap * np));
+          ASL_TRY(cI3.reserve((size_t)cap * np));
+          ASL_TRY(K3.reserve((size_t)cap * k));
+          HIP_TRY(hipMemsetAsync(rowlist.p, 0, (size_t)cap * sizeof(int64_t), st));
+          ASL_TRY(rescan_list(reinterpret_cast<const u64k *>(Br.p), reinterpret_cast<const u64k *>(Mn.p), (int64_t)all, cap,
+                              rowlist.p, rmap.p, reinterpret_cast<int *>(flag.p + 1), flag.p));
+          if (entries) {               // (rows of 4-byte words)
+            ASL_TRY(e3.reserve((size_t)cap * 64));
+            ASL_TRY(c3.reserve((size_t)cap));
+            ASL_TRY(gather_rows_f32(reinterpret_cast<const float *>(e_all.p), 128, rowlist.p, cap, 128,
+                                    reinterpret_cast<float *>(e3.p), 128));
+            ASL_TRY(gather_rows_f32(reinterpret_cast<const float *>(c_all.p), 1, rowlist.p, cap, 1,
+                                    reinterpret_cast<float *>(c3.p), 1));
+          } else {
+            ASL_TRY(x3.reserve((size_t)cap * d));
+            ASL_TRY(gather_rows_f32(x_all.p, d, rowlist.p, cap, d, x3.p, d));
+          }
+          ASL_TRY(gather_rows_f32(cD_all.p, np, rowlist.p, cap, np, cD3.p, np));
+          ASL_TRY(gather_rows_f32(reinterpret_cast<const float *>(cI_all.p), np, rowlist.p, cap, np,
+                                  reinterpret_cast<float *>(cI3.p), np));      // (4-byte words)
+          ASL_TRY(index_swap_unordered(ix, 2, &prev));
+          const int rc3 = index_search_device(ix, cap, entries ? nullptr : x3.p, k, np, nullptr, K3.p, nullptr, cD3.p,
+                                              cI3.p, true, reinterpret_cast<const int *>(flag.p + 1),
+                                              entries ? e3.p : nullptr, entries ? c3.p : nullptr);
+          ASL_TRY(index_swap_unordered(ix, prev, nullptr));
+          ASL_TRY(rc3);
+          rm = rmap.p;
+        }
+        ASL_TRY(keys_extras(reinterpret_cast<const u64k *>(Kp.p), Fl.p, (int64_t)all, ks, reinterpret_cast<const u64k *>(Br.p),
+                            nq, xcap, reinterpret_cast<u64k *>(Xs.p), cursor.p, flag.p, rm,
+                            reinterpret_cast<const u64k *>(K3.p), k));
+        ASL_TRY(all_to_all(Xs.p, Xr.p, (size_t)nq + (size_t)xcap));
+        xr = Xr.p;
+      }
+      if (second || entries) {
+        // a full buffer ANYWHERE sends every rank down the full exchange, a query without an entry
+        // list ANYWHERE sends them back to dense rows: all ranks take the same branch
+        HIP_TRY(hipMemcpyAsync(mine.p, flag.p, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        if (entries)
+          HIP_TRY(hipMemcpyAsync(mine.p + 2, over.p, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        else
+          HIP_TRY(hipMemsetAsync(mine.p + 2, 0, sizeof(int32_t), st));
+        ASL_TRY(agree(h));
+        for (int r = 0; r < world; ++r) {
+          overflow |= second && h[(size_t)r * 4] != 0;
+          redo_dense |= h[(size_t)r * 4 + 2] != 0;
+        }
+        if (redo_dense) return ASL_OK;
+      }
+      if (!overflow)
+        return keys_merge(reinterpret_cast<const u64k *>(Hr.p), world, nq, kp, k, reinterpret_cast<const u64k *>(xr),
+                          xr ? xcap : 0, reinterpret_cast<const u64k *>(Ko.p), need.p, nullptr, nullptr, I, D, 1);
+    }
+    // 2. the local lists, for all queries (rank-major rows), as exact top-k sets
+    //    (unordered mode: un-refined ADC rows, see annsolo_mi.h at asl_index_set_refine)
+    ASL_TRY(Dp.reserve(all * k));
+    ASL_TRY(Ip.reserve(all * k));
+    ASL_TRY(Dr.reserve(all * k));
+    ASL_TRY(Ir.reserve(all * k));
+    int prev_unordered = 0;
+    ASL_TRY(index_swap_unordered(ix, 1, &prev_unordered));
+    const int rc_scan = index_search_device(ix, (int)all, xs, k, np, Dp.p, Ip.p, nullptr, cD_all.p, cI_all.p, true,
+                                            nullptr, es, cs);
+    ASL_TRY(index_swap_unordered(ix, prev_unordered, nullptr));
+    ASL_TRY(rc_scan);
+    // 3. rank r receives the `world` partial rows of its own queries
+    RCCL_TRY(R.GroupStart());
+    for (int r = 0; r < world; ++r) {
+      RCCL_TRY(R.Send(Dp.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_FLOAT32, r, comm, st));
+      RCCL_TRY(R.Recv(Dr.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_FLOAT32, r, comm, st));
+      RCCL_TRY(R.Send(Ip.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_INT64, r, comm, st));
+      RCCL_TRY(R.Recv(Ir.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_INT64, r, comm, st));
+    }
+    RCCL_TRY(R.GroupEnd());
+    // 4. merge (and the exact re-rank of the merged short-list)
+    static DevBuf<int64_t> &Im = *new DevBuf<int64_t>();
+    float *Dout = D;
+    if (!Dout || refine) {
+      ASL_TRY(Dtmp.reserve((size_t)nq * k));
+      Dout = Dtmp.p;
+    }
+    if (!refine) return topk_merge(Dr.p, Ir.p, world, nq, k, Dout, I);
+    ASL_TRY(Im.reserve((size_t)nq * k));
+    ASL_TRY(topk_merge(Dr.p, Ir.p, world, nq, k, Dout, Im.p));
+    static DevBuf<float> &Dfin = *new DevBuf<float>();
+    float *Df = D;
+    if (!Df) {
+      ASL_TRY(Dfin.reserve((size_t)nq * k_out));
+      Df = Dfin.p;
+    }
+    return index_refine_device(ix, nq, xq, k, Im.p, k_out, Df, I);
+  };
+  ASL_TRY(run(keys_everywhere));
+  if (redo_dense) {
+    redo_dense = false;
+    return run(false);
   }
-  // 2. the local lists, for all queries (rank-major rows), as exact top-k sets
-  //    (unordered mode: un-refined ADC rows, see annsolo_mi.h at asl_index_set_refine)
-  ASL_TRY(Dp.reserve(all * k));
-  ASL_TRY(Ip.reserve(all * k));
-  ASL_TRY(Dr.reserve(all * k));
-  ASL_TRY(Ir.reserve(all * k));
-  int prev_unordered = 0;
-  ASL_TRY(index_swap_unordered(ix, 1, &prev_unordered));
-  const int rc_scan = index_search_device(ix, (int)all, x_all.p, k, np, Dp.p, Ip.p, nullptr, cD_all.p, cI_all.p, true,
-                                          nullptr);
-  ASL_TRY(index_swap_unordered(ix, prev_unordered, nullptr));
-  ASL_TRY(rc_scan);
-  // 3. rank r receives the `world` partial rows of its own queries
-  RCCL_TRY(R.GroupStart());
-  for (int r = 0; r < world; ++r) {
-    RCCL_TRY(R.Send(Dp.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_FLOAT32, r, comm, st));
-    RCCL_TRY(R.Recv(Dr.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_FLOAT32, r, comm, st));
-    RCCL_TRY(R.Send(Ip.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_INT64, r, comm, st));
-    RCCL_TRY(R.Recv(Ir.p + (size_t)r * nq * k, (size_t)nq * k, NCCL_INT64, r, comm, st));
-  }
-  RCCL_TRY(R.GroupEnd());
-  // 4. merge (and the exact re-rank of the merged short-list)
-  static DevBuf<int64_t> &Im = *new DevBuf<int64_t>();
-  float *Dout = D;
-  if (!Dout || refine) {
-    ASL_TRY(Dtmp.reserve((size_t)nq * k));
-    Dout = Dtmp.p;
-  }
-  if (!refine) return topk_merge(Dr.p, Ir.p, world, nq, k, Dout, I);
-  ASL_TRY(Im.reserve((size_t)nq * k));
-  ASL_TRY(topk_merge(Dr.p, Ir.p, world, nq, k, Dout, Im.p));
-  static DevBuf<float> &Dfin = *new DevBuf<float>();
-  float *Df = D;
-  if (!Df) {
-    ASL_TRY(Dfin.reserve((size_t)nq * k_out));
-    Df = Dfin.p;
-  }
-  return index_refine_device(ix, nq, xq, k, Im.p, k_out, Df, I);
+  return ASL_OK;
 }
 
 extern "C" int asl_index_search_sharded(asl_index_t *ix, void *rccl_comm, int32_t nq,

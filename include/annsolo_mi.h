@@ -200,7 +200,9 @@ int asl_index_shard(asl_index_t *idx, int32_t rank, int32_t world);
 /* The sharded search itself, for hosts that bind the C ABI directly: every rank
  * of `rccl_comm` (an ncclComm_t the caller created; one rank per GPU) calls this with ITS nq
  * queries -- the same nq everywhere, device pointers only -- after asl_index_shard(idx, rank,
- * world) on an index that was filled identically on every rank. All-gather of the queries and of
+ * world) on an index that was filled identically on every rank. All-gather of the queries (as
+ * entry lists, 516 bytes per query, whenever the packed-key scans run; a batch holding a query with
+ * more than 64 non-zero components is repeated with dense rows) and of
  * the probe lists, scan of the local inverted lists for all world x nq queries, grouped
  * send/recv of the per-shard top-k (all-to-all), merge: D / I [nq, k] equal the unsharded
  * index's rows for these queries. Enqueued on the library's stream; RCCL is resolved from the

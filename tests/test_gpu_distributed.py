@@ -268,6 +268,23 @@ for index in ('ivfpq', 'ivfflat'):
         assert torch.equal(I[:nq_].sort(1).values, I0[:nq_].sort(1).values), (index, nq_, head, sk, xper)
         assert torch.equal(D[:nq_].sort(1).values, D0[:nq_].sort(1).values), (index, nq_, head, sk, xper)
         assert torch.equal(I[:nq_], I0[:nq_]), (index, nq_, head, sk, xper)
+    # the queries travel as entry lists (<= 64 non-zero components); a query with more has no such
+    # form: the ranks notice in the step's agreement and repeat the batch with dense rows
+    vec2 = vec.clone()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    for r_ in (5, 200):
+        dense = torch.rand(vec.shape[1], generator=g).to(dev) * (torch.rand(vec.shape[1], generator=g).to(dev) < 0.2)
+        vec2[r_] = dense / dense.norm()
+    assert int((vec2[5] != 0).sum()) > 64
+    D2, I2 = idx.search(vec2, 256)      # (sharding over one rank leaves the index as it is)
+    for head, sk, xper in ((0, 0, -1), (100, 160, 256), (100, 0, 0)):
+        D.fill_(-5.0)
+        I.fill_(-5)
+        rc = L.asl_index_search_sharded_ex(idx._h, comm, q.n, _lib.ptr(vec2), 256, 16, _lib.ptr(D), _lib.ptr(I),
+                                           head, sk, xper)
+        assert rc == 0, (L.asl_last_error(), head, sk, xper)
+        torch.cuda.synchronize()
+        assert torch.equal(I, I2) and torch.equal(D, D2), (index, 'dense query', head, sk, xper)
     # host pointers and missing communicators are errors, not crashes
     assert L.asl_index_search_sharded(idx._h, None, q.n, _lib.ptr(vec), 256, 16, _lib.ptr(D), _lib.ptr(I)) < 0
     host = np.zeros((q.n, 256), np.int64)
