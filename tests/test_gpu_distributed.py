@@ -237,9 +237,12 @@ dev = torch.device('cuda', 0)
 lib, aux = synthetic.make_library(20000, seed=5, device=dev, charges=(2,), charge_p=(1.0,))
 q, _ = synthetic.make_queries(lib, aux, 300, seed=6, open_range=300.0, charge=2)
 L = _lib.lib()
-for index in ('ivfpq', 'ivfflat'):
-    sl = SpectralLibrary(lib, config=Config.open_search(num_list=64, num_probe=16, num_candidates=256, index=index,
-                                            kmeans_niter=4), device=dev)
+for index in ('ivfpq', 'ivfflat', 'ivfpq+refine'):
+    # ('ivfpq+refine': the exact re-rank on -- the shards' un-refined k' rows travel whole, the owner
+    # re-ranks the merged short-list: the (D, I) exchange inside the library)
+    sl = SpectralLibrary(lib, config=Config.open_search(num_list=64, num_probe=16, num_candidates=256,
+                                            index=index.split('+')[0], kmeans_niter=4,
+                                            refine_k=400 if index.endswith('refine') else None), device=dev)
     idx = sl._get_ann_index(2)
     vec = sl._encode(q)
     idx.nprobe = 16
