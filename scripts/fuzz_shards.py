@@ -18,7 +18,7 @@ from ann_solo_amd.spectral_library import Config, SpectralLibrary
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 t_end = time.time() + budget
-trials = bad = two_phase = third_runs = third_asked = 0
+trials = bad = two_phase = third_runs = third_asked = entry_runs = 0
 dev = torch.device('cuda', 0)
 tmp = tempfile.mkdtemp()
 while time.time() < t_end:
@@ -45,10 +45,17 @@ while time.time() < t_end:
     faiss.write_index(idx, path)
     owner = idx.shard_map(W)
     parts, keys, keys_s, nloc = [], [], [], 0
+    ok_e = True
     use_keys = bool(_lib.lib().asl_index_supports_keys(idx._h, k, nprobe))
     # a random head and a random shard-side k between the head and k (second scans answered from the full rows)
     hk = int(rng.integers(1, k + 1)) if rng.random() < 0.7 else min(k, -(-2 * k // W))
     ks = int(rng.integers(hk + 1, k)) if hk + 1 < k and rng.random() < 0.6 else k
+    # half of the runs: the shards search the queries as ENTRY LISTS (asl_encode_entries_batch ->
+    # asl_index_search_entries) instead of dense rows -- the same packed-key rows are expected
+    be0 = HipShardBackend.__new__(HipShardBackend)
+    be0.sl, be0.device = sl, dev
+    eq = be0.encode_entries(q) if rng.random() < 0.5 else None
+    entry_runs += eq is not None
     for r in range(W):
         sh = faiss.read_index(path)
         sh.shard(r, W)
@@ -56,13 +63,19 @@ while time.time() < t_end:
         if use_keys:
             use_keys = bool(_lib.lib().asl_index_supports_keys(sh._h, k, nprobe))      # (an empty / dense shard)
         if use_keys:
-            keys.append(sh.search_preassigned_keys(vec, k, cD, cI))
-            keys_s.append(sh.search_preassigned_keys(vec, ks, cD, cI) if ks < k else keys[-1])
+            if eq is not None:
+                keys.append(sh.search_entries_keys(eq.entries, eq.counts, k, cD, cI))
+                keys_s.append(sh.search_entries_keys(eq.entries, eq.counts, ks, cD, cI) if ks < k else keys[-1])
+                if r == 0:      # ... and they ARE the dense call's rows (as sets)
+                    ok_e = torch.equal(keys[-1].sort(1).values, sh.search_preassigned_keys(vec, k, cD, cI).sort(1).values)
+            else:
+                keys.append(sh.search_preassigned_keys(vec, k, cD, cI))
+                keys_s.append(sh.search_preassigned_keys(vec, ks, cD, cI) if ks < k else keys[-1])
         sh.set_unordered(True)
         parts.append(sh.search_preassigned(vec, k, cD, cI))
         del sh
     Dm, Im = faiss.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
-    ok = nloc == n and torch.equal(Im, I) and torch.equal(Dm.view(torch.int32), D.view(torch.int32))
+    ok = nloc == n and torch.equal(Im, I) and torch.equal(Dm.view(torch.int32), D.view(torch.int32)) and ok_e
     ok &= set(owner.tolist()) <= set(range(W))
     if use_keys and len(keys) == W:
         Dk, Ik = faiss.topk_merge_keys(torch.stack(keys))
@@ -120,4 +133,5 @@ while time.time() < t_end:
         print('MISMATCH', desc, flush=True)
     sl.shutdown()
 print(f'{trials} trials ({two_phase} also through the two-phase exchange, {third_runs} of them with a shard-side '
-      f'k < k: {third_asked} rows answered from a second scan), {bad} mismatches')
+      f'k < k: {third_asked} rows answered from a second scan; {entry_runs} with the queries as entry lists), '
+      f'{bad} mismatches')
