@@ -40,22 +40,28 @@ constexpr int RS_MCAP = 512;   // generated peak matches per pair the kernels ac
 
 enum { RS_STATUS_OK = 0, RS_STATUS_PEAKS = 1, RS_STATUS_MATCHES = 2 };
 
-struct WaveLds {
-  float c_mz[RS_MAXP];
-  float c_int[RS_MAXP];
-  unsigned long long keys[RS_MCAP];
-  uint32_t pay[RS_MCAP];
-  uint8_t c_chg[RS_MAXP];
+template <int MAXP_, int MCAP_>
+struct WaveLdsT {
+  static constexpr int MAXP = MAXP_, MCAP = MCAP_;
+  float c_mz[MAXP_];
+  float c_int[MAXP_];
+  unsigned long long keys[MCAP_];
+  uint32_t pay[MCAP_];
+  uint8_t c_chg[MAXP_];
   uint8_t own_q[RS_MAXP];   // resolve fast path: last lane that claimed a query / candidate peak
   uint8_t own_c[RS_MAXP];
   int counter;
   int pad[3];
 };
+typedef WaveLdsT<RS_MAXP, RS_MCAP> WaveLds;
 
-struct QueryLds {
-  float mz[RS_MAXP];
-  float inten[RS_MAXP];
+template <int MAXP_>
+struct QueryLdsT {
+  static constexpr int MAXP = MAXP_;
+  float mz[MAXP_];
+  float inten[MAXP_];
 };
+typedef QueryLdsT<RS_MAXP> QueryLds;
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -225,17 +231,21 @@ __device__ double resolve_matches(int lane, WL &W, uint32_t *out_pairs, int out_
 // Wave-cooperative SpectrumMatcher::dot for one pair. All 64 lanes call it with
 // identical arguments; returns the score in every lane. EMIT: lane 0 writes the
 // greedy (query_peak, candidate_peak) pairs.
-template <bool EMIT>
-__device__ double dot_pair_wave(int lane, const QueryLds &Q, int qn, double q_pmz,
+// DEFER (the small-LDS instantiation of the matches kernel): a pair that does not fit the
+// structures -- more candidate peaks or generated matches than they hold -- is not an error, the
+// call returns -1 and the pair is left to the full-size instantiation.
+template <bool EMIT, bool DEFER = false, class QL = QueryLds, class WL = WaveLds>
+__device__ double dot_pair_wave(int lane, const QL &Q, int qn, double q_pmz,
                                 const DevPeaks &L, int row, double tol, int allow_shift,
-                                WaveLds &W, uint32_t *out_pairs, int out_cap, int *out_count,
+                                WL &W, uint32_t *out_pairs, int out_cap, int *out_count,
                                 int *status) {
   const int co = L.offsets[row];
   int cn = L.offsets[row + 1] - co;
   if (EMIT && out_count && lane == 0) *out_count = 0;
-  if (cn > RS_MAXP) {
+  if (cn > WL::MAXP) {
+    if (DEFER) return -1.0;
     if (lane == 0) atomicOr(status, RS_STATUS_PEAKS);
-    cn = RS_MAXP;
+    cn = WL::MAXP;
   }
   if (cn <= 0 || qn <= 0) return 0.0;
   for (int i = lane; i < cn; i += 64) {
@@ -278,7 +288,7 @@ __device__ double dot_pair_wave(int lane, const QueryLds &Q, int qn, double q_pm
           if (mult > 0.0) {
             const float prod = (float)(mult * (double)q_int * (double)W.c_int[j]);  // cpp:81
             const int slot = atomicAdd(&W.counter, 1);
-            if (slot < RS_MCAP) {
+            if (slot < WL::MCAP) {
               const uint32_t gen = (uint32_t)((qi * S + s) * cn + j);
               W.keys[slot] = ((unsigned long long)__float_as_uint(prod) << 32) |
                              (unsigned long long)(0xFFFFFFFFu - gen);
@@ -291,16 +301,18 @@ __device__ double dot_pair_wave(int lane, const QueryLds &Q, int qn, double q_pm
     }
   }
   wave_sync();
-  return resolve_matches<EMIT>(lane, W, out_pairs, out_cap, out_count, status);
+  if (DEFER && W.counter > WL::MCAP) return -1.0;     // (wave-uniform: the counter is final)
+  return resolve_matches<EMIT>(lane, W, out_pairs, out_cap, out_count, status, 0, -1, WL::MCAP);
 }
 
+template <class QL>
 __device__ __forceinline__ void load_query(int tid, int nthreads, const DevPeaks &Qs, int q,
-                                           QueryLds &Q, int &qn, int *status) {
+                                           QL &Q, int &qn, int *status) {
   const int qo = Qs.offsets[q];
   qn = Qs.offsets[q + 1] - qo;
-  if (qn > RS_MAXP) {
+  if (qn > QL::MAXP) {
     if (tid == 0) atomicOr(status, RS_STATUS_PEAKS);
-    qn = RS_MAXP;
+    qn = QL::MAXP;
   }
   for (int i = tid; i < qn; i += nthreads) {
     Q.mz[i] = Qs.mz[qo + i];
@@ -1221,16 +1233,28 @@ __global__ __launch_bounds__(64) void rescore_argmax_kernel(
   }
 }
 
+// One wave per query, and a wave is a chain of dependent memory round trips (winner's slot -> its
+// row -> its peaks) around little arithmetic: the kernel lives on the number of waves in flight,
+// i.e. on the LDS a wave needs. SMALL: structures for spectra of <= 128 peaks and <= 128
+// generated matches (4 KB per wave instead of 11: 32 waves per CU instead of 12); a query beyond
+// them is marked in m_defer and done by the full-size instantiation, which runs second and only
+// looks at marked queries.
+constexpr int RS_SMALL_P = 128, RS_SMALL_M = 128;
+template <bool SMALL>
 __global__ __launch_bounds__(64 * RS_WAVES) void rescore_matches_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, int nq, const long long *__restrict__ best_slot,
     double tol, int allow_shift, int32_t *__restrict__ pm_count,
     uint32_t *__restrict__ pm_pairs, int pm_stride, int32_t *__restrict__ best_row,
-    int *status) {
-  __shared__ QueryLds Q[RS_WAVES];
-  __shared__ WaveLds W[RS_WAVES];
+    int *status, int *__restrict__ m_defer) {
+  typedef QueryLdsT<SMALL ? RS_SMALL_P : RS_MAXP> QL;
+  typedef WaveLdsT<SMALL ? RS_SMALL_P : RS_MAXP, SMALL ? RS_SMALL_M : RS_MCAP> WL;
+  __shared__ QL Q[RS_WAVES];
+  __shared__ WL W[RS_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int q = blockIdx.x * RS_WAVES + wave;
   if (q >= nq) return;
+  if (!SMALL && !m_defer[q]) return;
+  if (SMALL && lane == 0) m_defer[q] = 0;
   const long long slot = best_slot[q];
   const long long row = slot >= 0 ? cv.row(slot) : -1;
   if (best_row && lane == 0) best_row[q] = (int32_t)row;
@@ -1241,14 +1265,22 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_matches_kernel(
     return;
   }
   if (!pm_count && !pm_pairs) return;
+  if (SMALL && Qs.offsets[q + 1] - Qs.offsets[q] > RS_SMALL_P) {
+    if (lane == 0) m_defer[q] = 1;
+    return;
+  }
   int qn;
   load_query(lane, 64, Qs, q, Q[wave], qn, status);
   wave_sync();
   int cnt_tmp = 0;
   __shared__ int s_cnt[RS_WAVES];
-  dot_pair_wave<true>(lane, Q[wave], qn, Qs.precursor_mz[q], L, (int)row, tol, allow_shift,
-                      W[wave], pm_pairs ? pm_pairs + (size_t)q * pm_stride * 2 : nullptr,
-                      pm_pairs ? pm_stride : 0, &s_cnt[wave], status);
+  const double sc = dot_pair_wave<true, SMALL>(lane, Q[wave], qn, Qs.precursor_mz[q], L, (int)row, tol, allow_shift,
+                                               W[wave], pm_pairs ? pm_pairs + (size_t)q * pm_stride * 2 : nullptr,
+                                               pm_pairs ? pm_stride : 0, &s_cnt[wave], status);
+  if (SMALL && sc < 0.0) {        // (wave-uniform) does not fit: the second launch does this query
+    if (lane == 0) m_defer[q] = 1;
+    return;
+  }
   wave_sync();
   cnt_tmp = s_cnt[wave];
   if (pm_count && lane == 0) pm_count[q] = cnt_tmp;
@@ -1307,9 +1339,15 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
   }
   {
     ProfScope ps("rescore_matches");
-    hipLaunchKernelGGL(rescore_matches_kernel, dim3((unsigned)cdiv(nq, RS_WAVES)),
+    static DevBuf<int> &m_defer = *new DevBuf<int>();   // process lifetime (one device per process)
+    ASL_TRY(m_defer.reserve((size_t)nq));
+    hipLaunchKernelGGL(rescore_matches_kernel<true>, dim3((unsigned)cdiv(nq, RS_WAVES)),
                        dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, nq, best_slot, tol,
-                       allow_shift, pm_count, pm_pairs, pm_stride, best_row, status);
+                       allow_shift, pm_count, pm_pairs, pm_stride, best_row, status, m_defer.p);
+    ASL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rescore_matches_kernel<false>, dim3((unsigned)cdiv(nq, RS_WAVES)),
+                       dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, nq, best_slot, tol,
+                       allow_shift, pm_count, pm_pairs, pm_stride, best_row, status, m_defer.p);
     ASL_CHECK_LAUNCH();
   }
   return ASL_OK;

@@ -193,6 +193,45 @@ def test_rescoring_few_queries_long_lists(O, data):
         _check_rescoring(O, Q, L, cand, off, tol, shift, res)
 
 
+def test_peak_matches_of_long_spectra_and_many_matches(O):
+    """The winner's peak matches are emitted by a kernel built for spectra of <= 128 peaks and <= 128
+    generated matches (small LDS: many waves in flight); anything beyond is left to the full-size
+    instantiation that runs behind it. Queries and library spectra of 20 .. 250 peaks on a coarse
+    m/z grid with a wide tolerance (many candidates per window, hundreds of generated matches):
+    winners, scores, counts and the match pairs equal the oracle's."""
+    from ann_solo_amd import spectrum_match
+    from ann_solo_amd.packed import PackedSpectra
+    rng = np.random.default_rng(77)
+
+    def spectra(n, sizes, charge):
+        offs, mzs, its, chs = [0], [], [], []
+        for i in range(n):
+            m = int(sizes[i % len(sizes)])
+            g = np.sort(rng.choice(np.arange(200, 1800), size=m, replace=False)).astype(np.float32)
+            mzs.append(g + rng.normal(0, 0.004, m).astype(np.float32))
+            its.append(rng.random(m).astype(np.float32) + np.float32(0.01))
+            chs.append(rng.integers(0, 3, m).astype(np.uint8))
+            offs.append(offs[-1] + m)
+        pmz = rng.uniform(400, 900, n)
+        pz = np.full(n, charge, np.int32)
+        order = [np.argsort(x, kind='stable') for x in mzs]
+        mzs = [x[o_] for x, o_ in zip(mzs, order)]
+        its = [x[o_] for x, o_ in zip(its, order)]
+        chs = [x[o_] for x, o_ in zip(chs, order)]
+        return PackedSpectra.from_numpy(np.asarray(offs, np.int32), np.concatenate(mzs), np.concatenate(its),
+                                        np.concatenate(chs), pmz, pz)
+    lib = spectra(60, [20, 50, 100, 128, 129, 200, 250], 2)
+    qq = spectra(24, [30, 127, 128, 129, 250, 60], 2)
+    L, Q = O.Spectra(*lib.numpy()), O.Spectra(*qq.numpy())
+    cands = [np.sort(rng.choice(lib.n, size=40, replace=False)).astype(np.int64) for _ in range(qq.n)]
+    off = np.concatenate([[0], np.cumsum([len(c) for c in cands])]).astype(np.int32)
+    cand = np.concatenate(cands)
+    for tol, shift in ((0.02, True), (0.4, True), (0.4, False)):
+        res = spectrum_match.rescore_batch(qq, lib, cand, off, tol, shift)
+        _check_rescoring(O, Q, L, cand, off, tol, shift, res)
+        assert res[2].max() > 40        # long match lists were produced
+
+
 def test_rescoring_many_hits_per_chunk(O):
     """A library of copies and near-copies of one spectrum, queried with it: every chunk of 32
     candidates holds > 1 000 (peak, shift) items whose bin is marked, so the per-wave queue of the
