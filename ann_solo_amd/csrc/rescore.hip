@@ -346,31 +346,50 @@ struct CandView {
   }
 };
 
+constexpr int RS_BS_GROUP = 16;      // queries per workgroup of the binary-search kernel
 __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
     double *__restrict__ pair_score, const int *__restrict__ q_defer, int *status) {
   __shared__ QueryLds Q;
   __shared__ WaveLds W[RS_WAVES];
-  const int q = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  long long c0, c1;
-  cv.range(q, c0, c1);
-  if (c0 >= c1) return;
+  // A workgroup takes RS_BS_GROUP consecutive queries: as the third launch of the rescoring the
+  // kernel normally finds nothing marked -- one coalesced read of the group's flags says so (a
+  // workgroup per query, 46 KB of LDS each, placed only to return, cost 0.02 ms of a step); when
+  // every query is marked (tol <= 0, long queries) nq / 16 workgroups still fill the chip.
   // deferred mode: only the pairs the fast kernels marked RS_DEFER_BS (-3)
-  if (q_defer && !(q_defer[q] & 2)) return;
-  int qn;
-  load_query(threadIdx.x, blockDim.x, Qs, q, Q, qn, status);
+  __shared__ unsigned long long s_todo;
+  const int q0 = blockIdx.x * RS_BS_GROUP;
+  if (wave == 0) {
+    const int qt = q0 + lane;
+    const unsigned long long m = __ballot(lane < RS_BS_GROUP && qt < Qs.n && (!q_defer || (q_defer[qt] & 2)));
+    if (lane == 0) s_todo = m;
+  }
   __syncthreads();
-  const double q_pmz = Qs.precursor_mz[q];
-  const long long step = (long long)RS_WAVES * gridDim.y;
-  for (long long c = c0 + (long long)blockIdx.y * RS_WAVES + wave; c < c1; c += step) {
-    if (q_defer && pair_score[c] != -3.0) continue;
-    const long long row = cv.cand(c, q_pmz, L.n);
-    double s = -1.0;
-    if (row >= 0)
-      s = dot_pair_wave<false>(lane, Q, qn, q_pmz, L, (int)row, tol, allow_shift, W[wave],
-                               nullptr, 0, nullptr, status);
-    if (lane == 0) pair_score[c] = s;
+  {
+   unsigned long long todo = s_todo;          // workgroup-uniform
+   while (todo) {
+    const int q = q0 + __builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    long long c0, c1;
+    cv.range(q, c0, c1);
+    if (c0 >= c1) continue;
+    int qn;
+    __syncthreads();              // the previous query's peaks are no longer read
+    load_query(threadIdx.x, blockDim.x, Qs, q, Q, qn, status);
+    __syncthreads();
+    const double q_pmz = Qs.precursor_mz[q];
+    const long long step = (long long)RS_WAVES * gridDim.y;
+    for (long long c = c0 + (long long)blockIdx.y * RS_WAVES + wave; c < c1; c += step) {
+      if (q_defer && pair_score[c] != -3.0) continue;
+      const long long row = cv.cand(c, q_pmz, L.n);
+      double s = -1.0;
+      if (row >= 0)
+        s = dot_pair_wave<false>(lane, Q, qn, q_pmz, L, (int)row, tol, allow_shift, W[wave],
+                                 nullptr, 0, nullptr, status);
+      if (lane == 0) pair_score[c] = s;
+    }
+   }
   }
 }
 
@@ -1240,21 +1259,13 @@ __global__ __launch_bounds__(64) void rescore_argmax_kernel(
 // them is marked in m_defer and done by the full-size instantiation, which runs second and only
 // looks at marked queries.
 constexpr int RS_SMALL_P = 128, RS_SMALL_M = 128;
-template <bool SMALL>
-__global__ __launch_bounds__(64 * RS_WAVES) void rescore_matches_kernel(
-    DevPeaks Qs, DevPeaks L, CandView cv, int nq, const long long *__restrict__ best_slot,
-    double tol, int allow_shift, int32_t *__restrict__ pm_count,
-    uint32_t *__restrict__ pm_pairs, int pm_stride, int32_t *__restrict__ best_row,
-    int *status, int *__restrict__ m_defer) {
-  typedef QueryLdsT<SMALL ? RS_SMALL_P : RS_MAXP> QL;
-  typedef WaveLdsT<SMALL ? RS_SMALL_P : RS_MAXP, SMALL ? RS_SMALL_M : RS_MCAP> WL;
-  __shared__ QL Q[RS_WAVES];
-  __shared__ WL W[RS_WAVES];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int q = blockIdx.x * RS_WAVES + wave;
-  if (q >= nq) return;
-  if (!SMALL && !m_defer[q]) return;
-  if (SMALL && lane == 0) m_defer[q] = 0;
+template <bool SMALL, class QL, class WL>
+__device__ __forceinline__ void matches_one(int q, int lane, QL &Qw, WL &Ww, int *s_cnt_w, const DevPeaks &Qs,
+                                            const DevPeaks &L, const CandView &cv,
+                                            const long long *__restrict__ best_slot, double tol, int allow_shift,
+                                            int32_t *__restrict__ pm_count, uint32_t *__restrict__ pm_pairs,
+                                            int pm_stride, int32_t *__restrict__ best_row, int *status,
+                                            int *__restrict__ m_defer) {
   const long long slot = best_slot[q];
   const long long row = slot >= 0 ? cv.row(slot) : -1;
   if (best_row && lane == 0) best_row[q] = (int32_t)row;
@@ -1270,23 +1281,58 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_matches_kernel(
     return;
   }
   int qn;
-  load_query(lane, 64, Qs, q, Q[wave], qn, status);
+  load_query(lane, 64, Qs, q, Qw, qn, status);
   wave_sync();
   int cnt_tmp = 0;
-  __shared__ int s_cnt[RS_WAVES];
-  const double sc = dot_pair_wave<true, SMALL>(lane, Q[wave], qn, Qs.precursor_mz[q], L, (int)row, tol, allow_shift,
-                                               W[wave], pm_pairs ? pm_pairs + (size_t)q * pm_stride * 2 : nullptr,
-                                               pm_pairs ? pm_stride : 0, &s_cnt[wave], status);
+  const double sc = dot_pair_wave<true, SMALL>(lane, Qw, qn, Qs.precursor_mz[q], L, (int)row, tol, allow_shift,
+                                               Ww, pm_pairs ? pm_pairs + (size_t)q * pm_stride * 2 : nullptr,
+                                               pm_pairs ? pm_stride : 0, s_cnt_w, status);
   if (SMALL && sc < 0.0) {        // (wave-uniform) does not fit: the second launch does this query
     if (lane == 0) m_defer[q] = 1;
     return;
   }
   wave_sync();
-  cnt_tmp = s_cnt[wave];
+  cnt_tmp = *s_cnt_w;
   if (pm_count && lane == 0) pm_count[q] = cnt_tmp;
   if (pm_pairs)
     for (int t = 2 * (cnt_tmp < pm_stride ? cnt_tmp : pm_stride) + lane; t < 2 * pm_stride; t += 64)
       pm_pairs[(size_t)q * pm_stride * 2 + t] = 0u;
+}
+
+// SMALL: a wave per query. Full size: a small grid whose waves walk the flags of 64 queries at a
+// time and do the marked ones (normally none: thousands of 44 KB workgroups that return at once
+// took 0.04 ms of a step just to be placed).
+template <bool SMALL>
+__global__ __launch_bounds__(64 * RS_WAVES) void rescore_matches_kernel(
+    DevPeaks Qs, DevPeaks L, CandView cv, int nq, const long long *__restrict__ best_slot,
+    double tol, int allow_shift, int32_t *__restrict__ pm_count,
+    uint32_t *__restrict__ pm_pairs, int pm_stride, int32_t *__restrict__ best_row,
+    int *status, int *__restrict__ m_defer) {
+  typedef QueryLdsT<SMALL ? RS_SMALL_P : RS_MAXP> QL;
+  typedef WaveLdsT<SMALL ? RS_SMALL_P : RS_MAXP, SMALL ? RS_SMALL_M : RS_MCAP> WL;
+  __shared__ QL Q[RS_WAVES];
+  __shared__ WL W[RS_WAVES];
+  __shared__ int s_cnt[RS_WAVES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (SMALL) {
+    const int q = blockIdx.x * RS_WAVES + wave;
+    if (q >= nq) return;
+    if (lane == 0) m_defer[q] = 0;
+    matches_one<true>(q, lane, Q[wave], W[wave], &s_cnt[wave], Qs, L, cv, best_slot, tol, allow_shift, pm_count,
+                      pm_pairs, pm_stride, best_row, status, m_defer);
+    return;
+  }
+  const int nwaves = gridDim.x * RS_WAVES;
+  for (int base = (blockIdx.x * RS_WAVES + wave) * 64; base < nq; base += nwaves * 64) {
+    unsigned long long todo = __ballot(base + lane < nq && m_defer[base + lane] != 0);
+    while (todo) {          // wave-uniform
+      const int l = __builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      matches_one<false>(base + l, lane, Q[wave], W[wave], &s_cnt[wave], Qs, L, cv, best_slot, tol, allow_shift,
+                         pm_count, pm_pairs, pm_stride, best_row, status, m_defer);
+      wave_sync();
+    }
+  }
 }
 
 // Host driver shared by asl_rescore_batch and asl_search_batch. All pointers are
@@ -1328,7 +1374,7 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
       hipLaunchKernelGGL(kern, dim3(nq, std::max(ysplit, RS_DEF_Y)), dim3(64 * RS_WAVES), 0, stream(), Q,
                          L, cv, tol, allow_shift, pair_score, q_defer.p, status);
       ASL_CHECK_LAUNCH();
-      hipLaunchKernelGGL(rescore_score_kernel, dim3(nq, ysplit), dim3(64 * RS_WAVES), 0,
+      hipLaunchKernelGGL(rescore_score_kernel, dim3((unsigned)cdiv(nq, RS_BS_GROUP), ysplit), dim3(64 * RS_WAVES), 0,
                          stream(), Q, L, cv, tol, allow_shift, pair_score,
                          (const int *)q_defer.p, status);
     }
@@ -1345,7 +1391,7 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
                        dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, nq, best_slot, tol,
                        allow_shift, pm_count, pm_pairs, pm_stride, best_row, status, m_defer.p);
     ASL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(rescore_matches_kernel<false>, dim3((unsigned)cdiv(nq, RS_WAVES)),
+    hipLaunchKernelGGL(rescore_matches_kernel<false>, dim3((unsigned)std::min<int64_t>(cdiv(nq, 64 * RS_WAVES), 256)),
                        dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, nq, best_slot, tol,
                        allow_shift, pm_count, pm_pairs, pm_stride, best_row, status, m_defer.p);
     ASL_CHECK_LAUNCH();
