@@ -460,9 +460,14 @@ static int coarse_transposed(asl_index *ix) {
 }
 
 // coarse quantiser: top-nprobe centroids by inner product -> ix->coarse_D / coarse_I
+// ent_out / cnt_out (caller buffers [nq * 64] / [nq], may be null): the queries' entry lists, which
+// the sparse coarse kernel lists anyway, for the scan that follows (*have_ent says whether they were
+// produced: only the sparse formulation makes them)
 static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe,
-                         float *out_D = nullptr, int32_t *out_I = nullptr) {
+                         float *out_D = nullptr, int32_t *out_I = nullptr, uint2 *ent_out = nullptr,
+                         int32_t *cnt_out = nullptr, bool *have_ent = nullptr) {
   const int nlist = ix->nlist, d = ix->d;
+  if (have_ent) *have_ent = false;
   if (!out_D) {
     ASL_TRY(ix->coarse_D.reserve((size_t)nq * nprobe));
     ASL_TRY(ix->coarse_I.reserve((size_t)nq * nprobe));
@@ -487,7 +492,9 @@ static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe,
       ProfScope ps("coarse_gemm");
       const int over_max = m / 64;
       if (sparse)
-        ASL_TRY(coarse_sparse(xq + (size_t)r0 * d, m, d, ix->centroids_t.p, nlist, ix->cs_ent.p, ix->cs_cnt.p,
+        ASL_TRY(coarse_sparse(xq + (size_t)r0 * d, m, d, ix->centroids_t.p, nlist,
+                              ent_out ? ent_out + (size_t)r0 * 64 : ix->cs_ent.p,
+                              cnt_out ? cnt_out + (size_t)r0 : ix->cs_cnt.p,
                               ix->cs_over.p, over_max, ix->ws_scores.p, nlist));
       ASL_TRY(gemm_nt_f32(xq + (size_t)r0 * d, ix->centroids.p, ix->ws_scores.p, m, nlist, d, d, d, nlist,
                           sparse ? ix->cs_over.p : nullptr, over_max));
@@ -498,6 +505,8 @@ static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe,
                        out_D + (size_t)r0 * nprobe, nullptr, out_I + (size_t)r0 * nprobe, nprobe));
     }
   }
+  // (own buffers: valid for the whole batch only when it was one chunk)
+  if (have_ent) *have_ent = sparse && coarse_sparse_cap() == 64 && ((ent_out && cnt_out) || nq <= rows);
   return ASL_OK;
 }
 
@@ -513,6 +522,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   // caller watches the producer's n_over
   if (pre_ent && (!pre_cnt || !pre_I || ix->kind == ASL_INDEX_FLAT))
     return fail(ASL_ERR_STATE, "entry-list search: needs the counts, the caller's probe lists and an IVF index");
+  // (with dense rows given as well, entry lists are a hint: a scan that does not read them ignores them)
   if (!xq && !pre_ent) return fail(ASL_ERR_INVALID, "search: null queries");
   // gate: a device-side count -- only the first *gate rows are searched (layout-specific scans only)
   if (gate && (!pre_I || ix->kind == ASL_INDEX_FLAT))
@@ -528,8 +538,9 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
     if (ivf) {
       nprobe = std::max(1, std::min(nprobe, ix->nlist));
       if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
+      bool own_ent = false;
       if (!pre_I) {
-        ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+        ASL_TRY(coarse_search(ix, xq, nq, nprobe, nullptr, nullptr, nullptr, nullptr, &own_ent));
       }
       // search_preassigned: the caller's probe lists are read where they lie (device memory that
       // stays valid until the scan has run: the pipeline's per-parity buffers, a caller's tensor on
@@ -541,11 +552,14 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       if (ix->unordered == 2 && !(use_inv && I64 && k + FLAT_KEYS_SLACK <= TK_MAX_K))
         return fail(ASL_ERR_STATE, "packed-key rows need the postings scan of IVF-Flat (sparse vectors, k <= 1280) and an int64 output");
       if (gate && !use_inv) return fail(ASL_ERR_STATE, "gated search: needs the postings scan of IVF-Flat");
-      if (pre_ent && !use_inv) return fail(ASL_ERR_STATE, "entry-list search: needs the postings scan of IVF-Flat");
+      if (pre_ent && !use_inv && !xq) return fail(ASL_ERR_STATE, "entry-list search: needs the postings scan of IVF-Flat");
       if (use_inv) {
         const uint2 *q_ent = pre_ent;
         const int32_t *q_cnt = pre_cnt;
-        if (!pre_ent) {
+        if (!pre_ent && own_ent) {           // the coarse stage of this very call listed them (same stream)
+          q_ent = ix->cs_ent.p;
+          q_cnt = ix->cs_cnt.p;
+        } else if (!pre_ent) {
           ASL_TRY(ix->scan_ent.reserve((size_t)nq * 64));
           ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
           ASL_TRY(ix->scan_over.reserve(1));
@@ -597,14 +611,15 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   nprobe = std::max(1, std::min(nprobe, ix->nlist));
   if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
   ASL_TRY(build_lists(ix));
-  if (!pre_D) ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+  bool own_ent = false;
+  if (!pre_D) ASL_TRY(coarse_search(ix, xq, nq, nprobe, nullptr, nullptr, nullptr, nullptr, &own_ent));
   // search_preassigned: the caller's probe lists, read where they lie (see the IVF-Flat branch)
   const float *cD = pre_D ? pre_D : ix->coarse_D.p;
   const int32_t *cI = pre_D ? pre_I : ix->coarse_I.p;
   // exact re-rank: the ADC scan returns k' > k candidates as a set, refine.hip keeps the k best
   const bool refine = ix->refine_k > k && ix->refine_rows && ix->unordered == 0;
   if (gate && refine) return fail(ASL_ERR_STATE, "gated search: not with the exact re-rank");
-  if (pre_ent && refine) return fail(ASL_ERR_STATE, "entry-list search: not with the exact re-rank (it reads the dense queries)");
+  if (pre_ent && refine && !xq) return fail(ASL_ERR_STATE, "entry-list search: not with the exact re-rank (it reads the dense queries)");
   float *fin_D = D;
   int64_t *fin_I64 = I64;
   int32_t *fin_I32 = I32;
@@ -629,7 +644,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
     if (ix->unordered == 2 && !(tiled && I64))
       return fail(ASL_ERR_STATE, "packed-key rows need the tiled IVF-PQ scan (m = 32, 8 bits) and an int64 output");
     if (gate && !tiled) return fail(ASL_ERR_STATE, "gated search: needs the tiled IVF-PQ scan");
-    if (pre_ent && !tiled) return fail(ASL_ERR_STATE, "entry-list search: needs the tiled IVF-PQ scan (m = 32, 8 bits)");
+    if (pre_ent && !tiled && !xq) return fail(ASL_ERR_STATE, "entry-list search: needs the tiled IVF-PQ scan (m = 32, 8 bits)");
     if (tiled) {
       if (!ix->cbt_ready) {
         const size_t ncb = (size_t)ix->pq_m * ix->ksub * ix->dsub;
@@ -649,7 +664,10 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
       // ~4 us saved per (query, shard) workgroup)
       const uint2 *q_ent = pre_ent;
       const int32_t *q_cnt = pre_cnt;
-      if (!pre_ent) {
+      if (!pre_ent && own_ent) {             // the coarse stage of this very call listed them (same stream)
+        q_ent = ix->cs_ent.p;
+        q_cnt = ix->cs_cnt.p;
+      } else if (!pre_ent) {
         ASL_TRY(ix->scan_ent.reserve((size_t)nq * 64));
         ASL_TRY(ix->scan_cnt.reserve((size_t)nq));
         ASL_TRY(ix->scan_over.reserve(1));
@@ -696,8 +714,8 @@ int index_prepare(asl_index *ix) {   // everything that may allocate or synchron
   return build_lists(ix);
 }
 int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, float *out_D,
-                        int32_t *out_I) {
-  return coarse_search(ix, xq, nq, nprobe, out_D, out_I);
+                        int32_t *out_I, uint2 *ent_out, int32_t *cnt_out, bool *have_ent) {
+  return coarse_search(ix, xq, nq, nprobe, out_D, out_I, ent_out, cnt_out, have_ent);
 }
 int index_agreed_keys(const asl_index *ix, int k, int np, int world) {
   return (ix->agreed_val >= 0 && ix->agreed_k == k && ix->agreed_np == np && ix->agreed_world == world) ? ix->agreed_val : -1;

@@ -28,7 +28,8 @@ int index_dim(const asl_index *ix);
 int index_nprobe(const asl_index *ix, int nprobe);
 int index_prepare(asl_index *ix);
 int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, float *out_D,
-                        int32_t *out_I);
+                        int32_t *out_I, uint2 *ent_out = nullptr, int32_t *cnt_out = nullptr,
+                        bool *have_ent = nullptr);
 // Window [lo,hi) of each query inside the precursor-sorted library.
 __global__ void window_range_kernel(const double *__restrict__ q_pmz, int nq,
                                     const float *__restrict__ sorted_pmz, int n, int charge,
@@ -97,7 +98,9 @@ struct asl_library {
   DevBuf<int32_t> knn, cand, lo, cnt, woff;
   // buffers that cross the two streams of the pipeline, by batch parity
   DevBuf<float> p_qvec[2], p_cD[2];
-  DevBuf<int32_t> p_cI[2], p_knn[2];
+  DevBuf<int32_t> p_cI[2], p_knn[2], p_cnt[2];
+  DevBuf<uint2> p_ent[2];          // the batch's entry lists: listed by the coarse stage, read by the scan
+  bool p_have_ent[2] = {false, false};
   DevBuf<double> pair_score;
   DevBuf<long long> best_slot;
   DevBuf<int> status;
@@ -396,6 +399,8 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
   ASL_TRY(L->p_cD[par].reserve((size_t)nq * nprobe));
   ASL_TRY(L->p_cI[par].reserve((size_t)nq * nprobe));
   ASL_TRY(L->p_knn[par].reserve((size_t)nq * k));
+  ASL_TRY(L->p_ent[par].reserve((size_t)nq * 64));
+  ASL_TRY(L->p_cnt[par].reserve((size_t)nq));
   ASL_TRY(L->pair_score.reserve((size_t)nq * k));
   ASL_TRY(L->best_slot.reserve((size_t)nq));
   pp.parity ^= 1;
@@ -415,16 +420,19 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
     if (pp.scan_recorded[par]) HIP_TRY(hipStreamWaitEvent(pp.A, pp.ev_scan[par], 0));
     ASL_TRY(encode_device(Q.dev.mz, Q.dev.intensity, Q.dev.offsets, nq, P->min_bound, P->bin_size,
                           d, P->hash_seed, 1, L->p_qvec[par].p));
-    ASL_TRY(index_coarse_device(idx, nq, L->p_qvec[par].p, nprobe, L->p_cD[par].p, L->p_cI[par].p));
+    ASL_TRY(index_coarse_device(idx, nq, L->p_qvec[par].p, nprobe, L->p_cD[par].p, L->p_cI[par].p,
+                                L->p_ent[par].p, L->p_cnt[par].p, &L->p_have_ent[par]));
     HIP_TRY(hipEventRecord(pp.ev_front[par], pp.A));
   }
   {
     StreamScope on_b(pp.B);
     HIP_TRY(hipStreamWaitEvent(pp.B, pp.ev_front[par], 0));
     if (pp.resc_recorded[par]) HIP_TRY(hipStreamWaitEvent(pp.B, pp.ev_resc[par], 0));
+    // (the entry lists of the coarse stage, when it made them: the scan does not list the rows again)
     ASL_TRY(index_search_device(idx, nq, L->p_qvec[par].p, k, nprobe, nullptr, knn_I,
                                 L->p_knn[par].p, L->p_cD[par].p, L->p_cI[par].p,
-                                knn_I == nullptr));
+                                knn_I == nullptr, nullptr, L->p_have_ent[par] ? L->p_ent[par].p : nullptr,
+                                L->p_have_ent[par] ? L->p_cnt[par].p : nullptr));
     HIP_TRY(hipEventRecord(pp.ev_scan[par], pp.B));
     pp.scan_recorded[par] = true;
   }

@@ -26,7 +26,8 @@ int index_dim(const asl_index *ix);
 int index_nprobe(const asl_index *ix, int nprobe);
 int index_prepare(asl_index *ix);
 int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, float *out_D,
-                        int32_t *out_I);
+                        int32_t *out_I, uint2 *ent_out = nullptr, int32_t *cnt_out = nullptr,
+                        bool *have_ent = nullptr);
 int index_shard_world(const asl_index *ix, int *rank);
 int index_agreed_keys(const asl_index *ix, int k, int np, int world);
 void index_set_agreed_keys(asl_index *ix, int k, int np, int world, int v);
