@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the open-modification search hot path on MI355X.
 
-One "step" = one batch of 16 384 same-charge query spectra through the whole hot
+One "step" = one batch of 32 768 same-charge query spectra through the whole hot
 path, device resident: encode (feature hashing) -> IVF-PQ retrieve (coarse GEMM on
 MFMA, ADC scan, top-1024) -> precursor-window post-filter -> (shifted) dot-product
 best match. Workload = BASELINE.json configs[2]: a MassIVE-KB-scale synthetic
@@ -12,7 +12,7 @@ nlist=4096, nprobe=128, k=1024, open window +-500 Da, fragment tolerance 0.02 Da
   (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 With N>1 the IVF lists are sharded over the ranks (ann_solo_amd/distributed.py) and
-every rank contributes its own 16 384-query slice per step (weak scaling).
+every rank contributes its own 32 768-query slice per step (weak scaling).
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how roofline.achieved
 (algorithmic bytes of the PQ scan / HIP-event kernel time) and cpu_baseline (the
 oracle on the host cores, bounded sample) are defined.
@@ -43,7 +43,9 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--library-size', type=int, default=2_100_000)
-    ap.add_argument('--batch', type=int, default=16384)
+    ap.add_argument('--batch', type=int, default=32768,
+                    help='query spectra per step and GPU (32 768: the throughput no longer grows beyond it -- '
+                         '16 384: 2.19 M, 32 768: 2.29 M, 65 536: 2.29 M spectra/s, profiles/r05_batch_size.txt)')
     ap.add_argument('--nlist', type=int, default=4096)
     ap.add_argument('--nprobe', type=int, default=128)
     ap.add_argument('--k', type=int, default=1024)
@@ -67,10 +69,10 @@ def main():
                     help='run the stages of consecutive batches strictly one after the other '
                          '(default: two-stream software pipeline, asl_set_pipeline)')
     ap.add_argument('--workload', default='batch', choices=['batch', 'cascade'],
-                    help="'batch' (default): BASELINE configs[2]/[3], one 16 384-query open-search "
+                    help="'batch' (default): BASELINE configs[2]/[3], one 32 768-query open-search "
                          "batch per step; 'cascade': configs[4], standard search -> FDR gate -> "
                          "open search of the unidentified remainder over the same library")
-    ap.add_argument('--cascade-batches', type=int, default=4,
+    ap.add_argument('--cascade-batches', type=int, default=2,
                     help='cascade workload: query batches per GPU in one pass')
     ap.add_argument('--accept-cosine', type=float, default=0.7,
                     help='cascade workload: stand-in for the mokapot/FDR gate between the levels '
@@ -633,7 +635,7 @@ def main():
 
 
     # ---- the reference's own default geometry (config.py:202-211: num_list 256, num_probe 128, IVF-Flat,
-    # k 1024, batch 16 384): configs[1] (an iPRG2012-sized library, ~9 k spectra) and the 2.1 M library
+    # k 1024): configs[1] (an iPRG2012-sized library, ~9 k spectra) and the 2.1 M library
     ref_geometry = None
     if world == 1 and rank == 0 and not args.no_reference_geometry and args.index == 'ivfpq' and not args.refine_k:
         from argparse import Namespace
@@ -738,6 +740,7 @@ def main():
         # post-path step of the same batch, outside the timed region: the 33 SSM similarity
         # features of every best match (utils._compute_ssm_features), one kernel launch
         from ann_solo_amd.spectrum_similarity import ssm_features
+        feats = ssm_features(q, part.spectra, res.best_row, res.pm_pairs, res.pm_count)      # (first call: code load, buffers)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         feats = ssm_features(q, part.spectra, res.best_row, res.pm_pairs, res.pm_count)
@@ -856,7 +859,7 @@ def cascade_pass(args, world, rank, dev, backend, sl, lib, aux, charge, cfg, par
     reference-shaped SSM records are materialised after the timed pass and reported). With N > 1 the
     library's IVF lists are sharded over the ranks (``enable_sharding``): level 1 is data-parallel
     over the queries, level 2 is the list-sharded search. One "step" = one pass over
-    ``cascade_batches`` x 16 384 queries per GPU. Returns the JSON object (rank 0; None elsewhere);
+    ``cascade_batches`` x ``batch`` queries per GPU. Returns the JSON object (rank 0; None elsewhere);
     ``parity_seconds`` > 0 adds ``parity_vs_oracle``: a sample of the pass's queries through the
     oracle's two levels (``cascade_parity``)."""
     import numpy as np
@@ -1207,8 +1210,8 @@ def _lib_handle():
     return _lib.lib()
 
 
-PMC_TRAFFIC_FILE = 'profiles/r05_pmc_traffic.json'
-PMC_TRAFFIC_FILE_FLAT = 'profiles/r05_ivfflat_np112_pmc_traffic.json'     # IVF-Flat (float32 postings, the default storage), nprobe 112
+PMC_TRAFFIC_FILE = 'profiles/r05b_pmc_traffic.json'
+PMC_TRAFFIC_FILE_FLAT = 'profiles/r05b_ivfflat_np112_pmc_traffic.json'     # IVF-Flat (float32 postings, the default storage), nprobe 112
 
 
 def pmc_traffic(args, world):
@@ -1218,7 +1221,7 @@ def pmc_traffic(args, world):
     measured by this run (counters cannot be collected from inside the process); the JSON says so
     in `traffic_source`. Only for the exact default workload; else (None, reason)."""
     default = (world == 1 and args.library_size == 2_100_000 and args.nlist == 4096 and
-               args.nprobe == 128 and args.k == 1024 and args.batch == 16384 and
+               args.nprobe == 128 and args.k == 1024 and args.batch == 32768 and
                args.index == 'ivfpq' and args.scan_variant == 0 and args.niter == 25)
     path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
     if not default:
@@ -1239,7 +1242,7 @@ def flat_pmc_traffic(args, nprobe):
     """Fabric bytes per launch of the postings scan from the committed PMC pass (same rule as
     ``pmc_traffic``: only for the workload the pass was taken on)."""
     ok = (args.library_size == 2_100_000 and args.nlist == 4096 and nprobe == 112 and
-          args.k == 1024 and args.batch == 16384 and args.niter == 25)
+          args.k == 1024 and args.batch == 32768 and args.niter == 25)
     path = os.path.join(ROOT, PMC_TRAFFIC_FILE_FLAT)
     if not ok or not os.path.exists(path):
         return None, 'no committed PMC pass for this workload'

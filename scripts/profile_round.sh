@@ -44,7 +44,7 @@ out = {}
 for k, v in vals.items():
     if 'FETCH_SIZE' in v:
         out = {'kernel': k.replace('void asl::', ''),
-               'workload': 'bench.py ' + (' '.join(sys.argv[4:]) or 'defaults (2.1M library, nlist 4096, nprobe 128, k 1024, 16384 queries)'),
+               'workload': 'bench.py ' + (' '.join(sys.argv[4:]) or 'defaults (2.1M library, nlist 4096, nprobe 128, k 1024, 32768 queries)'),
                'FETCH_SIZE_KiB_per_dispatch': v['FETCH_SIZE'],
                'WRITE_SIZE_KiB_per_dispatch': v.get('WRITE_SIZE'),
                'correction': 'x2 on FETCH_SIZE (gfx950, wide coalesced 16-B/lane stream; MI355X_MICROARCH.md HBM section); WRITE_SIZE uncorrected',
