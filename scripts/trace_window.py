@@ -1,6 +1,6 @@
 import csv, sys, collections
 rows=list(csv.DictReader(open(sys.argv[1])))
-scan=[r for r in rows if "pq_scan_v3" in r["Kernel_Name"] and int(r["Grid_Size_X"])//max(int(r["Workgroup_Size_X"]),1)==16384]
+scan=[r for r in rows if "pq_scan_v3" in r["Kernel_Name"] and int(r["Grid_Size_X"])//max(int(r["Workgroup_Size_X"]),1)==32768]
 t0=int(scan[-20]["Start_Timestamp"]); t1=int(scan[-1]["End_Timestamp"])
 g=collections.defaultdict(list)
 for r in rows:
