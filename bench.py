@@ -429,6 +429,31 @@ def main():
     sl.synchronize()
     L.asl_profile_enable(0)
     scanned = L.asl_profile_scanned_vectors()
+    # the same step at the reference's own default --batch_size (config.py:195-198: 16 384): the
+    # first 16 384 queries of every batch of the ring, twice the steps (N = 1 only; not `value`)
+    ref_batch = None
+    REF_BATCH = 16384
+    if world == 1 and pipelined and args.batch > REF_BATCH:
+        halves = [b.select(torch.arange(REF_BATCH, device=dev)).contiguous() for b in q_ring]
+        pos = [0]
+
+        def half_step():
+            b = halves[pos[0] % len(halves)]
+            pos[0] += 1
+            return sl._search_batch(b, charge, 'open', device_out=True)
+        for _ in range(max(args.warmup, 2)):
+            half_step()
+        sl.synchronize()
+        n_half = 2 * args.steps
+        el_half, _ = timed(half_step, n_half)
+        sl.synchronize()
+        ref_batch = {'batch': REF_BATCH, 'value': round(REF_BATCH * n_half / el_half, 2), 'unit': 'query spectra/s',
+                     'ms_per_step': round(el_half / n_half * 1e3, 3), 'steps': n_half,
+                     'note': 'the reference\'s default --batch_size (src/ann_solo/config.py:195-198); a 16 384-query '
+                             'launch is 21.3 rounds of the chip\'s 768 resident workgroups: the partial last round and '
+                             'the spread of the workgroups\' durations cost ~3 % of the scan, the rescoring launches\' '
+                             'tails as much again (profiles/r05_batch_size.txt)'}
+        del halves
     sl.set_pipeline(False)
     # batch 0 once more, synchronously: the result the parity / post-path legs below refer to
     q_keep, q_ring[:] = q_ring[:], [q]
@@ -781,6 +806,7 @@ def main():
                                    f'k={args.k}{f" (exact re-rank of {args.refine_k})" if args.refine_k else ""}, open +-{args.open_da:g} Da, shifted dot, '
                                    f'fragment tol 0.02 Da',
                        'library_size': args.library_size, 'batch_per_gpu': args.batch,
+                       'reference_default_batch_size': 16384,
                        'distinct_batches_in_the_timed_loop': ring,
                        'global_batch': world * args.batch, 'index': args.index,
                        'nlist': args.nlist, 'nprobe': args.nprobe, 'k': args.k,
@@ -819,6 +845,7 @@ def main():
             'stages_ms_per_step': {k: round(v['ms_total'] / args.steps, 3) for k, v in stages.items()},
             'stages_gbs': stages_gbs,
             'post_path': {'ssm_features_ms_per_batch': round(feat_ms, 3), 'ssms': n_ssm},
+            'at_reference_batch_size': ref_batch,
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
