@@ -349,20 +349,20 @@ struct CandView {
 constexpr int RS_BS_GROUP = 16;      // queries per workgroup of the binary-search kernel
 __global__ __launch_bounds__(64 * RS_WAVES) void rescore_score_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, double tol, int allow_shift,
-    double *__restrict__ pair_score, const int *__restrict__ q_defer, int *status) {
+    double *__restrict__ pair_score, const int *__restrict__ q_defer, int *status, int group) {
   __shared__ QueryLds Q;
   __shared__ WaveLds W[RS_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // A workgroup takes RS_BS_GROUP consecutive queries: as the third launch of the rescoring the
+  // A workgroup takes `group` (RS_BS_GROUP; 1 for small batches) consecutive queries: as the third launch of the rescoring the
   // kernel normally finds nothing marked -- one coalesced read of the group's flags says so (a
   // workgroup per query, 46 KB of LDS each, placed only to return, cost 0.02 ms of a step); when
   // every query is marked (tol <= 0, long queries) nq / 16 workgroups still fill the chip.
   // deferred mode: only the pairs the fast kernels marked RS_DEFER_BS (-3)
   __shared__ unsigned long long s_todo;
-  const int q0 = blockIdx.x * RS_BS_GROUP;
+  const int q0 = blockIdx.x * group;
   if (wave == 0) {
     const int qt = q0 + lane;
-    const unsigned long long m = __ballot(lane < RS_BS_GROUP && qt < Qs.n && (!q_defer || (q_defer[qt] & 2)));
+    const unsigned long long m = __ballot(lane < group && qt < Qs.n && (!q_defer || (q_defer[qt] & 2)));
     if (lane == 0) s_todo = m;
   }
   __syncthreads();
@@ -1299,9 +1299,10 @@ __device__ __forceinline__ void matches_one(int q, int lane, QL &Qw, WL &Ww, int
       pm_pairs[(size_t)q * pm_stride * 2 + t] = 0u;
 }
 
-// SMALL: a wave per query. Full size: a small grid whose waves walk the flags of 64 queries at a
-// time and do the marked ones (normally none: thousands of 44 KB workgroups that return at once
-// took 0.04 ms of a step just to be placed).
+// SMALL: a wave per query. Full size: a wave per RS_MF_GROUP queries, which reads their flags at once
+// and does the marked ones (normally none: a 44 KB workgroup per four queries -- one per 64 now --, placed only to
+// return, took 0.04 ms of a step).
+constexpr int RS_MF_GROUP = 16;
 template <bool SMALL>
 __global__ __launch_bounds__(64 * RS_WAVES) void rescore_matches_kernel(
     DevPeaks Qs, DevPeaks L, CandView cv, int nq, const long long *__restrict__ best_slot,
@@ -1322,16 +1323,16 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_matches_kernel(
                       pm_pairs, pm_stride, best_row, status, m_defer);
     return;
   }
-  const int nwaves = gridDim.x * RS_WAVES;
-  for (int base = (blockIdx.x * RS_WAVES + wave) * 64; base < nq; base += nwaves * 64) {
-    unsigned long long todo = __ballot(base + lane < nq && m_defer[base + lane] != 0);
-    while (todo) {          // wave-uniform
-      const int l = __builtin_ctzll(todo);
-      todo &= todo - 1ull;
-      matches_one<false>(base + l, lane, Q[wave], W[wave], &s_cnt[wave], Qs, L, cv, best_slot, tol, allow_shift,
-                         pm_count, pm_pairs, pm_stride, best_row, status, m_defer);
-      wave_sync();
-    }
+  // a wave takes RS_MF_GROUP consecutive queries: one read of their flags; if every query is marked
+  // (spectra of more than 128 peaks) the grid still holds nq / 16 workgroups
+  const int base = (blockIdx.x * RS_WAVES + wave) * RS_MF_GROUP;
+  unsigned long long todo = __ballot(lane < RS_MF_GROUP && base + lane < nq && m_defer[base + lane] != 0);
+  while (todo) {          // wave-uniform
+    const int l = __builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    matches_one<false>(base + l, lane, Q[wave], W[wave], &s_cnt[wave], Qs, L, cv, best_slot, tol, allow_shift,
+                       pm_count, pm_pairs, pm_stride, best_row, status, m_defer);
+    wave_sync();
   }
 }
 
@@ -1374,9 +1375,12 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
       hipLaunchKernelGGL(kern, dim3(nq, std::max(ysplit, RS_DEF_Y)), dim3(64 * RS_WAVES), 0, stream(), Q,
                          L, cv, tol, allow_shift, pair_score, q_defer.p, status);
       ASL_CHECK_LAUNCH();
-      hipLaunchKernelGGL(rescore_score_kernel, dim3((unsigned)cdiv(nq, RS_BS_GROUP), ysplit), dim3(64 * RS_WAVES), 0,
+      // (small batches keep a workgroup per query: when every query is marked -- tol <= 0, queries
+      // of more than 100 peaks -- they need all the parallelism there is)
+      const int bs_group = nq >= 4096 ? RS_BS_GROUP : 1;
+      hipLaunchKernelGGL(rescore_score_kernel, dim3((unsigned)cdiv(nq, bs_group), ysplit), dim3(64 * RS_WAVES), 0,
                          stream(), Q, L, cv, tol, allow_shift, pair_score,
-                         (const int *)q_defer.p, status);
+                         (const int *)q_defer.p, status, bs_group);
     }
     ASL_CHECK_LAUNCH();
     hipLaunchKernelGGL(rescore_argmax_kernel, dim3(nq), dim3(64), 0, stream(), cv, nq,
@@ -1391,7 +1395,7 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
                        dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, nq, best_slot, tol,
                        allow_shift, pm_count, pm_pairs, pm_stride, best_row, status, m_defer.p);
     ASL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(rescore_matches_kernel<false>, dim3((unsigned)std::min<int64_t>(cdiv(nq, 64 * RS_WAVES), 256)),
+    hipLaunchKernelGGL(rescore_matches_kernel<false>, dim3((unsigned)cdiv(nq, RS_MF_GROUP * RS_WAVES)),
                        dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, nq, best_slot, tol,
                        allow_shift, pm_count, pm_pairs, pm_stride, best_row, status, m_defer.p);
     ASL_CHECK_LAUNCH();
