@@ -9,7 +9,9 @@ library (2.1 M processed spectra in one precursor-charge partition), IVF-PQ m=32
 nlist=4096, nprobe=128, k=1024, open window +-500 Da, fragment tolerance 0.02 Da.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  (N>1: the same line -- without a launcher's WORLD_SIZE in the environment the process starts the N
+  ranks itself as children of `python -m torch.distributed.run`; launched BY torch.distributed.run,
+  as the driver does, every rank runs main() directly)
 
 With N>1 the IVF lists are sharded over the ranks (ann_solo_amd/distributed.py) and
 every rank contributes its own 32 768-query slice per step (weak scaling).
@@ -115,11 +117,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks. Nothing here
+        # has touched the GPU (torch is not even imported yet) and the process is not replaced:
+        # the ranks are CHILDREN, rank 0's JSON line passes through, their exit code is ours.
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('--gpus N > 1 must be launched with torch.distributed.run '
-                     '(one process per GPU)')
         args.gpus = world
+    if os.environ.get('ASL_BENCH_LAUNCH_CHECK') == '1':
+        sys.exit(launch_check(args, world, rank))
 
     import numpy as np
     import torch
@@ -1138,6 +1144,57 @@ def cascade_parity(args, sl, part, charge, cfg, q, ids, thr, seconds, ctx, nprob
             'cosine_max_abs_diff': float(dmax),
             'all_equal': bool(set(want) == set(got) and rows_equal == len(want) and dmax <= 1e-9),
             'seconds': round(time.time() - t0, 1)}
+
+
+def self_launch(n):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a
+    child process (the launch line the driver itself uses for N > 1) on a free local port and return
+    its exit code. Called before any import of torch: the launcher never initialises a GPU."""
+    import socket
+    import subprocess
+    port = os.environ.get('MASTER_PORT')
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(('127.0.0.1', 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this pool
+    env.pop('MASTER_PORT', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+    log(f'[bench] --gpus {n} without a launcher: starting {n} ranks as child processes (port {port})')
+    child = subprocess.Popen(cmd, env=env)
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        try:
+            return child.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            child.kill()
+            return child.wait()
+
+
+def launch_check(args, world, rank):
+    """ASL_BENCH_LAUNCH_CHECK=1: the ranks only prove that they were started and can talk (rendezvous,
+    one all-reduce over gloo on host tensors, no GPU, no library); rank 0 prints one JSON line. What the
+    CPU-box test of the launcher runs (tests/test_cabi_and_host.py)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if world > 1:
+        dist.init_process_group('gloo')
+        x = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(x)
+        total = int(x[0])
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        total = 1
+    if rank == 0:
+        print(json.dumps({'launch_check': True, 'n_gpus': world, 'rank_sum': total,
+                          'steps': args.steps, 'warmup': args.warmup}), flush=True)
+    return 0 if total == world * (world + 1) // 2 else 19
 
 
 def preflight(args, world, rank, dev, backend):

@@ -294,3 +294,38 @@ def test_measurement_scripts_and_bench_compile():
         compile(open(f).read(), f, 'exec')
     for f in sorted(glob.glob(os.path.join(root, 'scripts', '*.sh'))):
         assert subprocess.run(['bash', '-n', f]).returncode == 0, f
+
+
+@pytest.mark.parametrize('n', [2, 3])
+def test_bench_starts_its_own_ranks(n):
+    """`python bench.py --gpus N` WITHOUT torch.distributed.run (no WORLD_SIZE in the environment): the
+    process starts the N ranks itself as child processes, relays rank 0's one JSON line and leaves
+    with the children's exit code. ASL_BENCH_LAUNCH_CHECK=1 makes the ranks stop after rendezvous + one
+    all-reduce (gloo, host tensors): a CPU box has no GPU for the rest."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['ASL_BENCH_LAUNCH_CHECK'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '3',
+                          '--warmup', '1'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec == {'launch_check': True, 'n_gpus': n, 'rank_sum': n * (n + 1) // 2, 'steps': 3, 'warmup': 1}
+
+
+def test_bench_passes_a_failing_rank_on():
+    """A rank that fails makes the self-launched job fail (exit code != 0), not hang or print a line."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    # no launch check: every rank reaches `bench.py needs an MI355X` on this CPU box and exits 1
+    if torch.cuda.is_available():
+        pytest.skip('CPU-box test')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]

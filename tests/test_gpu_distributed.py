@@ -70,6 +70,24 @@ def test_two_rank_sharded_bench_path(degree, index, extra):
         assert d['config']['parallelism'] == 'replicas x2' and d['alt_layouts'] is None
 
 
+def test_plain_bench_command_starts_two_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher in front: bench.py starts the two ranks itself
+    (children of torch.distributed.run; the parent never touches the GPU) and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['ASL_BENCH_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'),
+           '--gpus', '2', '--steps', '1', '--warmup', '1', '--library-size', '60000', '--nlist',
+           '256', '--niter', '4', '--batch', '1024', '--recall-queries', '64']
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1, out.stderr[-2000:]
+    d = json.loads(line[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2048
+    assert d['shard_check']['sharded_equals_unsharded'] is True and d['value'] > 0
+
+
 @pytest.mark.parametrize('index,extra', [
     ('ivfpq', []), ('ivfflat', ['--head-keys', '600', '--shard-keys', '768', '--extras-per-query', '512']),
     ('ivfpq', ['--head-keys', '700'])])

@@ -6,11 +6,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _spectra(rng, n, sizes, z=2, dense=False):
+def _spectra(rng, n, sizes, z=2, dense=False, exact=False):
     from ann_solo_amd.packed import PackedSpectra
     offs, mzs, its, chg, pmz = [0], [], [], [], []
     for s in range(n):
-        k = int(rng.choice(sizes))
+        k = int(sizes[s]) if exact else int(rng.choice(sizes))
         if dense:      # many peaks inside a narrow window: long match lists at a wide tolerance
             mz = np.sort(rng.uniform(400, 1000, k)).astype(np.float32)
         else:
@@ -62,6 +62,43 @@ def test_deferred_rescoring_cases_match_oracle(O, tol, shift):
     n_match = _check(O, q, lib, np.concatenate(cands), np.array(off, np.int32), tol, shift)
     if tol == 0.5:
         assert n_match > 64          # the long-match-list path was exercised
+
+
+def _grouped_case(O, nq, marked, tol, shift, seed):
+    """nq queries of 30 peaks except the MARKED ones (101 .. 200 peaks: left to the binary-search
+    kernel; beyond 128 peaks also to the full-size matches kernel), 3 .. 8 candidates each."""
+    rng = np.random.default_rng(seed)
+    lib = _spectra(rng, 300, [20, 50, 64, 65, 90, 129, 150], dense=tol > 0.1)
+    sizes = np.full(nq, 30)
+    marked = np.asarray(sorted(set(int(m) for m in marked if 0 <= m < nq)), np.int64)
+    sizes[marked] = rng.choice([101, 128, 129, 200], len(marked))
+    q = _spectra(rng, nq, sizes, dense=tol > 0.1, exact=True)
+    n_c = rng.integers(3, 9, nq)
+    off = np.concatenate([[0], np.cumsum(n_c)]).astype(np.int32)
+    cand = rng.integers(0, lib.n, int(off[-1])).astype(np.int64)
+    _check(O, q, lib, cand, off, tol, shift)
+
+
+@pytest.mark.parametrize('nq', [4095, 4096, 4097])
+def test_grouped_deferred_rescoring_every_query_marked(O, nq):
+    """From 4 096 queries on the binary-search kernel takes RS_BS_GROUP = 16 queries per workgroup
+    and the full-size matches kernel 16 per wave (``rescore_device``, csrc/rescore.hip). tol = 0
+    marks EVERY query for the binary-search kernel; every 3rd query has more than 100 peaks
+    (half of those more than 128: full-size matches). Around the switch: 4 095 (one workgroup
+    per query), 4 096 and 4 097 (grouped; a last group of one). Against ``SpectrumMatch.cpp:8-133``
+    as the oracle restates it, query by query."""
+    _grouped_case(O, nq, range(0, nq, 3), 0.0, True, 900 + nq)
+
+
+@pytest.mark.parametrize('tol,shift', [(0.02, True), (0.5, False)])
+def test_grouped_deferred_rescoring_sparse_marks(O, tol, shift):
+    """1 query in 50 marked, plus marks at the group boundaries (15 / 16 / 17, 31 / 32, the first
+    and the last query of the batch, the last -- partial -- group of 4 100 = 256 groups + 4 queries),
+    two adjacent groups fully marked and one group with its last query alone."""
+    nq = 4100
+    marked = list(range(7, nq, 50)) + [0, 15, 16, 17, 31, 32, 63, 64, 4079, 4080, 4095, 4096, 4097, 4099] + \
+        list(range(1024, 1056)) + [2063]
+    _grouped_case(O, nq, marked, tol, shift, 77)
 
 
 @pytest.mark.parametrize('z', [3, 4, 5, 7, 31])
