@@ -39,6 +39,15 @@ int ensure_device();  // ASL_OK if a HIP device is usable
 bool is_device_ptr(const void *p);
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// An AQL dispatch packet holds a dimension's grid size in WORK-ITEMS as a uint32: a launch of 2^32
+// or more work-items along x runs cut short, with no error (found at 134 M PQ codes: 4.3e9
+// per-byte threads -- profiles/r06_pq_beyond_llc_notes.txt). Launches whose size grows with the
+// library take their blocks from this 2-D grid and read their index through block_linear().
+inline dim3 grid_2d(int64_t blocks) {
+  const int64_t gx = std::min<int64_t>(std::max<int64_t>(blocks, 1), 1 << 20);
+  return dim3((unsigned)gx, (unsigned)cdiv(std::max<int64_t>(blocks, 1), gx));
+}
+__device__ __forceinline__ int64_t block_linear() { return (int64_t)blockIdx.y * gridDim.x + blockIdx.x; }
 
 // Grow-only device buffer.
 template <class T>

@@ -22,7 +22,7 @@ namespace asl {
 // grid of 2^-22): such an index keeps float postings
 __global__ void count_nnz_kernel(const float *__restrict__ vecs, int d, int64_t n,
                                  int32_t *__restrict__ nnz, int32_t *__restrict__ nnz_max) {
-  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t v = block_linear() * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (v >= n) return;
   int c = 0;
@@ -44,13 +44,13 @@ __global__ void count_nnz_kernel(const float *__restrict__ vecs, int d, int64_t 
 // multiple of 2^-22 (ties to even; the largest is 1 - 2^-22); anything else is stored as given
 // (and keeps the whole index on float postings). The oracle's orc_quantize_fx22 is the same rule.
 __global__ void quantize_fx22_kernel(float *__restrict__ x, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = block_linear() * blockDim.x + threadIdx.x;
   if (i < n) x[i] = fx22_round(x[i]);
 }
 
 int quantize_fx22(float *x, int64_t n) {
   if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(quantize_fx22_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream(), x, n);
+  hipLaunchKernelGGL(quantize_fx22_kernel, grid_2d(cdiv(n, 256)), dim3(256), 0, stream(), x, n);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -58,7 +58,7 @@ int quantize_fx22(float *x, int64_t n) {
 int count_nnz(const float *vecs, int d, int64_t n, int32_t *nnz, int32_t *nnz_max_dev) {
   HIP_TRY(hipMemsetAsync(nnz_max_dev, 0, 2 * sizeof(int32_t), stream()));
   if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(count_nnz_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
+  hipLaunchKernelGGL(count_nnz_kernel, grid_2d(cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
                      n, nnz, nnz_max_dev);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
@@ -603,7 +603,7 @@ __global__ void inv_count_kernel(const float *__restrict__ vecs, int d,
                                  const int32_t *__restrict__ order,
                                  const int32_t *__restrict__ pos_blk, int64_t n,
                                  uint32_t *__restrict__ cnt) {
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t i = block_linear() * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
   const float *row = vecs + (size_t)order[i] * d;
@@ -619,7 +619,7 @@ __global__ void inv_fill_kernel(const float *__restrict__ vecs, int d,
                                 const uint32_t *__restrict__ blk_base,
                                 const uint32_t *__restrict__ seg_tab,
                                 uint32_t *__restrict__ cursor, char *__restrict__ seg_bytes) {
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t i = block_linear() * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
   const float *row = vecs + (size_t)order[i] * d;
@@ -725,7 +725,7 @@ int inv_order(int64_t nblocks, int d, const uint32_t *blk_base, const uint32_t *
 int inv_count(const float *vecs, int d, const int32_t *order, const int32_t *pos_blk, int64_t n,
               uint32_t *cnt) {
   if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(inv_count_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
+  hipLaunchKernelGGL(inv_count_kernel, grid_2d(cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
                      order, pos_blk, n, cnt);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
@@ -735,7 +735,7 @@ int inv_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_
              const uint16_t *pos_loc, int64_t n, const uint32_t *blk_base,
              const uint32_t *seg_tab, uint32_t *cursor, char *seg_bytes) {
   if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(inv_fill_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
+  hipLaunchKernelGGL(inv_fill_kernel, grid_2d(cdiv(n, 4)), dim3(256), 0, stream(), vecs, d,
                      order, pos_blk, pos_loc, n, blk_base, seg_tab, cursor, seg_bytes);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
@@ -798,7 +798,7 @@ __global__ void fx_fill_kernel(const float *__restrict__ vecs, int d,
                                const uint16_t *__restrict__ pos_loc, int64_t n,
                                const uint32_t *__restrict__ seg_line,
                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ words) {
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t i = block_linear() * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
   const float *row = vecs + (size_t)order[i] * d;
@@ -843,7 +843,7 @@ int fx_fill(const float *vecs, int d, const int32_t *order, const int32_t *pos_b
             const uint16_t *pos_loc, int64_t n, const uint32_t *seg_line, uint32_t *cursor,
             uint32_t *words) {
   if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(fx_fill_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), vecs, d, order,
+  hipLaunchKernelGGL(fx_fill_kernel, grid_2d(cdiv(n, 4)), dim3(256), 0, stream(), vecs, d, order,
                      pos_blk, pos_loc, n, seg_line, cursor, words);
   ASL_CHECK_LAUNCH();
   return ASL_OK;

@@ -520,8 +520,9 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   // then be null -- only the layout-specific scans read their queries in that form, and a row
   // whose count is negative (more than 64 non-zeros) is searched as an all-zero query: the
   // caller watches the producer's n_over
-  if (pre_ent && (!pre_cnt || !pre_I || ix->kind == ASL_INDEX_FLAT))
-    return fail(ASL_ERR_STATE, "entry-list search: needs the counts, the caller's probe lists and an IVF index");
+  if (pre_ent && (!pre_cnt || !pre_I || (!xq && !pre_D) || ix->kind == ASL_INDEX_FLAT))
+    return fail(ASL_ERR_STATE, "entry-list search: needs the counts, the caller's probe lists (with their scores when "
+                               "no dense rows are given) and an IVF index");
   // (with dense rows given as well, entry lists are a hint: a scan that does not read them ignores them)
   if (!xq && !pre_ent) return fail(ASL_ERR_INVALID, "search: null queries");
   // gate: a device-side count -- only the first *gate rows are searched (layout-specific scans only)
@@ -786,6 +787,7 @@ int asl_index_set_flat_storage(asl_index_t *ix, int32_t mode) {
   if (ix->ntotal > 0 && mode != ix->flat_storage)
     return fail(ASL_ERR_STATE, "set_flat_storage: set before add() (stored components are rounded as they arrive)");
   ix->flat_storage = mode;
+  ix->agreed_val = -1;      // what asl_index_supports_keys answers may change: the ranks agree again
   return ASL_OK;
 }
 
@@ -806,6 +808,7 @@ int asl_index_set_scan_variant(asl_index_t *ix, int32_t variant) {
   if (!ix || variant < 0 || variant > 1)
     return fail(ASL_ERR_INVALID, "set_scan_variant: 0 (layout-specific scan) or 1 (generic kernels)");
   ix->scan_variant = variant;
+  ix->agreed_val = -1;      // asl_index_supports_keys depends on the variant: the ranks agree again
   return ASL_OK;
 }
 
@@ -966,6 +969,7 @@ static int index_add_impl(asl_index_t *ix, int64_t n, const float *x, const int3
   ix->n_store += n;
   ix->ntotal += n;
   ix->lists_dirty = true;
+  ix->agreed_val = -1;
   return ASL_OK;
 }
 
@@ -980,6 +984,7 @@ int asl_index_set_refine(asl_index_t *ix, int32_t kprime) {
     ix->refine_rows = true;
   }
   ix->refine_k = kprime;
+  ix->agreed_val = -1;
   return ASL_OK;
 }
 

@@ -377,7 +377,8 @@ int row_argmax(const float *scores, int64_t ld, int rows, int n, int32_t *out) {
 __global__ void gather_rows_f32_kernel(const float *__restrict__ src, int64_t ld_src,
                                        const int64_t *__restrict__ rows, int64_t n, int d,
                                        float *__restrict__ dst, int64_t ld_dst) {
-  const int64_t i = blockIdx.x;
+  const int64_t i = block_linear();
+  if (i >= n) return;
   const int64_t r = rows ? rows[i] : i;
   for (int j = threadIdx.x; j < d; j += blockDim.x)
     dst[i * ld_dst + j] = src[r * ld_src + j];
@@ -385,7 +386,7 @@ __global__ void gather_rows_f32_kernel(const float *__restrict__ src, int64_t ld
 int gather_rows_f32(const float *src, int64_t ld_src, const int64_t *rows, int64_t n, int d,
                     float *dst, int64_t ld_dst) {
   if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((unsigned)n), dim3(256), 0, stream(), src,
+  hipLaunchKernelGGL(gather_rows_f32_kernel, grid_2d(n), dim3(256), 0, stream(), src,
                      ld_src, rows, n, d, dst, ld_dst);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
@@ -394,7 +395,7 @@ int gather_rows_f32(const float *src, int64_t ld_src, const int64_t *rows, int64
 __global__ void gather_rows_u8_kernel(const uint8_t *__restrict__ src,
                                       const int32_t *__restrict__ rows, int64_t n, int m,
                                       uint8_t *__restrict__ dst) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = block_linear() * blockDim.x + threadIdx.x;
   if (t >= n * m) return;
   const int64_t i = t / m;
   const int j = (int)(t - i * m);
@@ -402,7 +403,7 @@ __global__ void gather_rows_u8_kernel(const uint8_t *__restrict__ src,
 }
 int gather_rows_u8(const uint8_t *src, const int32_t *rows, int64_t n, int m, uint8_t *dst) {
   if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(gather_rows_u8_kernel, dim3((unsigned)cdiv(n * m, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(gather_rows_u8_kernel, grid_2d(cdiv(n * m, 256)), dim3(256), 0,
                      stream(), src, rows, n, m, dst);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256) void l2_assign_kernel(const float *__restrict_
   float *s_cb = reinterpret_cast<float *>(smem);
   for (int i = threadIdx.x; i < ksub * dsub; i += 256) s_cb[i] = cb[i];
   __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = block_linear() * 256 + threadIdx.x;
   if (i >= n) return;
   float bs = INFINITY;
   int best = 0;
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256) void l2_assign_kernel(const float *__restrict_
 int l2_assign(const float *x, int64_t ld, int64_t n, int dsub, const float *cb, int ksub,
               int32_t *assign) {
   if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(l2_assign_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256),
+  hipLaunchKernelGGL(l2_assign_kernel, grid_2d(cdiv(n, 256)), dim3(256),
                      (size_t)ksub * dsub * 4, stream(), x, ld, n, dsub, cb, ksub, assign);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
@@ -515,7 +516,8 @@ int l2_assign(const float *x, int64_t ld, int64_t n, int dsub, const float *cb, 
 __global__ void residual_kernel(const float *__restrict__ x, const int32_t *__restrict__ assign,
                                 const float *__restrict__ centroids, int64_t n, int d,
                                 float *__restrict__ dst) {
-  const int64_t i = blockIdx.x;
+  const int64_t i = block_linear();
+  if (i >= n) return;
   const float *c = centroids + (size_t)assign[i] * d;
   for (int j = threadIdx.x; j < d; j += blockDim.x)
     dst[i * d + j] = x[i * d + j] - c[j];
@@ -523,7 +525,7 @@ __global__ void residual_kernel(const float *__restrict__ x, const int32_t *__re
 int residual(const float *x, const int32_t *assign, const float *centroids, int64_t n, int d,
              float *dst) {
   if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(residual_kernel, dim3((unsigned)n), dim3(256), 0, stream(), x, assign,
+  hipLaunchKernelGGL(residual_kernel, grid_2d(n), dim3(256), 0, stream(), x, assign,
                      centroids, n, d, dst);
   ASL_CHECK_LAUNCH();
   return ASL_OK;

@@ -39,6 +39,23 @@
 namespace asl {
 
 constexpr int V3_CHUNK = 256;   // tile-table entries per chunk
+// Tuning constants of the code stream (scripts/build_variant.sh rewrites them for same-box A/Bs;
+// profiles/r06_pq_beyond_llc_*: measured both where the codes sit in the Infinity Cache and where
+// they come from DRAM).
+constexpr int V3_DEPTH = 1;     // rounds of tiles in flight ahead of the one being scored
+constexpr int V3_NT = 0;        // 1: non-temporal loads of the codes (streamed once per query)
+constexpr int V3_WAVES_PER_SIMD = 6;   // occupancy the 2048-key instantiation is compiled for (3 workgroups per CU)
+
+template <int NT_>
+__device__ __forceinline__ uint4 load_codes16(const uint8_t *p) {
+  if (NT_) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(w));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const uint4 *>(p);
+}
 
 // LDS tile-table entry, 8 bytes: tile index (26 bits: ids are int32, so an index holds fewer
 // than 2^25 + nlist tiles) | nvalid - 1 (6 bits), coarse term. Half the size of TileEnt: 256
@@ -54,7 +71,7 @@ struct TileEnt8 {
 // 157 -- measured 8.28 -> 7.46 ms at the bench config (with ONE round of prefetch: at this
 // occupancy the second prefetch stage only costs registers).
 template <int CAP, int T, int NW, int DEPTH>
-__global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <= 2048 ? 3 : 1))) void pq_scan_v3_kernel(
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? V3_WAVES_PER_SIMD : 4) : (CAP <= 2048 ? 3 : 1))) void pq_scan_v3_kernel(
     const float *__restrict__ xq, int d, const float *__restrict__ codebooks, int dsub,
     const float *__restrict__ coarse_D, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ tile_offsets,
@@ -64,7 +81,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
   // gate: a device-side row count -- workgroups past it leave at once (a launch of fixed size over
   // a list whose length only the device knows: the shard-side rescans of exchange.hip)
   if (gate && (int)blockIdx.x >= *gate) return;
-  static_assert(DEPTH == 1, "one round of prefetch: at 24 waves per CU a second stage only costs registers");
+  static_assert(DEPTH >= 1 && DEPTH <= 3, "rounds of prefetch");
   constexpr int NT = 64 * NW, ROUND_TILES = NW * T, ROUND_VECS = ROUND_TILES * 64;
   using TopK = HistTopK<CAP, ROUND_VECS, NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -123,47 +140,53 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? 6 : 4) : (CAP <=
     __syncthreads();
     const int nent = min(V3_CHUNK, total - c0);
     const int nrounds = (nent + ROUND_TILES - 1) / ROUND_TILES;
-    // Register pipeline, one round deep (the codes of round rr + 1 are in flight while round rr
-    // is scored).
-    uint4 A0[T], B0[T], A1[T], B1[T];
-    TileEnt e0[T], e1[T];
-    auto fetch = [&](int rr, uint4 *a, uint4 *b, TileEnt *e) {
+    // Register pipeline, DEPTH rounds deep (the codes of rounds rr + 1 .. rr + DEPTH are in flight
+    // while round rr is scored). DEPTH + 1 register sets, rotated by full unrolling: every index
+    // below is a compile-time constant.
+    constexpr int NS = DEPTH + 1;
+    uint4 A[NS][T], B[NS][T];
+    TileEnt e[NS][T];
+    auto fetch = [&](int rr, uint4 *a, uint4 *b, TileEnt *en) {
 #pragma unroll
       for (int u = 0; u < T; ++u) {
         // the entry is the same for the whole wave: keep it in scalar registers
         const int i = rr * ROUND_TILES + wave_u * T + u;
         const TileEnt8 t = table[i < nent ? i : 0];
         const uint32_t tn = __builtin_amdgcn_readfirstlane(t.tile_nv);
-        e[u].tile = tn & 0x3ffffffu;
-        e[u].coarse = __builtin_bit_cast(
+        en[u].tile = tn & 0x3ffffffu;
+        en[u].coarse = __builtin_bit_cast(
             float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t.coarse)));
-        e[u].nvalid = i < nent ? (int)(tn >> 26) + 1 : 0;
-        const uint8_t *base = codes_tiled + (size_t)e[u].tile * 2048;
-        a[u] = *reinterpret_cast<const uint4 *>(base + chunkA);
-        b[u] = *reinterpret_cast<const uint4 *>(base + chunkB);
+        en[u].nvalid = i < nent ? (int)(tn >> 26) + 1 : 0;
+        const uint8_t *base = codes_tiled + (size_t)en[u].tile * 2048;
+        a[u] = load_codes16<V3_NT>(base + chunkA);
+        b[u] = load_codes16<V3_NT>(base + chunkB);
       }
     };
-    auto process = [&](const uint4 *a, const uint4 *b, const TileEnt *e) {
+    auto process = [&](const uint4 *a, const uint4 *b, const TileEnt *en) {
       top.begin_round();
       int appended = 0;
 #pragma unroll
       for (int u = 0; u < T; ++u) {
-        if (e[u].nvalid > 0) {  // wave-uniform
-          const float score = e[u].coarse + tile_adc(lut_bytes, a[u], b[u], offA, offB);
-          const bool take = top.offer(lane < e[u].nvalid, score,
-                                      e[u].tile * 64u + (uint32_t)lane);
+        if (en[u].nvalid > 0) {  // wave-uniform
+          const float score = en[u].coarse + tile_adc(lut_bytes, a[u], b[u], offA, offB);
+          const bool take = top.offer(lane < en[u].nvalid, score,
+                                      en[u].tile * 64u + (uint32_t)lane);
           appended += __popcll(__ballot(take));
         }
       }
       top.end_round(appended);
     };
-    fetch(0, A0, B0, e0);
-    for (int rr = 0; rr < nrounds; rr += 2) {
-      if (rr + 1 < nrounds) fetch(rr + 1, A1, B1, e1);
-      process(A0, B0, e0);
-      if (rr + 1 < nrounds) {
-        if (rr + 2 < nrounds) fetch(rr + 2, A0, B0, e0);
-        process(A1, B1, e1);
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s)
+      if (s < nrounds) fetch(s, A[s], B[s], e[s]);
+    for (int rr = 0; rr < nrounds; rr += NS) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int r = rr + s;
+        if (r < nrounds) {          // block-uniform
+          if (r + DEPTH < nrounds) fetch(r + DEPTH, A[(s + DEPTH) % NS], B[(s + DEPTH) % NS], e[(s + DEPTH) % NS]);
+          process(A[s], B[s], e[s]);
+        }
       }
     }
     __syncthreads();
@@ -213,8 +236,8 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
   if (nq <= 0) return ASL_OK;
 #define V3_ARGS xq, nq, d, codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets, \
                 codes_tiled, ids_tiled, k, D, I64, I32, set_mode, ent, ent_cnt, gate
-  if (k + 256 + 512 <= 2048) return launch_v3<2048, 1, 8, 1>(V3_ARGS);
-  return launch_v3<4096, 1, 8, 1>(V3_ARGS);
+  if (k + 256 + 512 <= 2048) return launch_v3<2048, 1, 8, V3_DEPTH>(V3_ARGS);
+  return launch_v3<4096, 1, 8, V3_DEPTH>(V3_ARGS);
 #undef V3_ARGS
 }
 
@@ -223,7 +246,7 @@ __global__ void tile_codes_kernel(const uint8_t *__restrict__ codes, const int32
                                   const int32_t *__restrict__ dst_slot, int64_t n,
                                   uint8_t *__restrict__ codes_tiled,
                                   int32_t *__restrict__ ids_tiled) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = block_linear() * blockDim.x + threadIdx.x;
   if (t >= n * PQT_M) return;
   const int64_t i = t >> 5;
   const int m = (int)(t & 31);
@@ -239,7 +262,7 @@ int tile_codes(const uint8_t *codes, const int32_t *ids, const int32_t *dst_slot
   HIP_TRY(hipMemsetAsync(codes_tiled, 0, (size_t)ntiles * 2048, stream()));
   HIP_TRY(hipMemsetAsync(ids_tiled, 0xff, (size_t)ntiles * 64 * 4, stream()));
   if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(tile_codes_kernel, dim3((unsigned)cdiv(n * PQT_M, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(tile_codes_kernel, grid_2d(cdiv(n * PQT_M, 256)), dim3(256), 0,
                      stream(), codes, ids, dst_slot, n, codes_tiled, ids_tiled);
   ASL_CHECK_LAUNCH();
   return ASL_OK;

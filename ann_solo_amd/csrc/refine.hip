@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void refine_rows_kernel(const float *__restric
                                                           float *__restrict__ r_val,
                                                           uint8_t *__restrict__ r_cnt,
                                                           int *__restrict__ status) {
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t i = block_linear() * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
   const float *row = x + (size_t)i * d;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(RF_NT) void refine_kernel(
 int refine_append_rows(const float *x, int64_t n, int d, int64_t row0, uint16_t *r_dim, float *r_val,
                        uint8_t *r_cnt, int *status) {
   if (n <= 0) return ASL_OK;
-  hipLaunchKernelGGL(refine_rows_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream(), x, n, d,
+  hipLaunchKernelGGL(refine_rows_kernel, grid_2d(cdiv(n, 4)), dim3(256), 0, stream(), x, n, d,
                      row0, r_dim, r_val, r_cnt, status);
   ASL_CHECK_LAUNCH();
   return ASL_OK;

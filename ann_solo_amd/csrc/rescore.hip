@@ -1344,9 +1344,11 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
                    double *pair_score, long long *best_slot, int32_t *best_cand,
                    int32_t *best_row, double *best_score, int32_t *n_valid,
                    int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride, int *status,
-                   const PrecFilter &filter, bool clear_status) {
+                   const PrecFilter &filter, bool clear_status, RescoreScratch *scratch) {
   const int nq = Q.n;
   if (nq == 0) return ASL_OK;
+  if (!scratch) return fail(ASL_ERR_INVALID, "rescore: no scratch (internal)");
+  DevBuf<int> &q_defer = scratch->q_defer, &m_defer = scratch->m_defer;
   CandView cv{rows64, rows32, cand_offsets, stride, filter};
   if (clear_status) HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), stream()));
   {
@@ -1358,7 +1360,6 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
     {
       // hash kernel, then the binary-search kernel on whatever it deferred (its blocks
       // return at once for queries with nothing deferred)
-      static DevBuf<int> &q_defer = *new DevBuf<int>();   // process lifetime (one device per process)
       ASL_TRY(q_defer.reserve((size_t)nq));
       HIP_TRY(hipMemsetAsync(q_defer.p, 0, sizeof(int) * (size_t)nq, stream()));
       const bool shaped = !cand_offsets && filter.meta && filter.wcol && L.charge && L.records &&
@@ -1389,7 +1390,6 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
   }
   {
     ProfScope ps("rescore_matches");
-    static DevBuf<int> &m_defer = *new DevBuf<int>();   // process lifetime (one device per process)
     ASL_TRY(m_defer.reserve((size_t)nq));
     hipLaunchKernelGGL(rescore_matches_kernel<true>, dim3((unsigned)cdiv(nq, RS_WAVES)),
                        dim3(64 * RS_WAVES), 0, stream(), Q, L, cv, nq, best_slot, tol,
@@ -1468,9 +1468,10 @@ extern "C" int asl_rescore_batch(const asl_peaks_t *queries, const asl_peaks_t *
   ASL_TRY(pair_score.reserve((size_t)std::max(total, 1)));
   ASL_TRY(best_slot.reserve(nq));
   ASL_TRY(status.reserve(1));
+  RescoreScratch scratch;      // lives until rescore_check_status below has synchronised
   ASL_TRY(rescore_device(Q.dev, L.dev, rows.d, nullptr, off.d, 0, total, tol, allow_shift, 0,
                          pair_score.p, best_slot.p, o_best.d, nullptr, o_score.d, nullptr,
-                         o_cnt.d, o_pairs.d, pm_stride, status.p));
+                         o_cnt.d, o_pairs.d, pm_stride, status.p, PrecFilter(), true, &scratch));
   ASL_TRY(o_best.finish());
   ASL_TRY(o_score.finish());
   ASL_TRY(o_cnt.finish());

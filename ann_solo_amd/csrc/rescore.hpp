@@ -62,6 +62,15 @@ __device__ __forceinline__ bool filter_pass(const PrecFilter &f, double q_pmz, l
   return precursor_ok(q_pmz, f.lib_pmz[row], f.charge, f.tol, f.mode);
 }
 
+// Per-query flags that pass from one rescoring launch to the next (which queries the flat kernel
+// left to the binary-search kernel, which winners the small matches kernel left to the full-size
+// one). Owned by whoever owns the stream the launches go to -- a library handle (its batches are
+// issued in order on its own stream) or a one-shot call -- so that two handles pipelined on
+// different streams never share, or re-allocate under each other, a buffer in flight.
+struct RescoreScratch {
+  DevBuf<int> q_defer, m_defer;
+};
+
 // Host driver shared by asl_rescore_batch, asl_search_batch and asl_rescore_knn. All pointers
 // are device pointers. pair_score scratch must hold one double per candidate slot.
 int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
@@ -70,7 +79,8 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
                    double *pair_score, long long *best_slot, int32_t *best_cand,
                    int32_t *best_row, double *best_score, int32_t *n_valid,
                    int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride, int *status,
-                   const PrecFilter &filter = PrecFilter(), bool clear_status = true);
+                   const PrecFilter &filter = PrecFilter(), bool clear_status = true,
+                   RescoreScratch *scratch = nullptr);
 int rescore_check_status(const int *status_dev);   // reads the flags back: synchronises
 int rescore_status_error(int status_bits);         // ASL_OK or the error the flags stand for
 

@@ -104,6 +104,7 @@ struct asl_library {
   DevBuf<double> pair_score;
   DevBuf<long long> best_slot;
   DevBuf<int> status;
+  RescoreScratch rs_scratch;       // per-query flags between the rescoring launches of THIS handle's stream
 };
 
 // one wave per spectrum: its row record and its peaks from the three arrays into its slot
@@ -358,7 +359,7 @@ int asl_rescore_knn(asl_library_t *L, const asl_peaks_t *queries, const asl_sear
   ASL_TRY(rescore_device(Q.dev, L->dev, knn.d, nullptr, nullptr, k, (int64_t)nq * k,
                          P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
                          L->best_slot.p, nullptr, o_row.d, o_score.d, o_ncand.d, o_cnt.d,
-                         o_pairs.d, pm_stride, L->status.p, flt));
+                         o_pairs.d, pm_stride, L->status.p, flt, true, &L->rs_scratch));
   ASL_TRY(o_row.finish());
   ASL_TRY(o_score.finish());
   ASL_TRY(o_ncand.finish());
@@ -452,7 +453,7 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
     ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->p_knn[par].p, nullptr, k, (int64_t)nq * k,
                            P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
                            L->best_slot.p, nullptr, best_row, best_score, n_cand, pm_count,
-                           pm_pairs, pm_stride, pp.status, flt, /*clear_status=*/false));
+                           pm_pairs, pm_stride, pp.status, flt, /*clear_status=*/false, &L->rs_scratch));
     HIP_TRY(hipEventRecord(pp.ev_resc[par], sc));
     pp.resc_recorded[par] = true;
   }
@@ -526,7 +527,7 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
     ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->knn.p, nullptr, k, (int64_t)nq * k,
                            P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
                            L->best_slot.p, nullptr, o_row.d, o_score.d, o_ncand.d, o_cnt.d,
-                           o_pairs.d, pm_stride, L->status.p, flt));
+                           o_pairs.d, pm_stride, L->status.p, flt, true, &L->rs_scratch));
   } else {
     int64_t total = 0;
     {
@@ -542,7 +543,7 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
     ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->cand.p, L->woff.p, 0, total,
                            P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
                            L->best_slot.p, nullptr, o_row.d, o_score.d, o_ncand.d, o_cnt.d,
-                           o_pairs.d, pm_stride, L->status.p, rows_only));
+                           o_pairs.d, pm_stride, L->status.p, rows_only, true, &L->rs_scratch));
   }
   ASL_TRY(o_row.finish());
   ASL_TRY(o_score.finish());

@@ -147,6 +147,12 @@ class HipShardBackend:
         rk = self.index.refine_k if self.index is not None else 0
         self.k_scan = rk if rk > self.k else self.k
 
+    @property
+    def index_epoch(self):
+        """Changes whenever the answer of ``supports_keys`` may: the index handle's own counter (add,
+        train, scan variant, storage, re-rank, sharding) and the probe count of the engine."""
+        return (getattr(self.index, 'epoch', 0), int(self.sl._num_probe)) if self.index is not None else (0, 0)
+
     def encode(self, queries: PackedSpectra) -> torch.Tensor:
         return self.sl._encode(queries.to(self.device))
 
@@ -582,7 +588,9 @@ def _agreed_keys(backend, world: int, group, k_scan: int) -> bool:
     if world == 1:
         return local
     cache = backend.__dict__.setdefault('_keys_agreed', {}) if hasattr(backend, '__dict__') else {}
-    key = (id(group), world, k_scan, getattr(backend, 'index_epoch', 0))
+    # the group object itself is part of the key (held, so its id cannot be recycled); index_epoch
+    # changes with every call that changes the index or how it is scanned -- the same on every rank
+    key = (group, world, k_scan, getattr(backend, 'index_epoch', 0))
     if key not in cache:
         t = torch.tensor([int(local)], dtype=torch.int32)
         if _direct(group):

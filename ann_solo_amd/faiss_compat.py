@@ -52,6 +52,10 @@ class Index:
         self.d = d
         self.nprobe = 1
         self.seed = DEFAULT_SEED
+        # bumped by every call that can change what a search over this handle does (contents, layout,
+        # scan variant, storage, sharding): SPMD drivers make these calls on every rank alike, so the
+        # counter is the same everywhere and keys what the ranks agreed on (distributed._agreed_keys)
+        self.epoch = 0
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -78,13 +82,16 @@ class Index:
         _lib.check(_lib.lib().asl_index_set_niter(self._h, int(niter)))
 
     def set_scan_variant(self, variant: int):
+        self.epoch += 1
         _lib.check(_lib.lib().asl_index_set_scan_variant(self._h, int(variant)))
 
     def train(self, x):
+        self.epoch += 1
         x = _as_f32(x, self.d)
         _lib.check(_lib.lib().asl_index_train(self._h, x.shape[0], _lib.ptr(x), self.seed))
 
     def add(self, x):
+        self.epoch += 1
         x = _as_f32(x, self.d)
         _lib.check(_lib.lib().asl_index_add(self._h, x.shape[0], _lib.ptr(x)))
 
@@ -106,6 +113,7 @@ class Index:
         return D, I
 
     def reset(self):
+        self.epoch += 1
         _lib.check(_lib.lib().asl_index_reset(self._h))
 
     def setNumProbes(self, nprobe: int):      # GpuIndexIVF spelling (spectral_library.py:495)
@@ -125,6 +133,7 @@ class Index:
         return out
 
     def set_trained(self, centroids, codebooks=None):
+        self.epoch += 1
         c = np.ascontiguousarray(centroids, np.float32)
         cb = None if codebooks is None else np.ascontiguousarray(codebooks, np.float32)
         _lib.check(_lib.lib().asl_index_set_trained(self._h, _lib.ptr(c), _lib.ptr(cb)))
@@ -194,6 +203,7 @@ class Index:
 
     def set_storage(self, storage: str):
         """IVF-Flat component storage, before the first ``add``: 'fx22' | 'fp32'."""
+        self.epoch += 1
         mode = {'fx22': 0, 'fp32': 1}[storage]
         _lib.check(_lib.lib().asl_index_set_flat_storage(self._h, mode))
 
@@ -213,6 +223,7 @@ class Index:
     def set_refine(self, kprime: int):
         """IVF-PQ: re-rank the ``kprime`` best ADC candidates with the exact inner product and
         return the k best (FAISS ``IndexRefineFlat``); call before ``add``. 0 switches it off."""
+        self.epoch += 1
         _lib.check(_lib.lib().asl_index_set_refine(self._h, int(kprime)))
 
     @property
@@ -279,6 +290,7 @@ class Index:
         return K
 
     def shard(self, rank: int, world: int):
+        self.epoch += 1
         _lib.check(_lib.lib().asl_index_shard(self._h, int(rank), int(world)))
 
     def shard_map(self, world: int):

@@ -43,7 +43,10 @@ for line in open(src):
 out = {}
 for k, v in vals.items():
     if 'FETCH_SIZE' in v:
+        sys.path.insert(0, '.')
+        import bench
         out = {'kernel': k.replace('void asl::', ''),
+               'kernel_source_sha1': bench.kernel_source_sha1('pq' if 'pq_scan' in k else 'flat'),
                'workload': 'bench.py ' + (' '.join(sys.argv[4:]) or 'defaults (2.1M library, nlist 4096, nprobe 128, k 1024, 32768 queries)'),
                'FETCH_SIZE_KiB_per_dispatch': v['FETCH_SIZE'],
                'WRITE_SIZE_KiB_per_dispatch': v.get('WRITE_SIZE'),

@@ -283,3 +283,54 @@ def test_cascade_std_then_open_on_the_remainder(world, O):
     right = np.array([int(by[f'scan={i}'].library_identifier) == src[i] if f'scan={i}' in by else False
                       for i in range(n)])
     assert right[unmod].mean() > 0.9 and right.mean() > 0.75
+
+
+def test_more_than_four_gib_of_pq_codes():
+    """134.4 M vectors = 4.3 GB of PQ codes (64 x MassIVE-KB): the index-building launches whose size grows
+    with the library (per code byte: 4.3e9 work-items) run past the 2^32 work-items an AQL packet
+    holds along x -- they were cut short without an error until round 6 (`grid_2d`, csrc/common.hpp).
+    The tiled scan and the generic scan must agree bit for bit, and a query must still find the
+    library spectrum it was drawn from (first chunk) at the head of its row."""
+    import torch
+    from ann_solo_amd import faiss_compat as faiss, synthetic
+    from ann_solo_amd.spectrum import spectra_to_vectors
+    dev = torch.device('cuda', 0)
+
+    def encode(sp):
+        out = torch.empty((sp.n, 800), dtype=torch.float32, device=dev)
+        spectra_to_vectors(sp.mz, sp.intensity, sp.offsets, 11, 2010, 0.04, 800, True, out)
+        return out
+    n = 2_100_000
+    lib0, aux0 = synthetic.make_library(n, seed=20240807, device=dev, charges=(2,), charge_p=(1.0,))
+    q, truth = synthetic.make_queries(lib0, aux0, 96, seed=42, open_range=500.0, charge=2)
+    xq = encode(q)
+    idx = faiss.IndexIVFPQ(faiss.IndexFlatIP(800), 800, 4096, 32, 8)
+    idx.seed = 1234
+    idx.set_niter(6)
+    x = encode(lib0)
+    idx.train(x)
+    idx.add(x)
+    del x, lib0, aux0
+    for c in range(1, 64):
+        lib_c, _ = synthetic.make_library(n, seed=7000 + c, device=dev, charges=(2,), charge_p=(1.0,))
+        x = encode(lib_c)
+        del lib_c
+        idx.add(x)
+        del x
+    assert idx.ntotal * 32 > 1 << 32
+    idx.nprobe = 128
+    rows = {}
+    for variant in (0, 1):
+        idx.set_scan_variant(variant)
+        D, I = idx.search(xq, 1024)
+        rows[variant] = (D.cpu().numpy(), I.cpu().numpy())
+    assert np.array_equal(rows[0][1], rows[1][1])
+    assert np.array_equal(rows[0][0].view(np.uint32), rows[1][0].view(np.uint32))
+    I0 = rows[0][1]
+    assert I0.min() >= 0 and I0.max() < idx.ntotal and np.isfinite(rows[0][0]).all()
+    src = truth['source_row'].cpu().numpy()
+    unmod = ~truth['is_modified'].cpu().numpy()
+    found = (I0[:, :8] == src[:, None]).any(1)
+    assert found[unmod].mean() > 0.9
+    del idx
+    torch.cuda.empty_cache()
