@@ -124,7 +124,7 @@ struct FiUnit {
 // query value: a power of two, exact) -- so ids and score bits equal the oracle's over the same
 // stored vectors. Measured on the bench library (scripts/flat_layout_model.py): 13 135 -> 8 980
 // lines per query at nprobe 112, and the row loop loses one of its two loads.
-template <int FI_CAP, bool FX>
+template <int FI_CAP, bool FX, bool WIDE>
 __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_kernel(
     const float *__restrict__ xq, int d, const int32_t *__restrict__ coarse_I, int nprobe,
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ blk_offsets,
@@ -156,18 +156,32 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   const bool fast = ecnt >= 0;
   if (!fast)
     for (int i = tid; i < d; i += FI_NT) s_q[i] = xq[(size_t)q * d + i];
-  int my_len = 0, my_pos = 0, my_b0 = 0, my_nb = 0;
-  if (tid < nprobe) {
-    const int l = coarse_I[(size_t)q * nprobe + tid];
-    if (l >= 0) {
-      my_pos = list_offsets[l];
-      my_len = list_offsets[l + 1] - my_pos;
-      my_b0 = blk_offsets[l];
-      my_nb = blk_offsets[l + 1] - my_b0;
+  // a thread per probe (WIDE: probes tid and tid + FI_NT -- nprobe up to 1024, the reference's clamp,
+  // spectral_library.py:77-81)
+  constexpr int PP = WIDE ? 2 : 1;
+  int my_len[PP], my_pos[PP], my_b0[PP], my_nb[PP], my_pre[PP];
+#pragma unroll
+  for (int pp = 0; pp < PP; ++pp) {
+    my_len[pp] = 0, my_pos[pp] = 0, my_b0[pp] = 0, my_nb[pp] = 0;
+    const int p = tid + pp * FI_NT;
+    if (p < nprobe) {
+      const int l = coarse_I[(size_t)q * nprobe + p];
+      if (l >= 0) {
+        my_pos[pp] = list_offsets[l];
+        my_len[pp] = list_offsets[l + 1] - my_pos[pp];
+        my_b0[pp] = blk_offsets[l];
+        my_nb[pp] = blk_offsets[l + 1] - my_b0[pp];
+      }
     }
   }
-  int total;
-  const int my_pre = block_excl_scan<FI_NW>(my_nb, s_misc, tid, total);   // barrier inside: s_q complete
+  int total = 0;
+#pragma unroll
+  for (int pp = 0; pp < PP; ++pp) {
+    int part_total;
+    if (pp) __syncthreads();      // the partial sums of the first scan have been read
+    my_pre[pp] = total + block_excl_scan<FI_NW>(my_nb[pp], s_misc, tid, part_total);   // barrier inside: s_q complete
+    total += part_total;
+  }
   if (wave == 0 && fast) {
     if (lane < ecnt) {
       const uint2 e = ent[(size_t)q * 64 + lane];
@@ -214,15 +228,16 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
   };
   auto sync_wanted = [&]() -> bool { return __builtin_amdgcn_readfirstlane(*s_flag) != 0; };
   for (int c0 = 0; c0 < total; c0 += FI_CHUNK) {
-    {
-      const int lo = max(my_pre, c0), hi = min(my_pre + my_nb, c0 + FI_CHUNK);
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
+      const int lo = max(my_pre[pp], c0), hi = min(my_pre[pp] + my_nb[pp], c0 + FI_CHUNK);
       for (int t = lo; t < hi; ++t) {
-        const int j = t - my_pre;
+        const int j = t - my_pre[pp];
         FiUnit u;
-        u.blk = (uint32_t)(my_b0 + j);
-        u.pos0 = my_pos + j * FI_BLK;
+        u.blk = (uint32_t)(my_b0[pp] + j);
+        u.pos0 = my_pos[pp] + j * FI_BLK;
         table[t - c0] = u;
-        s_nbv[t - c0] = (uint16_t)min(FI_BLK, my_len - j * FI_BLK);
+        s_nbv[t - c0] = (uint16_t)min(FI_BLK, my_len[pp] - j * FI_BLK);
       }
     }
     __syncthreads();
@@ -468,10 +483,10 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
 }
 
 bool flat_inv_supported(int d, int k, int nprobe) {
-  return d <= 4096 && nprobe <= FI_NT && k >= 1 && k + FI_NT + 256 <= 4096;
+  return d <= 4096 && nprobe <= 2 * FI_NT && k >= 1 && k + FI_NT + 256 <= 4096;
 }
 
-template <int FI_CAP, bool FX>
+template <int FI_CAP, bool FX, bool WIDE>
 static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                            const int32_t *list_offsets, const int32_t *blk_offsets,
                            const uint32_t *blk_base, const uint32_t *seg_tab,
@@ -483,9 +498,9 @@ static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse
                      (size_t)FI_CHUNK * (sizeof(FiUnit) + 2) + 64 + (size_t)((d + 7) & ~7) * 2;
   if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "flat scan: d=%d does not fit LDS", d);
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)flat_inv_scan_kernel<FI_CAP, FX>,
+    HIP_TRY(hipFuncSetAttribute((const void *)flat_inv_scan_kernel<FI_CAP, FX, WIDE>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((flat_inv_scan_kernel<FI_CAP, FX>), dim3(nq), dim3(FI_NT), lds, stream(), xq, d,
+  hipLaunchKernelGGL((flat_inv_scan_kernel<FI_CAP, FX, WIDE>), dim3(nq), dim3(FI_NT), lds, stream(), xq, d,
                      coarse_I, nprobe, list_offsets, blk_offsets, blk_base, seg_tab, seg_bytes, ids,
                      k, D, I64, I32, set_mode, ent, ent_cnt, tab_stride, gate);
   ASL_CHECK_LAUNCH();
@@ -503,9 +518,16 @@ int flat_inv_scan(int layout, const float *xq, int nq, int d, const int32_t *coa
   if (nq <= 0) return ASL_OK;
   const uint32_t *tab = reinterpret_cast<const uint32_t *>(seg_tab);
   const bool small = k + FI_NT + 256 <= 2048;
-#define FI_LAUNCH(CAP, FX)                                                                           \
-  return launch_flat_inv<CAP, FX>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base, \
-                                  tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt, tab_stride, gate)
+#define FI_LAUNCH(CAP, FX)                                                                                 \
+  do {                                                                                                     \
+    if (nprobe > FI_NT)       /* two probes per thread (the one-probe form keeps its registers) */          \
+      return launch_flat_inv<CAP, FX, true>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base, \
+                                            tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt,      \
+                                            tab_stride, gate);                                                \
+    return launch_flat_inv<CAP, FX, false>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base, \
+                                           tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt,      \
+                                           tab_stride, gate);                                                \
+  } while (0)
   if (layout == 2) {
     if (small) FI_LAUNCH(2048, true);
     FI_LAUNCH(4096, true);

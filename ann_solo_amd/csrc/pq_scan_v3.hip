@@ -70,7 +70,7 @@ struct TileEnt8 {
 // waves that share one LUT and one key buffer: 24 waves per CU at 80 VGPRs instead of 12 at
 // 157 -- measured 8.28 -> 7.46 ms at the bench config (with ONE round of prefetch: at this
 // occupancy the second prefetch stage only costs registers).
-template <int CAP, int T, int NW, int DEPTH>
+template <int CAP, int T, int NW, int DEPTH, bool WIDE>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? V3_WAVES_PER_SIMD : 4) : (CAP <= 2048 ? 3 : 1))) void pq_scan_v3_kernel(
     const float *__restrict__ xq, int d, const float *__restrict__ codebooks, int dsub,
     const float *__restrict__ coarse_D, const int32_t *__restrict__ coarse_I, int nprobe,
@@ -90,17 +90,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? V3_WAVES_PER_SIM
   float *s_q = reinterpret_cast<float *>(smem);  // aliases the key buffer during the LUT build
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
-  // ---- my probe (thread p < nprobe): its dependent gathers are issued before the table build
-  // and complete under it
-  int my_len = 0, my_tile0 = 0, my_nt = 0;
-  float my_coarse = 0.0f;
-  if (tid < nprobe) {
-    const int l = coarse_I[(size_t)q * nprobe + tid];
-    if (l >= 0) {
-      my_len = list_offsets[l + 1] - list_offsets[l];
-      my_tile0 = tile_offsets[l];
-      my_nt = (my_len + 63) >> 6;
-      my_coarse = coarse_D[(size_t)q * nprobe + tid];
+  // ---- my probe (thread p < nprobe; WIDE: probes p and p + NT -- nprobe up to 2 x NT = 1024, the
+  // reference's clamp, spectral_library.py:77-81): its dependent gathers are issued before the
+  // table build and complete under it
+  constexpr int PP = WIDE ? 2 : 1;
+  int my_len[PP], my_tile0[PP], my_nt[PP], my_pre[PP];
+  float my_coarse[PP];
+#pragma unroll
+  for (int pp = 0; pp < PP; ++pp) {
+    my_len[pp] = 0, my_tile0[pp] = 0, my_nt[pp] = 0, my_coarse[pp] = 0.0f;
+    const int p = tid + pp * NT;
+    if (p < nprobe) {
+      const int l = coarse_I[(size_t)q * nprobe + p];
+      if (l >= 0) {
+        my_len[pp] = list_offsets[l + 1] - list_offsets[l];
+        my_tile0[pp] = tile_offsets[l];
+        my_nt[pp] = (my_len[pp] + 63) >> 6;
+        my_coarse[pp] = coarse_D[(size_t)q * nprobe + p];
+      }
     }
   }
   build_lut_cbt<NT>(xq + (size_t)q * d, d, codebooks, dsub, s_q, s_lut, reinterpret_cast<uint8_t *>(table),
@@ -109,11 +116,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? V3_WAVES_PER_SIM
                                                                         // not live yet; entry lists only: a row with
                                                                         // more than 64 non-zeros is searched as all-zero
 
-  // ---- exclusive scan of the probes' tile counts
-  int total;
+  // ---- exclusive scan of the probes' tile counts (probe order: p, then p + NT)
+  int total = 0;
   int *scan_part = reinterpret_cast<int *>(table);   // table is not live yet
-  const int my_pre = block_excl_scan<NW>(my_nt, scan_part, tid, total);
-  __syncthreads();
+#pragma unroll
+  for (int pp = 0; pp < PP; ++pp) {
+    int part_total;
+    my_pre[pp] = total + block_excl_scan<NW>(my_nt[pp], scan_part, tid, part_total);
+    total += part_total;
+    __syncthreads();
+  }
 
   TopK top;   // init zeroes the keys (which aliased s_q)
   top.init(smem, k, ids_tiled, tid);
@@ -127,13 +139,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? V3_WAVES_PER_SIM
   const uint32_t chunkA = (uint32_t)(rho * 512 + ma * 16), chunkB = (uint32_t)(rho * 512 + mb * 16);
 
   for (int c0 = 0; c0 < total; c0 += V3_CHUNK) {
-    {
-      const int lo = max(my_pre, c0), hi = min(my_pre + my_nt, c0 + V3_CHUNK);
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
+      const int lo = max(my_pre[pp], c0), hi = min(my_pre[pp] + my_nt[pp], c0 + V3_CHUNK);
       for (int t = lo; t < hi; ++t) {
-        const int local = t - my_pre;
+        const int local = t - my_pre[pp];
         TileEnt8 e;
-        e.tile_nv = (uint32_t)(my_tile0 + local) | ((uint32_t)(min(64, my_len - local * 64) - 1) << 26);
-        e.coarse = my_coarse;
+        e.tile_nv = (uint32_t)(my_tile0[pp] + local) | ((uint32_t)(min(64, my_len[pp] - local * 64) - 1) << 26);
+        e.coarse = my_coarse[pp];
         table[t - c0] = e;
       }
     }
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? V3_WAVES_PER_SIM
                I32 ? I32 + (size_t)q * k : nullptr);
 }
 
-template <int CAP, int T, int NW, int DEPTH>
+template <int CAP, int T, int NW, int DEPTH, bool WIDE>
 static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                      const float *coarse_D, const int32_t *coarse_I, int nprobe,
                      const int32_t *list_offsets, const int32_t *tile_offsets,
@@ -213,9 +226,9 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                      (size_t)V3_CHUNK * sizeof(TileEnt8);
   if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "pq scan: k=%d does not fit LDS", k);
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)pq_scan_v3_kernel<CAP, T, NW, DEPTH>,
+    HIP_TRY(hipFuncSetAttribute((const void *)pq_scan_v3_kernel<CAP, T, NW, DEPTH, WIDE>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((pq_scan_v3_kernel<CAP, T, NW, DEPTH>), dim3(nq), dim3(64 * NW), lds, stream(), xq, d,
+  hipLaunchKernelGGL((pq_scan_v3_kernel<CAP, T, NW, DEPTH, WIDE>), dim3(nq), dim3(64 * NW), lds, stream(), xq, d,
                      codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets,
                      codes_tiled, ids_tiled, k, D, I64, I32, set_mode, ent, ent_cnt, gate);
   ASL_CHECK_LAUNCH();
@@ -223,7 +236,7 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
 }
 
 bool pq_scan_tiled_supported(int m, int ksub, int k, int nprobe) {
-  return m == PQT_M && ksub == PQT_KSUB && nprobe <= 256 && k >= 1 && k <= TK_MAX_K;
+  return m == PQT_M && ksub == PQT_KSUB && nprobe <= 1024 && k >= 1 && k <= TK_MAX_K;
 }
 
 // k <= 1280: 2048-key buffer, three workgroups per CU; larger k: 4096 keys, two per CU
@@ -236,8 +249,12 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
   if (nq <= 0) return ASL_OK;
 #define V3_ARGS xq, nq, d, codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets, \
                 codes_tiled, ids_tiled, k, D, I64, I32, set_mode, ent, ent_cnt, gate
-  if (k + 256 + 512 <= 2048) return launch_v3<2048, 1, 8, V3_DEPTH>(V3_ARGS);
-  return launch_v3<4096, 1, 8, V3_DEPTH>(V3_ARGS);
+  if (nprobe > 512) {         // two probes per thread (the one-probe form keeps its registers)
+    if (k + 256 + 512 <= 2048) return launch_v3<2048, 1, 8, V3_DEPTH, true>(V3_ARGS);
+    return launch_v3<4096, 1, 8, V3_DEPTH, true>(V3_ARGS);
+  }
+  if (k + 256 + 512 <= 2048) return launch_v3<2048, 1, 8, V3_DEPTH, false>(V3_ARGS);
+  return launch_v3<4096, 1, 8, V3_DEPTH, false>(V3_ARGS);
 #undef V3_ARGS
 }
 

@@ -9,8 +9,8 @@ best match IS the source spectrum -- on the HARD synthetic queries (calibrated t
 exact-search hit@1024 of 75 %) and on the default ones.
 
   python scripts/hyperparameter_grid.py [--library-size N] [--nlists 64,256,...] > grid.json
-(num_probe > 512 is outside the postings scan's launch shape and is skipped: the reference's grid
-has three such points, all with num_list 4096 / 16384.)"""
+(num_probe 1024 -- the reference's clamp, spectral_library.py:77-81 -- runs on the two-probes-per-thread
+form of the scans since round 6: the grid's two such points, num_list 4096 and 16384.)"""
 import argparse
 import json
 import os
@@ -27,7 +27,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16384)
     ap.add_argument('--k', type=int, default=1024)
     ap.add_argument('--nlists', default='64,256,1024,4096,16384')
-    ap.add_argument('--nprobes', default='1,8,32,64,128,256,512')
+    ap.add_argument('--nprobes', default='1,8,32,64,128,256,512,1024')
     ap.add_argument('--steps', type=int, default=3)
     args = ap.parse_args()
     import torch

@@ -687,3 +687,43 @@ def test_error_behaviour(vecs):
         idx.train(xb[:5])                # fewer points than lists
     with pytest.raises(ValueError):
         idx.train(xb[:, :10])
+
+
+@pytest.mark.parametrize('kind', ['ivfpq', 'ivfflat'])
+def test_more_than_512_probes_equal_the_oracle(O, kind):
+    """The reference sweeps nprobe up to 1 024 (notebooks/iprg2012_ann_hyperparameters.ipynb:100-101) and
+    clamps there on its GPU path (spectral_library.py:77-81). Beyond 512 probes the layout-specific
+    scans take two probes per thread (`WIDE`, csrc/pq_scan_v3.hip, csrc/flat_scan.hip): ids and score
+    bits must equal the oracle's, the generic kernels' and -- nprobe = nlist -- exact search over the
+    stored payload."""
+    from ann_solo_amd import faiss_compat as faiss, synthetic
+    lib, aux = synthetic.make_library(12000, seed=77, device='cpu', charges=(2,), charge_p=(1.0,))
+    q, _ = synthetic.make_queries(lib, aux, 24, seed=78, charge=2)
+    o, mz, inten, *_ = lib.numpy()
+    xb = O.encode_batch(mz, inten, o, 10.96, 0.04, 800)
+    o, mz, inten, *_ = q.numpy()
+    xq = O.encode_batch(mz, inten, o, 10.96, 0.04, 800)
+    nlist = 1100
+    if kind == 'ivfpq':
+        idx = faiss.IndexIVFPQ(faiss.IndexFlatIP(800), 800, nlist, 32, 8)
+    else:
+        idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, nlist)
+    idx.seed = SEED
+    idx.set_niter(2)
+    idx.train(xb)
+    idx.add(xb)
+    off, ids, payload = idx.lists()
+    ivf = O.HostIVF.__new__(O.HostIVF)
+    ivf.centroids, ivf.nlist, ivf.d = idx.centroids(), nlist, 800
+    ivf.list_offsets, ivf.ids, ivf.payload = off, ids, payload
+    ivf.codebooks, ivf.kind = (idx.codebooks(), 1) if kind == 'ivfpq' else (None, 0)
+    for k, nprobe in ((1024, 513), (1024, 700), (1024, 1024), (100, 1023), (2048, 1024), (1024, 1100)):
+        idx.nprobe = nprobe
+        Do, Io = ivf.search(xq, k, nprobe)
+        for variant in (0, 1):
+            idx.set_scan_variant(variant)
+            D, I = idx.search(xq, k)
+            assert np.array_equal(I, Io), (variant, k, nprobe)
+            assert np.array_equal(D.view(np.uint32), Do.view(np.uint32)), (variant, k, nprobe)
+    idx.set_scan_variant(0)
+    assert idx.info().nlist == nlist
