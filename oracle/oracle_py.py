@@ -39,11 +39,20 @@ def build(force=False):
         subprocess.check_call(['make', '-C', _HERE, 'ref'])
 
 
+def _sanitized():
+    """ASL_ORACLE_SANITIZE=1: the ASan + UBSan builds of `make -C oracle sanitize` (oracle/_san/) stand in
+    for liboracle.so and _ref/ (scripts/sanitize_cpu.sh; the interpreter must run with libasan preloaded)."""
+    return os.environ.get('ASL_ORACLE_SANITIZE') == '1'
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        build()
-        _LIB = C.CDLL(os.path.join(_HERE, 'liboracle.so'))
+        if _sanitized():
+            _LIB = C.CDLL(os.path.join(_HERE, '_san', 'liboracle.so'))
+        else:
+            build()
+            _LIB = C.CDLL(os.path.join(_HERE, 'liboracle.so'))
         L = _LIB
         L.orc_murmur3_32.restype = C.c_uint32
         L.orc_murmur3_32.argtypes = [C.c_char_p, C.c_int, C.c_uint32]
@@ -70,8 +79,8 @@ def ref_lib():
     """The reference's own SpectrumMatch.cpp (None if it was never built)."""
     global _REF
     if _REF is None:
-        p = os.path.join(_HERE, '_ref', 'libref_spectrummatch.so')
-        if not os.path.exists(p):
+        p = os.path.join(_HERE, '_san' if _sanitized() else '_ref', 'libref_spectrummatch.so')
+        if not os.path.exists(p) and not _sanitized():
             build()
         if not os.path.exists(p):
             return None
