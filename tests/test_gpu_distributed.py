@@ -70,6 +70,26 @@ def test_two_rank_sharded_bench_path(degree, index, extra):
         assert d['config']['parallelism'] == 'replicas x2' and d['alt_layouts'] is None
 
 
+@pytest.mark.parametrize('how', ['raise', 'hang'])
+def test_a_failing_sharded_path_still_yields_the_replicas_line(how):
+    """Insurance for a first multi-GPU lease: once the replicas layout is measured, a sharded path that
+    raises -- or sits in a collective until the watchdog fires -- ends the run with THAT measurement as
+    the one JSON line (`sharded_path_failed` says why) and exit code 0."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(ASL_BENCH_BACKEND='gloo', ASL_BENCH_INJECT=how)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'),
+           '--gpus', '2', '--steps', '1', '--warmup', '1', '--library-size', '60000', '--nlist',
+           '256', '--niter', '4', '--batch', '1024', '--recall-queries', '64', '--sharded-watchdog-seconds', '15']
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1, out.stderr[-2000:]
+    d = json.loads(line[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['parallelism'] == 'replicas x2'
+    assert ('injected' if how == 'raise' else 'watchdog') in d['sharded_path_failed']
+
+
 def test_plain_bench_command_starts_two_ranks():
     """`python bench.py --gpus 2 ...` with no launcher in front: bench.py starts the two ranks itself
     (children of torch.distributed.run; the parent never touches the GPU) and relays rank 0's line."""
