@@ -22,7 +22,8 @@ c_u8p = C.POINTER(C.c_uint8)
 c_u32p = C.POINTER(C.c_uint32)
 
 
-TK_MAX_K = 2048      # largest k / nprobe of the LDS top-k (csrc/ivf_kernels.hpp)
+TK_MAX_K = 2048      # largest nprobe / single-pass k of the LDS top-k (csrc/ivf_kernels.hpp)
+TK_MAX_K_PASSES = 16384   # largest k of a search (bounded passes beyond TK_MAX_K)
 
 
 class AnnSoloMiError(RuntimeError):

@@ -16,7 +16,8 @@ takes every value from the parsed reference object.
 
 Capacity limits of the device kernels are checked at construction (``ValueError``), not deep
 inside a search: ``max_peaks_used`` / ``max_peaks_used_library`` <= 256 (the reference has no
-limit; its default is 50), ``num_candidates`` and ``num_probe`` <= 2048.
+limit; its default is 50), ``num_probe`` <= 2048, ``num_candidates`` <= 16 384 (beyond 2 048 the
+search runs ceil(k / 2048) bounded passes of the generic kernels: exact, slower).
 ``Config.from_reference(obj)`` snapshots any configuration object -- in particular the
 reference's own ``ann_solo.config.config`` singleton, whose ``__getattr__`` answers unknown
 options with ``KeyError`` (config.py:285-291), not ``AttributeError`` -- so the engine can be
@@ -78,7 +79,8 @@ class Config:
                                             # components in [0, 1), 4-byte postings, |dx| <= 1.2e-7)
 
     MAX_PEAKS = 256      # peaks per spectrum the preprocessing / rescoring kernels hold (csrc/process.hip)
-    MAX_TOPK = 2048      # largest k / nprobe of the LDS top-k (csrc/ivf_kernels.hpp: TK_MAX_K)
+    MAX_TOPK = 2048      # largest nprobe / single-pass k of the LDS top-k (csrc/ivf_kernels.hpp: TK_MAX_K)
+    MAX_CANDIDATES = 16384   # largest num_candidates: beyond MAX_TOPK in bounded passes (TK_MAX_K_PASSES)
 
     def __post_init__(self):
         for name in ('max_peaks_used', 'max_peaks_used_library'):
@@ -86,10 +88,10 @@ class Config:
             if v is not None and int(v) > self.MAX_PEAKS:
                 raise ValueError(f'{name} = {v}: the device kernels hold at most {self.MAX_PEAKS} '
                                  'peaks per spectrum (the reference has no limit; its default is 50)')
-        for name in ('num_candidates', 'num_probe'):
+        for name, lim in (('num_candidates', self.MAX_CANDIDATES), ('num_probe', self.MAX_TOPK)):
             v = getattr(self, name)
-            if v is not None and int(v) > self.MAX_TOPK:
-                raise ValueError(f'{name} = {v}: the device top-k holds at most {self.MAX_TOPK} entries')
+            if v is not None and int(v) > lim:
+                raise ValueError(f'{name} = {v}: the device top-k holds at most {lim} entries')
         if self.flat_storage not in ('fx22', 'fp32'):
             raise ValueError(f"flat_storage = {self.flat_storage!r}: 'fx22' or 'fp32'")
 

@@ -511,6 +511,74 @@ static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe,
 }
 
 // Search with all-device arguments. Exactly one of I64 / I32 may be non-null (or both).
+// k > TK_MAX_K: ceil(k / TK_MAX_K) bounded passes of the generic kernels. Every hit has a unique
+// 64-bit key (score, ~id); a pass keeps the TK_MAX_K best keys strictly below the row's bound = the
+// smallest key the pass before it wrote (0 once a row is exhausted), and writes them behind the
+// earlier ones: the rows are the exact (score desc, id asc) top-k, -1 padded, as for small k.
+// IndexFlatIP / IVF-Flat: the scores of a row chunk are computed once (GEMM) and selected from
+// ceil(k / 2048) times; IVF-PQ: the ADC scan of the generic kernel is repeated per pass.
+static int index_search_large_k(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
+                                int64_t *I64, int32_t *I32, const float *pre_D, const int32_t *pre_I) {
+  const int d = ix->d;
+  const int64_t n = ix->n_store;
+  DevBuf<uint64_t> upper;
+  ASL_TRY(upper.reserve((size_t)nq));
+  auto out_at = [&](auto *base, int64_t r0, int c0) { return base ? base + (size_t)r0 * k + c0 : nullptr; };
+  if (ix->kind == ASL_INDEX_FLAT || ix->kind == ASL_INDEX_IVFFLAT) {
+    const bool ivf = ix->kind == ASL_INDEX_IVFFLAT;
+    int words = 0;
+    if (ivf) {
+      nprobe = std::max(1, std::min(nprobe, ix->nlist));
+      if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
+      if (!pre_I) ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+      const int32_t *cI = pre_I ? pre_I : ix->coarse_I.p;
+      ASL_TRY(build_lists(ix));
+      words = (ix->nlist + 31) / 32;
+      ASL_TRY(ix->bitmap.reserve((size_t)nq * words));
+      ASL_TRY(probe_bitmap(cI, nq, nprobe, ix->bitmap.p, words));
+      if (n > 0 && prof_counts())
+        if (unsigned long long *acc = prof_scanned_dev())
+          ASL_TRY(scanned_count(cI, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
+    }
+    const int64_t ncol = std::max<int64_t>(n, 1);
+    int rows = (int)std::min<int64_t>(nq, std::max<int64_t>(1, (int64_t)(SCORE_CHUNK_BYTES / ((size_t)ncol * 4))));
+    ASL_TRY(ix->ws_scores.reserve((size_t)rows * ncol));
+    for (int r0 = 0; r0 < nq; r0 += rows) {
+      const int m = std::min(rows, nq - r0);
+      ProfScope ps("scan");
+      if (n > 0)
+        ASL_TRY(gemm_nt_f32(xq + (size_t)r0 * d, ix->vecs.p, ix->ws_scores.p, m, (int)n, d, d, d, (int)n));
+      for (int c0 = 0; c0 < k; c0 += TK_MAX_K) {
+        const int kp = std::min<int>(TK_MAX_K, k - c0);
+        ASL_TRY(row_topk(ix->ws_scores.p, n, m, (int)n, kp, ix->has_vids ? ix->vids.p : nullptr, 0,
+                         ivf ? ix->vlist.p : nullptr, ivf ? ix->bitmap.p + (size_t)r0 * words : nullptr, words,
+                         out_at(D, r0, c0), out_at(I64, r0, c0), out_at(I32, r0, c0), k,
+                         c0 ? upper.p + r0 : nullptr, upper.p + r0));
+      }
+    }
+    return sync_stream();       // `upper` is freed on return
+  }
+  nprobe = std::max(1, std::min(nprobe, ix->nlist));
+  if (nprobe > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: nprobe=%d > %d", nprobe, TK_MAX_K);
+  ASL_TRY(build_lists(ix));
+  if (!pre_D) ASL_TRY(coarse_search(ix, xq, nq, nprobe));
+  const float *cD = pre_D ? pre_D : ix->coarse_D.p;
+  const int32_t *cI = pre_D ? pre_I : ix->coarse_I.p;
+  {
+    ProfScope ps("scan");
+    for (int c0 = 0; c0 < k; c0 += TK_MAX_K) {
+      const int kp = std::min<int>(TK_MAX_K, k - c0);
+      ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, cD, cI, nprobe, ix->list_offsets.p,
+                      ix->ids.p, ix->codes.p, kp, out_at(D, 0, c0), out_at(I64, 0, c0), out_at(I32, 0, c0), k,
+                      c0 ? upper.p : nullptr, upper.p));
+    }
+  }
+  if (prof_counts())
+    if (unsigned long long *acc = prof_scanned_dev())
+      ASL_TRY(scanned_count(cI, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
+  return sync_stream();
+}
+
 int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprobe, float *D,
                         int64_t *I64, int32_t *I32, const float *pre_D = nullptr,
                         const int32_t *pre_I = nullptr, bool set_mode = false, const int *gate = nullptr,
@@ -529,7 +597,16 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
   if (gate && (!pre_I || ix->kind == ASL_INDEX_FLAT))
     return fail(ASL_ERR_STATE, "gated search: needs the caller's probe lists and an IVF index");
   if (!ix->trained) return fail(ASL_ERR_STATE, "search: index is not trained");
-  if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "search: k=%d outside 1..%d", k, TK_MAX_K);
+  if (k <= 0 || k > TK_MAX_K_PASSES) return fail(ASL_ERR_CAPACITY, "search: k=%d outside 1..%d", k, TK_MAX_K_PASSES);
+  if (k > TK_MAX_K) {
+    // beyond the LDS top-k (the reference's CPU path has no bound on --num_candidates, config.py:188-192;
+    // its notebooks evaluate 5 000+ neighbours): ordered dense searches only, in bounded passes
+    // (rows asked for as an unordered set are served ordered: a valid answer)
+    if (gate || (pre_ent && !xq) || ix->unordered == 2)
+      return fail(ASL_ERR_STATE, "search: k=%d > %d is served from dense queries only (no packed keys, "
+                                 "entry-list-only queries or gates)", k, TK_MAX_K);
+    return index_search_large_k(ix, nq, xq, k, nprobe, D, I64, I32, pre_D, pre_I);
+  }
   const int d = ix->d;
   const int64_t n = ix->n_store;
   if (ix->kind == ASL_INDEX_FLAT || ix->kind == ASL_INDEX_IVFFLAT) {

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(TK_NT) void row_topk_kernel(
     const float *__restrict__ scores, int64_t ld, int n, int k, int cap,
     const int32_t *__restrict__ ids, int32_t id_base, const int32_t *__restrict__ vlist,
     const uint32_t *__restrict__ bitmap, int bitmap_words, float *__restrict__ D,
-    int64_t *__restrict__ I64, int32_t *__restrict__ I32, int64_t out_ld) {
+    int64_t *__restrict__ I64, int32_t *__restrict__ I32, int64_t out_ld,
+    const u64 *__restrict__ upper_in, u64 *__restrict__ upper_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u64 *buf = reinterpret_cast<u64 *>(smem);
   u64 *thr = buf + cap;
@@ -40,6 +41,9 @@ __global__ __launch_bounds__(TK_NT) void row_topk_kernel(
   tk.init(buf, ctl, thr, cap, k, tid);
   const float *row = scores + (size_t)r * ld;
   const uint32_t *bm = bitmap ? bitmap + (size_t)r * bitmap_words : nullptr;
+  // bounded pass (k beyond the LDS top-k, index.hip: search_large_k): only keys strictly below
+  // the row's bound take part -- the keys at or above it were emitted by the earlier passes
+  const u64 ub = upper_in ? upper_in[r] : ~0ull;
   for (int base = 0; base < n; base += TK_NT) {
     const int c = base + tid;
     u64 key = 0ull;
@@ -50,11 +54,14 @@ __global__ __launch_bounds__(TK_NT) void row_topk_kernel(
         vis = (bm[l >> 5] >> (l & 31)) & 1u;
       }
       if (vis) key = make_key(row[c], (uint32_t)(ids ? ids[c] : id_base + c));
+      if (key >= ub) key = 0ull;
     }
     tk.push(key, tid);
   }
   tk.finish(D ? D + (size_t)r * out_ld : nullptr, I64 ? I64 + (size_t)r * out_ld : nullptr,
             I32 ? I32 + (size_t)r * out_ld : nullptr, tid);
+  // the next pass's bound: the smallest key of a FULL row (0 = the row is exhausted: nothing passes)
+  if (upper_out && tid == 0) upper_out[r] = ctl[0] >= k ? buf[k - 1] : 0ull;
 }
 
 // Short rows (n <= 4096, k <= 256; the coarse quantiser's top-nprobe of nlist): the whole row
@@ -169,11 +176,12 @@ __global__ __launch_bounds__(TK_NT) void row_select_kernel(
 
 int row_topk(const float *scores, int64_t ld, int rows, int n, int k, const int32_t *ids,
              int32_t id_base, const int32_t *vlist, const uint32_t *bitmap, int bitmap_words,
-             float *D, int64_t *I64, int32_t *I32, int64_t out_ld) {
+             float *D, int64_t *I64, int32_t *I32, int64_t out_ld, const uint64_t *upper_in,
+             uint64_t *upper_out) {
   if (rows <= 0) return ASL_OK;
   if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "top-k: k=%d outside 1..%d", k, TK_MAX_K);
   const int cap = topk_cap_for(k);
-  if (n <= SEL_VPT * TK_NT && k <= 256 && !ids && id_base == 0 && !bitmap) {
+  if (n <= SEL_VPT * TK_NT && k <= 256 && !ids && id_base == 0 && !bitmap && !upper_in && !upper_out) {
     const size_t lds_sel = (size_t)std::max(cap, SEL_CAP) * 8 + 8 + 12 * 4 + SEL_NB * 4 + 8 * 4;
     hipLaunchKernelGGL(row_select_kernel, dim3(rows), dim3(TK_NT), lds_sel, stream(), scores, ld,
                        n, k, cap, D, I64, I32, out_ld);
@@ -185,7 +193,8 @@ int row_topk(const float *scores, int64_t ld, int rows, int n, int k, const int3
     HIP_TRY(hipFuncSetAttribute((const void *)row_topk_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(row_topk_kernel, dim3(rows), dim3(TK_NT), lds, stream(), scores, ld, n,
-                     k, cap, ids, id_base, vlist, bitmap, bitmap_words, D, I64, I32, out_ld);
+                     k, cap, ids, id_base, vlist, bitmap, bitmap_words, D, I64, I32, out_ld,
+                     reinterpret_cast<const u64 *>(upper_in), reinterpret_cast<u64 *>(upper_out));
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -678,7 +687,8 @@ __global__ __launch_bounds__(TK_NT) void pq_scan_kernel(
     int dsub, const float *__restrict__ coarse_D, const int32_t *__restrict__ coarse_I,
     int nprobe, const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ ids,
     const uint8_t *__restrict__ codes, int k, int cap, float *__restrict__ D,
-    int64_t *__restrict__ I64, int32_t *__restrict__ I32) {
+    int64_t *__restrict__ I64, int32_t *__restrict__ I32, int64_t out_ld,
+    const u64 *__restrict__ upper_in, u64 *__restrict__ upper_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u64 *buf = reinterpret_cast<u64 *>(smem);
   u64 *thr = buf + cap;
@@ -689,6 +699,7 @@ __global__ __launch_bounds__(TK_NT) void pq_scan_kernel(
   build_lut_lds(xq + (size_t)q * d, d, codebooks, M, ksub, dsub, s_q, s_lut, tid);
   StreamTopK<TK_NT> tk;
   tk.init(buf, ctl, thr, cap, k, tid);
+  const u64 ub = upper_in ? upper_in[q] : ~0ull;      // bounded pass, see row_topk_kernel
   for (int p = 0; p < nprobe; ++p) {
     const int l = coarse_I[(size_t)q * nprobe + p];
     if (l < 0) continue;  // uniform
@@ -700,19 +711,22 @@ __global__ __launch_bounds__(TK_NT) void pq_scan_kernel(
       if (i < len) {
         const uint32_t *cw = reinterpret_cast<const uint32_t *>(codes + (size_t)(start + i) * M);
         key = make_key(adc_score<M>(s_lut, ksub, cw, coarse), (uint32_t)ids[start + i]);
+        if (key >= ub) key = 0ull;
       }
       tk.push(key, tid);
     }
   }
-  tk.finish(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
-            I32 ? I32 + (size_t)q * k : nullptr, tid);
+  tk.finish(D ? D + (size_t)q * out_ld : nullptr, I64 ? I64 + (size_t)q * out_ld : nullptr,
+            I32 ? I32 + (size_t)q * out_ld : nullptr, tid);
+  if (upper_out && tid == 0) upper_out[q] = ctl[0] >= k ? buf[k - 1] : 0ull;
 }
 
 template <int M>
 static int launch_pq_scan(const float *xq, int nq, int d, const float *codebooks, int ksub,
                           int dsub, const float *coarse_D, const int32_t *coarse_I, int nprobe,
                           const int32_t *list_offsets, const int32_t *ids, const uint8_t *codes,
-                          int k, float *D, int64_t *I64, int32_t *I32) {
+                          int k, float *D, int64_t *I64, int32_t *I32, int64_t out_ld,
+                          const uint64_t *upper_in, uint64_t *upper_out) {
   const int cap = topk_cap_for(k);
   const size_t lds = (size_t)cap * 8 + 16 + ((size_t)M * ksub + d) * 4;
   if (lds > 160 * 1024) return fail(ASL_ERR_CAPACITY, "pq scan: k=%d / m=%d do not fit LDS", k, M);
@@ -721,7 +735,8 @@ static int launch_pq_scan(const float *xq, int nq, int d, const float *codebooks
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(pq_scan_kernel<M>, dim3(nq), dim3(TK_NT), lds, stream(), xq, d, codebooks,
                      ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, cap,
-                     D, I64, I32);
+                     D, I64, I32, out_ld > 0 ? out_ld : (int64_t)k, reinterpret_cast<const u64 *>(upper_in),
+                     reinterpret_cast<u64 *>(upper_out));
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -729,15 +744,16 @@ static int launch_pq_scan(const float *xq, int nq, int d, const float *codebooks
 int pq_scan(const float *xq, int nq, int d, const float *codebooks, int m, int ksub, int dsub,
             const float *coarse_D, const int32_t *coarse_I, int nprobe,
             const int32_t *list_offsets, const int32_t *ids, const uint8_t *codes, int k,
-            float *D, int64_t *I64, int32_t *I32) {
+            float *D, int64_t *I64, int32_t *I32, int64_t out_ld, const uint64_t *upper_in,
+            uint64_t *upper_out) {
   if (nq <= 0) return ASL_OK;
   if (k <= 0 || k > TK_MAX_K) return fail(ASL_ERR_CAPACITY, "pq scan: k=%d outside 1..%d", k, TK_MAX_K);
   switch (m) {
-    case 4: return launch_pq_scan<4>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32);
-    case 8: return launch_pq_scan<8>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32);
-    case 16: return launch_pq_scan<16>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32);
-    case 32: return launch_pq_scan<32>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32);
-    case 64: return launch_pq_scan<64>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32);
+    case 4: return launch_pq_scan<4>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32, out_ld, upper_in, upper_out);
+    case 8: return launch_pq_scan<8>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32, out_ld, upper_in, upper_out);
+    case 16: return launch_pq_scan<16>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32, out_ld, upper_in, upper_out);
+    case 32: return launch_pq_scan<32>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32, out_ld, upper_in, upper_out);
+    case 64: return launch_pq_scan<64>(xq, nq, d, codebooks, ksub, dsub, coarse_D, coarse_I, nprobe, list_offsets, ids, codes, k, D, I64, I32, out_ld, upper_in, upper_out);
     default: return fail(ASL_ERR_INVALID, "pq scan: pq_m must be one of 4,8,16,32,64 (got %d)", m);
   }
 }

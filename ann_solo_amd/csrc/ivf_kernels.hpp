@@ -9,6 +9,7 @@ namespace asl {
 
 constexpr int TK_NT = 256;        // threads per top-k workgroup
 constexpr int TK_MAX_K = 2048;    // largest k / nprobe the LDS top-k supports
+constexpr int TK_MAX_K_PASSES = 16384;   // largest k of a search: beyond TK_MAX_K in bounded passes of the generic kernels
 constexpr int PQ_MAX_DSUB = 32;   // register fast path of the PQ L2 kernels
 
 // gate != nullptr: the kernel returns at once when *gate <= gate_max (device-side choice
@@ -26,7 +27,10 @@ int coarse_sparse(const float *xq, int nq, int d, const float *Ct, int nlist, ui
                   int32_t *cnt, int *n_over, int over_max, float *scores, int ld, int64_t ldq = 0);
 int row_topk(const float *scores, int64_t ld, int rows, int n, int k, const int32_t *ids,
              int32_t id_base, const int32_t *vlist, const uint32_t *bitmap, int bitmap_words,
-             float *D, int64_t *I64, int32_t *I32, int64_t out_ld);
+             float *D, int64_t *I64, int32_t *I32, int64_t out_ld,
+             // bounded pass (k beyond TK_MAX_K in passes of <= TK_MAX_K): only keys below upper_in[row]
+             // take part; upper_out[row] = the smallest key written by a full row, else 0
+             const uint64_t *upper_in = nullptr, uint64_t *upper_out = nullptr);
 int topk_merge(const float *Ds, const int64_t *Is, int S, int nq, int k, float *D, int64_t *I);
 int topk_merge_keys(const int64_t *Ks, int S, int nq, int k, float *D, int64_t *I, int unordered);
 int probe_bitmap(const int32_t *coarse_I, int nq, int nprobe, uint32_t *bitmap, int words);
@@ -49,7 +53,8 @@ int pq_lut(const float *xq, int nq, int d, const float *codebooks, int m, int ks
 int pq_scan(const float *xq, int nq, int d, const float *codebooks, int m, int ksub, int dsub,
             const float *coarse_D, const int32_t *coarse_I, int nprobe,
             const int32_t *list_offsets, const int32_t *ids, const uint8_t *codes, int k,
-            float *D, int64_t *I64, int32_t *I32);
+            float *D, int64_t *I64, int32_t *I32, int64_t out_ld = 0,
+            const uint64_t *upper_in = nullptr, uint64_t *upper_out = nullptr);
 // tiled IVF-PQ scan (pq_scan_v3.hip): m = 32 sub-quantisers of 8 bits
 bool pq_scan_tiled_supported(int m, int ksub, int k, int nprobe);
 int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,

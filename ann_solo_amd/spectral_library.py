@@ -139,11 +139,12 @@ class SpectralLibrary:
             # implementation's LDS top-k holds 2048 -- same warning, the larger limit
             logging.warning('Using num_probe=%d (maximum supported value on the GPU), %d was '
                             'supplied', k_max, cfg.num_probe)
-        if cfg.num_candidates > k_max:
+        c_max = _lib.TK_MAX_K_PASSES       # beyond k_max the index searches in bounded passes (exact, slower)
+        if cfg.num_candidates > c_max:
             logging.warning('Using num_candidates=%d (maximum supported value on the GPU), %d '
-                            'was supplied', k_max, cfg.num_candidates)
+                            'was supplied', c_max, cfg.num_candidates)
         self._num_probe = min(cfg.num_probe, k_max)
-        self._num_candidates = min(cfg.num_candidates, k_max)
+        self._num_candidates = min(cfg.num_candidates, c_max)
         self._use_gpu = True
         self._ann_filenames: Dict[int, str] = {}
         self._faiss_filenames: Dict[int, str] = {}      # reference caches that can be imported

@@ -85,12 +85,13 @@ def test_config_refuses_what_the_kernels_cannot_hold():
     ``Config``, not an error deep inside a search."""
     from ann_solo_amd.config import Config
     for kw in (dict(max_peaks_used=257), dict(max_peaks_used_library=1000),
-               dict(num_candidates=4096), dict(num_probe=2049), dict(flat_storage='fp16')):
+               dict(num_candidates=16385), dict(num_probe=2049), dict(flat_storage='fp16')):
         with pytest.raises(ValueError):
             Config(**kw)
     with pytest.raises(ValueError):
         Config.from_reference(dict(max_peaks_used=500))
     assert Config(max_peaks_used=256, num_candidates=2048).max_peaks_used == 256
+    assert Config(num_candidates=5000).num_candidates == 5000      # beyond 2 048: bounded passes (index.hip)
 
 
 def test_hyperparameter_hash_formula():

@@ -727,3 +727,50 @@ def test_more_than_512_probes_equal_the_oracle(O, kind):
             assert np.array_equal(D.view(np.uint32), Do.view(np.uint32)), (variant, k, nprobe)
     idx.set_scan_variant(0)
     assert idx.info().nlist == nlist
+
+
+@pytest.mark.parametrize('kind', ['flat', 'ivfflat', 'ivfpq'])
+def test_k_beyond_the_lds_top_k_in_bounded_passes(O, vecs, trained, kind):
+    """The reference's CPU path has no bound on --num_candidates (config.py:188-192; its notebooks look at
+    5 000+ neighbours, notebooks/iprg2012_num_candidates.ipynb:282-288). Beyond 2 048 the index searches
+    in ceil(k / 2048) bounded passes (csrc/index.hip: index_search_large_k): rows equal the oracle's --
+    ids, score bits, (score desc, id asc) order, -1 padding where a query reaches fewer than k vectors
+    (4 000 stored) -- on every index kind, with host and device outputs."""
+    import torch
+    from ann_solo_amd import faiss_compat as faiss
+    xb, xq = vecs
+    cen, cb = trained
+    xq = xq[:40]
+    if kind == 'flat':
+        idx = faiss.IndexFlatIP(800)
+        idx.add(xb)
+        ref = lambda k, nprobe: O.flat_search(xb, xq, k)
+    elif kind == 'ivfflat':
+        idx = faiss.IndexIVFFlat(faiss.IndexFlatIP(800), 800, 16)
+        idx.set_trained(cen)
+        idx.add(xb)
+        ivf = O.HostIVF(cen, O.assign(xb, cen, 0), xb)
+        ref = lambda k, nprobe: ivf.search(xq, k, nprobe)
+    else:
+        idx = faiss.IndexIVFPQ(faiss.IndexFlatIP(800), 800, 16, 32, 8)
+        idx.set_trained(cen, cb)
+        idx.add(xb)
+        a = O.assign(xb, cen, 0)
+        ivf = O.HostIVF(cen, a, O.pq_encode(xb, cen, a, cb), cb)
+        ref = lambda k, nprobe: ivf.search(xq, k, nprobe)
+    for k, nprobe in ((2049, 16), (3000, 9), (4096, 16), (5000, 16), (2500, 3)):
+        idx.nprobe = nprobe
+        D, I = idx.search(xq, k)
+        Do, Io = ref(k, nprobe)
+        if kind == 'flat':      # fewer than k vectors stored: the oracle's padding is the same -1
+            assert (I[:, len(xb):] == -1).all() if k > len(xb) else True
+        assert np.array_equal(I, Io), (k, nprobe)
+        valid = Io >= 0
+        assert np.array_equal(D.view(np.uint32)[valid], Do.view(np.uint32)[valid]), (k, nprobe)
+    Dt, It = idx.search(torch.from_numpy(xq).cuda(), 3000)
+    idx.nprobe = 16
+    D, I = idx.search(xq, 3000)
+    Dt, It = idx.search(torch.from_numpy(xq).cuda(), 3000)
+    assert np.array_equal(It.cpu().numpy(), I) and np.array_equal(Dt.cpu().numpy().view(np.uint32), D.view(np.uint32))
+    with pytest.raises(Exception):
+        idx.search(xq, 16385)

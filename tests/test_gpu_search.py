@@ -66,6 +66,38 @@ def test_open_search_batch_matches_oracle(O, world, index):
         assert hit[unmod].mean() > 0.9
 
 
+@pytest.mark.parametrize('index', ['ivfpq', 'ivfflat'])
+def test_open_search_with_more_than_2048_candidates(O, world, index):
+    """num_candidates = 3 000 through the fused batch call (the index searches in bounded passes, the
+    rescoring walks 3 000-wide rows), pipelined and not: neighbours, winners, scores and peak matches
+    equal the oracle's."""
+    from ann_solo_amd import synthetic
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    lib, aux, sl0 = world
+    cfg = Config.open_search(**{**sl0.config.__dict__, 'index': index, 'num_candidates': 3000, 'num_probe': 12})
+    sl = SpectralLibrary(lib, config=cfg)
+    z = 2
+    q, truth = synthetic.make_queries(lib, aux, 150, seed=91, charge=z)
+    res = sl._search_batch(q, z, 'open', want_knn=True)
+    L, pmz32, ivf = _oracle_partition(O, sl, z)
+    ref = O.search_batch(O.Spectra(*q.numpy()), L, pmz32, z, ivf, 3000, 12, 300, 'Da', 0.02, True,
+                         pm_stride=res.pm_pairs.shape[1], want_knn=True)
+    assert np.array_equal(res.knn, ref['knn_I'])
+    assert np.array_equal(res.n_candidates, ref['n_cand'])
+    assert np.array_equal(res.best_row, ref['best_row'])
+    assert np.array_equal(res.best_score, ref['best_score'])
+    assert np.array_equal(res.pm_count, ref['pm_count'])
+    sl.set_pipeline(True)
+    a = sl._search_batch(q.to('cuda:0'), z, 'open', device_out=True)
+    b = sl._search_batch(q.to('cuda:0'), z, 'open', device_out=True)
+    sl.synchronize()
+    sl.set_pipeline(False)
+    for r in (a, b):
+        assert np.array_equal(r.best_row.cpu().numpy(), ref['best_row'])
+        assert np.array_equal(r.best_score.cpu().numpy(), ref['best_score'])
+    sl.shutdown()
+
+
 def test_std_and_bruteforce_modes_match_oracle(O, world):
     """Cascade level 'std' (20 ppm window, no ANN) and --mode bf open search: candidates =
     the whole precursor window (spectral_library.py:417-429)."""
