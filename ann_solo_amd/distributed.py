@@ -83,22 +83,24 @@ def pick_shard_degree(index_bytes: int, replicated_bytes: int, world: int,
     return world
 
 
-def make_shard_groups(degree: int):
-    """Split the default process group into ``world // degree`` shard groups of ``degree``
-    consecutive ranks (consecutive = same xGMI neighbourhood, and the same node first when
-    a job spans nodes). Collective over ALL ranks (every rank creates every group, as
-    ``dist.new_group`` requires). Returns (group of this rank or None when degree == 1 /
-    degree == world, rank inside the group, index of the group)."""
+def make_shard_groups(degree: int, backend: Optional[str] = None, world_group=None):
+    """Split the job into ``world // degree`` shard groups of ``degree`` consecutive ranks
+    (consecutive = same xGMI neighbourhood, and the same node first when a job spans nodes).
+    Collective over ALL ranks (every rank creates every group, as ``dist.new_group`` requires).
+    ``backend``: the backend of the new groups when it is not the default group's (a job whose
+    default group is gloo -- the control plane -- and whose data plane is RCCL: 'nccl');
+    ``world_group``: the all-ranks group of that backend, returned when degree == world (None =
+    the default group). Returns (group of this rank, rank inside the group, index of the group)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if degree < 1 or world % degree:
         raise ValueError(f'shard degree {degree} does not divide the world size {world}')
     if degree == world:
-        return None, rank, 0
+        return world_group, rank, 0
     mine = None
     for g in range(world // degree):
         ranks = list(range(g * degree, (g + 1) * degree))
-        grp = dist.new_group(ranks)
+        grp = dist.new_group(ranks, backend=backend) if backend else dist.new_group(ranks)
         if rank in ranks:
             mine = grp
     return mine, rank % degree, rank // degree

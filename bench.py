@@ -158,18 +158,37 @@ def main():
     _lib.check(_lib.lib().asl_set_device(dev_index))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(backend)
-            if os.environ.get('ASL_DIRECT_COLLECTIVES') == '1':
-                # the collectives in their RCCL form (all_to_all_single / all_gather_into_tensor on the
-                # device tensors as they are, asynchronous handles, four pieces per batch) over gloo:
-                # what tests/test_gpu_distributed.py can run of the multi-GPU path on a 1-GPU box
-                from ann_solo_amd import distributed as _dist_mod
-                _dist_mod.FORCE_DIRECT_COLLECTIVES = True
-        if args.preflight_seconds > 0:
-            preflight(args, world, rank, dev, backend)
+        # CONTROL plane = gloo on host tensors, always (barriers, the max-over-ranks clock, parity
+        # flags): it does not depend on RCCL / xGMI coming up. The DATA plane -- the collectives of the
+        # list-sharded search -- is its own RCCL group, created only once the replicas layout has
+        # been measured and that line is held in reserve (data_plane() below): no multi-GPU
+        # hardware was available to any round, so nothing RCCL does may stand between the start
+        # of a run and its first complete result.
+        dist.init_process_group('gloo')
+        if backend != 'nccl' and os.environ.get('ASL_DIRECT_COLLECTIVES') == '1':
+            # the collectives in their RCCL form (all_to_all_single / all_gather_into_tensor on the
+            # device tensors as they are, asynchronous handles, four pieces per batch) over gloo:
+            # what tests/test_gpu_distributed.py can run of the multi-GPU path on a 1-GPU box
+            from ann_solo_amd import distributed as _dist_mod
+            _dist_mod.FORCE_DIRECT_COLLECTIVES = True
+
+    data = {'ready': False, 'world_group': None}
+
+    def data_plane():
+        """The RCCL group of all ranks (None = the default gloo group under ASL_BENCH_BACKEND=gloo),
+        created and preflighted on first use."""
+        if not data['ready']:
+            _FALLBACK['stage'] = 'creating the RCCL group of the data plane'
+            if backend == 'nccl':
+                try:
+                    data['world_group'] = dist.new_group(list(range(world)), backend='nccl', device_id=dev)
+                except TypeError:       # an older new_group without device_id
+                    data['world_group'] = dist.new_group(list(range(world)), backend='nccl')
+            if args.preflight_seconds > 0:
+                _FALLBACK['stage'] = 'preflight of the collectives'
+                preflight(args, world, rank, dev, backend, data['world_group'])
+            data['ready'] = True
+        return data['world_group']
 
     t_build = time.time()
     charge = 2
@@ -189,7 +208,8 @@ def main():
             f'nlist={args.nlist} built in {time.time() - t_build:.1f}s')
 
     if args.workload == 'cascade':
-        run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg)
+        run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg,
+                    data_plane() if world > 1 else None)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -336,8 +356,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64,
-                             device=dev if backend == 'nccl' else 'cpu')
+            t = torch.tensor([el], dtype=torch.float64)          # control plane: gloo, host tensor
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, out
@@ -387,16 +406,18 @@ def main():
                            'global_batch': world * args.batch, 'index': args.index, 'nlist': args.nlist,
                            'nprobe': args.nprobe, 'k': args.k, 'parallelism': f'replicas x{world}'},
                 'roofline': None, 'cpu_baseline': None})
-        group, shard_rank, _ = make_shard_groups(degree)
         if degree > 1:
+            world_group = data_plane()          # RCCL comes up here, behind the fallback line
+            _FALLBACK['stage'] = 'sharding the index'
+            group, shard_rank, _ = make_shard_groups(degree, backend='nccl' if backend == 'nccl' else None,
+                                                     world_group=world_group)
             idx.shard(shard_rank, degree)
             shard_backend = HipShardBackend(sl, charge, 'open')
 
             # the row width of the peak all-gather must be the same number on every rank: agreed
             # once, outside the timed loop (every step then runs without that all-reduce)
-            wmax = torch.tensor([max(int(q.max_peaks()), int(cfg.max_peaks_used))], dtype=torch.int64,
-                                device=dev if backend == 'nccl' else 'cpu')
-            dist.all_reduce(wmax, op=dist.ReduceOp.MAX, group=group)
+            wmax = torch.tensor([max(int(q.max_peaks()), int(cfg.max_peaks_used))], dtype=torch.int64)
+            dist.all_reduce(wmax, op=dist.ReduceOp.MAX)          # control plane
             peak_width = int(wmax.item())
 
             comm_log, xstats = CommLog(), {}
@@ -418,8 +439,8 @@ def main():
         got = step()                     # (ring element 0 = q)
         same = bool(torch.equal(got.best_row[:ns], ref.best_row) and
                     torch.equal(got.best_score[:ns], ref.best_score))
-        flag = torch.tensor([int(same)], device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        flag = torch.tensor([int(same)])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # control plane
         shard_check = {'queries_per_rank': ns, 'sharded_equals_unsharded': bool(flag.item())}
     else:
         step = unsharded_step
@@ -458,9 +479,8 @@ def main():
         comm['fallbacks_to_full_exchange'] = xstats.get('fallback', 0)
         # (query, owner) rows the shards scanned a second time with the full k, per step, summed
         # over the ranks of the job (the "third phase" of VERDICT r4, done on the shard inside phase 2)
-        t3 = torch.tensor([xstats.get('third_phase_queries', 0)], dtype=torch.int64,
-                          device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t3, op=dist.ReduceOp.SUM)
+        t3 = torch.tensor([xstats.get('third_phase_queries', 0)], dtype=torch.int64)
+        dist.all_reduce(t3, op=dist.ReduceOp.SUM)               # control plane
         comm['third_phase_queries'] = round(int(t3[0]) / max(args.steps, 1), 2)
         comm['third_phase_share_of_rows'] = round(int(t3[0]) / max(args.steps, 1) / (degree * degree * args.batch), 6)
         comm['collective_ms_alone'] = time_collectives(comm_log, group, degree, dev, backend, args.steps)
@@ -952,14 +972,14 @@ class _LibraryMeta:
                 'precursor_mz': float(self.pmz[r]), 'is_decoy': False}
 
 
-def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg):
-    out = cascade_pass(args, world, rank, dev, backend, sl, lib, aux, charge, cfg,
+def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg, data_group=None):
+    out = cascade_pass(args, world, rank, dev, backend, sl, lib, aux, charge, cfg, data_group,
                        parity_seconds=min(args.cpu_seconds, 10.0) if world == 1 else 0.0)
     if out is not None:
         print(json.dumps(out), flush=True)
 
 
-def cascade_pass(args, world, rank, dev, backend, sl, lib, aux, charge, cfg, parity_seconds=0.0,
+def cascade_pass(args, world, rank, dev, backend, sl, lib, aux, charge, cfg, data_group=None, parity_seconds=0.0,
                  oracle_ctx=None, index_name=None, nprobe=None):
     """BASELINE configs[4]: the reference's two-level cascade (spectral_library.py:237-259) --
     standard search (20 ppm window, no ANN) of every query, a gate standing for the mokapot FDR
@@ -1004,11 +1024,11 @@ def cascade_pass(args, world, rank, dev, backend, sl, lib, aux, charge, cfg, par
         ns = min(2 * args.batch // 8 + 37, nq)          # ragged against batch and world
         qs, qm = sub(ns)
         ref = key(sl.search(qs, qm, lmeta, score_ssms=gate))
-        sl.enable_sharding()
+        sl.enable_sharding(data_group)       # the data plane's group (RCCL; None = the default gloo group)
         got = key(sl.search(qs, qm, lmeta, score_ssms=gate))
         same = all(np.array_equal(a, b) for a, b in zip(ref, got))
-        flag = torch.tensor([int(same)], device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        flag = torch.tensor([int(same)])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # control plane: gloo, host tensor
         check = {'queries': ns, 'identifications': int(len(ref[0])),
                  'sharded_cascade_equals_unsharded': bool(flag.item())}
     for _ in range(args.warmup):
@@ -1029,7 +1049,7 @@ def cascade_pass(args, world, rank, dev, backend, sl, lib, aux, charge, cfg, par
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     # the device stages of ONE more pass, events around every stage (not part of `value`)
@@ -1378,7 +1398,7 @@ def launch_check(args, world, rank):
     return 0 if total == world * (world + 1) // 2 else 19
 
 
-def preflight(args, world, rank, dev, backend):
+def preflight(args, world, rank, dev, backend, group=None):
     """Every collective the sharded path uses, once, at a tiny size, under a watchdog: a job whose
     RCCL / xGMI set-up hangs ends here with a diagnostic line and exit code 17 instead of running
     into the driver's limit with nothing to read. The watchdog is a thread that leaves through
@@ -1395,6 +1415,8 @@ def preflight(args, world, rank, dev, backend):
                          f'LOCAL_RANK={os.environ.get("LOCAL_RANK")} '
                          f'HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}\n')
         sys.stderr.flush()
+        if _emit_fallback(f'preflight: collective "{state["at"]}" did not finish within {args.preflight_seconds:g} s'):
+            os._exit(0)          # the replicas line is out: the run has its result
         os._exit(17)
     dog = threading.Timer(args.preflight_seconds, bark)
     dog.daemon = True
@@ -1411,21 +1433,23 @@ def preflight(args, world, rank, dev, backend):
             torch.cuda.synchronize()
         took[name] = round((time.perf_counter() - t) * 1e3, 2)
     x = torch.full((world * 8,), rank, dtype=torch.int64, device=cdev)
-    run('barrier', dist.barrier)
-    run('all_reduce(max)', lambda: dist.all_reduce(x.clone(), op=dist.ReduceOp.MAX))
+    run('barrier', lambda: dist.barrier(group=group))
+    run('all_reduce(max)', lambda: dist.all_reduce(x.clone(), op=dist.ReduceOp.MAX, group=group))
     if backend == 'nccl':
         out = torch.empty(world * x.numel(), dtype=torch.int64, device=cdev)
-        run('all_gather_into_tensor', lambda: dist.all_gather_into_tensor(out, x))
+        run('all_gather_into_tensor', lambda: dist.all_gather_into_tensor(out, x, group=group))
         y = torch.empty_like(x)
-        run('all_to_all_single', lambda: dist.all_to_all_single(y, x))
+        run('all_to_all_single', lambda: dist.all_to_all_single(y, x, group=group))
         ok = bool((y.view(world, 8) == torch.arange(world, device=cdev).unsqueeze(1)).all())
     else:
         parts = [torch.empty_like(x) for _ in range(world)]
-        run('all_gather', lambda: dist.all_gather(parts, x))
+        run('all_gather', lambda: dist.all_gather(parts, x, group=group))
         ok = all(int(p_[0]) == r for r, p_ in enumerate(parts))
     dog.cancel()
     if not ok:
         sys.stderr.write(f'[bench] PREFLIGHT: rank {rank} received wrong data from a collective\n')
+        if _emit_fallback('preflight: a collective delivered wrong data'):
+            os._exit(0)
         os._exit(18)
     if rank == 0:
         log(f'[bench] preflight ok in {time.perf_counter() - t0:.2f}s: {took} ms (first call of each)')

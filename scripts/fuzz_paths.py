@@ -25,10 +25,10 @@ dev = torch.device('cuda', 0)
 while time.time() < t_end and trials < int(os.environ.get('FUZZ_MAX', 10 ** 9)):
     n = int(rng.choice([1500, 4000, 12000, 40000]))
     z = int(rng.choice([2, 3]))
-    nlist = int(rng.choice([8, 16, 64, 200]))
+    nlist = int(rng.choice([8, 16, 64, 200, 200, 1100]))       # 1100: more than 512 probes (two probes per thread)
     nlist = min(nlist, n // 40)
     nprobe = int(rng.integers(1, nlist + 1))
-    k = int(rng.choice([1, 17, 128, 512, 1024, 2048]))
+    k = int(rng.choice([1, 17, 128, 512, 1024, 2048, 1024, 2049, 3000, 5000]))   # > 2048: bounded passes
     index = str(rng.choice(['ivfpq', 'ivfflat']))
     pq_m = int(rng.choice([8, 16, 32]))
     pq_bits = int(rng.choice([6, 8])) if pq_m != 32 or rng.random() < 0.3 else 8

@@ -255,6 +255,57 @@ def test_rccl_collectives_at_world_one(index, tmp_path):
     assert 'rccl-world1-ok' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
 
 
+_PLANES_WORLD1 = r'''
+import os, sys
+from argparse import Namespace
+sys.path.insert(0, sys.argv[1])
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2], RANK='0', WORLD_SIZE='1')
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+dist.init_process_group('gloo')                                     # control plane, as bench.py sets it up
+try:
+    g = dist.new_group([0], backend='nccl', device_id=dev)          # data plane
+except TypeError:
+    g = dist.new_group([0], backend='nccl')
+assert dist.get_backend() == 'gloo' and dist.get_backend(g) == 'nccl'
+import bench
+bench.preflight(Namespace(preflight_seconds=120.0), 1, 0, dev, 'nccl', g)
+from ann_solo_amd import synthetic
+from ann_solo_amd.spectral_library import Config, SpectralLibrary
+from ann_solo_amd.distributed import HipShardBackend, make_shard_groups, sharded_search_batch
+group, srank, gi = make_shard_groups(1, backend='nccl', world_group=g)
+assert group is g and srank == 0 and gi == 0
+lib, aux = synthetic.make_library(20000, seed=5, device=dev, charges=(2,), charge_p=(1.0,))
+cfg = Config.open_search(num_list=64, num_probe=16, num_candidates=256, index='ivfpq', pq_m=32,
+             kmeans_niter=4, mode='ann', batch_size=512)
+sl = SpectralLibrary(lib, config=cfg, device=dev)
+q, _ = synthetic.make_queries(lib, aux, 512, seed=6, open_range=300.0, charge=2)
+ref = sl._search_batch(q, 2, 'open', device_out=True)
+sl._get_ann_index(2).shard(0, 1)
+be = HipShardBackend(sl, 2, 'open')
+got = sharded_search_batch(be, q, group=group, device_out=True, _force_exchange=True, check_sizes=True)
+assert torch.equal(got.best_row, ref.best_row) and torch.equal(got.best_score, ref.best_score)
+t = torch.tensor([3.5], dtype=torch.float64)                       # the clock's reduction: gloo, host tensor
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+assert float(t) == 3.5
+dist.destroy_process_group()
+print('planes-world1-ok')
+'''
+
+
+def test_gloo_control_plane_with_an_rccl_data_plane_at_world_one(tmp_path):
+    """bench.py at N > 1 keeps barriers / the clock / flags on a gloo default group and creates the
+    RCCL group of the sharded search's collectives only after the replicas line is in reserve. The
+    same set-up at world 1: default group gloo, `new_group(backend='nccl')`, bench's own preflight over
+    it, `make_shard_groups(..., backend='nccl', world_group=...)`, a sharded batch on that group."""
+    script = tmp_path / 'planes1.py'
+    script.write_text(_PLANES_WORLD1)
+    out = subprocess.run([sys.executable, str(script), ROOT, '29541'], capture_output=True, text=True, timeout=600)
+    assert 'planes-world1-ok' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
 _RCCL_CABI = r'''
 import ctypes as C, os, sys
 sys.path.insert(0, sys.argv[1])
