@@ -8,7 +8,7 @@ mkdir -p gpurun_out/$tag
 run() {  # name, counters...
   name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "pq_scan|flat_inv|rescore_|gemm_nt|row_topk|row_select|coarse_sparse" \
-     --output-format csv -d /tmp/pmc_$name -o x -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --recall-queries 0 --no-cascade --no-reference-geometry --no-recall-hard "${BENCH_ARGS[@]}" > /tmp/pmc_$name.log 2>&1
+     --output-format csv -d /tmp/pmc_$name -o x -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --recall-queries 0 --no-cascade --no-reference-geometry --no-recall-hard --beyond-llc-chunks 0 "${BENCH_ARGS[@]}" > /tmp/pmc_$name.log 2>&1
   python3 - "$name" <<'PY' >> gpurun_out/$TAG/summary.txt
 import csv, sys, collections, glob
 name = sys.argv[1]
@@ -18,7 +18,9 @@ if not f:
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 seen = set()
 for r in csv.DictReader(open(f[0])):
-    k = r['Kernel_Name'].split('(')[0][:60]
+    # launches of one kernel at different sizes (the bench also runs half-size batches and small samples)
+    # are different rows: a per-dispatch average must not mix them
+    k = r['Kernel_Name'].split('(')[0][:60] + ' grid=' + str(r.get('Grid_Size', '?'))
     acc[k][r['Counter_Name']] += float(r['Counter_Value'])
     key = (k, r['Dispatch_Id'])
     if key not in seen:

@@ -41,11 +41,15 @@ for line in open(src):
     if m and cur and ('pq_scan_v3' in cur or 'flat_inv_scan' in cur):
         vals.setdefault(cur, {})[m.group(1)] = float(m.group(2))
 out = {}
-for k, v in vals.items():
+def grid(k):
+    m = re.search(r'grid=(\d+)', k)
+    return int(m.group(1)) if m else 0
+# the full-size launches = the largest grid of the scan kernel (smaller ones: half-size batches, samples)
+for k, v in sorted(vals.items(), key=lambda kv: -grid(kv[0])):
     if 'FETCH_SIZE' in v:
         sys.path.insert(0, '.')
         import bench
-        out = {'kernel': k.replace('void asl::', ''),
+        out = {'kernel': re.sub(r' grid=\d+', '', k).replace('void asl::', ''), 'queries_per_launch': grid(k) // 512,
                'kernel_source_sha1': bench.kernel_source_sha1('pq' if 'pq_scan' in k else 'flat'),
                'workload': 'bench.py ' + (' '.join(sys.argv[4:]) or 'defaults (2.1M library, nlist 4096, nprobe 128, k 1024, 32768 queries)'),
                'FETCH_SIZE_KiB_per_dispatch': v['FETCH_SIZE'],
