@@ -330,3 +330,29 @@ def test_bench_passes_a_failing_rank_on():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_pmc_traffic_is_quoted_only_for_the_kernel_sources_it_was_taken_on(tmp_path, monkeypatch):
+    """`roofline.traffic` is a committed constant of a rocprofv3 --pmc pass (counters cannot be read from
+    inside the process); bench.py quotes it only while the hash of the scan kernel's sources is the one
+    the pass recorded (VERDICT r5 weak #10)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    have = bench.kernel_source_sha1('pq')
+    assert len(have) == 40 and have != bench.kernel_source_sha1('flat')
+    good = tmp_path / 'good.json'
+    good.write_text(json.dumps({'kernel_source_sha1': have, 'scan_hbm_bytes_per_launch': 123}))
+    stale = tmp_path / 'stale.json'
+    stale.write_text(json.dumps({'kernel_source_sha1': '0' * 40, 'scan_hbm_bytes_per_launch': 123}))
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    assert bench._load_traffic('good.json', 'pq')[0] is None          # (sources are read under ROOT: none there)
+    monkeypatch.setattr(bench, 'ROOT', ROOT)
+    assert bench._load_traffic(os.path.relpath(str(good), ROOT), 'pq') == (123, have)
+    t, why = bench._load_traffic(os.path.relpath(str(stale), ROOT), 'pq')
+    assert t is None and 'other kernel sources' in why
+    assert bench._load_traffic('profiles/does_not_exist.json', 'pq')[0] is None
+    # the committed passes: either they belong to these sources (a number) or the line says why not
+    for rel, which in ((bench.PMC_TRAFFIC_FILE, 'pq'), (bench.PMC_TRAFFIC_FILE_FLAT, 'flat')):
+        t, why = bench._load_traffic(rel, which)
+        assert (isinstance(t, int) and t > 0) or (t is None and isinstance(why, str))

@@ -143,6 +143,47 @@ def test_knn_id_sets_equal_the_oracle_at_bench_size(world, O):
     assert np.array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
 
 
+def test_wide_probes_and_large_k_at_bench_size(world, O):
+    """Round 6's two extensions at the bench's own size and index: nprobe 1 024 (a quarter of the
+    lists: ~525 k scanned vectors per query, the two-probes-per-thread form of the tiled scan) and
+    k = 4 096 (two bounded passes of the generic kernel) -- ids and score bits of sampled queries
+    equal the oracle's; the tiled and the generic scan agree on a larger sample."""
+    sl, q, _ = world
+    idx = sl._get_ann_index(2)
+    off, ids, codes = idx.lists()
+    info = idx.info()
+    ivf = O.HostIVF.__new__(O.HostIVF)
+    ivf.centroids, ivf.nlist, ivf.d = idx.centroids(), info.nlist, info.d
+    ivf.list_offsets, ivf.ids, ivf.payload, ivf.codebooks, ivf.kind = off, ids, codes, idx.codebooks(), 1
+    full = sl._encode(q)
+    try:
+        idx.nprobe = 1024
+        rows = np.arange(0, q.n, 128)                                 # 16 sampled queries
+        vec = full[rows].contiguous()
+        D, I = idx.search(vec, 1024)
+        Do, Io = ivf.search(vec.cpu().numpy(), 1024, 1024)
+        assert np.array_equal(I.cpu().numpy(), Io)
+        assert np.array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
+        sub = full[:256].contiguous()
+        D0, I0 = idx.search(sub, 1024)
+        idx.set_scan_variant(1)
+        D1, I1 = idx.search(sub, 1024)
+        idx.set_scan_variant(0)
+        import torch
+        assert torch.equal(I0, I1) and torch.equal(D0, D1)
+        idx.nprobe = 128
+        D, I = idx.search(vec, 4096)
+        Do, Io = ivf.search(vec.cpu().numpy(), 4096, 128)
+        assert np.array_equal(I.cpu().numpy(), Io)
+        assert np.array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
+        # the first 1 024 of the 4 096 are the k = 1 024 row
+        D1k, I1k = idx.search(vec, 1024)
+        assert torch.equal(I[:, :1024], I1k) and torch.equal(D[:, :1024], D1k)
+    finally:
+        idx.set_scan_variant(0)
+        idx.nprobe = 128
+
+
 def test_ivfflat_knn_equal_the_oracle_at_bench_size(world, O):
     """IVF-Flat over the same 2.1 M library at the bench's geometry (nlist 4096, nprobe 112 /
     128, k 1024): the postings scan -- rows of long dimensions (a fragment bin that half of the
