@@ -23,7 +23,8 @@ dev = torch.device('cuda', 0)
 tmp = tempfile.mkdtemp()
 while time.time() < t_end:
     n = int(rng.choice([3000, 12000, 50000]))
-    nlist = int(rng.choice([8, 32, 128]))
+    nlist = int(rng.choice([8, 32, 128, 128, 1100]))      # 1100: up to 1 100 probes (> 512: two probes per thread; > 1024: generic)
+    nlist = min(nlist, n // 40)
     nprobe = int(rng.integers(1, nlist + 1))
     k = int(rng.choice([1, 50, 256, 1024, 1280, 2048]))
     W = int(rng.choice([2, 3, 4, 8]))
