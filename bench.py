@@ -41,6 +41,26 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# The contract is ONE JSON line on stdout. Libraries under a rank write there too (Gloo announces its
+# connections on stdout, once per group): protect_stdout() points file descriptor 1 at stderr for the
+# rest of the process and keeps the real stdout for emit_line() alone.
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+
+
+def emit_line(line):
+    out = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    out.write(line + '\n')
+    out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -135,6 +155,7 @@ def main():
         sys.exit(self_launch(args.gpus))
     if world != args.gpus:
         args.gpus = world
+    protect_stdout()
     if os.environ.get('ASL_BENCH_LAUNCH_CHECK') == '1':
         sys.exit(launch_check(args, world, rank))
 
@@ -950,7 +971,7 @@ def main():
             'cpu_baseline': cpu,
         }
         _disarm_fallback()
-        print(json.dumps(out), flush=True)
+        emit_line(json.dumps(out))
     _disarm_fallback()
     if world > 1:
         dist.barrier()
@@ -976,7 +997,7 @@ def run_cascade(args, world, rank, dev, backend, sl, lib, aux, charge, cfg, data
     out = cascade_pass(args, world, rank, dev, backend, sl, lib, aux, charge, cfg, data_group,
                        parity_seconds=min(args.cpu_seconds, 10.0) if world == 1 else 0.0)
     if out is not None:
-        print(json.dumps(out), flush=True)
+        emit_line(json.dumps(out))
 
 
 def cascade_pass(args, world, rank, dev, backend, sl, lib, aux, charge, cfg, data_group=None, parity_seconds=0.0,
@@ -1343,7 +1364,7 @@ def _emit_fallback(why):
     log(f'[bench] rank {_FALLBACK["rank"]}: list-sharded path failed: {why} -- falling back to the replicas line')
     if _FALLBACK['rank'] == 0:
         line = dict(line, sharded_path_failed=why)
-        print(json.dumps(line), flush=True)
+        emit_line(json.dumps(line))
     return True
 
 
@@ -1393,8 +1414,8 @@ def launch_check(args, world, rank):
     else:
         total = 1
     if rank == 0:
-        print(json.dumps({'launch_check': True, 'n_gpus': world, 'rank_sum': total,
-                          'steps': args.steps, 'warmup': args.warmup}), flush=True)
+        emit_line(json.dumps({'launch_check': True, 'n_gpus': world, 'rank_sum': total,
+                              'steps': args.steps, 'warmup': args.warmup}))
     return 0 if total == world * (world + 1) // 2 else 19
 
 

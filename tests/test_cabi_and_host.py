@@ -311,8 +311,8 @@ def test_bench_starts_its_own_ranks(n):
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '3',
                           '--warmup', '1'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, out.stdout
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), out.stdout      # ONE line: nothing else reaches stdout
     rec = json.loads(lines[0])
     assert rec == {'launch_check': True, 'n_gpus': n, 'rank_sum': n * (n + 1) // 2, 'steps': 3, 'warmup': 1}
 

@@ -101,8 +101,8 @@ def test_plain_bench_command_starts_two_ranks():
            '256', '--niter', '4', '--batch', '1024', '--recall-queries', '64']
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(line) == 1, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(line) == 1 and line[0].startswith('{'), (out.stdout[:500], out.stderr[-2000:])   # nothing else on stdout
     d = json.loads(line[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2048
     assert d['shard_check']['sharded_equals_unsharded'] is True and d['value'] > 0
