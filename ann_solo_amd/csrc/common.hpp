@@ -200,6 +200,48 @@ struct DevPeaks {
 __host__ __device__ inline int rec_int0(int n) { return n + ((n + 3) >> 2); }
 __host__ __device__ inline uint64_t rec_bytes(uint64_t n) { return 4ull * (uint64_t)rec_int0((int)n) + 4ull * n; }
 
+// spectral_library.py:421-427 (numexpr evaluates in float64): is library precursor m/z `lib` (the
+// float32 column of spec_info) inside the query's window?
+__device__ __forceinline__ bool precursor_ok(double q, float lib, int charge, double tol,
+                                             int mode) {
+  const double l = (double)lib;
+  if (mode == ASL_TOL_DA) return fabs(q - l) * (double)charge <= tol;
+  return fabs(q - l) / l * 1000000.0 <= tol;
+}
+
+// The precursor-window post-filter (spectral_library.py:441-446: AFTER the top-k) applied where the
+// top-k ends: a scan's set-mode finish that is given one writes only the hits that pass, compacted at
+// the front of the row, and their number -- the rescoring then walks ~1/6 of a 1 024-wide row and
+// gathers no window column (33.5 M random 4-byte gathers per batch: 0.27 ms,
+// profiles/r06_rescore_prefilter.txt). idpay[slot] = (vector id, bits of the library's float32
+// window column for that id; NaN = never a candidate): the value arrives with the id the finish
+// gathers anyway. count[q] = -1: the row holds the k UNFILTERED hits (the exact-flush fallback of a
+// row with mass ties emits through another path): the rescoring filters that row itself.
+struct ScanPostFilter {
+  const int2 *idpay = nullptr;      // nullptr: no filter (every other field unused)
+  const double *q_pmz = nullptr;    // per query
+  int32_t *count = nullptr;         // per query, out
+  double tol = 0.0;
+  int mode = ASL_TOL_DA;
+  int charge = 0;
+};
+
+// What search.hip hands an index for its NEXT search (index_set_post_filter): the library's window
+// column by vector id (device, float32, NaN = never a candidate; the index keeps (id, value) pairs
+// per storage slot, rebuilt when the column or the lists change), the queries' precursor m/z and the
+// window; count[nq] receives the rows' lengths. index_post_filter_applied() says whether the scan
+// that ran could take it (set-mode int32 rows of the layout-specific scans, k <= 1280); if not, the
+// rows are the k unfiltered hits as ever.
+struct IndexPostFilter {
+  const float *payload = nullptr;
+  int64_t n = 0;
+  const double *q_pmz = nullptr;
+  int32_t *count = nullptr;
+  double tol = 0.0;
+  int mode = ASL_TOL_DA;
+  int charge = 0;
+};
+
 struct PeaksStage {  // stages an asl_peaks_t whose arrays may be on the host
   In<int32_t> offsets, pcharge;
   In<float> mz, intensity;

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
     const char *__restrict__ seg_bytes, const int32_t *__restrict__ ids, int k,
     float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode,
     const uint2 *__restrict__ ent, const int32_t *__restrict__ ent_cnt, int tab_stride,
-    const int *__restrict__ gate) {
+    const int *__restrict__ gate, const ScanPostFilter pf) {
   if (gate && (int)blockIdx.x >= *gate) return;      // device-side row count (see pq_scan_v3_kernel)
   constexpr float FX_SCALE = FX ? 1.0f / 4194304.0f : 1.0f;      // 2^-22, folded into the query values
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
@@ -474,7 +474,10 @@ __global__ __launch_bounds__(FI_NT, FI_CAP <= 2048 ? 6 : 4) void flat_inv_scan_k
     __syncthreads();
   }
   top.free_done();
-  if (set_mode && (size_t)FI_CAP * 8 <= (size_t)FI_NW * FI_BLK * 4)   // unordered exact top-k; the accumulators are dead: scratch
+  if (set_mode && (size_t)FI_CAP * 9 <= (size_t)FI_NW * FI_BLK * 4)   // unordered exact top-k; the accumulators are dead: scratch
+    top.finish_set(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
+                   I32 ? I32 + (size_t)q * k : nullptr, reinterpret_cast<u64 *>(s_acc), &pf, q);
+  else if (set_mode && (size_t)FI_CAP * 8 <= (size_t)FI_NW * FI_BLK * 4)
     top.finish_set(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
                    I32 ? I32 + (size_t)q * k : nullptr, reinterpret_cast<u64 *>(s_acc));
   else
@@ -492,7 +495,7 @@ static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse
                            const uint32_t *blk_base, const uint32_t *seg_tab,
                            const char *seg_bytes, const int32_t *ids, int k, float *D,
                            int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent,
-                           const int32_t *ent_cnt, int tab_stride, const int *gate) {
+                           const int32_t *ent_cnt, int tab_stride, const int *gate, const ScanPostFilter &pf) {
   using TopK = HistTopK<FI_CAP, FI_NT, FI_NT>;
   const size_t lds = TopK::lds_bytes() + (size_t)FI_NW * FI_BLK * 4 + (size_t)((d + 3) & ~3) * 4 +
                      (size_t)FI_CHUNK * (sizeof(FiUnit) + 2) + 64 + (size_t)((d + 7) & ~7) * 2;
@@ -502,7 +505,7 @@ static int launch_flat_inv(const float *xq, int nq, int d, const int32_t *coarse
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((flat_inv_scan_kernel<FI_CAP, FX, WIDE>), dim3(nq), dim3(FI_NT), lds, stream(), xq, d,
                      coarse_I, nprobe, list_offsets, blk_offsets, blk_base, seg_tab, seg_bytes, ids,
-                     k, D, I64, I32, set_mode, ent, ent_cnt, tab_stride, gate);
+                     k, D, I64, I32, set_mode, ent, ent_cnt, tab_stride, gate, pf);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -514,19 +517,25 @@ int flat_inv_scan(int layout, const float *xq, int nq, int d, const int32_t *coa
                   const int32_t *list_offsets, const int32_t *blk_offsets,
                   const uint32_t *blk_base, const void *seg_tab, int tab_stride, const char *seg_bytes,
                   const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode,
-                  const uint2 *ent, const int32_t *ent_cnt, const int *gate) {
+                  const uint2 *ent, const int32_t *ent_cnt, const int *gate, const ScanPostFilter *post) {
   if (nq <= 0) return ASL_OK;
   const uint32_t *tab = reinterpret_cast<const uint32_t *>(seg_tab);
   const bool small = k + FI_NT + 256 <= 2048;
+  ScanPostFilter pf;       // the set-mode finish of the 2048-key instantiation only (scratch behind the keys)
+  if (post && post->idpay) {
+    if (!(set_mode == 1 && I32 && small))
+      return fail(ASL_ERR_STATE, "postings scan: a post-filter needs set-mode int32 rows and k <= 1280");
+    pf = *post;
+  }
 #define FI_LAUNCH(CAP, FX)                                                                                 \
   do {                                                                                                     \
     if (nprobe > FI_NT)       /* two probes per thread (the one-probe form keeps its registers) */          \
       return launch_flat_inv<CAP, FX, true>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base, \
                                             tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt,      \
-                                            tab_stride, gate);                                                \
+                                            tab_stride, gate, pf);                                            \
     return launch_flat_inv<CAP, FX, false>(xq, nq, d, coarse_I, nprobe, list_offsets, blk_offsets, blk_base, \
                                            tab, seg_bytes, ids, k, D, I64, I32, set_mode, ent, ent_cnt,      \
-                                           tab_stride, gate);                                                \
+                                           tab_stride, gate, pf);                                            \
   } while (0)
   if (layout == 2) {
     if (small) FI_LAUNCH(2048, true);

@@ -309,12 +309,26 @@ struct HistTopK {
   // first, so ties break by id exactly as in the sorted order) and the best k - n_above of
   // them fill the rest of the row. Rows hold min(k, candidates) hits in an unspecified
   // order, then -FLT_MAX / -1 padding. `scratch`: CAP keys of LDS that are dead by now.
-  __device__ __forceinline__ void finish_set(float *D, int64_t *I64, int32_t *I32, u64 *scratch) {
+  // pf (ScanPostFilter, common.hpp; pf->idpay != nullptr): the precursor-window post-filter applied
+  // to the k hits right here -- the ids AND their window values come from pf->idpay[slot] (one 8-byte
+  // gather instead of slot_ids' 4), only the passing hits are written (I32, unordered, compacted at
+  // the front of the row through an LDS counter) and pf->count[q] says how many. The SELECTION of the
+  // k hits is untouched (filter after top-k). Needs CAP more bytes of scratch behind the CAP keys.
+  __device__ __forceinline__ void finish_set(float *D, int64_t *I64, int32_t *I32, u64 *scratch,
+                                             const ScanPostFilter *pf = nullptr, int q = 0) {
     __syncthreads();
+    const bool filt = pf != nullptr && pf->idpay != nullptr && !out_keys && I32 != nullptr;
     if (sort_mode) {               // exact flushes were in use: the sorted row is a valid set
       tk.emit_keys = out_keys;
       tk.finish(out_keys ? nullptr : D, I64, out_keys ? nullptr : I32, tid);
+      if (filt && tid == 0) pf->count[q] = -1;       // the k unfiltered hits: the rescoring filters this row
       return;
+    }
+    double f_q = 0.0;
+    uint8_t *sflag = reinterpret_cast<uint8_t *>(scratch + CAP);
+    if (filt) {
+      f_q = pf->q_pmz[q];
+      if (tid == 0) ctl[C_USER] = 0;                 // (update_bstar's barriers order it before the first append)
     }
     // the last compaction, fused: keys below the threshold bucket are dropped in registers (no
     // write-back, no second pass over the buffer)
@@ -322,15 +336,29 @@ struct HistTopK {
     const int bs = ctl[C_BSTAR];
     u64 kk[PER];
     int32_t idv[PER];
+    bool okf[PER];       // (filt) the hit passes the window
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int i = tid + u * NT;
       kk[u] = i < fill ? keys[i] : 0ull;
       if (kk[u] != 0ull && score_bucket(ord2f((uint32_t)(kk[u] >> 32))) < bs) kk[u] = 0ull;
+      okf[u] = true;
     }
+    if (filt) {
+      int2 ip[PER];
 #pragma unroll
-    for (int u = 0; u < PER; ++u)   // all gathers of a thread in flight together
-      idv[u] = (kk[u] != 0ull && slot_ids) ? slot_ids[(uint32_t)kk[u]] : 0;
+      for (int u = 0; u < PER; ++u)   // all gathers of a thread in flight together
+        ip[u] = kk[u] != 0ull ? pf->idpay[(uint32_t)kk[u]] : make_int2(0, 0);
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        idv[u] = ip[u].x;
+        okf[u] = ip[u].x >= 0 && precursor_ok(f_q, __int_as_float(ip[u].y), pf->charge, pf->tol, pf->mode);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < PER; ++u)   // all gathers of a thread in flight together
+        idv[u] = (kk[u] != 0ull && slot_ids) ? slot_ids[(uint32_t)kk[u]] : 0;
+    }
     int na = 0, nb = 0;
     bool above[PER];
 #pragma unroll
@@ -349,7 +377,11 @@ struct HistTopK {
     const int pre = block_excl_scan<NW>(na | (nb << 16), ctl + C_PART_C, tid, tot);
     const int n_above = tot & 0xffff, n_bound = tot >> 16;
     int pa = pre & 0xffff, pb = pre >> 16;
-    auto emit = [&](int pos, u64 key) {
+    auto emit = [&](int pos, u64 key, bool pass) {
+      if (filt) {               // survivors only, wherever the counter puts them (a set)
+        if (pass) I32[atomicAdd(&ctl[C_USER], 1)] = (int32_t)key_id(key);
+        return;
+      }
       if (out_keys) {
         I64[pos] = (int64_t)key;
         return;
@@ -361,16 +393,18 @@ struct HistTopK {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       if (kk[u] == 0ull) continue;
-      if (above[u])
-        emit(pa++, kk[u]);
-      else
+      if (above[u]) {
+        emit(pa++, kk[u], okf[u]);
+      } else {
+        if (filt) sflag[pb] = (uint8_t)okf[u];
         scratch[pb++] = kk[u];
+      }
     }
     __syncthreads();
     const int r = k - n_above;          // > 0
     const int take = n_bound < r ? n_bound : r;
     if (n_bound <= r) {                  // block-uniform: the whole threshold bucket is in
-      for (int i = tid; i < n_bound; i += NT) emit(n_above + i, scratch[i]);
+      for (int i = tid; i < n_bound; i += NT) emit(n_above + i, scratch[i], !filt || sflag[i] != 0);
     } else if (n_bound <= NT) {          // block-uniform
       // rank = number of larger keys, counted by ALL threads: the bucket's keys padded to a power
       // of two n_pad, the NT / n_pad groups of n_pad threads each count over their share of the
@@ -389,15 +423,20 @@ struct HistTopK {
       if (tid < n_bound) {
         int rank = 0;
         for (int pp = 0; pp < P; ++pp) rank += hist[pp * n_pad + tid];
-        if (rank < take) emit(n_above + rank, scratch[tid]);
+        if (rank < take) emit(n_above + rank, scratch[tid], !filt || sflag[tid] != 0);
       }
     } else {
       for (int i = tid; i < n_bound; i += NT) {
         const u64 key = scratch[i];
         int rank = 0;
         for (int j = 0; j < n_bound; ++j) rank += scratch[j] > key;
-        if (rank < take) emit(n_above + rank, key);
+        if (rank < take) emit(n_above + rank, key, !filt || sflag[i] != 0);
       }
+    }
+    if (filt) {                 // the row's length; nothing is padded behind it
+      __syncthreads();
+      if (tid == 0) pf->count[q] = ctl[C_USER];
+      return;
     }
     for (int i = n_above + take + tid; i < k; i += NT) {
       if (out_keys) {

@@ -92,6 +92,15 @@ struct asl_index {
   // 64-vector tiles for the tiled scan, pq_scan_v3.hip (m = 32)
   DevBuf<uint8_t> codes_tiled;
   DevBuf<int32_t> ids_tiled, tile_offsets;
+  // post-filter in the scan's finish (common.hpp: ScanPostFilter): (id, window value) per storage slot
+  // -- per tile slot (IVF-PQ) or per list position (IVF-Flat) --, built from pay_src on demand
+  DevBuf<int2> idpay;
+  int64_t n_tile_slots = 0;
+  const float *pay_src = nullptr;
+  int64_t pay_n = 0;
+  bool idpay_ready = false;
+  IndexPostFilter post;          // for the next search only
+  bool post_set = false, post_applied = false;
   bool has_tiles = false;
   // dimension-major postings for flat_inv_scan (IVF-Flat): blocks of FI_BLK vectors
   DevBuf<int32_t> blk_offsets;   // [nlist + 1] first block of each list
@@ -289,6 +298,7 @@ static int pq_train_device(asl_index *ix, const float *x, int64_t n, uint64_t se
 static int build_lists(asl_index *ix) {
   if (!ix->lists_dirty) return ASL_OK;
   ix->agreed_val = -1;
+  ix->idpay_ready = false;
   const int64_t n = ix->n_store;
   std::vector<int32_t> h_vlist((size_t)n), h_order((size_t)n), h_ids;
   ix->h_list_offsets.assign((size_t)ix->nlist + 1, 0);
@@ -336,6 +346,7 @@ static int build_lists(asl_index *ix) {
     ASL_TRY(ix->tile_offsets.upload(tile_off.data(), tile_off.size()));
     ASL_TRY(ix->codes_tiled.reserve((size_t)ntiles * 2048));
     ASL_TRY(ix->ids_tiled.reserve((size_t)ntiles * 64));
+    ix->n_tile_slots = ntiles * 64;
     ASL_TRY(tile_codes(ix->codes.p, ix->ids.p, slot_dev.p, n, ntiles, ix->codes_tiled.p, ix->ids_tiled.p));
     ASL_TRY(sync_stream());
     ix->has_tiles = true;
@@ -511,6 +522,46 @@ static int coarse_search(asl_index *ix, const float *xq, int nq, int nprobe,
 }
 
 // Search with all-device arguments. Exactly one of I64 / I32 may be non-null (or both).
+// (id, window value) per storage slot for the post-filter of the scans' finish
+__global__ void make_idpay_kernel(const int32_t *__restrict__ slot_ids, int64_t nslots,
+                                  const float *__restrict__ payload, int64_t n, int2 *__restrict__ out) {
+  const int64_t i = block_linear() * blockDim.x + threadIdx.x;
+  if (i >= nslots) return;
+  const int32_t id = slot_ids[i];
+  const float v = (id >= 0 && id < n) ? payload[id] : __builtin_nanf("");
+  out[i] = make_int2(id, __float_as_int(v));
+}
+
+// the scan's post-filter for this call, or an empty one (and post_applied = false)
+static int take_post_filter(asl_index *ix, bool usable, const int32_t *slot_ids, int64_t nslots,
+                            ScanPostFilter &pf) {
+  pf = ScanPostFilter();
+  ix->post_applied = false;
+  if (!ix->post_set) return ASL_OK;
+  ix->post_set = false;
+  const IndexPostFilter &p = ix->post;
+  if (!usable || !p.payload || !p.q_pmz || !p.count || p.n != ix->ntotal || ix->has_vids) return ASL_OK;
+  if (!ix->idpay_ready || ix->pay_src != p.payload || ix->pay_n != p.n) {
+    ASL_TRY(ix->idpay.reserve((size_t)std::max<int64_t>(nslots, 1)));
+    if (nslots > 0) {
+      hipLaunchKernelGGL(make_idpay_kernel, grid_2d(cdiv(nslots, 256)), dim3(256), 0, stream(), slot_ids, nslots,
+                         p.payload, p.n, ix->idpay.p);
+      ASL_CHECK_LAUNCH();
+    }
+    ix->pay_src = p.payload;
+    ix->pay_n = p.n;
+    ix->idpay_ready = true;
+  }
+  pf.idpay = ix->idpay.p;
+  pf.q_pmz = p.q_pmz;
+  pf.count = p.count;
+  pf.tol = p.tol;
+  pf.mode = p.mode;
+  pf.charge = p.charge;
+  ix->post_applied = true;
+  return ASL_OK;
+}
+
 // k > TK_MAX_K: ceil(k / TK_MAX_K) bounded passes of the generic kernels. Every hit has a unique
 // 64-bit key (score, ~id); a pass keeps the TK_MAX_K best keys strictly below the row's bound = the
 // smallest key the pass before it wrote (0 once a row is exhausted), and writes them behind the
@@ -605,6 +656,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
     if (gate || (pre_ent && !xq) || ix->unordered == 2)
       return fail(ASL_ERR_STATE, "search: k=%d > %d is served from dense queries only (no packed keys, "
                                  "entry-list-only queries or gates)", k, TK_MAX_K);
+    ix->post_set = ix->post_applied = false;
     return index_search_large_k(ix, nq, xq, k, nprobe, D, I64, I32, pre_D, pre_I);
   }
   const int d = ix->d;
@@ -645,6 +697,9 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
           q_ent = ix->scan_ent.p;
           q_cnt = ix->scan_cnt.p;
         }
+        const int mode_ = ix->unordered ? ix->unordered : (set_mode ? 1 : 0);
+        ScanPostFilter pf;
+        ASL_TRY(take_post_filter(ix, mode_ == 1 && I32 && !I64 && !D && !gate && k + FLAT_KEYS_SLACK <= 2048, ix->ids.p, n, pf));
         {
           ProfScope ps("scan");     // the scan kernel itself
           const bool fx = ix->inv_layout == 2;
@@ -652,7 +707,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
                                 ix->blk_offsets.p, ix->blk_base.p,
                                 fx ? (const void *)ix->inv_tab8.p : (const void *)ix->inv_tab.p,
                                 ix->tab_stride, ix->inv_data.p, ix->ids.p, k, D, I64, I32,
-                                ix->unordered ? ix->unordered : (set_mode ? 1 : 0), q_ent, q_cnt, gate));
+                                mode_, q_ent, q_cnt, gate, &pf));
         }
         if (prof_counts() && !gate) {
           // vectors scored by this launch, summed on the device (nothing waits inside a step)
@@ -670,6 +725,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
           ASL_TRY(scanned_count(cI, (int64_t)nq * nprobe, ix->list_offsets.p, acc));
       }
     }
+    ix->post_set = ix->post_applied = false;      // the generic kernels take no post-filter
     const int64_t ncol = std::max<int64_t>(n, 1);
     int rows = (int)std::min<int64_t>(nq, std::max<int64_t>(1, (int64_t)(SCORE_CHUNK_BYTES / ((size_t)ncol * 4))));
     ASL_TRY(ix->ws_scores.reserve((size_t)rows * ncol));
@@ -753,12 +809,16 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
         q_ent = ix->scan_ent.p;
         q_cnt = ix->scan_cnt.p;
       }
+      const int mode_ = ix->unordered ? ix->unordered : (set_mode ? 1 : 0);
+      ScanPostFilter pf;
+      ASL_TRY(take_post_filter(ix, mode_ == 1 && I32 && !I64 && !D && !gate && !refine && k + 768 <= 2048,
+                               ix->ids_tiled.p, ix->n_tile_slots, pf));
       ProfScope ps("scan");     // the scan kernel itself
       ASL_TRY(pq_scan_v3(xq, nq, d, ix->codebooks_t.p, ix->dsub, cD, cI,
                          nprobe, ix->list_offsets.p, ix->tile_offsets.p, ix->codes_tiled.p,
-                         ix->ids_tiled.p, k, D, I64, I32, ix->unordered ? ix->unordered : (set_mode ? 1 : 0),
-                         q_ent, q_cnt, gate));
+                         ix->ids_tiled.p, k, D, I64, I32, mode_, q_ent, q_cnt, gate, &pf));
     } else {
+      ix->post_set = ix->post_applied = false;      // the generic kernel takes no post-filter
       ProfScope ps("scan");
       ASL_TRY(pq_scan(xq, nq, d, ix->codebooks.p, ix->pq_m, ix->ksub, ix->dsub, cD,
                       cI, nprobe, ix->list_offsets.p, ix->ids.p, ix->codes.p, k, D,
@@ -779,6 +839,16 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
 }
 
 int index_dim(const asl_index *ix) { return ix->d; }
+void index_set_post_filter(asl_index *ix, const IndexPostFilter &p) {
+  ix->post = p;
+  ix->post_set = true;
+  ix->post_applied = false;
+}
+bool index_post_filter_applied(asl_index *ix) {
+  const bool a = ix->post_applied;
+  ix->post_set = ix->post_applied = false;
+  return a;
+}
 
 // The two halves of an IVF search for the two-stream pipeline (search.hip): the coarse
 // quantiser into caller-owned buffers, then index_search_device with those as pre_D / pre_I.

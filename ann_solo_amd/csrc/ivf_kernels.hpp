@@ -7,6 +7,8 @@
 
 namespace asl {
 
+struct ScanPostFilter;            // common.hpp
+
 constexpr int TK_NT = 256;        // threads per top-k workgroup
 constexpr int TK_MAX_K = 2048;    // largest k / nprobe the LDS top-k supports
 constexpr int TK_MAX_K_PASSES = 16384;   // largest k of a search: beyond TK_MAX_K in bounded passes of the generic kernels
@@ -63,7 +65,8 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
                int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent = nullptr,
                const int32_t *ent_cnt = nullptr,    // ent / ent_cnt: list_nonzeros (64 entries per query)
-               const int *gate = nullptr);          // device-side row count: workgroups past it return at once
+               const int *gate = nullptr,
+               const ScanPostFilter *post = nullptr);   // (common.hpp) set-mode int32 rows, k <= 1280 only          // device-side row count: workgroups past it return at once
 int tile_codes(const uint8_t *codes, const int32_t *ids, const int32_t *dst_slot, int64_t n,
                int64_t ntiles, uint8_t *codes_tiled, int32_t *ids_tiled);
 // dimension-major IVF-Flat (flat_scan.hip): blocks of FI_BLK vectors with per-dimension postings
@@ -76,7 +79,8 @@ int flat_inv_scan(int layout, const float *xq, int nq, int d, const int32_t *coa
                   const int32_t *list_offsets, const int32_t *blk_offsets,
                   const uint32_t *blk_base, const void *seg_tab, int tab_stride, const char *seg_bytes,
                   const int32_t *ids, int k, float *D, int64_t *I64, int32_t *I32, int set_mode,
-                  const uint2 *ent, const int32_t *ent_cnt, const int *gate = nullptr);
+                  const uint2 *ent, const int32_t *ent_cnt, const int *gate = nullptr,
+                  const ScanPostFilter *post = nullptr);   // set-mode int32 rows, k <= 1280 only
 int flat_inv_work(const float *xq, int nq, int d, const int32_t *coarse_I, int nprobe,
                   const int32_t *blk_offsets, const uint32_t *seg_tab, unsigned long long *out_dev);
 uint32_t inv_place_block(const uint32_t *cnt, int d, uint32_t *tab, bool *ok);

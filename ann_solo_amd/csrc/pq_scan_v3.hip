@@ -77,7 +77,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? V3_WAVES_PER_SIM
     const int32_t *__restrict__ list_offsets, const int32_t *__restrict__ tile_offsets,
     const uint8_t *__restrict__ codes_tiled, const int32_t *__restrict__ ids_tiled, int k,
     float *__restrict__ D, int64_t *__restrict__ I64, int32_t *__restrict__ I32, int set_mode,
-    const uint2 *__restrict__ ent, const int32_t *__restrict__ ent_cnt, const int *__restrict__ gate) {
+    const uint2 *__restrict__ ent, const int32_t *__restrict__ ent_cnt, const int *__restrict__ gate,
+    const ScanPostFilter pf) {
   // gate: a device-side row count -- workgroups past it leave at once (a launch of fixed size over
   // a list whose length only the device knows: the shard-side rescans of exchange.hip)
   if (gate && (int)blockIdx.x >= *gate) return;
@@ -204,7 +205,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (CAP <= 2048 ? V3_WAVES_PER_SIM
     }
     __syncthreads();
   }
-  if (set_mode && CAP * 8 <= PQT_KSUB * PQT_M * 4)   // unordered exact top-k; the LUT is dead: scratch
+  if (set_mode && CAP * 9 <= PQT_KSUB * PQT_M * 4)   // unordered exact top-k; the LUT is dead: scratch
+    top.finish_set(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
+                   I32 ? I32 + (size_t)q * k : nullptr, reinterpret_cast<u64 *>(s_lut), &pf, q);
+  else if (set_mode && CAP * 8 <= PQT_KSUB * PQT_M * 4)
     top.finish_set(D ? D + (size_t)q * k : nullptr, I64 ? I64 + (size_t)q * k : nullptr,
                    I32 ? I32 + (size_t)q * k : nullptr, reinterpret_cast<u64 *>(s_lut));
   else
@@ -218,7 +222,7 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                      const int32_t *list_offsets, const int32_t *tile_offsets,
                      const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
                      int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent,
-                     const int32_t *ent_cnt, const int *gate) {
+                     const int32_t *ent_cnt, const int *gate, const ScanPostFilter &pf) {
   if ((size_t)d * 4 > (size_t)CAP * 8 || dsub > 64 ||
       (size_t)d * 2 + 8 > (size_t)V3_CHUNK * sizeof(TileEnt8) || d != PQT_M * dsub)
     return fail(ASL_ERR_CAPACITY, "pq scan: d=%d too large for the LDS staging", d);
@@ -230,7 +234,7 @@ static int launch_v3(const float *xq, int nq, int d, const float *codebooks, int
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((pq_scan_v3_kernel<CAP, T, NW, DEPTH, WIDE>), dim3(nq), dim3(64 * NW), lds, stream(), xq, d,
                      codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets,
-                     codes_tiled, ids_tiled, k, D, I64, I32, set_mode, ent, ent_cnt, gate);
+                     codes_tiled, ids_tiled, k, D, I64, I32, set_mode, ent, ent_cnt, gate, pf);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
 }
@@ -245,10 +249,17 @@ int pq_scan_v3(const float *xq, int nq, int d, const float *codebooks, int dsub,
                const int32_t *list_offsets, const int32_t *tile_offsets,
                const uint8_t *codes_tiled, const int32_t *ids_tiled, int k, float *D,
                int64_t *I64, int32_t *I32, int set_mode, const uint2 *ent, const int32_t *ent_cnt,
-               const int *gate) {
+               const int *gate, const ScanPostFilter *post) {
   if (nq <= 0) return ASL_OK;
+  // the post-filter needs the set-mode finish of the 2048-key instantiation (its scratch behind the keys)
+  ScanPostFilter pf;
+  if (post && post->idpay) {
+    if (!(set_mode == 1 && I32 && k + 256 + 512 <= 2048))
+      return fail(ASL_ERR_STATE, "pq scan: a post-filter needs set-mode int32 rows and k <= 1280");
+    pf = *post;
+  }
 #define V3_ARGS xq, nq, d, codebooks, dsub, coarse_D, coarse_I, nprobe, list_offsets, tile_offsets, \
-                codes_tiled, ids_tiled, k, D, I64, I32, set_mode, ent, ent_cnt, gate
+                codes_tiled, ids_tiled, k, D, I64, I32, set_mode, ent, ent_cnt, gate, pf
   if (nprobe > 512) {         // two probes per thread (the one-probe form keeps its registers)
     if (k + 256 + 512 <= 2048) return launch_v3<2048, 1, 8, V3_DEPTH, true>(V3_ARGS);
     return launch_v3<4096, 1, 8, V3_DEPTH, true>(V3_ARGS);

@@ -327,6 +327,11 @@ struct CandView {
   const int32_t *offsets;
   int32_t stride;
   PrecFilter flt;
+  // fixed-stride rows whose length the producer wrote (the scans' post-filter, common.hpp:
+  // ScanPostFilter): counts[q] >= 0: the row holds that many hits, ALREADY filtered by the
+  // precursor window; -1: the row holds `stride` unfiltered hits (filter here, as without counts)
+  const int32_t *counts = nullptr;
+  __device__ __forceinline__ bool prefiltered(int q) const { return counts != nullptr && counts[q] >= 0; }
   // row of slot c if it is a candidate of the query (in range, passes the filter), else -1
   __device__ __forceinline__ long long cand(long long c, double q_pmz, int n_lib) const {
     const long long r = row(c);
@@ -338,7 +343,12 @@ struct CandView {
       c1 = offsets[q + 1];
     } else {
       c0 = (long long)q * stride;
-      c1 = c0 + stride;
+      int len = stride;
+      if (counts) {
+        const int c = counts[q];
+        if (c >= 0) len = c < stride ? c : stride;
+      }
+      c1 = c0 + len;
     }
   }
   __device__ __forceinline__ long long row(long long c) const {
@@ -924,12 +934,21 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
   const int qo = Qs.offsets[q];
   const int qn = Qs.offsets[q + 1] - qo;
   const double q_pmz = Qs.precursor_mz[q];
+  // the row was filtered where it was made (block-uniform): every slot in range is a candidate
+  const bool pre = cv.prefiltered(q);
+  auto is_cand = [&](long long c) -> bool {
+    if (pre) {
+      const long long r = cv.row(c);
+      return r >= 0 && r < L.n;
+    }
+    return cv.cand(c, q_pmz, L.n) >= 0;
+  };
   // (same bin filter as the pair kernel: see there)
   const double margin = 1e-3 + (tol > 0.0 ? (0.5 / tol) * (3.75e-4 + 2600.0 * 1.2e-7) : 1.0);
   if (!(tol > 0.0) || qn > RS_HQ_MAX || margin > 0.45) {   // uniform: whole query deferred
     for (long long c = c0 + (long long)blockIdx.y * blockDim.x + tid; c < c1;
          c += (long long)blockDim.x * gridDim.y) {
-      pair_score[c] = cv.cand(c, q_pmz, L.n) >= 0 ? RS_DEFER_BS : -1.0;
+      pair_score[c] = is_cand(c) ? RS_DEFER_BS : -1.0;
     }
     if (tid == 0) atomicOr(&q_defer[q], RS_QD_BS);
     return;
@@ -976,7 +995,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, RF_OCC) void rescore_flat_kernel(
       const int i = i0 + tid;
       bool ok = false;
       if (i < sn) {
-        ok = cv.cand(sb + i, q_pmz, L.n) >= 0;
+        ok = is_cand(sb + i);
         if (!ok && blockIdx.y == 0) pair_score[sb + i] = -1.0;
         ok = ok && (ny == 1 || ((i >> 5) % ny) == (int)blockIdx.y);   // (see the pair kernel)
       }
@@ -1344,12 +1363,14 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
                    double *pair_score, long long *best_slot, int32_t *best_cand,
                    int32_t *best_row, double *best_score, int32_t *n_valid,
                    int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride, int *status,
-                   const PrecFilter &filter, bool clear_status, RescoreScratch *scratch) {
+                   const PrecFilter &filter, bool clear_status, RescoreScratch *scratch,
+                   const int32_t *row_counts) {
   const int nq = Q.n;
   if (nq == 0) return ASL_OK;
   if (!scratch) return fail(ASL_ERR_INVALID, "rescore: no scratch (internal)");
   DevBuf<int> &q_defer = scratch->q_defer, &m_defer = scratch->m_defer;
   CandView cv{rows64, rows32, cand_offsets, stride, filter};
+  cv.counts = cand_offsets ? nullptr : row_counts;
   if (clear_status) HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), stream()));
   {
     ProfScope ps("rescore");

@@ -45,13 +45,7 @@ __device__ __forceinline__ const RowMeta *meta_row(const PrecFilter &f, long lon
   return reinterpret_cast<const RowMeta *>(reinterpret_cast<const char *>(f.meta) + (size_t)row * f.meta_stride);
 }
 
-// spectral_library.py:421-427 (numexpr evaluates in float64)
-__device__ __forceinline__ bool precursor_ok(double q, float lib, int charge, double tol,
-                                             int mode) {
-  const double l = (double)lib;
-  if (mode == ASL_TOL_DA) return fabs(q - l) * (double)charge <= tol;
-  return fabs(q - l) / l * 1000000.0 <= tol;
-}
+// precursor_ok (spectral_library.py:421-427): common.hpp -- the scans' finish applies it too
 
 __device__ __forceinline__ bool filter_pass(const PrecFilter &f, double q_pmz, long long row) {
   if (f.pass_all) return true;
@@ -80,7 +74,9 @@ int rescore_device(const DevPeaks &Q, const DevPeaks &L, const int64_t *rows64,
                    int32_t *best_row, double *best_score, int32_t *n_valid,
                    int32_t *pm_count, uint32_t *pm_pairs, int32_t pm_stride, int *status,
                    const PrecFilter &filter = PrecFilter(), bool clear_status = true,
-                   RescoreScratch *scratch = nullptr);
+                   RescoreScratch *scratch = nullptr,
+                   // fixed-stride rows: their lengths as the scans' post-filter wrote them (-1: unfiltered row)
+                   const int32_t *row_counts = nullptr);
 int rescore_check_status(const int *status_dev);   // reads the flags back: synchronises
 int rescore_status_error(int status_bits);         // ASL_OK or the error the flags stand for
 

@@ -25,6 +25,8 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
                         bool set_mode, const int *gate = nullptr, const uint2 *pre_ent = nullptr,
                         const int32_t *pre_cnt = nullptr);
 int index_dim(const asl_index *ix);
+void index_set_post_filter(asl_index *ix, const IndexPostFilter &p);
+bool index_post_filter_applied(asl_index *ix);
 int index_nprobe(const asl_index *ix, int nprobe);
 int index_prepare(asl_index *ix);
 int index_coarse_device(asl_index *ix, int nq, const float *xq, int nprobe, float *out_D,
@@ -99,6 +101,7 @@ struct asl_library {
   // buffers that cross the two streams of the pipeline, by batch parity
   DevBuf<float> p_qvec[2], p_cD[2];
   DevBuf<int32_t> p_cI[2], p_knn[2], p_cnt[2];
+  DevBuf<int32_t> p_rows[2], rows_len;   // lengths of the neighbour rows when the scan applied the precursor filter
   DevBuf<uint2> p_ent[2];          // the batch's entry lists: listed by the coarse stage, read by the scan
   bool p_have_ent[2] = {false, false};
   DevBuf<double> pair_score;
@@ -134,6 +137,29 @@ static int pack_peak_records(const int32_t *offsets, const float *mz, const floa
                      mz, inten, chg, meta, n, slot, rec);
   ASL_CHECK_LAUNCH();
   return ASL_OK;
+}
+
+// The precursor window applied inside the scan's finish (ScanPostFilter, common.hpp) whenever the
+// neighbour rows are consumed as a set; ASL_SCAN_POSTFILTER=0 keeps it in the rescoring (A/B runs).
+static bool scan_postfilter_on() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("ASL_SCAN_POSTFILTER");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on == 1;
+}
+static void offer_post_filter(asl_library *L, asl_index *idx, const DevPeaks &Q, const asl_search_params_t *P,
+                              int32_t *row_len) {
+  IndexPostFilter pf;
+  pf.payload = L->wcol.p;
+  pf.n = L->n;
+  pf.q_pmz = Q.precursor_mz;
+  pf.count = row_len;
+  pf.tol = P->precursor_tol;
+  pf.mode = P->precursor_mode;
+  pf.charge = P->charge;
+  index_set_post_filter(idx, pf);
 }
 
 // the precursor filter / row records of a library handle
@@ -402,6 +428,7 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
   ASL_TRY(L->p_knn[par].reserve((size_t)nq * k));
   ASL_TRY(L->p_ent[par].reserve((size_t)nq * 64));
   ASL_TRY(L->p_cnt[par].reserve((size_t)nq));
+  ASL_TRY(L->p_rows[par].reserve((size_t)nq));
   ASL_TRY(L->pair_score.reserve((size_t)nq * k));
   ASL_TRY(L->best_slot.reserve((size_t)nq));
   pp.parity ^= 1;
@@ -411,6 +438,7 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
   HIP_TRY(hipStreamWaitEvent(pp.B, pp.ev_in, 0));
   HIP_TRY(hipStreamWaitEvent(pp.C, pp.ev_in, 0));
   pp.inflight = true;
+  bool rows_filtered = false;
   {
     StreamScope on_a(pp.A);
     // The buffers of this parity were last read by the scan of batch i-2: the front of batch i
@@ -430,10 +458,13 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
     HIP_TRY(hipStreamWaitEvent(pp.B, pp.ev_front[par], 0));
     if (pp.resc_recorded[par]) HIP_TRY(hipStreamWaitEvent(pp.B, pp.ev_resc[par], 0));
     // (the entry lists of the coarse stage, when it made them: the scan does not list the rows again)
-    ASL_TRY(index_search_device(idx, nq, L->p_qvec[par].p, k, nprobe, nullptr, knn_I,
-                                L->p_knn[par].p, L->p_cD[par].p, L->p_cI[par].p,
-                                knn_I == nullptr, nullptr, L->p_have_ent[par] ? L->p_ent[par].p : nullptr,
-                                L->p_have_ent[par] ? L->p_cnt[par].p : nullptr));
+    if (knn_I == nullptr && scan_postfilter_on()) offer_post_filter(L, idx, Q.dev, P, L->p_rows[par].p);
+    const int rc_scan = index_search_device(idx, nq, L->p_qvec[par].p, k, nprobe, nullptr, knn_I,
+                                            L->p_knn[par].p, L->p_cD[par].p, L->p_cI[par].p,
+                                            knn_I == nullptr, nullptr, L->p_have_ent[par] ? L->p_ent[par].p : nullptr,
+                                            L->p_have_ent[par] ? L->p_cnt[par].p : nullptr);
+    rows_filtered = index_post_filter_applied(idx);
+    ASL_TRY(rc_scan);
     HIP_TRY(hipEventRecord(pp.ev_scan[par], pp.B));
     pp.scan_recorded[par] = true;
   }
@@ -453,7 +484,8 @@ static int search_batch_pipelined(asl_library *L, asl_index *idx, const asl_peak
     ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->p_knn[par].p, nullptr, k, (int64_t)nq * k,
                            P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
                            L->best_slot.p, nullptr, best_row, best_score, n_cand, pm_count,
-                           pm_pairs, pm_stride, pp.status, flt, /*clear_status=*/false, &L->rs_scratch));
+                           pm_pairs, pm_stride, pp.status, flt, /*clear_status=*/false, &L->rs_scratch,
+                           rows_filtered ? L->p_rows[par].p : nullptr));
     HIP_TRY(hipEventRecord(pp.ev_resc[par], sc));
     pp.resc_recorded[par] = true;
   }
@@ -515,8 +547,12 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
                           d, P->hash_seed, 1, L->qvec.p));
     // the candidates are consumed as a set (filter + best match): no final sort unless the
     // caller asked for the ordered neighbour list
-    ASL_TRY(index_search_device(idx, nq, L->qvec.p, k, P->nprobe, nullptr, o_knn.d, L->knn.p,
-                                nullptr, nullptr, knn_I == nullptr));
+    ASL_TRY(L->rows_len.reserve((size_t)nq));
+    if (knn_I == nullptr && scan_postfilter_on()) offer_post_filter(L, idx, Q.dev, P, L->rows_len.p);
+    const int rc_scan = index_search_device(idx, nq, L->qvec.p, k, P->nprobe, nullptr, o_knn.d, L->knn.p,
+                                            nullptr, nullptr, knn_I == nullptr);
+    const bool rows_filtered = index_post_filter_applied(idx);
+    ASL_TRY(rc_scan);
     PrecFilter flt;
     flt.lib_pmz = L->pmz32.p;
     flt.valid = L->has_valid ? L->valid.p : nullptr;
@@ -527,7 +563,8 @@ int asl_search_batch(asl_library_t *L, asl_index_t *idx, const asl_peaks_t *quer
     ASL_TRY(rescore_device(Q.dev, L->dev, nullptr, L->knn.p, nullptr, k, (int64_t)nq * k,
                            P->fragment_mz_tolerance, P->allow_shift, 1, L->pair_score.p,
                            L->best_slot.p, nullptr, o_row.d, o_score.d, o_ncand.d, o_cnt.d,
-                           o_pairs.d, pm_stride, L->status.p, flt, true, &L->rs_scratch));
+                           o_pairs.d, pm_stride, L->status.p, flt, true, &L->rs_scratch,
+                           rows_filtered ? L->rows_len.p : nullptr));
   } else {
     int64_t total = 0;
     {
