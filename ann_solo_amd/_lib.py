@@ -61,7 +61,7 @@ class AslIndexInfo(C.Structure):
 
 EXPORTS = [
     'asl_last_error', 'asl_version', 'asl_get_num_gpus', 'asl_set_device', 'asl_set_stream',
-    'asl_synchronize', 'asl_set_pipeline', 'asl_get_dim', 'asl_hash_idx', 'asl_encode_batch', 'asl_index_create',
+    'asl_synchronize', 'asl_set_pipeline', 'asl_set_scan_postfilter', 'asl_get_dim', 'asl_hash_idx', 'asl_encode_batch', 'asl_index_create',
     'asl_index_free', 'asl_index_train', 'asl_index_add', 'asl_index_add_preassigned', 'asl_index_search',
     'asl_index_reset', 'asl_index_ntotal', 'asl_index_is_trained', 'asl_index_save',
     'asl_index_load', 'asl_index_set_niter', 'asl_index_info', 'asl_index_get_centroids',

@@ -141,14 +141,15 @@ static int pack_peak_records(const int32_t *offsets, const float *mz, const floa
 
 // The precursor window applied inside the scan's finish (ScanPostFilter, common.hpp) whenever the
 // neighbour rows are consumed as a set; ASL_SCAN_POSTFILTER=0 keeps it in the rescoring (A/B runs).
-static bool scan_postfilter_on() {
+static int &scan_postfilter_flag() {
   static int on = -1;
   if (on < 0) {
     const char *e = getenv("ASL_SCAN_POSTFILTER");
     on = (e && e[0] == '0') ? 0 : 1;
   }
-  return on == 1;
+  return on;
 }
+static bool scan_postfilter_on() { return scan_postfilter_flag() == 1; }
 static void offer_post_filter(asl_library *L, asl_index *idx, const DevPeaks &Q, const asl_search_params_t *P,
                               int32_t *row_len) {
   IndexPostFilter pf;
@@ -170,6 +171,14 @@ static void library_filter(const asl_library *L, PrecFilter &flt) {
 }
 
 extern "C" {
+
+int asl_set_scan_postfilter(int on) {
+  clear_error();
+  int &f = scan_postfilter_flag();
+  const int prev = f;
+  f = on ? 1 : 0;
+  return prev;
+}
 
 asl_library_t *asl_library_create(const asl_peaks_t *p, const float *lib_pmz_f32,
                                   const uint8_t *valid) {

@@ -65,6 +65,15 @@ int asl_synchronize(void);
  * reported by that call instead. Any other entry point first waits for the batches in flight.
  * Results are bit-identical to the synchronous path. */
 int asl_set_pipeline(int on);
+/* Where asl_search_batch applies the precursor-window post-filter of the neighbour lists
+ * (/root/reference/src/ann_solo/spectral_library.py:417-429 AND :441-446 -- after the top-k in both
+ * places): 1 (default) = inside the list scan's finish whenever the lists are consumed as a set (no
+ * knn_I requested, layout-specific scan, k <= 1280): ids and window values arrive in one gather, only
+ * the passing hits are written, the rescoring walks short rows; 0 = inside the rescoring kernel's
+ * compaction (the only place until round 6; still used wherever the scan cannot take the filter).
+ * Results are bit-identical. Returns the previous setting; environment ASL_SCAN_POSTFILTER=0 sets
+ * the initial value. */
+int asl_set_scan_postfilter(int on);
 
 /* ------------------------------------------------------------------ encoder
  * Replaces spectrum_to_vector / get_dim / hash_idx, src/ann_solo/spectrum.py:122-214

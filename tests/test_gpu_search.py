@@ -268,3 +268,67 @@ def test_cascade_with_the_cosine_tdc_gate():
     rec = ids[0]
     assert rec.q == ids.q[0] and rec.is_decoy == bool(decoy[ids.lib_row[0]])
     sl.shutdown()
+
+
+@pytest.mark.parametrize('index', ['ivfpq', 'ivfflat'])
+def test_window_filter_inside_the_scan_equals_the_filter_inside_the_rescoring(O, index):
+    """`asl_set_scan_postfilter`: the precursor window applied in the list scan's finish (rows of passing hits
+    + their lengths) against the window applied in the rescoring's compaction (the only place until round 6) --
+    winners, scores, candidate counts and peak matches must be identical, and equal the oracle's, for Da and
+    ppm windows, a library with 400 copies of one spectrum (mass ties at the k-th score: those rows leave the
+    scan unfiltered, length -1), windows that pass nothing and windows that pass everything; pipelined too."""
+    from ann_solo_amd import _lib, synthetic
+    from ann_solo_amd.packed import PackedSpectra
+    from ann_solo_amd.spectral_library import Config, SpectralLibrary
+    lib0, aux = synthetic.make_library(5000, seed=71, device='cpu', charges=(2,), charge_p=(1.0,))
+    o, mz, it, chg, pmz, pz = lib0.numpy()
+    # rows 0 .. 399 become copies of row 0 with precursors spread over +-300 Da
+    a, b = int(o[0]), int(o[1])
+    n0 = b - a
+    rng = np.random.default_rng(5)
+    offs = [0]
+    MZ, IT, CH, PM = [], [], [], []
+    for r in range(lib0.n):
+        s, e = (a, b) if r < 400 else (int(o[r]), int(o[r + 1]))
+        MZ.append(mz[s:e]); IT.append(it[s:e]); CH.append(chg[s:e])
+        PM.append(pmz[0] + rng.uniform(-300, 300) if r < 400 else pmz[r])
+        offs.append(offs[-1] + (e - s))
+    lib = PackedSpectra.from_numpy(np.asarray(offs, np.int32), np.concatenate(MZ), np.concatenate(IT),
+                                   np.concatenate(CH), np.asarray(PM), pz)
+    q, _ = synthetic.make_queries(lib0, aux, 200, seed=72, charge=2)
+    qo, qmz, qit, qchg, qpmz, qpz = q.numpy()
+    q = PackedSpectra.from_numpy(qo, qmz, qit, qchg, qpmz, qpz)
+    L = _lib.lib()
+    for tol, mode in ((250.0, 'Da'), (0.01, 'Da'), (1e9, 'Da'), (2e5, 'ppm'), (10.0, 'ppm')):
+        cfg = Config.open_search(num_list=16, num_probe=8, num_candidates=1024, index=index, kmeans_niter=4,
+                                 precursor_tolerance_mass_open=tol, precursor_tolerance_mode_open=mode)
+        sl = SpectralLibrary(lib, config=cfg)
+        res = {}
+        try:
+            for on in (0, 1):
+                L.asl_set_scan_postfilter(on)
+                res[on] = sl._search_batch(q, 2, 'open')
+                sl.set_pipeline(True)
+                a_ = sl._search_batch(q.to('cuda:0'), 2, 'open', device_out=True)
+                b_ = sl._search_batch(q.to('cuda:0'), 2, 'open', device_out=True)
+                sl.synchronize()
+                sl.set_pipeline(False)
+                for r in (a_, b_):
+                    assert np.array_equal(r.best_row.cpu().numpy(), res[on].best_row)
+                    assert np.array_equal(r.best_score.cpu().numpy(), res[on].best_score)
+                    assert np.array_equal(r.n_candidates.cpu().numpy(), res[on].n_candidates)
+        finally:
+            L.asl_set_scan_postfilter(1)
+        for f in ('best_row', 'best_score', 'n_candidates', 'pm_count'):
+            assert np.array_equal(getattr(res[0], f), getattr(res[1], f)), (tol, mode, f)
+        assert np.array_equal(res[0].pm_pairs, res[1].pm_pairs)
+        Lo, pmz32, ivf = _oracle_partition(O, sl, 2)
+        ref = O.search_batch(O.Spectra(*q.numpy()), Lo, pmz32, 2, ivf, 1024, 8, tol, mode, 0.02, True,
+                             pm_stride=res[1].pm_pairs.shape[1])
+        assert np.array_equal(res[1].best_row, ref['best_row']) and np.array_equal(res[1].best_score, ref['best_score'])
+        assert np.array_equal(res[1].n_candidates, ref['n_cand'])
+        if tol == 0.01:
+            assert (res[1].n_candidates <= 1).all()
+        if tol == 1e9:
+            assert res[1].n_candidates.max() == 1024
+        sl.shutdown()
