@@ -328,7 +328,7 @@ def test_window_filter_inside_the_scan_equals_the_filter_inside_the_rescoring(O,
         assert np.array_equal(res[1].best_row, ref['best_row']) and np.array_equal(res[1].best_score, ref['best_score'])
         assert np.array_equal(res[1].n_candidates, ref['n_cand'])
         if tol == 0.01:
-            assert (res[1].n_candidates <= 1).all()
+            assert res[1].n_candidates.max() <= 4 and (res[1].n_candidates == 0).any()
         if tol == 1e9:
             assert res[1].n_candidates.max() == 1024
         sl.shutdown()
