@@ -72,15 +72,20 @@ int pipeline_init() {
   if (p.A) return ASL_OK;
   // non-blocking: no implicit ordering against the null stream (the caller's, PyTorch's) --
   // the ordering that matters is expressed with events
-  // the scan/rescoring chain (B) is the critical path of a step, the front (A) only has to be
-  // ready one batch ahead: B's workgroups are dispatched first, A's fill what is left
+  // Priorities. Every phase of a step keeps the chip busy, so overlapping conserves the work: the
+  // step is the sum of the kernels' stand-alone times whichever stream goes first; the priorities
+  // only decide WHICH kernel the short front stage (A: encode + coarse quantiser, ~0.9 ms of a
+  // 14 ms step) lands on. Until round 6 the front had the lowest priority and filled what scan +
+  // rescoring left (profiles/r02_pipeline_ab.txt; round 5 re-measured all three arrangements: no
+  // difference in the step). Since the precursor filter moved into the scan's finish the rescoring
+  // is shorter, and the front at the HIGHEST priority -- done early inside the scan, which then
+  // runs undisturbed -- measures 0.9 % (32 768-query batches) to 2 % (16 384) faster
+  // (profiles/r06_rescore_prefilter.txt).
   int least = 0, greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  // (front stages at the lowest, scan + rescoring at the highest priority: measured in
-  // profiles/r02_pipeline_ab.txt)
-  HIP_TRY(hipStreamCreateWithPriority(&p.A, hipStreamNonBlocking, least));
-  HIP_TRY(hipStreamCreateWithPriority(&p.B, hipStreamNonBlocking, greatest));
-  HIP_TRY(hipStreamCreateWithPriority(&p.C, hipStreamNonBlocking, greatest));
+  HIP_TRY(hipStreamCreateWithPriority(&p.A, hipStreamNonBlocking, greatest));
+  HIP_TRY(hipStreamCreateWithPriority(&p.B, hipStreamNonBlocking, least));
+  HIP_TRY(hipStreamCreateWithPriority(&p.C, hipStreamNonBlocking, least));
   HIP_TRY(hipEventCreateWithFlags(&p.ev_in, hipEventDisableTiming));
   for (int i = 0; i < 2; i++) {
     HIP_TRY(hipEventCreateWithFlags(&p.ev_front[i], hipEventDisableTiming));
