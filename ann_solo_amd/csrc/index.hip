@@ -98,7 +98,6 @@ struct asl_index {
   int64_t n_tile_slots = 0;
   const float *pay_src = nullptr;
   int64_t pay_n = 0;
-  uint64_t pay_serial = 0, post_serial = 0;
   bool idpay_ready = false;
   IndexPostFilter post;          // for the next search only
   bool post_set = false, post_applied = false;
@@ -542,7 +541,7 @@ static int take_post_filter(asl_index *ix, bool usable, const int32_t *slot_ids,
   ix->post_set = false;
   const IndexPostFilter &p = ix->post;
   if (!usable || !p.payload || !p.q_pmz || !p.count || p.n != ix->ntotal || ix->has_vids) return ASL_OK;
-  if (!ix->idpay_ready || ix->pay_src != p.payload || ix->pay_n != p.n || ix->pay_serial != ix->post_serial) {
+  if (!ix->idpay_ready || ix->pay_src != p.payload || ix->pay_n != p.n) {
     ASL_TRY(ix->idpay.reserve((size_t)std::max<int64_t>(nslots, 1)));
     if (nslots > 0) {
       hipLaunchKernelGGL(make_idpay_kernel, grid_2d(cdiv(nslots, 256)), dim3(256), 0, stream(), slot_ids, nslots,
@@ -551,7 +550,6 @@ static int take_post_filter(asl_index *ix, bool usable, const int32_t *slot_ids,
     }
     ix->pay_src = p.payload;
     ix->pay_n = p.n;
-    ix->pay_serial = ix->post_serial;
     ix->idpay_ready = true;
   }
   pf.idpay = ix->idpay.p;
@@ -841,11 +839,8 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
 }
 
 int index_dim(const asl_index *ix) { return ix->d; }
-// serial: identity of the column's owner (a library handle) -- address + length alone would match
-// another library created where a freed one lay
-void index_set_post_filter(asl_index *ix, const IndexPostFilter &p, uint64_t serial) {
+void index_set_post_filter(asl_index *ix, const IndexPostFilter &p) {
   ix->post = p;
-  ix->post_serial = serial;
   ix->post_set = true;
   ix->post_applied = false;
 }

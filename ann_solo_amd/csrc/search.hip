@@ -25,7 +25,7 @@ int index_search_device(asl_index *ix, int nq, const float *xq, int k, int nprob
                         bool set_mode, const int *gate = nullptr, const uint2 *pre_ent = nullptr,
                         const int32_t *pre_cnt = nullptr);
 int index_dim(const asl_index *ix);
-void index_set_post_filter(asl_index *ix, const IndexPostFilter &p, uint64_t serial);
+void index_set_post_filter(asl_index *ix, const IndexPostFilter &p);
 bool index_post_filter_applied(asl_index *ix);
 int index_nprobe(const asl_index *ix, int nprobe);
 int index_prepare(asl_index *ix);
@@ -90,7 +90,6 @@ struct asl_library {
   DevBuf<uint8_t> records;   // n * slot bytes (DevPeaks::records)
   uint32_t slot = 0;         // bytes per row (a multiple of 128)
   DevBuf<float> wcol;     // window column alone, NaN for invalid spectra
-  uint64_t serial = 0;    // unique per handle (asl_library_create): what an index keys its copy of wcol on
   bool has_valid = false;
   DevPeaks dev;
   // precursor-sorted view (window search)
@@ -161,7 +160,7 @@ static void offer_post_filter(asl_library *L, asl_index *idx, const DevPeaks &Q,
   pf.tol = P->precursor_tol;
   pf.mode = P->precursor_mode;
   pf.charge = P->charge;
-  index_set_post_filter(idx, pf, L->serial);
+  index_set_post_filter(idx, pf);
 }
 
 // the precursor filter / row records of a library handle
@@ -192,8 +191,6 @@ asl_library_t *asl_library_create(const asl_peaks_t *p, const float *lib_pmz_f32
   PeaksStage st;
   if (st.init(p) != ASL_OK) return nullptr;
   asl_library *L = new asl_library();
-  static uint64_t next_serial = 0;
-  L->serial = ++next_serial;
   L->n = p->n;
   const size_t n = (size_t)p->n, np = (size_t)st.dev.n_peaks;
   bool ok = true;
