@@ -356,3 +356,48 @@ def test_pmc_traffic_is_quoted_only_for_the_kernel_sources_it_was_taken_on(tmp_p
     for rel, which in ((bench.PMC_TRAFFIC_FILE, 'pq'), (bench.PMC_TRAFFIC_FILE_FLAT, 'flat')):
         t, why = bench._load_traffic(rel, which)
         assert (isinstance(t, int) and t > 0) or (t is None and isinstance(why, str))
+
+
+def test_bench_stdout_protection_and_the_fallback_line(tmp_path):
+    """bench.py's insurance, without a GPU: (1) after protect_stdout() whatever a library writes to file
+    descriptor 1 lands on stderr and emit_line() alone reaches stdout; (2) an armed fallback line is printed
+    by the watchdog (exit code 0) when the run stops, with the stage it stopped in; (3) ... and by the
+    exception path, once only."""
+    import subprocess
+    import sys
+    script = tmp_path / 'fb.py'
+    script.write_text(f'''
+import os, sys, time
+sys.path.insert(0, {ROOT!r})
+import bench
+mode = sys.argv[1]
+bench.protect_stdout()
+os.write(1, b"[Gloo] Rank 0 is connected to 1 peer ranks.\\n")      # what a library prints to fd 1
+print("python-level print")                                          # sys.stdout writes to fd 1 too
+if mode == "line":
+    bench.emit_line('{{"ok": true}}')
+elif mode == "watchdog":
+    bench._arm_fallback(0, 1.0, {{"value": 7, "config": {{"parallelism": "replicas x2"}}}})
+    bench._FALLBACK["stage"] = "timed steps"
+    time.sleep(30)
+elif mode == "raise":
+    bench._arm_fallback(0, 0, {{"value": 7}})
+    assert bench._emit_fallback("RuntimeError: boom") is True
+    assert bench._emit_fallback("again") is False
+elif mode == "other-rank":
+    bench._arm_fallback(1, 0, {{"value": 7}})
+    assert bench._emit_fallback("RuntimeError: boom") is True        # armed, but only rank 0 prints
+''')
+    def run(mode):
+        return subprocess.run([sys.executable, str(script), mode], capture_output=True, text=True, timeout=120)
+    out = run('line')
+    assert out.returncode == 0 and out.stdout == '{"ok": true}\n', (out.stdout, out.stderr[-500:])
+    assert '[Gloo]' in out.stderr and 'python-level print' in out.stderr
+    out = run('watchdog')
+    assert out.returncode == 0, out.stderr[-500:]
+    rec = json.loads(out.stdout)
+    assert rec['value'] == 7 and 'watchdog' in rec['sharded_path_failed'] and 'timed steps' in rec['sharded_path_failed']
+    out = run('raise')
+    assert out.returncode == 0 and json.loads(out.stdout)['sharded_path_failed'] == 'RuntimeError: boom'
+    out = run('other-rank')
+    assert out.returncode == 0 and out.stdout == ''
