@@ -205,8 +205,18 @@ def _replica_worker(rank, world, port, out_dir):
     ref = be.rescore_knn(q, torch.from_numpy(I))
     ok = (np.array_equal(res['best_row'], ref['best_row'])
           and np.array_equal(res['best_score'], ref['best_score']))
+    # the data-plane form bench.py uses at N > 1 (default group = control plane, the shard groups on
+    # another backend; here both are gloo): degree == world hands back the caller's all-ranks group,
+    # smaller degrees create their groups on the named backend
+    g_all = dist.new_group(list(range(world)), backend='gloo')
+    g2, r2, gi2 = make_shard_groups(world, backend='gloo', world_group=g_all)
+    g3, r3, gi3 = make_shard_groups(1, backend='gloo', world_group=g_all)
+    t = torch.tensor([rank + 1])
+    dist.all_reduce(t, group=g2)
+    planes_ok = (g2 is g_all and r2 == rank and gi2 == 0 and dist.get_world_size(g3) == 1 and r3 == 0
+                 and gi3 == rank and int(t) == world * (world + 1) // 2)
     shape_ok = (g_full is None and r_full == rank and gi_full == 0 and srank == 0
-                and gidx == rank and dist.get_world_size(group) == 1)
+                and gidx == rank and dist.get_world_size(group) == 1 and planes_ok)
     with open(os.path.join(out_dir, f'rank{rank}.txt'), 'w') as f:
         f.write(f'{int(ok)} {int(shape_ok)}')
     dist.barrier()
