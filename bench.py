@@ -85,7 +85,7 @@ def main():
                          '0 = off (the default workload)')
     ap.add_argument('--no-recall-hard', action='store_true',
                     help='skip the `recall_hard` block (recall / hit@k / the fixed-recall operating point on the '
-                         'HARD synthetic queries, calibrated to the reference\'s exact-search hit@1024 of 75 %)')
+                         'HARD synthetic queries, calibrated to the reference\'s exact-search hit@1024 of 75 %%)')
     ap.add_argument('--no-fixed-recall', action='store_true',
                     help='skip the IVF-Flat measurement at the fixed-recall operating point '
                          '(default run, N = 1, IVF-PQ: same library, same coarse quantiser)')

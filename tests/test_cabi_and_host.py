@@ -401,3 +401,12 @@ elif mode == "other-rank":
     assert out.returncode == 0 and json.loads(out.stdout)['sharded_path_failed'] == 'RuntimeError: boom'
     out = run('other-rank')
     assert out.returncode == 0 and out.stdout == ''
+
+
+def test_bench_help_prints():
+    """`python bench.py --help` (argparse expands % in help strings: a bare one raised ValueError)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0 and '--beyond-llc-chunks' in out.stdout, out.stderr[-500:]
